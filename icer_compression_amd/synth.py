@@ -1,0 +1,77 @@
+"""Deterministic synthetic frames used by the tests and by bench.py.
+
+This is our own generator, not reference code: a 32-bit LCG
+(`s = s*1664525 + 1013904223`, one draw `s >> 8` per pixel in raster order, seed 12345 + frame
+index) added to a smooth ramp ("natural-like", mode 1) or used directly (mode 0, stress).
+8-bit values are stored widened to uint16, exactly how the reference's own CLI feeds
+`icer_compress_image_uint16` (example/src/icer_util.c:163-168).
+
+The colour generator draws three values per pixel (R, G, B order) and converts them with the
+integer RGB->YCbCr formulas the reference's example apps use before calling the YUV encoder
+(example/inc/color_util.h:27-29, app-side code; restated here only to build inputs).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LCG_A = np.uint32(1664525)
+LCG_C = np.uint32(1013904223)
+DEFAULT_SEED = 12345
+
+
+def lcg_draws(n: int, seed: int) -> np.ndarray:
+    """First `n` outputs (state >> 8) of the LCG, vectorised by jump-ahead (mod 2**32)."""
+    with np.errstate(over="ignore"):
+        a_pow = np.empty(n + 1, dtype=np.uint32)
+        a_pow[0] = 1
+        if n:
+            a_pow[1:] = LCG_A
+            np.cumprod(a_pow, dtype=np.uint32, out=a_pow)      # a^k mod 2^32
+        geo = np.cumsum(a_pow[:-1], dtype=np.uint32)          # sum_{j<k+1} a^j mod 2^32
+        state = a_pow[1:] * np.uint32(seed & 0xFFFFFFFF) + LCG_C * geo
+    return state >> np.uint32(8)
+
+
+def _ramp(w: int, h: int, base: float, kx: float, ky: float) -> np.ndarray:
+    x = np.arange(w, dtype=np.float64) / w - 0.5
+    y = np.arange(h, dtype=np.float64) / h - 0.5
+    # same association order as the C expression  base + kx*(x/W-0.5) + ky*(y/H-0.5)
+    return ((base + kx * x[None, :]) + ky * y[:, None]).astype(np.int64)
+
+
+def gray_frame(w: int, h: int, seed: int = DEFAULT_SEED, mode: int = 1) -> np.ndarray:
+    """(h, w) uint16 frame with 8-bit range content."""
+    r = lcg_draws(w * h, seed).reshape(h, w)
+    if mode == 0:
+        v = (r & np.uint32(255)).astype(np.int64)
+    elif mode == 1:
+        v = _ramp(w, h, 128.0, 60.0, 50.0) + (r % np.uint32(17)).astype(np.int64) - 8
+    elif mode == 2:
+        # 12-bit-range stress content for true 16-bit paths (beyond what 9 planes code losslessly)
+        v = (r & np.uint32(4095)).astype(np.int64)
+        return v.astype(np.uint16)
+    else:
+        raise ValueError("mode must be 0, 1 or 2")
+    return np.clip(v, 0, 255).astype(np.uint16)
+
+
+def gray_batch(n: int, w: int, h: int, seed: int = DEFAULT_SEED, mode: int = 1) -> np.ndarray:
+    return np.stack([gray_frame(w, h, seed + k, mode) for k in range(n)])
+
+
+def color_frame_yuv(w: int, h: int, seed: int = DEFAULT_SEED):
+    """Three (h, w) uint16 planes Y, Cb, Cr built from a synthetic RGB frame."""
+    r3 = lcg_draws(3 * w * h, seed).reshape(h, w, 3)
+    n = (r3 % np.uint32(17)).astype(np.int64) - 8
+    x = np.arange(w, dtype=np.float64) / w - 0.5
+    y = np.arange(h, dtype=np.float64) / h - 0.5
+    zx, zy = np.zeros_like(x), np.zeros_like(y)
+    rr = ((128.0 + 60.0 * x[None, :]) + 50.0 * y[:, None]).astype(np.int64) + n[..., 0]
+    gg = ((100.0 + 80.0 * y[:, None]) + zx[None, :]).astype(np.int64) + n[..., 1]
+    bb = ((140.0 - 70.0 * x[None, :]) + zy[:, None]).astype(np.int64) + n[..., 2]
+    rr, gg, bb = (np.clip(c, 0, 255) for c in (rr, gg, bb))
+    clip = lambda v: np.clip(v, 0, 255)
+    yy = clip((19595 * rr + 38470 * gg + 7471 * bb) >> 16)
+    cb = clip(((36962 * (bb - yy)) >> 16) + 128)
+    cr = clip(((46727 * (rr - yy)) >> 16) + 128)
+    return yy.astype(np.uint16), cb.astype(np.uint16), cr.astype(np.uint16)

@@ -1,0 +1,665 @@
+/*
+ * icer_oracle.c -- TEST INFRASTRUCTURE ONLY (see icer_oracle.h).
+ *
+ * A from-scratch, plain-C restatement of the encoder hot path of lib_icer
+ * (TheRealOrange/icer_compression).  Every function cites the reference file:line whose
+ * behaviour it restates.  It is written for clarity, not speed: out-of-place 1-D lifting
+ * instead of the in-place shuffle, an explicit event/codeword model of the interleaved
+ * entropy coder, and a closed-form byte-quota walk.  All reference quirks that influence the
+ * byte stream are reproduced on purpose (see the comments marked QUIRK).
+ *
+ * Parity status: PINNED by tests/test_oracle_vs_ref.py (against oracle/_ref/libicer_ref.so,
+ * built from the untouched sources) and by the digests in tests/golden/.
+ */
+#include "icer_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define PLANES 9            /* ICER_BITPLANES_TO_COMPRESS_16, icer.h:44-46 */
+#define RING_WORDS 2048     /* ICER_CIRC_BUF_SIZE, icer.h:27 */
+#define HEADER_BYTES 28     /* sizeof(icer_image_segment_typedef), icer.h:293-305 */
+#define MAX_SEGMENTS 32     /* ICER_MAX_SEGMENTS, icer.h:29-31 */
+#define MAX_STAGES 6        /* ICER_MAX_DECOMP_STAGES, icer.h:32-34 */
+#define MAX_PACKETS 800     /* ICER_MAX_PACKETS_16, icer.h:38-40 */
+
+enum { SB_LL = 0, SB_HL = 1, SB_LH = 2, SB_HH = 3 };   /* icer.h:181-187 */
+
+/* ------------------------------------------------------------------------------------------
+ * helpers
+ * ---------------------------------------------------------------------------------------- */
+static int32_t floordiv(int32_t a, int32_t b)          /* icer.h:562-566 (b > 0 here) */
+{
+    int32_t q = a / b;
+    if ((a % b) != 0 && a < 0) q--;
+    return q;
+}
+static size_t ceil_shift(size_t v, int s) { return (v + (((size_t)1 << s) - 1)) >> s; }
+/* icer_get_dim_n_low_stages / _high_stages, icer_wavelet.c:107-113 */
+static size_t dim_low(size_t d, int level) { return ceil_shift(d, level); }
+static size_t dim_high(size_t d, int level) { return ceil_shift(d, level - 1) / 2; }
+
+/* ------------------------------------------------------------------------------------------
+ * a-1..a-4  forward lifting DWT (icer_wavelet.c:57-77, 155-171, 385-465; filter table
+ * icer_config.c:18-24).  The reference lifts pairs in place, un-shuffles in place and then
+ * runs the prediction step in place; only the resulting layout [lows | highs] and values
+ * matter, so this restatement works on copies.
+ * ---------------------------------------------------------------------------------------- */
+static const int FILT[7][4] = {   /* alpha_-1, alpha_0, alpha_1, beta   (x16) */
+    {0, 4, 4, 0}, {0, 4, 6, 4}, {-1, 4, 8, 6}, {0, 4, 5, 2}, {0, 3, 8, 6}, {0, 3, 9, 8}, {0, 4, 4, 4}};
+
+static int fits16(int32_t v) { return v >= -32768 && v <= 32767; }
+
+int orc_dwt_1d(int16_t *line, size_t n, size_t stride, int filt)
+{
+    size_t nl = (n + 1) / 2, nh = n / 2;
+    int odd = (int)(n & 1);
+    int overflow = 0;
+    int16_t *lo = (int16_t *)malloc(sizeof(int16_t) * (nl + 1));
+    int16_t *hi = (int16_t *)malloc(sizeof(int16_t) * (nh + 2));
+    int16_t *out = (int16_t *)malloc(sizeof(int16_t) * (nh + 1));
+
+    /* step 1 (icer_wavelet.c:402-426): pair average (floor) and difference, truncating stores */
+    for (size_t k = 0; k < nh; k++) {
+        int32_t a = line[(2 * k) * stride], b = line[(2 * k + 1) * stride];
+        int32_t l = floordiv(a + b, 2), h = a - b;
+        if (!fits16(l) || !fits16(h)) overflow = 1;
+        lo[k] = (int16_t)l;
+        hi[k] = (int16_t)h;
+    }
+    if (odd) lo[nl - 1] = line[(n - 1) * stride];        /* lone last sample is a low */
+    hi[nh] = 0;                                          /* get_d_int16 :210-212: missing last high reads as 0 */
+
+    /* step 2 (icer_wavelet.c:430-462).  r[k] = (int16)(lo[k-1]-lo[k]) -- QUIRK W1b: the
+     * difference is wrapped to 16 bits without an overflow flag (get_r_int16 :206-208). */
+#define R(k) ((int32_t)(int16_t)(lo[(k) - 1] - lo[(k)]))
+    const int am1 = FILT[filt][0], a0 = FILT[filt][1], a1 = FILT[filt][2], be = FILT[filt][3];
+    for (size_t k = 0; k < nh; k++) {
+        int32_t sub;
+        if (k == 0) {
+            sub = floordiv(R(1), 4);
+        } else if (k == 1 && am1 != 0) {
+            /* QUIRK W3 (filter C only): the reference passes offset=low_N, so the "d[2]" of the
+             * ICER paper is really d[1] (still unmodified), and 0 when n is odd and nl == 3. */
+            int32_t x = (odd && nl == 3) ? 0 : hi[1];
+            sub = floordiv(2 * R(1) + 3 * R(2) - 2 * x + 4, 8);
+        } else if (!odd && k == nh - 1) {
+            sub = floordiv(R(nh - 1), 4);
+        } else {
+            int32_t rm = (k >= 2) ? R(k - 1) : 1;        /* r[0] reads as 1; only ever multiplied by alpha_-1 == 0 */
+            int32_t dn = (odd && k + 1 == nl - 1) ? 0 : hi[k + 1];
+            sub = floordiv(am1 * rm + a0 * R(k) + a1 * R(k + 1) - be * dn + 8, 16);
+        }
+        int32_t h = (int32_t)hi[k] - sub;
+        if (!fits16(h)) overflow = 1;
+        out[k] = (int16_t)h;
+    }
+#undef R
+    for (size_t k = 0; k < nl; k++) line[k * stride] = lo[k];
+    for (size_t k = 0; k < nh; k++) line[(nl + k) * stride] = out[k];
+    free(lo); free(hi); free(out);
+    return overflow ? ORC_INTEGER_OVERFLOW : ORC_OK;
+}
+
+int orc_dwt_stages_u16(uint16_t *img, size_t w, size_t h, int stages, int filt)
+{
+    /* icer_wavelet.c:57-77: refuse when the final LL would be thinner than 3 */
+    if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return ORC_TOO_MANY_STAGES;
+    int overflow = 0;
+    size_t cw = w, ch = h;
+    int16_t *s = (int16_t *)img;
+    for (int st = 0; st < stages; st++) {
+        /* icer_wavelet.c:155-171: every row of the current LL region, then every column */
+        for (size_t r = 0; r < ch; r++) overflow |= (orc_dwt_1d(s + r * w, cw, 1, filt) != ORC_OK);
+        for (size_t c = 0; c < cw; c++) overflow |= (orc_dwt_1d(s + c, ch, w, filt) != ORC_OK);
+        cw = (cw + 1) / 2;
+        ch = (ch + 1) / 2;
+    }
+    return overflow ? ORC_INTEGER_OVERFLOW : ORC_OK;
+}
+
+/* a-6  icer_to_sign_magnitude_int16, icer_wavelet.c:871-877 */
+void orc_sign_magnitude(uint16_t *data, size_t len)
+{
+    for (size_t i = 0; i < len; i++) {
+        int16_t v = (int16_t)data[i];
+        if (v < 0) data[i] = (uint16_t)(0x8000u | (uint16_t)(-(int32_t)v));   /* -32768 -> 0x8000 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-8  segment grid, icer_partition.c:7-54 (ICER paper's partition rule)
+ * ---------------------------------------------------------------------------------------- */
+int orc_partition_make(orc_partition *p, size_t w, size_t h, unsigned segments)
+{
+    if (segments > w * h || segments > MAX_SEGMENTS) return ORC_TOO_MANY_SEGMENTS;
+    size_t s = segments;
+    size_t r;
+    if (h > (s - 1) * w) r = s;
+    else for (r = 1; r < s && (r + 1) * r * w < h * s; r++) {}
+    size_t c = s / r;
+    size_t r_t = (c + 1) * r - s;
+    size_t h_t = ((2 * h * c * r_t + s) / 2) / s;
+    if (h_t < r_t) h_t = r_t;
+    size_t x_t = w / c, c_t0 = (x_t + 1) * c - w;
+    size_t y_t = h_t / r_t, r_t0 = (y_t + 1) * r_t - h_t;
+    size_t x_b = 0, c_b0 = 0, y_b = 0, r_b0 = 0;
+    if (r_t < r) {
+        x_b = w / (c + 1);
+        c_b0 = (x_b + 1) * (c + 1) - w;
+        y_b = (h - h_t) / (r - r_t);
+        r_b0 = (y_b + 1) * (r - r_t) - (h - h_t);
+    }
+    /* all fields are uint16_t in the reference (icer.h:126-142): truncating stores */
+    p->w = (uint16_t)w; p->h = (uint16_t)h; p->s = (uint16_t)s;
+    p->r = (uint16_t)r; p->c = (uint16_t)c; p->r_t = (uint16_t)r_t; p->h_t = (uint16_t)h_t;
+    p->x_t = (uint16_t)x_t; p->c_t0 = (uint16_t)c_t0; p->y_t = (uint16_t)y_t; p->r_t0 = (uint16_t)r_t0;
+    p->x_b = (uint16_t)x_b; p->c_b0 = (uint16_t)c_b0; p->y_b = (uint16_t)y_b; p->r_b0 = (uint16_t)r_b0;
+    return ORC_OK;
+}
+
+/* segment rectangles in coding order: top region row-major, then bottom region row-major
+ * (icer_partition.c:299-385).  Returns the number of rectangles (== p->s for a valid grid). */
+int orc_partition_rects(const orc_partition *p, orc_rect *rects)
+{
+    int n = 0;
+    uint32_t y = 0;
+    for (unsigned row = 0; row < p->r_t; row++) {
+        uint32_t sh = p->y_t + (row >= p->r_t0 ? 1u : 0u), x = 0;
+        for (unsigned col = 0; col < p->c; col++) {
+            uint32_t sw = p->x_t + (col >= p->c_t0 ? 1u : 0u);
+            rects[n].x = x; rects[n].y = y; rects[n].w = sw; rects[n].h = sh; n++;
+            x += sw;
+        }
+        y += sh;
+    }
+    for (unsigned row = 0; row < (unsigned)(p->r - p->r_t); row++) {
+        uint32_t sh = p->y_b + (row >= p->r_b0 ? 1u : 0u), x = 0;
+        for (unsigned col = 0; col < (unsigned)(p->c + 1); col++) {
+            uint32_t sw = p->x_b + (col >= p->c_b0 ? 1u : 0u);
+            rects[n].x = x; rects[n].y = y; rects[n].w = sw; rects[n].h = sh; n++;
+            x += sw;
+        }
+        y += sh;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-7  packet list + priority order (gray: icer_compress.c:315-365; YUV: icer_color.c:398-458;
+ * comparator icer_compress.c:8-15).  glibc's qsort is a stable merge sort, so ties keep
+ * generation order: restated here as a stable insertion sort.
+ * ---------------------------------------------------------------------------------------- */
+int orc_packet_list(orc_packet *out, int stages, int channels)
+{
+    int n = 0;
+    if (channels == 1) {
+        for (int st = 1; st <= stages; st++) {
+            uint64_t pr = (uint64_t)1 << st;
+            for (int lsb = 0; lsb < PLANES; lsb++) {
+                out[n++] = (orc_packet){(uint8_t)st, SB_HL, (uint8_t)lsb, 0, pr << lsb};
+                out[n++] = (orc_packet){(uint8_t)st, SB_LH, (uint8_t)lsb, 0, pr << lsb};
+                out[n++] = (orc_packet){(uint8_t)st, SB_HH, (uint8_t)lsb, 0, ((pr / 2) << lsb) + 1};
+            }
+        }
+        uint64_t pr = (uint64_t)1 << stages;
+        for (int lsb = 0; lsb < PLANES; lsb++)
+            out[n++] = (orc_packet){(uint8_t)stages, SB_LL, (uint8_t)lsb, 0, (2 * pr) << lsb};
+    } else {
+        /* QUIRK D4: the YUV variant doubles a uint32 `priority` once per (lsb, Y) and never
+         * resets it inside the lsb loop, so it grows by 2 per plane *in addition* to << lsb. */
+        for (int st = 1; st <= stages; st++) {
+            uint32_t pr = (uint32_t)1 << st;
+            for (int lsb = 0; lsb < PLANES; lsb++) {
+                for (int ch = 0; ch < channels; ch++) {
+                    if (ch == 0) pr *= 2;
+                    out[n++] = (orc_packet){(uint8_t)st, SB_HL, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(pr << lsb)};
+                    out[n++] = (orc_packet){(uint8_t)st, SB_LH, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(pr << lsb)};
+                    out[n++] = (orc_packet){(uint8_t)st, SB_HH, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(((pr / 2) << lsb) + 1)};
+                }
+            }
+        }
+        uint32_t pr = (uint32_t)1 << stages;
+        for (int lsb = 0; lsb < PLANES; lsb++)
+            for (int ch = 0; ch < channels; ch++) {
+                if (ch == 0) pr *= 2;
+                out[n++] = (orc_packet){(uint8_t)stages, SB_LL, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)((2 * pr) << lsb)};
+            }
+    }
+    /* stable: priority descending, then subband ascending */
+    for (int i = 1; i < n; i++) {
+        orc_packet key = out[i];
+        int j = i - 1;
+        while (j >= 0 && (out[j].priority < key.priority ||
+                          (out[j].priority == key.priority && out[j].subband > key.subband))) {
+            out[j + 1] = out[j];
+            j--;
+        }
+        out[j + 1] = key;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-15  CRC-32 (reflected 0xEDB88320, init/final 0xFFFFFFFF), crc32.c:72-116,157-169
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t crc_table[256];
+static int crc_ready = 0;
+uint32_t orc_crc32(const uint8_t *buf, size_t len)
+{
+    if (!crc_ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+            crc_table[i] = c;
+        }
+        crc_ready = 1;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < len; i++) c = crc_table[(c ^ buf[i]) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-12..a-14  interleaved entropy coder (icer_encoding.c:15-206; tables icer_config.c:69-107,
+ * icer_init.c:124-256).
+ * ---------------------------------------------------------------------------------------- */
+/* probability cut-offs x65536 between bins (icer_config.c:69-87) */
+static const uint32_t CUT[17] = {35298, 37345, 40503, 43591, 47480, 50133, 53645, 55902, 57755,
+                                 58894, 60437, 62267, 63613, 64557, 65134, 65392, 65536};
+/* Golomb parameter m for bins 8..16 (icer_config.c:89-107) */
+static const uint16_t GOLOMB_M[17] = {0, 0, 0, 0, 0, 0, 0, 0, 5, 6, 7, 11, 17, 31, 70, 200, 512};
+
+/* variable-to-variable codes of bins 1..7 (icer_init.c:124-188): {input value, input bits,
+ * output code, output bits}; input bits arrive LSB first. */
+typedef struct { uint8_t in_val, in_bits, out_code, out_bits; } v2v;
+static const v2v V2V[8][9] = {
+    {{0, 0, 0, 0}},
+    {{1, 2, 2, 2}, {2, 2, 1, 2}, {3, 3, 3, 3}, {4, 3, 4, 3}, {7, 4, 15, 4}, {8, 4, 8, 4}, {15, 4, 16, 5}, {0, 5, 7, 4}, {16, 5, 0, 5}},
+    {{1, 2, 6, 3}, {2, 2, 1, 2}, {4, 3, 0, 2}, {7, 3, 10, 4}, {0, 4, 3, 3}, {3, 4, 7, 4}, {11, 4, 2, 5}, {8, 5, 15, 4}, {24, 5, 18, 5}},
+    {{1, 2, 1, 2}, {2, 2, 2, 2}, {3, 2, 7, 3}, {0, 3, 0, 2}, {4, 3, 3, 3}},
+    {{0, 2, 1, 1}, {2, 3, 0, 3}, {3, 3, 12, 4}, {5, 3, 2, 4}, {6, 3, 10, 4}, {7, 3, 22, 5}, {9, 4, 14, 4}, {1, 5, 4, 4}, {17, 5, 6, 5}},
+    {{1, 1, 2, 2}, {2, 3, 3, 3}, {4, 3, 5, 3}, {6, 3, 15, 4}, {8, 4, 1, 3}, {0, 5, 0, 2}, {16, 5, 7, 4}},
+    {{3, 2, 7, 4}, {0, 3, 0, 1}, {1, 3, 3, 3}, {2, 3, 5, 3}, {4, 3, 1, 3}, {5, 3, 31, 5}, {6, 3, 15, 5}},
+    {{1, 2, 3, 3}, {2, 2, 5, 3}, {3, 2, 31, 5}, {4, 3, 1, 3}, {0, 4, 0, 1}, {8, 5, 7, 4}, {24, 5, 15, 5}},
+};
+/* bits appended to a partial input of bins 1..7 when it is force-completed
+ * (icer_init.c:191-237): {partial value, bits so far, appended bits, #appended} */
+typedef struct { uint8_t val, nbits, add, nadd; } v2v_flush;
+static const v2v_flush V2VF[8][7] = {
+    {{0, 0, 0, 0}},
+    {{1, 1, 0, 1}, {3, 2, 0, 1}, {7, 3, 0, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {0, 3, 1, 1}, {0, 4, 0, 1}},
+    {{0, 1, 1, 1}, {0, 2, 1, 1}, {0, 3, 0, 1}, {8, 4, 0, 1}, {1, 1, 0, 1}, {3, 2, 1, 1}, {3, 3, 0, 1}},
+    {{0, 1, 1, 1}, {0, 2, 0, 1}, {1, 1, 0, 1}},
+    {{0, 1, 0, 1}, {2, 2, 0, 1}, {1, 2, 1, 1}, {1, 3, 1, 1}, {1, 4, 0, 1}, {1, 1, 1, 2}, {3, 2, 0, 1}},
+    {{0, 1, 1, 2}, {1, 2, 0, 1}, {0, 2, 1, 1}, {0, 3, 1, 1}, {0, 4, 0, 1}},
+    {{0, 1, 0, 2}, {0, 2, 0, 1}, {2, 2, 0, 1}, {1, 1, 1, 1}, {1, 2, 0, 1}},
+    {{0, 1, 1, 1}, {0, 2, 1, 1}, {0, 3, 0, 1}, {8, 4, 0, 1}, {1, 1, 0, 1}},
+};
+
+/* dense look-ups in the reference's indexing (value-indexed, zero = "no entry") */
+static struct { uint8_t in_bits, out_bits, out_code; } code_lut[17][32];
+static struct { uint8_t add, nadd; } flush_lut[17][9][6];
+static struct { uint16_t m, l, i; } golomb[17];
+static int coder_ready = 0;
+
+static void coder_tables_init(void)
+{
+    if (coder_ready) return;
+    memset(code_lut, 0, sizeof code_lut);
+    memset(flush_lut, 0, sizeof flush_lut);
+    memset(golomb, 0, sizeof golomb);
+    for (int b = 1; b <= 7; b++) {
+        for (int k = 0; k < 9; k++) {
+            v2v e = V2V[b][k];
+            if (e.in_bits == 0) continue;
+            code_lut[b][e.in_val].in_bits = e.in_bits;
+            code_lut[b][e.in_val].out_bits = e.out_bits;
+            code_lut[b][e.in_val].out_code = e.out_code;
+        }
+        for (int k = 0; k < 7; k++) {
+            v2v_flush f = V2VF[b][k];
+            if (f.nbits == 0) continue;
+            flush_lut[b][f.val][f.nbits].add = f.add;
+            flush_lut[b][f.val][f.nbits].nadd = f.nadd;
+        }
+    }
+    for (int b = 8; b <= 16; b++) {                      /* icer_init.c:239-256 */
+        unsigned m = GOLOMB_M[b], l = 0;
+        while ((1u << l) < m) l++;                       /* ceil(log2 m) */
+        golomb[b].m = (uint16_t)m; golomb[b].l = (uint16_t)l; golomb[b].i = (uint16_t)((1u << l) - m);
+    }
+    coder_ready = 1;
+}
+
+/* icer_compute_bin, icer_util.c:48-56 */
+int orc_pick_bin(uint32_t zero, uint32_t total)
+{
+    uint32_t lhs = zero * 65536u;
+    for (int b = 16; b >= 1; b--)
+        if (lhs >= total * CUT[b - 1]) return b;
+    return 0;
+}
+
+typedef struct {
+    uint8_t bin;        /* owner bin while open */
+    uint8_t done;
+    uint8_t nbits;      /* output bits once done */
+    uint16_t value;     /* open: Golomb run length / v2v partial input; done: output code */
+} ring_word;
+
+typedef struct {
+    ring_word ring[RING_WORDS];
+    unsigned head, used;
+    int open_slot[17];          /* -1 = bin has no open word */
+    int in_bits[17];            /* v2v bins: input bits accumulated so far */
+    uint8_t *out;
+    size_t out_cap;
+    uint64_t bitpos;            /* bits emitted so far */
+    int full;                   /* ran out of out_cap */
+} coder;
+
+static void coder_init(coder *c, uint8_t *out, size_t cap)
+{
+    c->head = c->used = 0;
+    for (int b = 0; b < 17; b++) { c->open_slot[b] = -1; c->in_bits[b] = 0; }
+    c->out = out; c->out_cap = cap; c->bitpos = 0; c->full = 0;
+    if (cap) memset(out, 0, cap);
+}
+
+static unsigned reverse_bits(unsigned v, int n)          /* icer.h:601-610 */
+{
+    unsigned r = 0;
+    for (int k = 0; k < n; k++) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+}
+
+/* icer_popbuf_while_avail, icer_encoding.c:114-139: drain finished words from the head,
+ * LSB-first bit packing */
+static void coder_drain(coder *c)
+{
+    while (c->used > 0 && c->ring[c->head].done) {
+        ring_word w = c->ring[c->head];
+        c->head = (c->head + 1) % RING_WORDS;
+        c->used--;
+        for (int k = 0; k < w.nbits; k++) {
+            size_t byte = (size_t)(c->bitpos >> 3);
+            if (byte >= c->out_cap) { c->full = 1; return; }
+            if ((w.value >> k) & 1) c->out[byte] |= (uint8_t)(1u << (c->bitpos & 7));
+            c->bitpos++;
+        }
+    }
+}
+
+static void golomb_close(ring_word *w, int bin, unsigned k)     /* icer_encoding.c:73-80 */
+{
+    unsigned code = k + (k >= golomb[bin].i ? golomb[bin].i : 0);
+    int n = golomb[bin].l + (k >= golomb[bin].i ? 1 : 0);
+    w->value = (uint16_t)(reverse_bits(code, n) & 0x3FF);
+    w->nbits = (uint8_t)n;
+    w->done = 1;
+}
+
+/* icer_flush_encode, icer_encoding.c:141-189: force-complete the oldest word */
+static void coder_flush_head(coder *c)
+{
+    ring_word *w = &c->ring[c->head];
+    if (!w->done) {
+        int bin = w->bin;
+        if (bin >= 8) {
+            unsigned k = w->value;
+            if (k == (unsigned)golomb[bin].m - 1) { w->value = 1; w->nbits = 1; w->done = 1; }
+            else golomb_close(w, bin, k);
+        } else if (bin >= 1) {
+            unsigned add = flush_lut[bin][w->value][c->in_bits[bin]].add;
+            unsigned pre = w->value | (add << c->in_bits[bin]);
+            /* QUIRK: no check that the completed input is a real code; the LUT entry is used as is */
+            w->value = code_lut[bin][pre & 31].out_code;
+            w->nbits = code_lut[bin][pre & 31].out_bits;
+            w->done = 1;
+            c->in_bits[bin] = 0;
+        }
+        if (bin >= 1) c->open_slot[bin] = -1;
+    }
+    coder_drain(c);
+}
+
+/* icer_encode_bit, icer_encoding.c:37-112 */
+static void coder_put(coder *c, int bit, uint32_t zero, uint32_t total)
+{
+    if (zero < (total >> 1)) { zero = total - zero; bit ^= 1; }
+    int bin = orc_pick_bin(zero, total);
+    if (c->open_slot[bin] < 0) {
+        if (c->used == RING_WORDS) coder_flush_head(c);          /* E5: ring full */
+        unsigned slot = (c->head + c->used) % RING_WORDS;
+        c->used++;
+        c->ring[slot].bin = (uint8_t)bin; c->ring[slot].done = 0; c->ring[slot].nbits = 0; c->ring[slot].value = 0;
+        c->open_slot[bin] = (int)slot;
+    }
+    ring_word *w = &c->ring[c->open_slot[bin]];
+    if (bin >= 8) {
+        if (bit) { golomb_close(w, bin, w->value); c->open_slot[bin] = -1; }
+        else if (++w->value >= golomb[bin].m) { w->value = 1; w->nbits = 1; w->done = 1; c->open_slot[bin] = -1; }
+    } else if (bin >= 1) {
+        w->value |= (uint16_t)(bit << c->in_bits[bin]);
+        c->in_bits[bin]++;
+        if (code_lut[bin][w->value & 31].in_bits == c->in_bits[bin]) {
+            unsigned pre = w->value & 31;
+            w->value = code_lut[bin][pre].out_code; w->nbits = code_lut[bin][pre].out_bits; w->done = 1;
+            c->open_slot[bin] = -1; c->in_bits[bin] = 0;
+        }
+    } else {
+        w->value = (uint16_t)bit; w->nbits = 1; w->done = 1; c->open_slot[0] = -1;
+    }
+    coder_drain(c);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-10, a-11  context modeller for one bit plane of one segment
+ * (icer_context_modeller.c:312-457, 607-613, 631-642; tables icer_config.c:26-67)
+ * ---------------------------------------------------------------------------------------- */
+static int ctx_plain(int h, int v, int d)                /* icer_context_table_ll_lh_hl */
+{
+    if (h == 2) return 8;
+    if (h == 1) return (v == 0) ? (d == 0 ? 5 : d == 1 ? 6 : 7) : 7;
+    if (v == 0) return d > 2 ? 2 : d;
+    return v == 1 ? 3 : 4;
+}
+static int ctx_hh(int hv, int d)                         /* icer_context_table_hh */
+{
+    if (d >= 3) return 8;
+    int k = hv > 2 ? 2 : hv;
+    if (d == 0) return k;
+    if (d == 1) return 3 + k;
+    return hv == 0 ? 6 : 7;
+}
+static const uint8_t SIGN_CTX[5][5] = {{14, 14, 15, 16, 16}, {14, 14, 15, 16, 16}, {13, 13, 12, 13, 13},
+                                       {16, 16, 15, 14, 14}, {16, 16, 15, 14, 14}};
+static const uint8_t SIGN_PRED[5][5] = {{1, 1, 1, 1, 1}, {1, 1, 1, 1, 1}, {0, 0, 0, 1, 1}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+
+static void model_update(uint32_t *zero, uint32_t *total, int was_zero)
+{
+    /* icer_context_modeller.c:396-402.  QUIRK C5: when zero <= total/2 at a rescale the
+     * reference computes a halved value and discards it, so zero is left untouched. */
+    (*total)++;
+    *zero += (uint32_t)was_zero;
+    if (*total >= 500) {
+        *total >>= 1;
+        if (*zero > *total) *zero >>= 1;
+    }
+}
+
+long orc_code_unit(const uint16_t *seg, size_t w, size_t h, size_t rowstride,
+                   int subband, int lsb, uint8_t *out, size_t out_cap)
+{
+    coder_tables_init();
+    if (lsb + 1 >= 16) return ORC_BITPLANE_OUT_OF_RANGE;
+    coder *c = (coder *)malloc(sizeof(coder));
+    coder_init(c, out, out_cap);
+    uint32_t zero[17], total[17];
+    for (int k = 0; k < 17; k++) { zero[k] = 2; total[k] = 4; }   /* :607-613 */
+
+#define MAG(r, cc) (seg[(r) * rowstride + (cc)] & 0x7FFFu)
+#define NEG(r, cc) (seg[(r) * rowstride + (cc)] >> 15)
+    /* significance of a neighbour at plane `l`; outside the segment = insignificant (:361-372) */
+#define SIG(r, cc, l) (((r) < 0 || (cc) < 0 || (r) >= (long)h || (cc) >= (long)w) ? 0 : ((MAG(r, cc) >> (l)) != 0))
+    /* QUIRK C6: only negative significant neighbours contribute (-1); positive ones give 0 */
+#define SGN(r, cc, l) ((SIG(r, cc, l) && NEG(r, cc)) ? -1 : 0)
+    for (long r = 0; r < (long)h && !c->full; r++) {
+        for (long cc = 0; cc < (long)w && !c->full; cc++) {
+            unsigned m = MAG(r, cc);
+            int msb = 0;
+            for (unsigned t = m | 1; t > 1; t >>= 1) msb++;
+            int cat = msb - lsb;
+            if (cat < 0) cat = 0;
+            if (cat > 3) cat = 3;
+            int bit = (int)((m >> lsb) & 1);
+            if (cat == 3) { coder_put(c, bit, 1, 2); continue; }          /* uncoded, no model update */
+            int ctx;
+            if (cat == 2) ctx = 11;
+            else {
+                int hh = SIG(r, cc - 1, lsb) + SIG(r, cc + 1, lsb + 1);
+                int vv = SIG(r - 1, cc, lsb) + SIG(r + 1, cc, lsb + 1);
+                int dd = SIG(r - 1, cc - 1, lsb) + SIG(r - 1, cc + 1, lsb) + SIG(r + 1, cc - 1, lsb + 1) + SIG(r + 1, cc + 1, lsb + 1);
+                if (cat == 1) ctx = (hh + vv == 0) ? 9 : 10;
+                else {
+                    if (subband == SB_HL) { int t = hh; hh = vv; vv = t; }
+                    ctx = (subband == SB_HH) ? ctx_hh(hh + vv, dd) : ctx_plain(hh, vv, dd);
+                }
+            }
+            coder_put(c, bit, zero[ctx], total[ctx]);
+            model_update(&zero[ctx], &total[ctx], !bit);
+            if (cat == 0 && bit) {
+                int sh = SGN(r, cc - 1, lsb) + SGN(r, cc + 1, lsb + 1) + 2;
+                int sv = SGN(r - 1, cc, lsb) + SGN(r + 1, cc, lsb + 1) + 2;
+                if (subband == SB_HL) { int t = sh; sh = sv; sv = t; }
+                int sctx = SIGN_CTX[sh][sv];
+                int agree = (SIGN_PRED[sh][sv] ^ (int)NEG(r, cc)) & 1;
+                coder_put(c, agree, zero[sctx], total[sctx]);
+                model_update(&zero[sctx], &total[sctx], agree == 0);
+            }
+        }
+    }
+#undef MAG
+#undef NEG
+#undef SIG
+#undef SGN
+    while (c->used > 0 && !c->full) coder_flush_head(c);            /* :452-455 */
+    long bits = c->full ? (long)ORC_BYTE_QUOTA_EXCEEDED : (long)c->bitpos;
+    free(c);
+    return bits;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a-5, a-9, a-15..a-17  frame driver (icer_compress.c:279-426, icer_color.c:343-530,
+ * icer_partition.c:279-388, icer_encoding.c:210-234)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint8_t *bytes;     /* header + payload */
+    size_t len;
+} unit_blob;
+
+static void put16(uint8_t *p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
+                     unsigned segments, size_t quota, uint8_t *out, size_t *size_used)
+{
+    *size_used = 0;
+    if (channels != 1 && channels != 3) return ORC_INVALID_INPUT;
+    if (stages < 1 || stages > MAX_STAGES) return ORC_TOO_MANY_STAGES;   /* reference is UB beyond 6 */
+
+    /* DWT per channel, aborting at the first failing channel (icer_color.c:347-354) */
+    for (int ch = 0; ch < channels; ch++) {
+        int res = orc_dwt_stages_u16(planes[ch], w, h, stages, filt);
+        if (res != ORC_OK) return res;
+    }
+    /* LL mean (icer_compress.c:286-302): unsigned sum, integer divide, must fit int16 */
+    size_t llw = dim_low(w, stages), llh = dim_low(h, stages);
+    uint16_t mean[3] = {0, 0, 0};
+    for (int ch = 0; ch < channels; ch++) {
+        uint64_t sum = 0;
+        for (size_t r = 0; r < llh; r++)
+            for (size_t c = 0; c < llw; c++) sum += planes[ch][r * w + c];
+        mean[ch] = (uint16_t)(sum / (llw * llh));
+    }
+    for (int ch = 0; ch < channels; ch++)
+        if (mean[ch] > 32767) return ORC_INTEGER_OVERFLOW;
+    for (int ch = 0; ch < channels; ch++) {
+        int16_t *s = (int16_t *)planes[ch];
+        for (size_t r = 0; r < llh; r++)
+            for (size_t c = 0; c < llw; c++) s[r * w + c] = (int16_t)(s[r * w + c] - (int16_t)mean[ch]);
+        orc_sign_magnitude(planes[ch], w * h);
+    }
+
+    orc_packet pk[MAX_PACKETS];
+    if ((3 * stages + 1) * PLANES * channels >= MAX_PACKETS) return ORC_PACKET_COUNT_EXCEEDED;
+    int npk = orc_packet_list(pk, stages, channels);
+
+    /* kept units, addressed [chan][level][subband][lsb][segment] for the final re-ordering */
+    static unit_blob kept[3][MAX_STAGES + 1][4][PLANES][MAX_SEGMENTS + 1];
+    memset(kept, 0, sizeof kept);
+
+    int rc = ORC_OK;
+    size_t used = 0;
+    orc_partition part;
+    int part_valid = 0;
+    orc_rect rects[MAX_SEGMENTS + 64];
+    for (int ip = 0; ip < npk && rc == ORC_OK; ip++) {
+        const orc_packet *p = &pk[ip];
+        size_t sw, sh, ox, oy;                                   /* icer_compress.c:378-399 */
+        switch (p->subband) {
+        case SB_LL: sw = dim_low(w, p->level);  sh = dim_low(h, p->level);  ox = 0; oy = 0; break;
+        case SB_HL: sw = dim_high(w, p->level); sh = dim_low(h, p->level);  ox = dim_low(w, p->level); oy = 0; break;
+        case SB_LH: sw = dim_low(w, p->level);  sh = dim_high(h, p->level); ox = 0; oy = dim_low(h, p->level); break;
+        default:    sw = dim_high(w, p->level); sh = dim_high(h, p->level); ox = dim_low(w, p->level); oy = dim_low(h, p->level); break;
+        }
+        /* QUIRK P1: the reference ignores the error return, re-using the previous packet's grid.
+         * A failure on the very first packet reads an uninitialised struct there; we refuse. */
+        if (orc_partition_make(&part, sw, sh, segments) == ORC_OK) part_valid = 1;
+        else if (!part_valid) return ORC_TOO_MANY_SEGMENTS;
+        int nseg = orc_partition_rects(&part, rects);
+        const uint16_t *base = planes[p->chan] + oy * w + ox;
+        for (int sg = 0; sg < nseg; sg++) {
+            /* P2/P3: header must fit, then the payload must end strictly inside the quota */
+            size_t rem = quota - used;
+            if (rem < HEADER_BYTES) { rc = ORC_BYTE_QUOTA_EXCEEDED; break; }
+            size_t cap = (size_t)rects[sg].w * rects[sg].h * 3 + 64;
+            uint8_t *blob = (uint8_t *)malloc(HEADER_BYTES + cap);
+            long bits = orc_code_unit(base + (size_t)rects[sg].y * w + rects[sg].x, rects[sg].w, rects[sg].h, w,
+                                      p->subband, p->lsb, blob + HEADER_BYTES, cap);
+            if (bits < 0) { free(blob); return ORC_FATAL_ERROR; }   /* cap is a strict upper bound */
+            if ((size_t)bits / 8 >= rem - HEADER_BYTES && bits > 0) { free(blob); rc = ORC_BYTE_QUOTA_EXCEEDED; break; }
+            size_t nbytes = ((size_t)bits + 7) / 8;
+            /* header, icer.h:293-305 / icer_encoding.c:210-234 (F1) */
+            put16(blob + 0, 0x605B);
+            put16(blob + 2, (uint8_t)mean[p->chan]);             /* QUIRK D1: mean passes through a uint8_t */
+            blob[4] = p->level; blob[5] = p->subband; blob[6] = (uint8_t)sg;
+            blob[7] = (uint8_t)(p->lsb | (p->chan << 4));
+            put32(blob + 8, (uint32_t)w); put32(blob + 12, (uint32_t)h);
+            put32(blob + 16, (uint32_t)bits);
+            put32(blob + 20, orc_crc32(blob + HEADER_BYTES, nbytes));
+            put32(blob + 24, orc_crc32(blob, 24));
+            kept[p->chan][p->level][p->subband][p->lsb][sg].bytes = blob;
+            kept[p->chan][p->level][p->subband][p->lsb][sg].len = HEADER_BYTES + nbytes;
+            used += HEADER_BYTES + nbytes;
+        }
+    }
+
+    /* D7: final order  segment up, subband down, level down, plane down, channel up
+     * (icer_compress.c:409-423, icer_color.c:508-527) */
+    size_t off = 0;
+    for (int sg = 0; sg <= MAX_SEGMENTS; sg++)
+        for (int sb = 3; sb >= 0; sb--)
+            for (int lv = MAX_STAGES; lv >= 0; lv--)
+                for (int lsb = PLANES - 1; lsb >= 0; lsb--)
+                    for (int ch = 0; ch < channels; ch++) {
+                        unit_blob *u = &kept[ch][lv][sb][lsb][sg];
+                        if (!u->bytes) continue;
+                        memcpy(out + off, u->bytes, u->len);
+                        off += u->len;
+                        free(u->bytes);
+                        u->bytes = NULL;
+                    }
+    *size_used = off;
+    return rc;
+}
