@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference interface for the encode path, over the C ABI of
+libicer_hip.so (include/icer_hip.h).
+
+The reference is a C library (lib_icer); its own callers do
+    icer_init(); icer_init_output_struct(&out, buf, len, quota);
+    rc = icer_compress_image_uint16(img, w, h, stages, filt, segments, &out);
+    fwrite(out.rearrange_start, out.size_used)
+(example/src/example_encode.c:36-77, example/src/icer_util.c:186-227).  The functions below keep the
+same names, argument order, in-place side effect on the image and return codes, with numpy arrays
+standing in for the raw pointers.  `Encoder` wraps the batched / device-resident extension
+(icerx_*), which is what bench.py times.
+
+There is no CPU fallback: importing works anywhere, but every compress call needs libicer_hip.so
+and a HIP device and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libicer_hip.so")
+
+# enum icer_status (lib_icer/inc/icer.h:92-105)
+ICER_RESULT_OK = 0
+ICER_INTEGER_OVERFLOW = -1
+ICER_OUTPUT_BUF_TOO_SMALL = -2
+ICER_TOO_MANY_SEGMENTS = -3
+ICER_TOO_MANY_STAGES = -4
+ICER_BYTE_QUOTA_EXCEEDED = -5
+ICER_BITPLANE_OUT_OF_RANGE = -6
+ICER_PACKET_COUNT_EXCEEDED = -9
+ICER_FATAL_ERROR = -10
+ICER_INVALID_INPUT = -11
+# enum icer_filter_types (icer.h:107-115)
+ICER_FILTER_A, ICER_FILTER_B, ICER_FILTER_C, ICER_FILTER_D, ICER_FILTER_E, ICER_FILTER_F, ICER_FILTER_Q = range(7)
+ICERX_NUM_STAGES = 4
+STAGE_NAMES = ("dwt", "ll_mean+sign_magnitude", "code_units", "scan+gather")
+
+
+class icer_output_data_buf_typedef(C.Structure):       # icer.h:307-312
+    _fields_ = [("size_used", C.c_size_t), ("size_allocated", C.c_size_t),
+                ("data_start", C.c_void_p), ("rearrange_start", C.c_void_p)]
+
+
+class IcerHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libicer_hip.so (RTLD_LOCAL: it exports the same icer_* names as the reference)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IcerHipError(f"{LIB_PATH} is missing: build it with `python -m icer_compression_amd.build` "
+                           "(hipcc, gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=os.RTLD_LOCAL)
+    u16 = C.c_void_p
+    L.icer_init.restype = C.c_int
+    L.icer_init_output_struct.argtypes = [C.POINTER(icer_output_data_buf_typedef), C.c_void_p, C.c_size_t, C.c_size_t]
+    L.icer_compress_image_uint16.argtypes = [u16, C.c_size_t, C.c_size_t, C.c_uint8, C.c_int, C.c_uint8,
+                                             C.POINTER(icer_output_data_buf_typedef)]
+    L.icer_compress_image_yuv_uint16.argtypes = [u16, u16, u16, C.c_size_t, C.c_size_t, C.c_uint8, C.c_int, C.c_uint8,
+                                                 C.POINTER(icer_output_data_buf_typedef)]
+    L.icerx_encoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int]
+    L.icerx_encoder_destroy.argtypes = [C.c_void_p]
+    L.icerx_encoder_destroy.restype = None
+    L.icerx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+    L.icerx_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.icerx_get_coefficients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.icerx_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    L.icerx_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+    L.icerx_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.icerx_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+# ---- lib_icer-shaped entry points --------------------------------------------------------------
+def icer_init() -> int:
+    return load_library().icer_init()
+
+
+def icer_init_output_struct(out: icer_output_data_buf_typedef, data: np.ndarray, buf_len: int, byte_quota: int) -> int:
+    return load_library().icer_init_output_struct(C.byref(out), data.ctypes.data, buf_len, byte_quota)
+
+
+def _check_plane(a: np.ndarray, w: int, h: int) -> None:
+    if a.dtype != np.uint16 or not a.flags["C_CONTIGUOUS"] or a.size != w * h:
+        raise ValueError("image planes must be C-contiguous uint16 arrays of w*h elements")
+
+
+def icer_compress_image_uint16(image: np.ndarray, image_w: int, image_h: int, stages: int, filt: int, segments: int,
+                               output_data: icer_output_data_buf_typedef) -> int:
+    _check_plane(image, image_w, image_h)
+    return load_library().icer_compress_image_uint16(image.ctypes.data, image_w, image_h, stages, filt, segments,
+                                                     C.byref(output_data))
+
+
+def icer_compress_image_yuv_uint16(y: np.ndarray, u: np.ndarray, v: np.ndarray, image_w: int, image_h: int, stages: int,
+                                   filt: int, segments: int, output_data: icer_output_data_buf_typedef) -> int:
+    for p in (y, u, v):
+        _check_plane(p, image_w, image_h)
+    return load_library().icer_compress_image_yuv_uint16(y.ctypes.data, u.ctypes.data, v.ctypes.data, image_w, image_h,
+                                                         stages, filt, segments, C.byref(output_data))
+
+
+def compress(planes, stages: int, filt: int, segments: int, byte_quota: int):
+    """Convenience wrapper used by the tests: same call sequence as the reference's CLI
+    (example/src/icer_util.c:186-227).  Returns (rc, stream bytes, planes as left by the call)."""
+    icer_init()
+    work = [np.ascontiguousarray(p, dtype=np.uint16).copy() for p in planes]
+    h, w = work[0].shape
+    buf = np.zeros(2 * byte_quota + 64, dtype=np.uint8)
+    out = icer_output_data_buf_typedef()
+    rc = icer_init_output_struct(out, buf, buf.size, byte_quota)
+    if rc != ICER_RESULT_OK:
+        return rc, b"", work
+    if len(work) == 1:
+        rc = icer_compress_image_uint16(work[0], w, h, stages, filt, segments, out)
+    else:
+        rc = icer_compress_image_yuv_uint16(work[0], work[1], work[2], w, h, stages, filt, segments, out)
+    return rc, bytes(buf[byte_quota: byte_quota + out.size_used]), work
+
+
+# ---- batched / device-resident extension ----------------------------------------------------------
+class Encoder:
+    """icerx_encoder: frames of one geometry, many per call, buffers resident on one GPU."""
+
+    def __init__(self, w: int, h: int, channels: int = 1, stages: int = 4, filt: int = ICER_FILTER_A, segments: int = 10,
+                 max_frames: int = 1, device: int = 0):
+        self.lib = load_library()
+        self.w, self.h, self.channels, self.max_frames, self.device = w, h, channels, max_frames, device
+        self.handle = C.c_void_p()
+        rc = self.lib.icerx_encoder_create(C.byref(self.handle), device, w, h, channels, stages, filt, segments, max_frames)
+        self.create_rc = rc
+        if rc != 0:
+            self.handle = C.c_void_p()
+            if rc == ICER_FATAL_ERROR:
+                raise IcerHipError(f"icerx_encoder_create failed: {self.lib.icerx_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.icerx_encoder_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    __del__ = close
+
+    def encode_device_ptrs(self, d_frames: int, n_frames: int, byte_quota: int, d_out: int, out_stride: int, d_sizes: int,
+                           d_rcs: int, stream: int = 0) -> None:
+        rc = self.lib.icerx_encode_device(self.handle, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs,
+                                          stream)
+        if rc != 0:
+            raise IcerHipError(f"icerx_encode_device rc={rc}: {self.lib.icerx_last_error().decode()}")
+
+    def encode_torch(self, frames, byte_quota: int, out, sizes, rcs) -> None:
+        """frames: cuda int16/uint16 tensor (n, channels, h, w) or (n, h, w); out: cuda uint8 (n, stride);
+        sizes: cuda int64 (n,); rcs: cuda int32 (n,).  Runs on torch's current stream."""
+        import torch
+        n = frames.shape[0]
+        st = torch.cuda.current_stream(frames.device).cuda_stream
+        self.encode_device_ptrs(frames.data_ptr(), n, byte_quota, out.data_ptr(), out.stride(0), sizes.data_ptr(),
+                                rcs.data_ptr(), st)
+
+    def encode_host(self, frames: np.ndarray, byte_quota: int):
+        """frames: uint16 array (n, channels, h, w) or (n, h, w).  Returns list of (rc, stream bytes)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint16)
+        n = frames.shape[0]
+        stride = byte_quota
+        out = np.zeros((n, stride), dtype=np.uint8)
+        sizes = np.zeros(n, dtype=np.uint64)
+        rcs = np.zeros(n, dtype=np.int32)
+        rc = self.lib.icerx_encode_host(self.handle, frames.ctypes.data, n, byte_quota, out.ctypes.data, stride,
+                                        sizes.ctypes.data, rcs.ctypes.data)
+        if rc != 0:
+            raise IcerHipError(f"icerx_encode_host rc={rc}: {self.lib.icerx_last_error().decode()}")
+        return [(int(rcs[i]), bytes(out[i, : int(sizes[i])])) for i in range(n)]
+
+    def coefficients(self, frame: int = 0, channel: int = 0) -> np.ndarray:
+        dst = np.zeros((self.h, self.w), dtype=np.uint16)
+        rc = self.lib.icerx_get_coefficients(self.handle, frame, channel, dst.ctypes.data)
+        if rc != 0:
+            raise IcerHipError(f"icerx_get_coefficients rc={rc}")
+        return dst
+
+    def timing_enable(self, on: bool = True) -> None:
+        self.lib.icerx_timing_enable(self.handle, 1 if on else 0)
+
+    def timing_read(self, reset: bool = True):
+        ms = (C.c_double * ICERX_NUM_STAGES)()
+        calls = C.c_uint64(0)
+        rc = self.lib.icerx_timing_read(self.handle, ms, C.byref(calls), 1 if reset else 0)
+        if rc != 0:
+            raise IcerHipError(f"icerx_timing_read rc={rc}")
+        return {n: ms[i] for i, n in enumerate(STAGE_NAMES)}, int(calls.value)
+
+    def info(self):
+        u, b, s = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self.lib.icerx_info(self.handle, C.byref(u), C.byref(b), C.byref(s))
+        return {"units_per_frame": u.value, "slot_bits_per_pixel": b.value, "slot_bytes_per_frame": s.value}

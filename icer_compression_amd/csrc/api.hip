@@ -1,0 +1,442 @@
+// api.hip -- C ABI of libicer_hip.so (declared in include/icer_hip.h) and the host-side pipeline
+// driver.  The reference's drivers icer_compress_image_uint16 (lib_icer/src/icer_compress.c:279-426)
+// and icer_compress_image_yuv_uint16 (icer_color.c:343-530) become: upload -> DWT stages -> LL mean
+// -> sign-magnitude -> one launch that codes every (frame, unit) -> quota scan -> gather.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/icer_hip.h"
+#include "kernels.hpp"
+
+using namespace icer;
+
+namespace {
+
+thread_local std::string g_last_error;
+CoderTables g_tables;
+bool g_tables_ready = false;
+std::recursive_mutex g_mutex;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    fprintf(stderr, "icer_hip: %s\n", buf);
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ICER_FATAL_ERROR;                                                          \
+        }                                                                                     \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;      // elements
+    int ensure(size_t want)
+    {
+        if (want <= n) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+            return ICER_FATAL_ERROR;
+        }
+        n = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct icerx_encoder {
+    int device = 0;
+    size_t w = 0, h = 0;
+    int channels = 1, stages = 0, filt = 0, segments = 0, max_frames = 0;
+    Plan plan;
+    size_t slot_quota = (size_t)-1;     // quota the current slot table was built for
+    unsigned bits_per_pixel = 3;        // slot bound; doubled on overflow
+    bool units_uploaded = false;
+
+    DevBuf<int16_t> coef, tmp;
+    DevBuf<unsigned long long> sums;
+    DevBuf<uint16_t> means;
+    DevBuf<int> flags;                  // [0,P) dwt overflow  [P,2P) mean overflow  [2P,2P+F) frame skip  [2P+F] bound overflow
+    DevBuf<UnitDesc> units;
+    DevBuf<uint32_t> work_order, final_order, unit_bits;
+    DevBuf<uint64_t> final_off;
+    DevBuf<uint8_t> slots;
+    DevBuf<CoderTables> tables;
+    // host-API staging
+    DevBuf<uint16_t> in;
+    DevBuf<uint8_t> out;
+    DevBuf<unsigned long long> sizes;
+    DevBuf<int32_t> rcs;
+
+    bool timing = false;
+    hipEvent_t ev[ICERX_NUM_STAGES + 1] = {};
+    double ms[ICERX_NUM_STAGES] = {};
+    uint64_t timed_calls = 0;
+    bool ev_pending = false;
+};
+
+namespace {
+
+__global__ void frame_status_kernel(const int *dwt_ovf, const int *mean_ovf, int channels, int n_frames, int *skip)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    int s = 0;
+    for (int c = 0; c < channels; c++) s |= dwt_ovf[f * channels + c] | mean_ovf[f * channels + c];
+    skip[f] = s;
+}
+
+int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
+{
+    if (e->units_uploaded && e->slot_quota == quota) return 0;
+    assign_slots(&e->plan, quota, e->bits_per_pixel);
+    const size_t n = e->plan.units.size();
+    if (e->units.ensure(n) || e->work_order.ensure(n) || e->final_order.ensure(n)) return ICER_FATAL_ERROR;
+    HIP_TRY(hipMemcpyAsync(e->units.p, e->plan.units.data(), n * sizeof(UnitDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->work_order.p, e->plan.work_order.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->final_order.p, e->plan.final_order.data(), n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));       // the host vectors may change on the next re-plan
+    e->slot_quota = quota;
+    e->units_uploaded = true;
+    return 0;
+}
+
+int accumulate_timing(icerx_encoder *e)
+{
+    if (!e->ev_pending) return 0;
+    HIP_TRY(hipEventSynchronize(e->ev[ICERX_NUM_STAGES]));
+    for (int i = 0; i < ICERX_NUM_STAGES; i++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]));
+        e->ms[i] += t;
+    }
+    e->timed_calls++;
+    e->ev_pending = false;
+    return 0;
+}
+
+// enqueue the whole pipeline once; returns 0 or ICER_FATAL_ERROR
+int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
+            unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
+{
+    const size_t W = e->w, H = e->h, plane = W * H;
+    const int C = e->channels, P = n_frames * C;
+    const uint32_t n_units = (uint32_t)e->plan.units.size();
+    int *dwt_ovf = e->flags.p, *mean_ovf = e->flags.p + (size_t)e->max_frames * C;
+    int *skip = mean_ovf + (size_t)e->max_frames * C, *bound_ovf = skip + e->max_frames;
+    const FilterTaps ft = filter_taps(e->filt);
+
+    HIP_TRY(hipMemsetAsync(e->flags.p, 0, e->flags.n * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(e->sums.p, 0, (size_t)P * sizeof(unsigned long long), st));
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
+
+    // ---- DWT: rows (src -> tmp), columns (tmp -> coef); stage 1 reads the caller's frames
+    size_t cw = W, ch = H;
+    for (int s = 0; s < e->stages; s++) {
+        const int16_t *src = s == 0 ? reinterpret_cast<const int16_t *>(d_frames) : e->coef.p;
+        const int nlw = (int)((cw + 1) / 2), nlh = (int)((ch + 1) / 2);
+        hipLaunchKernelGGL(dwt_rows_kernel, dim3((nlw + 255) / 256, (unsigned)ch, P), dim3(256), 0, st, src, plane,
+                           (uint32_t)W, e->tmp.p, plane, (uint32_t)W, (int)cw, ft, dwt_ovf);
+        hipLaunchKernelGGL(dwt_cols_kernel, dim3((unsigned)((cw + 63) / 64), (nlh + 3) / 4, P), dim3(64, 4), 0, st,
+                           e->tmp.p, plane, (uint32_t)W, e->coef.p, plane, (uint32_t)W, (int)cw, (int)ch, ft, dwt_ovf);
+        cw = (cw + 1) / 2;
+        ch = (ch + 1) / 2;
+    }
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
+
+    // ---- LL mean, frame status, sign-magnitude
+    const uint32_t llw = (uint32_t)cw, llh = (uint32_t)ch;
+    unsigned sum_blocks = (llw * llh + 255) / 256;
+    if (sum_blocks > 64) sum_blocks = 64;
+    hipLaunchKernelGGL(ll_sum_kernel, dim3(sum_blocks, P), dim3(256), 0, st, reinterpret_cast<const uint16_t *>(e->coef.p),
+                       plane, (uint32_t)W, llw, llh, e->sums.p);
+    hipLaunchKernelGGL(ll_mean_kernel, dim3((P + 63) / 64), dim3(64), 0, st, e->sums.p, (uint32_t)P, llw * llh,
+                       e->means.p, mean_ovf);
+    hipLaunchKernelGGL(frame_status_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, dwt_ovf, mean_ovf, C, n_frames, skip);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, P), dim3(256), 0, st,
+                       reinterpret_cast<uint16_t *>(e->coef.p), plane, (uint32_t)W, llw, llh, e->means.p, skip, C);
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
+
+    // ---- coding units
+    hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64), 0, st,
+                       reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                       e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes,
+                       e->unit_bits.p);
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
+
+    // ---- quota scan + gather into final stream order
+    hipLaunchKernelGGL(scan_kernel, dim3(n_frames), dim3(64), 0, st, e->unit_bits.p, e->final_order.p, n_units,
+                       (uint64_t)quota, skip, e->final_off.p, d_sizes, d_rcs, e->units.p, bound_ovf);
+    hipLaunchKernelGGL(gather_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->slots.p, e->plan.slot_bytes,
+                       e->units.p, n_units, e->unit_bits.p, e->final_off.p, d_out, out_stride);
+    if (e->timing) {
+        HIP_TRY(hipEventRecord(e->ev[4], st));
+        e->ev_pending = true;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *icerx_last_error(void) { return g_last_error.c_str(); }
+
+int icer_init(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mutex);
+    if (!g_tables_ready) {
+        build_coder_tables(&g_tables);
+        g_tables_ready = true;
+    }
+    return ICER_RESULT_OK;
+}
+
+int icer_init_output_struct(icer_output_data_buf_typedef *out, uint8_t *data, size_t buf_len, size_t byte_quota)
+{
+    if (byte_quota * 2 > buf_len) return ICER_OUTPUT_BUF_TOO_SMALL;
+    out->size_used = 0;
+    out->data_start = data;
+    out->size_allocated = byte_quota;
+    out->rearrange_start = data + byte_quota;
+    return ICER_RESULT_OK;
+}
+
+int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, int channels, int stages, int filt,
+                         int segments, int max_frames)
+{
+    *out = nullptr;
+    icer_init();
+    if (filt < 0 || filt > 6 || max_frames < 1) return ICER_INVALID_INPUT;
+    icerx_encoder *e = new icerx_encoder();
+    e->device = device; e->w = w; e->h = h; e->channels = channels; e->stages = stages; e->filt = filt;
+    e->segments = segments; e->max_frames = max_frames;
+    const int rc = build_plan(&e->plan, w, h, channels, stages, segments);
+    if (rc != kOk) { delete e; return rc; }
+
+    int count = 0;
+    hipError_t he = hipGetDeviceCount(&count);
+    if (he != hipSuccess || count <= 0 || device >= count) {
+        set_error("no usable HIP device (hipGetDeviceCount: %s, count=%d, requested=%d); this library has no CPU path",
+                  hipGetErrorString(he), count, device);
+        delete e;
+        return ICER_FATAL_ERROR;
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
+    if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
+        e->flags.ensure(2 * P + max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
+        e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
+        e->rcs.ensure(max_frames)) {
+        icerx_encoder_destroy(e);
+        return ICER_FATAL_ERROR;
+    }
+    HIP_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
+    for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    *out = e;
+    return 0;
+}
+
+void icerx_encoder_destroy(icerx_encoder *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release();
+    e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->out.release();
+    e->sizes.release(); e->rcs.release();
+    for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                        size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+{
+    if (!e || !d_frames || !d_out || !d_sizes || !d_rcs || n_frames < 1 || n_frames > e->max_frames) {
+        set_error("icerx_encode_device: invalid arguments");
+        return ICER_INVALID_INPUT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (accumulate_timing(e)) return ICER_FATAL_ERROR;
+    int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * e->channels + e->max_frames;
+    for (;;) {
+        if (upload_units(e, byte_quota, st)) return ICER_FATAL_ERROR;
+        if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
+        if (out_stride < byte_quota && out_stride < e->plan.slot_bytes) {
+            set_error("icerx_encode_device: out_stride %zu smaller than the byte quota %zu", out_stride, byte_quota);
+            return ICER_INVALID_INPUT;
+        }
+        if (enqueue(e, d_frames, n_frames, byte_quota, d_out, out_stride, (unsigned long long *)d_sizes, d_rcs, st))
+            return ICER_FATAL_ERROR;
+        int ovf = 0;
+        HIP_TRY(hipMemcpyAsync(&ovf, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!ovf) break;
+        if (e->bits_per_pixel >= 24) {
+            set_error("coding-unit slot overflow at the theoretical bound");
+            return ICER_FATAL_ERROR;
+        }
+        // a unit produced more than the provisioned bits per pixel: enlarge the slots and redo the batch
+        e->ev_pending = false;
+        e->bits_per_pixel = e->bits_per_pixel * 2 > 24 ? 24 : e->bits_per_pixel * 2;
+        e->units_uploaded = false;
+    }
+    return 0;
+}
+
+int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, size_t byte_quota, uint8_t *out,
+                      size_t out_stride, uint64_t *sizes, int32_t *rcs)
+{
+    if (!e || n_frames < 1 || n_frames > e->max_frames) return ICER_INVALID_INPUT;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t plane = e->w * e->h, P = (size_t)n_frames * e->channels;
+    if (upload_units(e, byte_quota, nullptr)) return ICER_FATAL_ERROR;
+    const size_t dstride = byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes;
+    if (e->in.ensure((size_t)e->max_frames * e->channels * plane)) return ICER_FATAL_ERROR;
+    HIP_TRY(hipMemcpy(e->in.p, frames, P * plane * 2, hipMemcpyHostToDevice));
+    for (;;) {   // the device stride depends on the slot bound, which a retry may enlarge
+        const size_t ds = byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes;
+        if (e->out.ensure((size_t)e->max_frames * (ds + 4))) return ICER_FATAL_ERROR;
+        const unsigned bpp = e->bits_per_pixel;
+        const int rc = icerx_encode_device(e, e->in.p, n_frames, byte_quota, e->out.p, ds + 4,
+                                           (uint64_t *)e->sizes.p, e->rcs.p, nullptr);
+        if (rc) return rc;
+        if (bpp == e->bits_per_pixel) {
+            HIP_TRY(hipMemcpy(sizes, e->sizes.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rcs, e->rcs.p, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
+            for (int f = 0; f < n_frames; f++)
+                if (sizes[f]) HIP_TRY(hipMemcpy(out + (size_t)f * out_stride, e->out.p + (size_t)f * (ds + 4), sizes[f], hipMemcpyDeviceToHost));
+            break;
+        }
+    }
+    (void)dstride;
+    return 0;
+}
+
+int icerx_get_coefficients(icerx_encoder *e, int frame, int channel, uint16_t *dst)
+{
+    if (!e || frame < 0 || frame >= e->max_frames || channel < 0 || channel >= e->channels) return ICER_INVALID_INPUT;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t plane = e->w * e->h;
+    HIP_TRY(hipMemcpy(dst, e->coef.p + ((size_t)frame * e->channels + channel) * plane, plane * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int icerx_timing_enable(icerx_encoder *e, int on)
+{
+    if (!e) return ICER_INVALID_INPUT;
+    e->timing = on != 0;
+    return 0;
+}
+
+int icerx_timing_read(icerx_encoder *e, double ms[ICERX_NUM_STAGES], uint64_t *calls, int reset)
+{
+    if (!e) return ICER_INVALID_INPUT;
+    HIP_TRY(hipSetDevice(e->device));
+    if (accumulate_timing(e)) return ICER_FATAL_ERROR;
+    for (int i = 0; i < ICERX_NUM_STAGES; i++) ms[i] = e->ms[i];
+    *calls = e->timed_calls;
+    if (reset) { for (auto &m : e->ms) m = 0; e->timed_calls = 0; }
+    return 0;
+}
+
+int icerx_info(icerx_encoder *e, uint32_t *units_per_frame, uint32_t *slot_bits_per_pixel, uint64_t *slot_bytes_per_frame)
+{
+    if (!e) return ICER_INVALID_INPUT;
+    *units_per_frame = (uint32_t)e->plan.units.size();
+    *slot_bits_per_pixel = e->bits_per_pixel;
+    *slot_bytes_per_frame = e->plan.slot_bytes;
+    return 0;
+}
+
+// ---- lib_icer drop-in entry points -------------------------------------------------------------
+static icerx_encoder *g_cached = nullptr;
+
+static int compress_planes(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt, int segments,
+                           icer_output_data_buf_typedef *od)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mutex);
+    if (!od) return ICER_INVALID_INPUT;
+    icerx_encoder *e = g_cached;
+    if (!e || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt ||
+        e->segments != segments) {
+        if (e) { icerx_encoder_destroy(e); g_cached = nullptr; }
+        const char *dev = getenv("ICER_HIP_DEVICE");
+        const int rc = icerx_encoder_create(&e, dev ? atoi(dev) : 0, w, h, channels, stages, filt, segments, 1);
+        if (rc) return rc;
+        g_cached = e;
+    }
+    const size_t plane = w * h, quota = od->size_allocated;
+    if (e->in.ensure((size_t)channels * plane)) return ICER_FATAL_ERROR;
+    for (int c = 0; c < channels; c++)
+        HIP_TRY(hipMemcpy(e->in.p + (size_t)c * plane, planes[c], plane * 2, hipMemcpyHostToDevice));
+    uint64_t size = 0;
+    int32_t rc = 0;
+    for (;;) {
+        if (upload_units(e, quota, nullptr)) return ICER_FATAL_ERROR;
+        const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
+        if (e->out.ensure(ds)) return ICER_FATAL_ERROR;
+        const unsigned bpp = e->bits_per_pixel;
+        const int r = icerx_encode_device(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, nullptr);
+        if (r) return r;
+        if (bpp == e->bits_per_pixel) break;
+    }
+    HIP_TRY(hipMemcpy(&size, e->sizes.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&rc, e->rcs.p, 4, hipMemcpyDeviceToHost));
+    if (rc == ICER_INTEGER_OVERFLOW) {
+        // The reference aborts before any output; it leaves transformed (not sign-magnitude) data in
+        // the planes it had already processed: channels up to the first DWT overflow, or all of them
+        // when only the LL-mean check failed (icer_color.c:347-381).
+        std::vector<int> fl(2 * (size_t)channels);
+        HIP_TRY(hipMemcpy(fl.data(), e->flags.p, sizeof(int) * channels, hipMemcpyDeviceToHost));
+        int last = channels - 1;
+        for (int c = 0; c < channels; c++) if (fl[c]) { last = c; break; }
+        for (int c = 0; c <= last; c++)
+            HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
+        return rc;
+    }
+    if (size) HIP_TRY(hipMemcpy(od->rearrange_start, e->out.p, size, hipMemcpyDeviceToHost));
+    for (int c = 0; c < channels; c++)
+        HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
+    od->size_used = size;
+    return rc;
+}
+
+int icer_compress_image_uint16(uint16_t *image, size_t image_w, size_t image_h, uint8_t stages,
+                               enum icer_filter_types filt, uint8_t segments, icer_output_data_buf_typedef *output_data)
+{
+    uint16_t *planes[1] = {image};
+    return compress_planes(planes, 1, image_w, image_h, stages, (int)filt, segments, output_data);
+}
+
+int icer_compress_image_yuv_uint16(uint16_t *y_channel, uint16_t *u_channel, uint16_t *v_channel, size_t image_w,
+                                   size_t image_h, uint8_t stages, enum icer_filter_types filt, uint8_t segments,
+                                   icer_output_data_buf_typedef *output_data)
+{
+    uint16_t *planes[3] = {y_channel, u_channel, v_channel};
+    return compress_planes(planes, 3, image_w, image_h, stages, (int)filt, segments, output_data);
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// assemble_core.hpp -- packet framing and stream assembly, one wavefront each.
+//
+//   finish_unit_wave   header + two CRC-32s of a coded unit
+//                      (icer_allocate_data_packet lib_icer/src/icer_encoding.c:210-234,
+//                       icer_calculate_segment_crc32 / _packet_crc32 icer_util.c:59-66,
+//                       crc32buf crc32.c:157-169; layout icer.h:293-305)
+//   scan_frame_wave    byte-quota walk in priority order + offsets in final stream order
+//                      (icer_partition.c:315-336 quota accounting, icer_compress.c:404-423)
+// Written with the SPMD macros of wave.hpp.
+#pragma once
+#include "coder_core.hpp"
+
+namespace icer {
+
+constexpr uint32_t kCrcPoly = 0xEDB88320u;     // reflected CRC-32, init/final 0xFFFFFFFF (= zlib crc32)
+
+// a(x) * b(x) mod P(x) in the reflected representation (bit 31 = x^0)
+ICER_DEV uint32_t gf_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m != 0; m >>= 1) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0) break;
+        }
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+
+// x^(8*nbytes) mod P, from the table x2n[k] = x^(2^k) mod P (period 32 in k)
+ICER_DEV uint32_t gf_xpow_bytes(const uint32_t *x2n, uint32_t nbytes)
+{
+    uint32_t p = 0x80000000u;                  // x^0
+    for (uint32_t k = 3; nbytes != 0; nbytes >>= 1, k++)
+        if (nbytes & 1u) p = gf_mulmod(x2n[k & 31u], p);
+    return p;
+}
+
+ICER_DEV void build_crc_table(CoderShared &s)
+{
+    DECL_LANE;
+    FOR_LANES
+    {
+        for (uint32_t i = (uint32_t)lane; i < 256; i += 64) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+            s.crc_tab[i] = c;
+        }
+    }
+    WAVE_SYNC();
+}
+
+struct FinishArgs {
+    uint32_t *slot_words;       // slot start: 7 header words, then the payload words
+    uint32_t bits;              // payload length in bits
+    uint32_t mean, level, subband, seg, lsb, chan, image_w, image_h;
+};
+
+// CRC-32 of the payload: every lane takes a contiguous piece, the 64 piece CRCs are combined with
+// crc(A||B) = crc(A) * x^(8|B|) + crc(B)  (valid for the init/final-xor form, cf. zlib crc32_combine)
+ICER_DEV void finish_unit_wave(CoderShared &s, const FinishArgs &f)
+{
+    DECL_LANE;
+    const uint32_t n = (f.bits + 7u) >> 3;
+    const uint32_t piece = (((n + 63u) >> 6) + 3u) & ~3u;
+    const uint32_t *payload = f.slot_words + kHeaderBytes / 4;
+    LANEVAR(uint32_t, part);
+    FOR_LANES
+    {
+        const uint32_t start = (uint32_t)lane * piece;
+        const uint32_t end = start + piece < n ? start + piece : n;
+        uint32_t c = 0;
+        if (start < end) {
+            c = 0xFFFFFFFFu;
+            for (uint32_t b = start; b < end; b += 4) {
+                uint32_t w = payload[b >> 2];
+                const uint32_t nb = end - b < 4u ? end - b : 4u;
+                for (uint32_t j = 0; j < nb; j++, w >>= 8) c = s.crc_tab[(c ^ w) & 0xFFu] ^ (c >> 8);
+            }
+            c = ~c;
+            if (n > end) c = gf_mulmod(gf_xpow_bytes(s.tab.x2n, n - end), c);
+        }
+        LV(part) = c;
+    }
+    uint32_t data_crc;
+    WAVE_XOR(data_crc, part);
+    FOR_LANES
+    {
+        if (lane == 0) {
+            uint32_t hw[6];
+            hw[0] = 0x605Bu | ((f.mean & 0xFFu) << 16);            // preamble, ll_mean (QUIRK D1: via uint8_t)
+            hw[1] = f.level | (f.subband << 8) | (f.seg << 16) | ((f.lsb | (f.chan << 4)) << 24);
+            hw[2] = f.image_w;
+            hw[3] = f.image_h;
+            hw[4] = f.bits;
+            hw[5] = data_crc;
+            uint32_t c = 0xFFFFFFFFu;
+            for (int i = 0; i < 6; i++) {
+                uint32_t w = hw[i];
+                for (int j = 0; j < 4; j++, w >>= 8) c = s.crc_tab[(c ^ w) & 0xFFu] ^ (c >> 8);
+                f.slot_words[i] = hw[i];
+            }
+            f.slot_words[6] = ~c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Quota walk + final offsets for one frame.
+//   bits[u]         payload bits of unit u (priority order), kUnitTooBig if it overflowed its slot
+//   final_order[j]  unit index of the j-th unit in final stream order
+//   final_off[u]    out: byte offset in the final stream, ~0 if the unit is dropped
+// Returns kept-unit count through *kept, stream length through *size_used and the reference
+// return code (0 or ICER_BYTE_QUOTA_EXCEEDED).
+// Rule (P3): walking units in priority order with `used` bytes so far, a unit is kept iff
+// 28 header bytes fit and floor(bits/8) < quota - used - 28; the first failing unit stops everything.
+// ------------------------------------------------------------------------------------------
+ICER_DEV int scan_frame_wave(const uint32_t *bits, const uint32_t *final_order, uint32_t n_units, uint64_t quota,
+                             uint64_t *final_off, uint32_t *kept, uint64_t *size_used)
+{
+    DECL_LANE;
+    uint64_t used = 0;
+    uint32_t K = n_units;
+    for (uint32_t base = 0; base < n_units && K == n_units; base += 64) {
+        LANEVAR(uint64_t, sz); LANEVAR(uint64_t, before); LANEVAR(uint32_t, b);
+        FOR_LANES
+        {
+            const uint32_t u = base + (uint32_t)lane;
+            const uint32_t v = u < n_units ? bits[u] : 0u;
+            LV(b) = v;
+            LV(sz) = u < n_units ? (uint64_t)kHeaderBytes + (((uint64_t)v + 7u) >> 3) : 0u;
+        }
+        uint64_t total;
+        WAVE_EXCL_SCAN(uint64_t, before, sz, total);
+        const uint64_t fail = BALLOT(
+            (base + (uint32_t)lane < n_units) &&
+            ((LV(b) == kUnitTooBig) || (used + LV(before) + kHeaderBytes > quota) ||
+             (LV(b) > 0u && (uint64_t)(LV(b) >> 3) + used + LV(before) + kHeaderBytes >= quota)));
+        if (fail) K = base + (uint32_t)ffs64(fail);
+        else used += total;
+    }
+    // final stream offsets
+    uint64_t off = 0;
+    for (uint32_t base = 0; base < n_units; base += 64) {
+        LANEVAR(uint64_t, sz); LANEVAR(uint64_t, before); LANEVAR(uint32_t, unit);
+        FOR_LANES
+        {
+            const uint32_t j = base + (uint32_t)lane;
+            const uint32_t u = j < n_units ? final_order[j] : 0xFFFFFFFFu;
+            LV(unit) = u;
+            LV(sz) = (u < K) ? (uint64_t)kHeaderBytes + (((uint64_t)bits[u] + 7u) >> 3) : 0u;
+        }
+        uint64_t total;
+        WAVE_EXCL_SCAN(uint64_t, before, sz, total);
+        FOR_LANES
+        {
+            if (LV(unit) != 0xFFFFFFFFu) final_off[LV(unit)] = (LV(unit) < K) ? off + LV(before) : ~0ull;
+        }
+        off += total;
+    }
+    *kept = K;
+    *size_used = off;
+    return K < n_units ? kByteQuotaExceeded : kOk;
+}
+
+}  // namespace icer

@@ -1,0 +1,207 @@
+// kernels.hpp -- gfx950 kernels of the ICER encoder (included once by api.hip).
+//
+//   dwt_rows_kernel / dwt_cols_kernel   one lifting pass over the current LL region (a-1..a-4)
+//   ll_sum_kernel / ll_mean_kernel      LL mean (a-5)
+//   finalize_kernel                     LL mean removal + sign-magnitude (a-5, a-6)
+//   code_units_kernel                   context modeller + entropy coder + framing (a-9..a-15)
+//   scan_kernel / gather_kernel         quota cut + final stream order (a-16, a-17)
+// HBM layout: planes are row-major int16/uint16 with row stride = image width; plane p of a batch
+// is frame-major then channel (p = frame * channels + chan).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "assemble_core.hpp"
+#include "coder_core.hpp"
+#include "dwt_core.hpp"
+#include "plan.hpp"
+
+namespace icer {
+
+// ------------------------------------------------------------------------------------------ DWT
+// One thread per output pair (low_k, high_k) of a row.  grid = (ceil(nl/256), rows, planes).
+__global__ void __launch_bounds__(256)
+dwt_rows_kernel(const int16_t *__restrict__ src, size_t src_plane, uint32_t src_stride,
+                int16_t *__restrict__ dst, size_t dst_plane, uint32_t dst_stride,
+                int cw, FilterTaps f, int *__restrict__ ovf)
+{
+    const int nl = (cw + 1) >> 1;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nl) return;
+    const int16_t *line = src + blockIdx.z * src_plane + (size_t)blockIdx.y * src_stride;
+    const DwtPair p = dwt_pair([line](int i) { return line[i]; }, cw, k, f.am1, f.a0, f.a1, f.be);
+    int16_t *out = dst + blockIdx.z * dst_plane + (size_t)blockIdx.y * dst_stride;
+    out[k] = p.low;
+    if (p.has_high) out[nl + k] = p.high;
+    if (p.overflow) atomicOr(&ovf[blockIdx.z], 1);
+}
+
+// One thread per output pair of a column; consecutive threads take consecutive columns so every
+// row access is a coalesced 128-byte line.  block = (64, 4); grid = (ceil(cw/64), ceil(nl/4), planes).
+__global__ void __launch_bounds__(256)
+dwt_cols_kernel(const int16_t *__restrict__ src, size_t src_plane, uint32_t src_stride,
+                int16_t *__restrict__ dst, size_t dst_plane, uint32_t dst_stride,
+                int cw, int ch, FilterTaps f, int *__restrict__ ovf)
+{
+    const int nl = (ch + 1) >> 1;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.y * 4 + threadIdx.y;
+    if (c >= cw || k >= nl) return;
+    const int16_t *col = src + blockIdx.z * src_plane + c;
+    const uint32_t ss = src_stride;
+    const DwtPair p = dwt_pair([col, ss](int i) { return col[(size_t)i * ss]; }, ch, k, f.am1, f.a0, f.a1, f.be);
+    int16_t *out = dst + blockIdx.z * dst_plane + c;
+    out[(size_t)k * dst_stride] = p.low;
+    if (p.has_high) out[(size_t)(nl + k) * dst_stride] = p.high;
+    if (p.overflow) atomicOr(&ovf[blockIdx.z], 1);
+}
+
+// ------------------------------------------------------------------------------------------ LL mean
+// sum of the LL samples read as unsigned 16-bit (icer_compress.c:286-296).  grid = (blocks, planes)
+__global__ void __launch_bounds__(256)
+ll_sum_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t stride, uint32_t llw, uint32_t llh,
+              unsigned long long *__restrict__ sums)
+{
+    const uint16_t *p = coef + blockIdx.y * plane;
+    const uint32_t n = llw * llh;
+    unsigned long long acc = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t r = i / llw, c = i - r * llw;
+        acc += p[(size_t)r * stride + c];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sums[blockIdx.y], acc);
+}
+
+// mean = sum / (llw*llh), must fit int16 (icer_compress.c:298-302).  One thread per plane.
+__global__ void ll_mean_kernel(const unsigned long long *__restrict__ sums, uint32_t n_planes, uint32_t ll_count,
+                               uint16_t *__restrict__ means, int *__restrict__ mean_ovf)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_planes) return;
+    const uint16_t m = (uint16_t)(sums[p] / ll_count);
+    means[p] = m;
+    mean_ovf[p] = m > 32767 ? 1 : 0;
+}
+
+// LL -= mean (int16 wrap), then two's complement -> sign-magnitude over the whole plane
+// (icer_compress.c:304-313, icer_wavelet.c:871-877).  grid = (ceil(w/256), h, planes)
+__global__ void __launch_bounds__(256)
+finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t llw, uint32_t llh,
+                const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= w) return;
+    if (frame_skip[blockIdx.z / channels]) return;     // aborted frame: keep the raw transform output
+    uint16_t *q = coef + blockIdx.z * plane + (size_t)r * w + c;
+    int16_t v = (int16_t)*q;
+    if (r < llh && c < llw) v = (int16_t)(v - (int16_t)means[blockIdx.z]);
+    const uint16_t mask = (uint16_t)(v >> 15);
+    *q = (uint16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
+}
+
+// ------------------------------------------------------------------------------------------ coder
+// One wavefront = one coding unit of one frame.  grid = (units, frames), block = 64.
+__global__ void __launch_bounds__(64)
+code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
+                  const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
+                  const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
+                  const int *__restrict__ frame_skip, uint8_t *__restrict__ slots, size_t slot_frame_stride,
+                  uint32_t *__restrict__ unit_bits)
+{
+    __shared__ CoderShared s;
+    const uint32_t frame = blockIdx.y;
+    const uint32_t ui = work_order[blockIdx.x];
+    if (frame_skip[frame]) {                      // DWT / mean overflow: the reference emits nothing
+        if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
+        return;
+    }
+    const UnitDesc u = units[ui];
+    {   // tables -> LDS
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
+        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64) dst[i] = src[i];
+    }
+    build_crc_table(s);
+
+    uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
+    UnitArgs a;
+    a.seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
+    a.stride = img_w;
+    a.w = u.w; a.h = u.h;
+    a.subband = (int)u.subband; a.lsb = (int)u.lsb;
+    a.out_words = slot_words + kHeaderBytes / 4;
+    a.cap_words = u.cap_words;
+    const uint32_t bits = code_unit_wave(s, a);
+
+    if (bits != kUnitTooBig) {
+        // make this wave's payload stores visible to its own loads before the CRC pass reads them
+        __threadfence();
+        FinishArgs f;
+        f.slot_words = slot_words;
+        f.bits = bits;
+        f.mean = means[(size_t)frame * channels + u.chan];
+        f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
+        f.image_w = img_w; f.image_h = img_h;
+        finish_unit_wave(s, f);
+    }
+    if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
+}
+
+// ------------------------------------------------------------------------------------------ assembly
+// One wavefront per frame: quota walk + final offsets.  grid = frames, block = 64.
+__global__ void __launch_bounds__(64)
+scan_kernel(const uint32_t *__restrict__ unit_bits, const uint32_t *__restrict__ final_order, uint32_t n_units,
+            uint64_t quota, const int *__restrict__ frame_skip, uint64_t *__restrict__ final_off,
+            unsigned long long *__restrict__ sizes, int32_t *__restrict__ rcs, const UnitDesc *__restrict__ units,
+            int *__restrict__ bound_overflow)
+{
+    const uint32_t frame = blockIdx.x;
+    uint64_t *foff = final_off + (size_t)frame * n_units;
+    if (frame_skip[frame]) {
+        for (uint32_t i = threadIdx.x; i < n_units; i += 64) foff[i] = ~0ull;
+        if (threadIdx.x == 0) { sizes[frame] = 0; rcs[frame] = kIntegerOverflow; }
+        return;
+    }
+    const uint32_t *bits = unit_bits + (size_t)frame * n_units;
+    uint32_t kept;
+    uint64_t used;
+    const int rc = scan_frame_wave(bits, final_order, n_units, quota, foff, &kept, &used);
+    // a unit that overflowed a slot sized by the bits-per-pixel bound (not by the quota) at or
+    // before the cut means the bound was too small: the host re-runs with a larger one
+    if (kept < n_units && threadIdx.x == 0 && bits[kept] == kUnitTooBig && units[kept].cap_is_bound)
+        atomicOr(bound_overflow, 1);
+    if (threadIdx.x == 0) { sizes[frame] = used; rcs[frame] = rc; }
+}
+
+// copy every kept unit (header + payload) to its place in the final stream.  grid = (units, frames)
+__global__ void __launch_bounds__(256)
+gather_kernel(const uint8_t *__restrict__ slots, size_t slot_frame_stride, const UnitDesc *__restrict__ units,
+              uint32_t n_units, const uint32_t *__restrict__ unit_bits, const uint64_t *__restrict__ final_off,
+              uint8_t *__restrict__ out, size_t out_stride)
+{
+    const uint32_t frame = blockIdx.y, ui = blockIdx.x;
+    const uint64_t off = final_off[(size_t)frame * n_units + ui];
+    if (off == ~0ull) return;
+    const uint32_t len = kHeaderBytes + ((unit_bits[(size_t)frame * n_units + ui] + 7u) >> 3);
+    const uint8_t *src = slots + (size_t)frame * slot_frame_stride + units[ui].slot_off;   // 4-byte aligned
+    uint8_t *dst = out + (size_t)frame * out_stride + off;
+    // destination is byte-aligned only: peel to a 4-byte boundary, then move aligned words built
+    // from two source words (v_alignbyte), then the tail
+    const uint32_t mis = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);
+    const uint32_t head = mis < len ? mis : len;
+    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    const uint32_t body_words = (len - head) >> 2;
+    const uint32_t *sw = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *dw = reinterpret_cast<uint32_t *>(dst + head);
+    const uint32_t shift = head * 8;              // source byte offset of the body is `head` (0..3)
+    for (uint32_t i = threadIdx.x; i < body_words; i += 256) {
+        const uint32_t lo = sw[i];
+        uint32_t v = lo;
+        if (shift) v = (lo >> shift) | (sw[i + 1] << (32 - shift));
+        dw[i] = v;
+    }
+    const uint32_t done = head + body_words * 4;
+    if (threadIdx.x < len - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+}  // namespace icer

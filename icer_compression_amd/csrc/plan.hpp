@@ -1,0 +1,224 @@
+// plan.hpp -- host-side planner: everything about a frame geometry that does not depend on pixel
+// values.  Built once per (w, h, channels, stages, segments) and uploaded as flat tables that the
+// kernels index by blockIdx.
+//
+// Restates, for the uint16 encoder:
+//   subband geometry            icer_get_dim_n_low/high_stages   lib_icer/src/icer_wavelet.c:107-113
+//   segment grid                icer_generate_partition_parameters   icer_partition.c:7-54
+//   segment walk order          icer_compress_partition_uint16       icer_partition.c:299-385
+//   packet list + priorities    icer_compress.c:315-363 (gray), icer_color.c:398-456 (YUV, quirk D4)
+//   priority order              comp_packet + qsort, icer_compress.c:8-15,365 (stable: glibc merge sort)
+//   final stream order          icer_compress.c:409-423, icer_color.c:508-527
+#pragma once
+#include <algorithm>
+#include <stdint.h>
+#include <vector>
+
+#include "icer_tables.hpp"
+
+namespace icer {
+
+struct Packet {
+    uint8_t level, subband, lsb, chan;
+    uint64_t priority;
+};
+
+// One coding unit = one (packet, segment).  Device-visible; identical for every frame of a batch.
+struct UnitDesc {
+    uint32_t x0, y0, w, h;          // rectangle in plane coordinates
+    uint32_t chan, level, subband, lsb, seg;
+    uint32_t cap_words;             // payload capacity of the slot (32-bit words)
+    uint32_t cap_is_bound;          // 1: capacity came from the bits-per-pixel bound, 0: from the byte quota
+    uint32_t pad_;
+    uint64_t slot_off;              // byte offset of the slot (28-byte header + payload) in the frame's slot area
+};
+
+struct SegmentGrid {
+    // field order of partition_param_typdef (icer.h:126-142)
+    uint16_t w, h, r, c, r_t, h_t, x_t, c_t0, y_t, r_t0, x_b, c_b0, y_b, r_b0, s;
+};
+
+inline size_t dim_low(size_t d, int level) { return (d + ((size_t(1) << level) - 1)) >> level; }
+inline size_t dim_high(size_t d, int level) { return dim_low(d, level - 1) / 2; }
+
+inline int make_grid(SegmentGrid *g, size_t w, size_t h, unsigned segments)
+{
+    if (segments > w * h || segments > (unsigned)kMaxSegments) return kTooManySegments;
+    const size_t s = segments;
+    size_t r;
+    if (h > (s - 1) * w) r = s;
+    else for (r = 1; r < s && (r + 1) * r * w < h * s; r++) {}
+    const size_t c = s / r, r_t = (c + 1) * r - s;
+    size_t h_t = ((2 * h * c * r_t + s) / 2) / s;
+    if (h_t < r_t) h_t = r_t;
+    const size_t x_t = w / c, c_t0 = (x_t + 1) * c - w, y_t = h_t / r_t, r_t0 = (y_t + 1) * r_t - h_t;
+    size_t x_b = 0, c_b0 = 0, y_b = 0, r_b0 = 0;
+    if (r_t < r) {
+        x_b = w / (c + 1);
+        c_b0 = (x_b + 1) * (c + 1) - w;
+        y_b = (h - h_t) / (r - r_t);
+        r_b0 = (y_b + 1) * (r - r_t) - (h - h_t);
+    }
+    *g = SegmentGrid{(uint16_t)w, (uint16_t)h, (uint16_t)r, (uint16_t)c, (uint16_t)r_t, (uint16_t)h_t,
+                     (uint16_t)x_t, (uint16_t)c_t0, (uint16_t)y_t, (uint16_t)r_t0, (uint16_t)x_b,
+                     (uint16_t)c_b0, (uint16_t)y_b, (uint16_t)r_b0, (uint16_t)s};
+    return kOk;
+}
+
+struct Rect { uint32_t x, y, w, h; };
+
+// rectangles in coding order: top region row-major, then bottom region row-major
+inline void grid_rects(const SegmentGrid &g, std::vector<Rect> *out)
+{
+    out->clear();
+    uint32_t y = 0;
+    for (unsigned row = 0; row < g.r_t; row++) {
+        const uint32_t sh = g.y_t + (row >= g.r_t0 ? 1u : 0u);
+        uint32_t x = 0;
+        for (unsigned col = 0; col < g.c; col++) {
+            const uint32_t sw = g.x_t + (col >= g.c_t0 ? 1u : 0u);
+            out->push_back(Rect{x, y, sw, sh});
+            x += sw;
+        }
+        y += sh;
+    }
+    for (unsigned row = 0; row < (unsigned)(g.r - g.r_t); row++) {
+        const uint32_t sh = g.y_b + (row >= g.r_b0 ? 1u : 0u);
+        uint32_t x = 0;
+        for (unsigned col = 0; col < (unsigned)(g.c + 1); col++) {
+            const uint32_t sw = g.x_b + (col >= g.c_b0 ? 1u : 0u);
+            out->push_back(Rect{x, y, sw, sh});
+            x += sw;
+        }
+        y += sh;
+    }
+}
+
+inline void make_packets(std::vector<Packet> *pk, int stages, int channels)
+{
+    pk->clear();
+    if (channels == 1) {
+        for (int st = 1; st <= stages; st++) {
+            const uint64_t pr = uint64_t(1) << st;
+            for (int lsb = 0; lsb < kPlanes; lsb++) {
+                pk->push_back(Packet{(uint8_t)st, kHL, (uint8_t)lsb, 0, pr << lsb});
+                pk->push_back(Packet{(uint8_t)st, kLH, (uint8_t)lsb, 0, pr << lsb});
+                pk->push_back(Packet{(uint8_t)st, kHH, (uint8_t)lsb, 0, ((pr / 2) << lsb) + 1});
+            }
+        }
+        const uint64_t pr = uint64_t(1) << stages;
+        for (int lsb = 0; lsb < kPlanes; lsb++) pk->push_back(Packet{(uint8_t)stages, kLL, (uint8_t)lsb, 0, (2 * pr) << lsb});
+    } else {
+        // QUIRK D4: a 32-bit priority doubled once per (plane, Y) and never reset per plane
+        for (int st = 1; st <= stages; st++) {
+            uint32_t pr = 1u << st;
+            for (int lsb = 0; lsb < kPlanes; lsb++)
+                for (int ch = 0; ch < channels; ch++) {
+                    if (ch == 0) pr *= 2;
+                    pk->push_back(Packet{(uint8_t)st, kHL, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(pr << lsb)});
+                    pk->push_back(Packet{(uint8_t)st, kLH, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(pr << lsb)});
+                    pk->push_back(Packet{(uint8_t)st, kHH, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(((pr / 2) << lsb) + 1)});
+                }
+        }
+        uint32_t pr = 1u << stages;
+        for (int lsb = 0; lsb < kPlanes; lsb++)
+            for (int ch = 0; ch < channels; ch++) {
+                if (ch == 0) pr *= 2;
+                pk->push_back(Packet{(uint8_t)stages, kLL, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)((2 * pr) << lsb)});
+            }
+    }
+    std::stable_sort(pk->begin(), pk->end(), [](const Packet &a, const Packet &b) {
+        if (a.priority != b.priority) return a.priority > b.priority;
+        return a.subband < b.subband;
+    });
+}
+
+struct Plan {
+    size_t w = 0, h = 0;
+    int channels = 0, stages = 0, segments = 0;
+    int error = kOk;                       // non-zero: the reference would refuse this geometry
+    std::vector<Packet> packets;           // priority order
+    std::vector<UnitDesc> units;           // priority order: packet order, then segment number
+    std::vector<uint32_t> final_order;     // D7 order -> index into units
+    std::vector<uint32_t> work_order;      // launch order (largest units first) -> index into units
+    size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
+};
+
+inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int segments)
+{
+    p->w = w; p->h = h; p->channels = channels; p->stages = stages; p->segments = segments;
+    p->units.clear(); p->final_order.clear(); p->work_order.clear();
+    if (channels != 1 && channels != 3) return p->error = kInvalidInput;
+    if (w == 0 || h == 0 || w > 65535 || h > 65535 || segments < 1) return p->error = kInvalidInput;
+    // beyond 6 stages / 32 segments the reference indexes past its static tables; we refuse instead
+    if (stages < 1 || stages > kMaxStages) return p->error = kTooManyStages;
+    if (segments > kMaxSegments) return p->error = kTooManySegments;
+    if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return p->error = kTooManyStages;   // icer_wavelet.c:63-68
+    if ((3 * stages + 1) * kPlanes * channels >= kMaxPackets) return p->error = kPacketCountExceeded;
+
+    make_packets(&p->packets, stages, channels);
+    SegmentGrid grid{};
+    bool grid_valid = false;
+    std::vector<Rect> rects;
+    // slot index for the final re-ordering
+    std::vector<int64_t> where((size_t)3 * (kMaxStages + 1) * 4 * kPlanes * (kMaxSegments + 1), -1);
+    auto key = [](int ch, int lv, int sb, int lsb, int sg) {
+        return ((((size_t)ch * (kMaxStages + 1) + lv) * 4 + sb) * kPlanes + lsb) * (kMaxSegments + 1) + sg;
+    };
+    for (const Packet &pk : p->packets) {
+        size_t sw, sh, ox, oy;
+        switch (pk.subband) {
+        case kLL: sw = dim_low(w, pk.level);  sh = dim_low(h, pk.level);  ox = 0; oy = 0; break;
+        case kHL: sw = dim_high(w, pk.level); sh = dim_low(h, pk.level);  ox = dim_low(w, pk.level); oy = 0; break;
+        case kLH: sw = dim_low(w, pk.level);  sh = dim_high(h, pk.level); ox = 0; oy = dim_low(h, pk.level); break;
+        default:  sw = dim_high(w, pk.level); sh = dim_high(h, pk.level); ox = dim_low(w, pk.level); oy = dim_low(h, pk.level); break;
+        }
+        // QUIRK P1: the reference ignores a failed grid and keeps using the previous packet's one
+        if (make_grid(&grid, sw, sh, (unsigned)segments) == kOk) grid_valid = true;
+        else if (!grid_valid) return p->error = kTooManySegments;   // reference reads an uninitialised struct here
+        grid_rects(grid, &rects);
+        for (size_t sg = 0; sg < rects.size(); sg++) {
+            UnitDesc u{};
+            u.x0 = (uint32_t)ox + rects[sg].x; u.y0 = (uint32_t)oy + rects[sg].y;
+            u.w = rects[sg].w; u.h = rects[sg].h;
+            u.chan = pk.chan; u.level = pk.level; u.subband = pk.subband; u.lsb = pk.lsb; u.seg = (uint32_t)sg;
+            where[key(pk.chan, pk.level, pk.subband, pk.lsb, (int)sg)] = (int64_t)p->units.size();
+            p->units.push_back(u);
+        }
+    }
+    // D7: segment up, subband down, level down, plane down, channel up
+    for (int sg = 0; sg <= kMaxSegments; sg++)
+        for (int sb = 3; sb >= 0; sb--)
+            for (int lv = kMaxStages; lv >= 0; lv--)
+                for (int lsb = kPlanes - 1; lsb >= 0; lsb--)
+                    for (int ch = 0; ch < channels; ch++) {
+                        const int64_t u = where[key(ch, lv, sb, lsb, sg)];
+                        if (u >= 0) p->final_order.push_back((uint32_t)u);
+                    }
+    p->work_order.resize(p->units.size());
+    for (size_t i = 0; i < p->units.size(); i++) p->work_order[i] = (uint32_t)i;
+    std::stable_sort(p->work_order.begin(), p->work_order.end(), [&](uint32_t a, uint32_t b) {
+        return (uint64_t)p->units[a].w * p->units[a].h > (uint64_t)p->units[b].w * p->units[b].h;
+    });
+    return p->error = kOk;
+}
+
+// Slot capacities: a unit's payload can never be useful beyond (quota - 28) bytes (P3), and we
+// provision `bits_per_pixel` bits per pixel otherwise (overflow of that bound is detected and the
+// batch is re-run with a larger bound).
+inline void assign_slots(Plan *p, size_t quota, unsigned bits_per_pixel)
+{
+    const uint64_t quota_cap = ((quota > (size_t)kHeaderBytes ? quota - kHeaderBytes : 0) + 3) / 4 + 1;   // words
+    uint64_t off = 0;
+    for (UnitDesc &u : p->units) {
+        const uint64_t bound = ((uint64_t)u.w * u.h * bits_per_pixel + 31) / 32 + 16;                     // words
+        const uint64_t cap = std::min(bound, quota_cap);
+        u.cap_words = (uint32_t)cap;
+        u.cap_is_bound = bound < quota_cap ? 1u : 0u;
+        u.slot_off = off;
+        off += kHeaderBytes + cap * 4;
+    }
+    p->slot_bytes = (size_t)off;
+}
+
+}  // namespace icer

@@ -1,0 +1,132 @@
+/*
+ * icer_hip.h -- C ABI of libicer_hip.so, the MI355X (gfx950) ICER encoder.
+ *
+ * Part 1 restates, with identical names, argument meaning, struct layout and return codes, the
+ * entry points of lib_icer that an application needs for ENCODING through the uint16 path
+ * (TheRealOrange/icer_compression, lib_icer/inc/icer.h).  A program written against lib_icer links
+ * against libicer_hip.so instead of libicer.a and produces byte-identical streams; the work runs
+ * on the GPU (there is no CPU fallback: without a usable HIP device every compress call returns
+ * ICER_FATAL_ERROR and prints the reason to stderr).
+ *
+ * Part 2 (prefix icerx_) is our extension for batches of frames and device-resident buffers,
+ * which is what bench.py measures.  Each frame's stream, length and return code equal those of a
+ * per-frame call of the Part-1 function on the same data.
+ *
+ * Plain C, LP64; no HIP or torch types appear in any signature (streams and device pointers are
+ * passed as void*).
+ */
+#ifndef ICER_HIP_H
+#define ICER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Part 1: lib_icer drop-in surface ------------------------------------------------------ */
+
+/* enum icer_status, lib_icer/inc/icer.h:92-105 (same numeric values) */
+enum icer_status {
+    ICER_RESULT_OK = 0,
+    ICER_INTEGER_OVERFLOW = -1,
+    ICER_OUTPUT_BUF_TOO_SMALL = -2,
+    ICER_TOO_MANY_SEGMENTS = -3,
+    ICER_TOO_MANY_STAGES = -4,
+    ICER_BYTE_QUOTA_EXCEEDED = -5,
+    ICER_BITPLANE_OUT_OF_RANGE = -6,
+    ICER_DECODER_OUT_OF_DATA = -7,
+    ICER_DECODED_INVALID_DATA = -8,
+    ICER_PACKET_COUNT_EXCEEDED = -9,
+    ICER_FATAL_ERROR = -10,
+    ICER_INVALID_INPUT = -11
+};
+
+/* enum icer_filter_types, lib_icer/inc/icer.h:107-115 */
+enum icer_filter_types {
+    ICER_FILTER_A = 0, ICER_FILTER_B, ICER_FILTER_C, ICER_FILTER_D, ICER_FILTER_E, ICER_FILTER_F, ICER_FILTER_Q
+};
+
+/* icer_output_data_buf_typedef, lib_icer/inc/icer.h:307-312 (32 bytes, same layout) */
+typedef struct {
+    size_t size_used;            /* out: length of the final stream at rearrange_start */
+    size_t size_allocated;       /* byte quota */
+    uint8_t *data_start;         /* staging half [0, quota): scratch, contents unspecified */
+    uint8_t *rearrange_start;    /* final stream */
+} icer_output_data_buf_typedef;
+
+/* replaces icer_init, lib_icer/inc/icer.h:370 (lib_icer/src/icer_init.c:24-35): builds the coder
+ * tables.  Idempotent.  Does not touch the GPU. */
+int icer_init(void);
+
+/* replaces icer_init_output_struct, icer.h:524 (lib_icer/src/icer_util.c:38-45).
+ * Returns ICER_OUTPUT_BUF_TOO_SMALL when 2*byte_quota > buf_len. */
+int icer_init_output_struct(icer_output_data_buf_typedef *out, uint8_t *data, size_t buf_len, size_t byte_quota);
+
+/* replaces icer_compress_image_uint16, icer.h:440-441 (lib_icer/src/icer_compress.c:279-426).
+ * `image` (host memory, w*h uint16, row-major) is overwritten with the sign-magnitude wavelet
+ * coefficients exactly as the reference leaves it.  Returns ICER_RESULT_OK or
+ * ICER_BYTE_QUOTA_EXCEEDED with a valid stream in output_data->rearrange_start[0..size_used),
+ * or an error code with size_used == 0. */
+int icer_compress_image_uint16(uint16_t *image, size_t image_w, size_t image_h, uint8_t stages,
+                               enum icer_filter_types filt, uint8_t segments,
+                               icer_output_data_buf_typedef *output_data);
+
+/* replaces icer_compress_image_yuv_uint16, icer.h:442-444 (lib_icer/src/icer_color.c:343-530). */
+int icer_compress_image_yuv_uint16(uint16_t *y_channel, uint16_t *u_channel, uint16_t *v_channel,
+                                   size_t image_w, size_t image_h, uint8_t stages,
+                                   enum icer_filter_types filt, uint8_t segments,
+                                   icer_output_data_buf_typedef *output_data);
+
+/* ---- Part 2: batched / device-resident extension -------------------------------------------- */
+
+typedef struct icerx_encoder icerx_encoder;
+
+/* Create an encoder for frames of w x h with `channels` (1 = gray, 3 = Y,U,V planes) on HIP device
+ * `device`.  All device memory for up to `max_frames` frames per call is allocated here.
+ * Returns 0, a (negative) icer_status the reference would return for this geometry
+ * (ICER_TOO_MANY_STAGES, ...), or ICER_FATAL_ERROR when no usable device exists. */
+int icerx_encoder_create(icerx_encoder **enc, int device, size_t w, size_t h, int channels, int stages,
+                         int filt, int segments, int max_frames);
+void icerx_encoder_destroy(icerx_encoder *enc);
+
+/* Encode n_frames frames that already live in device memory.
+ *   d_frames   device pointer, n_frames * channels planes of w*h uint16 (frame-major, then channel);
+ *              not modified
+ *   byte_quota per-frame byte quota (the reference's icer_output_data_buf_typedef.size_allocated)
+ *   d_out      device pointer, n_frames * out_stride bytes; frame f's stream starts at f*out_stride
+ *              (out_stride >= byte_quota)
+ *   d_sizes    device pointer, n_frames uint64: stream lengths
+ *   d_rcs      device pointer, n_frames int32: per-frame reference return codes
+ *   stream     hipStream_t (as void*), NULL = default stream.  The call is asynchronous unless a
+ *              slot-capacity retry is needed (rare), in which case it synchronises.
+ * Returns 0 or ICER_FATAL_ERROR (HIP failure) / ICER_INVALID_INPUT. */
+int icerx_encode_device(icerx_encoder *enc, const uint16_t *d_frames, int n_frames, size_t byte_quota,
+                        uint8_t *d_out, size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
+
+/* Host-buffer convenience wrapper: H2D, icerx_encode_device, D2H, synchronous. */
+int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, size_t byte_quota,
+                      uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs);
+
+/* Copy the sign-magnitude coefficient plane of (frame, channel) of the last encode to host
+ * memory (what the reference leaves in the caller's image buffer). */
+int icerx_get_coefficients(icerx_encoder *enc, int frame, int channel, uint16_t *dst);
+
+/* Kernel timing with HIP events on the encode stream.  When enabled, every icerx_encode_device
+ * call records events around each pipeline stage; icerx_timing_read synchronises and accumulates.
+ * stage ids: 0 = DWT (all stages), 1 = LL mean + sign-magnitude, 2 = coding units (dominant),
+ * 3 = quota scan + stream gather.  ms[i] = accumulated milliseconds, calls = number of encodes. */
+#define ICERX_NUM_STAGES 4
+int icerx_timing_enable(icerx_encoder *enc, int on);
+int icerx_timing_read(icerx_encoder *enc, double ms[ICERX_NUM_STAGES], uint64_t *calls, int reset);
+
+/* Number of coding units per frame and the bits-per-pixel slot bound currently in use. */
+int icerx_info(icerx_encoder *enc, uint32_t *units_per_frame, uint32_t *slot_bits_per_pixel, uint64_t *slot_bytes_per_frame);
+
+const char *icerx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICER_HIP_H */

@@ -1,0 +1,152 @@
+// TESTS ONLY: builds the kernel cores (csrc/coder_core.hpp, assemble_core.hpp, dwt_core.hpp) and the
+// host planner (csrc/plan.hpp) as a CPU lane-loop emulation (-DICER_WAVE_EMU, see csrc/wave.hpp), so
+// the wave-parallel algorithms can be compared with the oracle in a container without a GPU.
+// Not part of the product library; nothing here is reachable from libicer_hip.so.
+#define ICER_WAVE_EMU 1
+#include "../../icer_compression_amd/csrc/assemble_core.hpp"
+#include "../../icer_compression_amd/csrc/coder_core.hpp"
+#include "../../icer_compression_amd/csrc/dwt_core.hpp"
+#include "../../icer_compression_amd/csrc/plan.hpp"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace icer;
+
+static CoderShared g_sh;
+
+extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
+                              uint8_t *out, size_t cap_bytes)
+{
+    memset(&g_sh, 0xA5, sizeof g_sh);             // the kernel must not depend on LDS contents
+    build_coder_tables(&g_sh.tab);
+    UnitArgs a;
+    a.seg = seg; a.stride = (uint32_t)stride; a.w = (uint32_t)w; a.h = (uint32_t)h;
+    a.subband = subband; a.lsb = lsb;
+    a.cap_words = (uint32_t)(cap_bytes / 4);
+    std::vector<uint32_t> words(a.cap_words + 1, 0);
+    a.out_words = words.data();
+    uint32_t bits = code_unit_wave(g_sh, a);
+    long res = (bits == kUnitTooBig) ? -5 : (long)bits;
+    if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
+    return res;
+}
+
+// forward DWT through dwt_pair with the same pass structure as the kernels (rows src->tmp, cols tmp->dst)
+extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt)
+{
+    if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return kTooManyStages;
+    const FilterTaps f = filter_taps(filt);
+    std::vector<int16_t> tmp(w * h);
+    int16_t *coef = (int16_t *)img;
+    size_t cw = w, ch = h;
+    bool ovf = false;
+    for (int s = 0; s < stages; s++) {
+        const int nlw = (int)((cw + 1) / 2), nlh = (int)((ch + 1) / 2);
+        for (size_t r = 0; r < ch; r++)
+            for (int k = 0; k < nlw; k++) {
+                const int16_t *line = coef + r * w;
+                DwtPair p = dwt_pair([line](int i) { return line[i]; }, (int)cw, k, f.am1, f.a0, f.a1, f.be);
+                tmp[r * w + k] = p.low;
+                if (p.has_high) tmp[r * w + nlw + k] = p.high;
+                ovf |= p.overflow;
+            }
+        for (size_t c = 0; c < cw; c++)
+            for (int k = 0; k < nlh; k++) {
+                const int16_t *col = tmp.data() + c;
+                DwtPair p = dwt_pair([col, w](int i) { return col[(size_t)i * w]; }, (int)ch, k, f.am1, f.a0, f.a1, f.be);
+                coef[(size_t)k * w + c] = p.low;
+                if (p.has_high) coef[(size_t)(nlh + k) * w + c] = p.high;
+                ovf |= p.overflow;
+            }
+        cw = (cw + 1) / 2;
+        ch = (ch + 1) / 2;
+    }
+    return ovf ? kIntegerOverflow : kOk;
+}
+
+// whole-frame pipeline with the structure of api.hip::enqueue, on host memory
+extern "C" int emu_compress(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
+                            int segments, size_t quota, unsigned bits_per_pixel, uint8_t *out, size_t *size_used,
+                            int *bound_overflow)
+{
+    *size_used = 0;
+    *bound_overflow = 0;
+    Plan plan;
+    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    if (rc) return rc;
+    for (int c = 0; c < channels; c++)
+        if ((rc = emu_dwt(planes[c], w, h, stages, filt)) != kOk) return rc;
+    const size_t llw = dim_low(w, stages), llh = dim_low(h, stages);
+    uint16_t means[3];
+    for (int c = 0; c < channels; c++) {
+        unsigned long long sum = 0;
+        for (size_t r = 0; r < llh; r++)
+            for (size_t x = 0; x < llw; x++) sum += planes[c][r * w + x];
+        means[c] = (uint16_t)(sum / (llw * llh));
+    }
+    for (int c = 0; c < channels; c++)
+        if (means[c] > 32767) return kIntegerOverflow;
+    for (int c = 0; c < channels; c++)
+        for (size_t r = 0; r < h; r++)
+            for (size_t x = 0; x < w; x++) {   // finalize_kernel
+                int16_t v = (int16_t)planes[c][r * w + x];
+                if (r < llh && x < llw) v = (int16_t)(v - (int16_t)means[c]);
+                const uint16_t mask = (uint16_t)(v >> 15);
+                planes[c][r * w + x] = (uint16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
+            }
+
+    assign_slots(&plan, quota, bits_per_pixel);
+    std::vector<uint8_t> slots(plan.slot_bytes + 8);
+    const uint32_t n_units = (uint32_t)plan.units.size();
+    std::vector<uint32_t> unit_bits(n_units);
+    memset(&g_sh, 0x5A, sizeof g_sh);
+    build_coder_tables(&g_sh.tab);
+    build_crc_table(g_sh);
+    for (uint32_t wi = 0; wi < n_units; wi++) {
+        const uint32_t ui = plan.work_order[wi];
+        const UnitDesc &u = plan.units[ui];
+        uint32_t *slot_words = (uint32_t *)(slots.data() + u.slot_off);
+        UnitArgs a;
+        a.seg = planes[u.chan] + (size_t)u.y0 * w + u.x0;
+        a.stride = (uint32_t)w; a.w = u.w; a.h = u.h; a.subband = (int)u.subband; a.lsb = (int)u.lsb;
+        a.out_words = slot_words + kHeaderBytes / 4;
+        a.cap_words = u.cap_words;
+        const uint32_t bits = code_unit_wave(g_sh, a);
+        if (bits != kUnitTooBig) {
+            FinishArgs f;
+            f.slot_words = slot_words; f.bits = bits; f.mean = means[u.chan];
+            f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
+            f.image_w = (uint32_t)w; f.image_h = (uint32_t)h;
+            finish_unit_wave(g_sh, f);
+        }
+        unit_bits[ui] = bits;
+    }
+    std::vector<uint64_t> final_off(n_units);
+    uint32_t kept;
+    uint64_t used;
+    rc = scan_frame_wave(unit_bits.data(), plan.final_order.data(), n_units, quota, final_off.data(), &kept, &used);
+    if (kept < n_units && unit_bits[kept] == kUnitTooBig && plan.units[kept].cap_is_bound) *bound_overflow = 1;
+    for (uint32_t ui = 0; ui < n_units; ui++) {
+        if (final_off[ui] == ~0ull) continue;
+        const size_t len = kHeaderBytes + ((unit_bits[ui] + 7u) >> 3);
+        memcpy(out + final_off[ui], slots.data() + plan.units[ui].slot_off, len);
+    }
+    *size_used = (size_t)used;
+    return rc;
+}
+
+// planner taps for the host-logic tests
+extern "C" int emu_plan_units(size_t w, size_t h, int channels, int stages, int segments, uint32_t *out /* n*9 */, int cap)
+{
+    Plan plan;
+    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    if (rc) return rc;
+    int n = (int)plan.units.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const UnitDesc &u = plan.units[i];
+        uint32_t *o = out + (size_t)i * 9;
+        o[0] = u.x0; o[1] = u.y0; o[2] = u.w; o[3] = u.h; o[4] = u.chan; o[5] = u.level; o[6] = u.subband; o[7] = u.lsb; o[8] = u.seg;
+    }
+    return n;
+}

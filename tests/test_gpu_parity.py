@@ -1,0 +1,125 @@
+"""Parity tests proper: the HIP path, called through the C ABI of libicer_hip.so, against the oracle
+(oracle/icer_oracle.c), the reference build where present (oracle/_ref) and the golden digests.
+Bar: bit-exact streams, identical return codes, identical in-place side effect on the image planes."""
+import hashlib
+import zlib
+
+import numpy as np
+import pytest
+
+from icer_compression_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return a[0] == b[0] and a[1] == b[1] and all(np.array_equal(p, q) for p, q in zip(a[2], b[2]))
+
+
+GRAY_CASES = [
+    # w, h, stages, filt, segments, quota
+    (64, 64, 2, 0, 4, 1 << 20), (200, 160, 3, 1, 1, 1 << 20), (100, 75, 3, 2, 7, 1 << 20), (128, 128, 4, 3, 16, 5000),
+    (96, 96, 2, 4, 3, 3000), (257, 131, 3, 5, 32, 1 << 20), (80, 80, 2, 6, 5, 900), (512, 512, 3, 0, 10, 1 << 20),
+    (64, 64, 2, 0, 4, 27), (64, 64, 2, 0, 4, 28), (64, 64, 2, 0, 4, 60), (5, 5, 1, 0, 1, 4096), (24, 24, 3, 0, 9, 1 << 16),
+    (1000, 37, 3, 0, 10, 1 << 20), (37, 1000, 3, 2, 10, 1 << 20),
+]
+
+
+@pytest.mark.parametrize("case", GRAY_CASES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dropin_gray_matches_oracle(oracle, case, mode):
+    w, h, st, f, sg, q = case
+    img = synth.gray_frame(w, h, 7, mode)
+    assert _same(api.compress([img], st, f, sg, q), oracle.compress([img], st, f, sg, q))
+
+
+@pytest.mark.parametrize("case", [(64, 64, 2, 0, 4, 1 << 20), (128, 96, 3, 0, 10, 6000), (100, 100, 3, 2, 6, 20000),
+                                  (256, 256, 4, 1, 10, 1 << 22)])
+def test_dropin_yuv_matches_oracle(oracle, case):
+    w, h, st, f, sg, q = case
+    planes = synth.color_frame_yuv(w, h, 3)
+    assert _same(api.compress(planes, st, f, sg, q), oracle.compress(planes, st, f, sg, q))
+
+
+def test_dropin_matches_reference_build(reference):
+    for (w, h, st, f, sg, q) in [(300, 200, 3, 0, 1, 1 << 20), (128, 128, 4, 2, 16, 7000)]:
+        img = synth.gray_frame(w, h, 11, 0)
+        assert _same(api.compress([img], st, f, sg, q), reference.compress([img], st, f, sg, q))
+
+
+def test_true_16bit_data_and_overflow_paths(oracle):
+    rng = np.random.default_rng(3)
+    # 12-bit data: more than 9 planes of content, exercises category 3 / large magnitudes
+    img = rng.integers(0, 4096, (96, 128)).astype(np.uint16)
+    assert _same(api.compress([img], 3, 0, 4, 1 << 20), oracle.compress([img], 3, 0, 4, 1 << 20))
+    # full-range data overflows int16 in the transform: rc -1, nothing emitted, image left transformed
+    img = rng.integers(0, 65536, (64, 64)).astype(np.uint16)
+    a, b = api.compress([img], 2, 0, 4, 1 << 20), oracle.compress([img], 2, 0, 4, 1 << 20)
+    assert a[0] == b[0] == api.ICER_INTEGER_OVERFLOW and a[1] == b""
+    assert np.array_equal(a[2][0], b[2][0])
+    # large unsigned values make the LL mean exceed INT16_MAX without transform overflow
+    img = np.full((64, 64), 40000, np.uint16)
+    a, b = api.compress([img], 2, 0, 4, 1 << 20), oracle.compress([img], 2, 0, 4, 1 << 20)
+    assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2][0], b[2][0])
+
+
+def test_geometry_errors(oracle):
+    img = synth.gray_frame(32, 32)
+    assert api.compress([img], 5, 0, 4, 1 << 16)[0] == api.ICER_TOO_MANY_STAGES == oracle.compress([img], 5, 0, 4, 1 << 16)[0]
+    out = api.icer_output_data_buf_typedef()
+    buf = np.zeros(100, np.uint8)
+    assert api.icer_init_output_struct(out, buf, 100, 51) == api.ICER_OUTPUT_BUF_TOO_SMALL
+
+
+def test_batch_extension_equals_per_frame_calls(oracle):
+    w, h, st, sg = 256, 192, 3, 6
+    frames = synth.gray_batch(5, w, h, 100, 1)
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=5)
+    for quota in (2 * w * h, 9000):
+        got = enc.encode_host(frames, quota)
+        for k in range(5):
+            rc, stream, planes = oracle.compress([frames[k]], st, 0, sg, quota)
+            assert got[k] == (rc, stream)
+            if quota > 9000:
+                assert np.array_equal(enc.coefficients(k, 0), planes[0])
+    enc.close()
+
+
+def test_batch_color(oracle):
+    w, h = 128, 128
+    fr = np.stack([np.stack(synth.color_frame_yuv(w, h, 50 + k)) for k in range(3)])
+    enc = api.Encoder(w, h, 3, 3, 0, 5, max_frames=3)
+    got = enc.encode_host(fr, 12000)
+    for k in range(3):
+        rc, stream, _ = oracle.compress(list(fr[k]), 3, 0, 5, 12000)
+        assert got[k] == (rc, stream)
+    enc.close()
+
+
+def test_slot_bound_retry(oracle):
+    """An adversarial plane (isolated ones in a sea of zeros, coded in the widest Golomb bin) exceeds the
+    default 3 bits/pixel slot bound: the library must notice and redo the batch with larger slots."""
+    w = h = 64
+    img = np.zeros((h, w), np.uint16)
+    assert _same(api.compress([img], 1, 0, 1, 1 << 16), oracle.compress([img], 1, 0, 1, 1 << 16))
+    rng = np.random.default_rng(9)
+    img = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint16)
+    assert _same(api.compress([img], 1, 0, 1, 1 << 18), oracle.compress([img], 1, 0, 1, 1 << 18))
+
+
+GOLDEN_ON_GPU = ["kat_512_m1", "kat_512_m0", "kat_512_quota30000", "kat_odd_517x389_filtC", "kat_1024_16seg",
+                 "kat_color_512_quota", "C2_4096_gray_5st_10seg", "C2_4096_gray_noise", "C3_4096_yuv_quota70000",
+                 "C4_2048_frame0", "C4_2048_frame1", "C5_8192_frame0"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_ON_GPU)
+def test_golden_vectors_full_size(golden, name):
+    g = golden[name]
+    planes = [synth.gray_frame(g["w"], g["h"], g["seed"], g["mode"])] if g["kind"] == "gray" else \
+        list(synth.color_frame_yuv(g["w"], g["h"], g["seed"]))
+    enc = api.Encoder(g["w"], g["h"], len(planes), g["stages"], g["filt"], g["segments"], max_frames=1)
+    (rc, stream), = enc.encode_host(np.stack(planes)[None], g["quota"])
+    enc.close()
+    assert rc == g["rc"] and len(stream) == g["size"]
+    assert "%08x" % zlib.crc32(stream) == g["crc32"]
+    assert hashlib.sha256(stream).hexdigest()[:16] == g["sha256_16"]
