@@ -61,7 +61,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from icer_compression_amd import api, synth
+    from icer_compression_amd import api, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -79,7 +79,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B = args.batch
-    seeds = [synth.DEFAULT_SEED + rank * B + k for k in range(B)]
+    seeds = shard.frame_seeds(synth.DEFAULT_SEED, rank, world, B)
     host_frames = np.stack([synth.gray_frame(W, H, s, 1) for s in seeds])
     frames = torch.from_numpy(host_frames.view(np.int16)).to(dev)             # resident in HBM before timing
     out = torch.empty((B, QUOTA), dtype=torch.uint8, device=dev)
@@ -119,10 +119,7 @@ def main():
     stage_ms, calls = enc.timing_read(reset=True)
     enc.timing_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t.item())
+    elapsed_max = shard.max_over_ranks(elapsed, dev)
 
     if rank == 0:
         n_pix = world * B * W * H * args.steps

@@ -150,3 +150,18 @@ extern "C" int emu_plan_units(size_t w, size_t h, int channels, int stages, int 
     }
     return n;
 }
+
+// raw copy of the product's coder tables (csrc/icer_tables.hpp) for tests/test_tables.py
+extern "C" size_t emu_get_tables(void *dst, size_t cap)
+{
+    CoderTables t;
+    build_coder_tables(&t);
+    if (cap >= sizeof t) memcpy(dst, &t, sizeof t);
+    return sizeof t;
+}
+extern "C" int emu_pick_bin(uint32_t zero, uint32_t total)
+{
+    CoderTables t;
+    build_coder_tables(&t);
+    return (int)pick_bin(t.cut, zero, total);
+}

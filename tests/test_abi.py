@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/icer_hip.h declares, and the pure-host entry points behave like the reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from icer_compression_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "icer_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(icerx?_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = api.load_library()
+    names = _declared_functions()
+    assert {"icer_init", "icer_init_output_struct", "icer_compress_image_uint16", "icer_compress_image_yuv_uint16",
+            "icerx_encoder_create", "icerx_encode_device"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_output_struct_layout_and_init():
+    # icer.h:307-312: four 8-byte fields
+    assert C.sizeof(api.icer_output_data_buf_typedef) == 32
+    assert api.icer_init() == api.ICER_RESULT_OK
+    out = api.icer_output_data_buf_typedef()
+    buf = np.zeros(1000, np.uint8)
+    assert api.icer_init_output_struct(out, buf, 1000, 501) == api.ICER_OUTPUT_BUF_TOO_SMALL     # icer_util.c:39
+    assert api.icer_init_output_struct(out, buf, 1000, 500) == api.ICER_RESULT_OK
+    assert (out.size_used, out.size_allocated) == (0, 500)
+    assert out.data_start == buf.ctypes.data and out.rearrange_start == buf.ctypes.data + 500
+
+
+def test_geometry_is_refused_like_the_reference_before_touching_the_gpu():
+    lib = api.load_library()
+    h = C.c_void_p()
+    # final LL thinner than 3 -> ICER_TOO_MANY_STAGES (icer_wavelet.c:63-68)
+    assert lib.icerx_encoder_create(C.byref(h), 0, 32, 32, 1, 5, 0, 4, 1) == api.ICER_TOO_MANY_STAGES
+    assert lib.icerx_encoder_create(C.byref(h), 0, 64, 64, 2, 2, 0, 4, 1) == api.ICER_INVALID_INPUT
+
+
+def test_no_cpu_fallback():
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    rc, stream, _ = api.compress([np.zeros((64, 64), np.uint16)], 2, 0, 4, 1 << 16)
+    assert rc == api.ICER_FATAL_ERROR and stream == b""
+    assert b"no usable HIP device" in api.load_library().icerx_last_error()

@@ -1,0 +1,68 @@
+"""The product's constant tables (csrc/icer_tables.hpp), entry by entry against the reference build."""
+import ctypes as C
+
+import numpy as np
+
+
+class CoderTables(C.Structure):     # mirrors icer::CoderTables
+    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
+                ("gm", C.c_uint16 * 17), ("gl", C.c_uint16 * 17), ("gi", C.c_uint16 * 17),
+                ("cut", C.c_uint32 * 16), ("x2n", C.c_uint32 * 32)]
+
+
+def _tables(emu):
+    emu.lib.emu_get_tables.restype = C.c_size_t
+    emu.lib.emu_get_tables.argtypes = [C.c_void_p, C.c_size_t]
+    t = CoderTables()
+    assert emu.lib.emu_get_tables(C.byref(t), C.sizeof(t)) == C.sizeof(t)
+    return t
+
+
+def test_tables_equal_reference(emu, reference):
+    t = _tables(emu)
+    for b in range(1, 8):
+        for pre in range(32):
+            nin, nout, code = reference.custom_code(b, pre)
+            e = t.v2v[b][pre]
+            assert (e & 15, (e >> 4) & 15, e >> 8) == ((nin, nout, code) if nin else (0, 0, 0)), (b, pre)
+        for pre in range(9):
+            for nb in range(6):
+                fb, fn = reference.flush_entry(b, pre, nb)
+                assert (t.v2v_flush[b][pre][nb] & 15, t.v2v_flush[b][pre][nb] >> 4) == (fb, fn), (b, pre, nb)
+    for b in range(8, 17):
+        assert (t.gm[b], t.gl[b], t.gi[b]) == reference.golomb(b)
+    for i in range(16):
+        assert t.cut[i] == reference.lib.ref_tap_cutoff(i)
+
+
+def test_pick_bin_equals_reference(emu, reference):
+    for total in list(range(1, 64)) + [100, 249, 250, 251, 400, 498, 499, 500]:
+        for zero in range((total + 1) // 2 if total > 1 else 0, total + 1):
+            assert emu.lib.emu_pick_bin(zero, total) == reference.lib.icer_compute_bin(zero, total), (zero, total)
+
+
+def test_crc_shift_table(emu):
+    """x2n[k] = x^(2^k) mod P: advancing a CRC state over 2^(k-3) zero bytes must equal multiplying by it."""
+    import zlib
+    t = _tables(emu)
+
+    def mulmod(a, b):
+        p = 0
+        m = 1 << 31
+        while m:
+            if a & m:
+                p ^= b
+                if a & (m - 1) == 0:
+                    break
+            m >>= 1
+            b = (b >> 1) ^ 0xEDB88320 if b & 1 else b >> 1
+        return p
+    a, bb = b"hello ICER", bytes(range(200)) * 3
+    op = 1 << 31
+    n, k = len(bb), 3
+    while n:
+        if n & 1:
+            op = mulmod(t.x2n[k & 31], op)
+        n >>= 1
+        k += 1
+    assert mulmod(op, zlib.crc32(a)) ^ zlib.crc32(bb) == zlib.crc32(a + bb)
