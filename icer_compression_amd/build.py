@@ -20,6 +20,18 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_profiling_library(verbose: bool = False) -> str:
+    """Separate build with per-phase s_memtime counters (-DICER_PHASE_TIMERS) for tools/phase_profile.py."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = os.path.join(PKG, "libicer_hip_prof.so")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DICER_PHASE_TIMERS", "-o", out] + \
+        [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB

@@ -87,6 +87,7 @@ struct icerx_encoder {
     DevBuf<uint8_t> out;
     DevBuf<unsigned long long> sizes;
     DevBuf<int32_t> rcs;
+    DevBuf<uint64_t> prof;              // profiling build only (-DICER_PHASE_TIMERS): per-phase cycle sums
 
     bool timing = false;
     hipEvent_t ev[ICERX_NUM_STAGES + 1] = {};
@@ -181,7 +182,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64), 0, st,
                        reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                        e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes,
-                       e->unit_bits.p);
+                       e->unit_bits.p, e->prof.p);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
@@ -234,6 +235,11 @@ int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, in
     e->segments = segments; e->max_frames = max_frames;
     const int rc = build_plan(&e->plan, w, h, channels, stages, segments);
     if (rc != kOk) { delete e; return rc; }
+    // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
+    if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
+        const int v = atoi(bpp);
+        if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
+    }
 
     int count = 0;
     hipError_t he = hipGetDeviceCount(&count);
@@ -253,6 +259,10 @@ int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, in
         return ICER_FATAL_ERROR;
     }
     HIP_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
+#ifdef ICER_PHASE_TIMERS
+    if (e->prof.ensure(16)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
+    HIP_TRY(hipMemset(e->prof.p, 0, 16 * sizeof(uint64_t)));
+#endif
     for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     *out = e;
     return 0;
@@ -265,13 +275,15 @@ void icerx_encoder_destroy(icerx_encoder *e)
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
     e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->out.release();
-    e->sizes.release(); e->rcs.release();
+    e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
-int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
-                        size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+// `stride_may_shrink`: the host wrappers size the output by min(quota, slot area); when a slot-bound retry
+// enlarges the slot area they must re-allocate, signalled by *regrow (the batch is then re-run by them).
+static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                              size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream, bool *regrow)
 {
     if (!e || !d_frames || !d_out || !d_sizes || !d_rcs || n_frames < 1 || n_frames > e->max_frames) {
         set_error("icerx_encode_device: invalid arguments");
@@ -285,6 +297,7 @@ int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames
         if (upload_units(e, byte_quota, st)) return ICER_FATAL_ERROR;
         if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
         if (out_stride < byte_quota && out_stride < e->plan.slot_bytes) {
+            if (regrow) { *regrow = true; return 0; }
             set_error("icerx_encode_device: out_stride %zu smaller than the byte quota %zu", out_stride, byte_quota);
             return ICER_INVALID_INPUT;
         }
@@ -306,6 +319,12 @@ int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames
     return 0;
 }
 
+int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                        size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+{
+    return encode_device_impl(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream, nullptr);
+}
+
 int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, size_t byte_quota, uint8_t *out,
                       size_t out_stride, uint64_t *sizes, int32_t *rcs)
 {
@@ -319,11 +338,11 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
     for (;;) {   // the device stride depends on the slot bound, which a retry may enlarge
         const size_t ds = byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes;
         if (e->out.ensure((size_t)e->max_frames * (ds + 4))) return ICER_FATAL_ERROR;
-        const unsigned bpp = e->bits_per_pixel;
-        const int rc = icerx_encode_device(e, e->in.p, n_frames, byte_quota, e->out.p, ds + 4,
-                                           (uint64_t *)e->sizes.p, e->rcs.p, nullptr);
+        bool regrow = false;
+        const int rc = encode_device_impl(e, e->in.p, n_frames, byte_quota, e->out.p, ds + 4,
+                                          (uint64_t *)e->sizes.p, e->rcs.p, nullptr, &regrow);
         if (rc) return rc;
-        if (bpp == e->bits_per_pixel) {
+        if (!regrow) {
             HIP_TRY(hipMemcpy(sizes, e->sizes.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(rcs, e->rcs.p, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
             for (int f = 0; f < n_frames; f++)
@@ -371,6 +390,17 @@ int icerx_info(icerx_encoder *e, uint32_t *units_per_frame, uint32_t *slot_bits_
     return 0;
 }
 
+#ifdef ICER_PHASE_TIMERS
+// profiling build only: summed s_memtime cycles per coder phase over all units since the last reset
+int icerx_prof_read(icerx_encoder *e, uint64_t out[12], int reset)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(out, e->prof.p, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(e->prof.p, 0, 16 * sizeof(uint64_t)));
+    return 0;
+}
+#endif
+
 // ---- lib_icer drop-in entry points -------------------------------------------------------------
 static icerx_encoder *g_cached = nullptr;
 
@@ -398,10 +428,10 @@ static int compress_planes(uint16_t *const planes[], int channels, size_t w, siz
         if (upload_units(e, quota, nullptr)) return ICER_FATAL_ERROR;
         const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
         if (e->out.ensure(ds)) return ICER_FATAL_ERROR;
-        const unsigned bpp = e->bits_per_pixel;
-        const int r = icerx_encode_device(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, nullptr);
+        bool regrow = false;
+        const int r = encode_device_impl(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, nullptr, &regrow);
         if (r) return r;
-        if (bpp == e->bits_per_pixel) break;
+        if (!regrow) break;
     }
     HIP_TRY(hipMemcpy(&size, e->sizes.p, 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&rc, e->rcs.p, 4, hipMemcpyDeviceToHost));

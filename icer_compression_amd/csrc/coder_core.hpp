@@ -11,15 +11,45 @@
 //   phase 2  (64 lanes)  adaptive counts seen by every event: ballot + v_mbcnt ranks per context,
 //                        including the single rescale a context can cross inside a chunk
 //   phase 3  (64 lanes)  probability fold + bin selection (16 compare/accumulate steps)
-//   phase 4              interleaved entropy coder.  The 2048-word ring, the allocation-order
-//                        output rule and the forced flush of the oldest open word (E5) make this
-//                        a sequential state machine; here it is executed exactly, in event order.
+//   phase 4              interleaved entropy coder.  Code words are delimited per bin, allocated to
+//                        the 2048-word ring in order of their first event and emitted in that order.
+//                        Fast path (the ring cannot fill up inside this chunk): Golomb bins 8..16 in
+//                        closed form on ballot masks (run length since the bin's last one, mod m),
+//                        bins 1..7 by one walker lane per bin over that bin's events, ring slots from
+//                        a prefix count of word-start flags, finished words drained 64 at a time
+//                        with a prefix sum of their lengths.  Exact path (ring nearly full, so the
+//                        forced flush of the oldest open word, E5, may trigger; also the end-of-unit
+//                        flush): one lane replays the reference state machine event by event.
 //   drain                finished words are packed LSB-first into an LDS bit stage and whole
 //                        32-bit words are written to the unit's payload slot in HBM (coalesced).
 // Written with the SPMD macros of wave.hpp (see there for the tests-only CPU build).
 #pragma once
 #include "icer_tables.hpp"
 #include "wave.hpp"
+
+#ifdef ICER_WAVE_EMU
+extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path chunks, [1] exact-path chunks
+#define ICER_EMU_COUNT(i) (g_emu_chunks[i]++)
+#else
+#define ICER_EMU_COUNT(i)
+#endif
+
+// Optional per-phase cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
+// -DICER_PHASE_TIMERS (a separate profiling build of the library, never the shipped one).
+#if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
+#define ICER_NUM_TIMERS 12
+#define ICER_TIMERS_DECL uint64_t tacc_[ICER_NUM_TIMERS] = {}; uint64_t tlast_ = __builtin_amdgcn_s_memtime();
+#define ICER_TIMER_PARAMS , uint64_t *tacc_, uint64_t &tlast_
+#define ICER_TIMER_PASS , tacc_, tlast_
+#define ICER_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc_[k] += t_ - tlast_; tlast_ = t_; }
+#define ICER_TIMERS_STORE(dst) { if (dst) { _Pragma("unroll") for (int i_ = 0; i_ < ICER_NUM_TIMERS; i_++) if (lane == 0) atomicAdd((unsigned long long *)&(dst)[i_], (unsigned long long)tacc_[i_]); } }
+#else
+#define ICER_TIMERS_DECL
+#define ICER_TIMER_PARAMS
+#define ICER_TIMER_PASS
+#define ICER_TICK(k)
+#define ICER_TIMERS_STORE(dst)
+#endif
 
 namespace icer {
 
@@ -36,6 +66,10 @@ struct CoderShared {
     CoderTables tab;
     uint32_t crc_tab[256];
     uint8_t ev[128];            // events of the current chunk in coding order: 0x80 | bit << 5 | bin
+    uint8_t evflag[128];        // bins 1..7, written by the walker lanes: bit0 word starts here, bit1 word ends here
+    uint8_t evstart[128];       // position of the start event of the word that ends here (255: carried-in word)
+    uint16_t evword[128];       // finished ring word of an end event
+    uint8_t bin_open_pos[32];   // per bin after the chunk: 255 unchanged, 254 closed, else start position of its open word
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
@@ -51,6 +85,7 @@ struct UnitArgs {
     int subband, lsb;
     uint32_t *out_words;        // payload slot (4-byte aligned)
     uint32_t cap_words;         // slot capacity in 32-bit words
+    uint64_t *timers;           // profiling build only (may be null)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -79,20 +114,13 @@ ICER_DEV void seq_drain(CoderShared &s)
     s.used = used;
 }
 
-ICER_DEV uint32_t reverse_low_bits(uint32_t v, uint32_t n)   // icer.h:601-610
-{
-    uint32_t r = 0;
-    for (uint32_t k = 0; k < n; k++) { r = (r << 1) | (v & 1u); v >>= 1; }
-    return r;
-}
-
 // Golomb codeword for a run of k zeros ended by a one (icer_encoding.c:73-80)
 ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
 {
     const uint32_t gi = t.gi[bin];
     const uint32_t code = k + (k >= gi ? gi : 0u);
     const uint32_t n = t.gl[bin] + (k >= gi ? 1u : 0u);
-    return kWordDone | (n << 11) | (reverse_low_bits(code, n) & 0x3FFu);
+    return kWordDone | (n << 11) | ((brev32(code) >> (32u - n)) & 0x3FFu);
 }
 
 // icer_flush_encode, icer_encoding.c:141-189: force-complete the oldest word, then drain
@@ -269,6 +297,240 @@ ICER_DEV bool flush_stage(CoderShared &s, const UnitArgs &a, bool final_partial)
     return fits && (bp >> 3) < a.cap_words * 4u;
 }
 
+// ------------------------------------------------------------------------------------------
+// phase 4, fast path: the whole chunk's events coded by 64 lanes
+// ------------------------------------------------------------------------------------------
+// Event coordinates: lane L carries the magnitude-bit event at position 2L and the sign event at
+// position 2L+1 (coding order = position order).  A set of events is a pair of 64-bit lane masks
+// (A1 for magnitude events, A2 for sign events).
+ICER_DEV uint64_t below64(uint32_t x) { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); }
+// events of the set strictly before position pos
+ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
+{
+    return (uint32_t)(popc64(A1 & below64((pos + 1u) >> 1)) + popc64(A2 & below64(pos >> 1)));
+}
+// latest position <= pos in the set, -1 if none
+ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
+{
+    const uint64_t c1 = A1 & below64((pos >> 1) + 1u), c2 = A2 & below64((pos + 1u) >> 1);
+    const int k1 = c1 ? 2 * (63 - clz64(c1)) : -1, k2 = c2 ? 2 * (63 - clz64(c2)) + 1 : -1;
+    return k1 > k2 ? k1 : k2;
+}
+ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u ? -1 : last_le(A1, A2, pos - 1u); }
+
+// one Golomb-bin event at position POS with bit BIT (lane-local); Z*/O* = zero/one events of the bin
+#define ICER_GOLOMB_EVENT(POS, BIT, FL, WD)                                                           \
+    {                                                                                                 \
+        const uint32_t zb_ = cnt_lt(Z1, Z2, (POS));                                                   \
+        const int lo_ = last_lt(O1, O2, (POS));                                                       \
+        const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : k_in + zb_;              \
+        const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                             \
+        FL = (kb_ == 0u ? 1u : 0u) | (((BIT) || kb_ + 1u == m) ? 2u : 0u);                            \
+        WD = (BIT) ? golomb_word(s.tab, b, kb_) : (kWordDone | (1u << 11) | 1u);                      \
+    }
+
+ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_t, ev2) ICER_TIMER_PARAMS)
+{
+    DECL_LANE;
+    LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
+    LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
+    LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
+    LANEVAR(uint64_t, wm1); LANEVAR(uint64_t, wm2); LANEVAR(uint64_t, wv1); LANEVAR(uint64_t, wv2);   // walker masks
+
+    FOR_LANES
+    {
+        LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
+        LV(wm1) = 0; LV(wm2) = 0; LV(wv1) = 0; LV(wv2) = 0;
+        if (lane < kNumBins) s.bin_open_pos[lane] = 255;
+        // bin 0 (uncoded): every event is a complete one-bit word (E3)
+        if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
+        if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
+    }
+    WAVE_SYNC();
+
+    // ---- Golomb bins 8..16: run length since the bin's previous one-event, modulo m ------------
+    for (int b = 8; b <= 16; b++) {
+        const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
+        const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
+        if (!(M1 | M2)) continue;
+        const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
+        const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
+        const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
+        const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = s.bin_acc[b];
+        FOR_LANES
+        {
+            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
+            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
+        }
+        const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
+        const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
+        FOR_LANES
+        {
+            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 2u)) {
+                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane);
+                LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+            }
+            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 2u)) {
+                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane + 1u);
+                LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
+            }
+        }
+        // bin state after the chunk (wave-uniform)
+        const int lastone = last_le(O1, O2, 127u);
+        const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
+        const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : k_in + ztot;
+        const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
+        const int laststart = last_le(SB1, SB2, 127u);
+        FOR_LANES
+        {
+            if (lane == 0) {
+                s.bin_acc[b] = k_out;
+                s.bin_open_pos[b] = (uint8_t)(k_out ? (laststart >= 0 ? laststart : 255) : 254);
+            }
+        }
+    }
+
+    ICER_TICK(4)
+    // ---- bins 1..7 (variable-to-variable codes): lane b walks the events of bin b ---------------
+    bool any_v2v = false;
+    for (int b = 1; b <= 7; b++) {
+        const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
+        const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
+        if (!(M1 | M2)) continue;
+        any_v2v = true;
+        const uint64_t V1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
+        const uint64_t V2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
+        FOR_LANES
+        {
+            if (lane == b) { LV(wm1) = M1; LV(wm2) = M2; LV(wv1) = V1; LV(wv2) = V2; }
+        }
+    }
+    if (any_v2v) {
+        FOR_LANES
+        {
+            if (lane >= 1 && lane <= 7 && (LV(wm1) | LV(wm2))) {
+                const int b = lane;
+                uint64_t m1 = LV(wm1), m2 = LV(wm2);
+                const uint64_t v1 = LV(wv1), v2 = LV(wv2);
+                uint32_t acc = s.bin_acc[b], nin = s.bin_nin[b];
+                uint32_t cur_start = 255;                       // an unfinished word carried in from earlier chunks
+                while (m1 | m2) {
+                    const int l1 = ffs64(m1), l2 = ffs64(m2);
+                    const bool first = l1 <= l2;                // magnitude event of lane l precedes its sign event
+                    const uint32_t pos = first ? 2u * (uint32_t)l1 : 2u * (uint32_t)l2 + 1u;
+                    const uint32_t bit = first ? (uint32_t)((v1 >> l1) & 1ull) : (uint32_t)((v2 >> l2) & 1ull);
+                    if (first) m1 &= m1 - 1ull; else m2 &= m2 - 1ull;
+                    uint32_t flag = 0;
+                    if (nin == 0) { flag = 1; cur_start = pos; }
+                    acc |= bit << nin;
+                    nin++;
+                    const uint32_t e = s.tab.v2v[b][acc & 31u];
+                    if ((e & 15u) == nin) {
+                        flag |= 2u;
+                        s.evword[pos] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
+                        s.evstart[pos] = (uint8_t)cur_start;
+                        acc = 0;
+                        nin = 0;
+                    }
+                    s.evflag[pos] = (uint8_t)flag;
+                }
+                s.bin_acc[b] = acc;
+                s.bin_nin[b] = nin;
+                s.bin_open_pos[b] = (uint8_t)(nin ? cur_start : 254u);
+            }
+        }
+        WAVE_SYNC();
+        FOR_LANES
+        {
+            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
+            if (b1 >= 0x81u && b1 <= 0x87u) {
+                LV(fl1) = s.evflag[2 * lane];
+                if (LV(fl1) & 2u) { LV(wd1) = s.evword[2 * lane]; LV(sp1) = s.evstart[2 * lane]; }
+            }
+            if (b2 >= 0x81u && b2 <= 0x87u) {
+                LV(fl2) = s.evflag[2 * lane + 1];
+                if (LV(fl2) & 2u) { LV(wd2) = s.evword[2 * lane + 1]; LV(sp2) = s.evstart[2 * lane + 1]; }
+            }
+        }
+    }
+
+    ICER_TICK(5)
+    // ---- ring slots in allocation order = order of the words' first events (E2) ------------------
+    const uint64_t S1 = BALLOT(LV(fl1) & 1u), S2 = BALLOT(LV(fl2) & 1u);
+    const uint32_t used = s.used, tail = s.head + used;
+    FOR_LANES
+    {
+        if (LV(fl1) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane)) & (kRingWords - 1)] = (uint16_t)(LV(ev1) & 31u);
+        if (LV(fl2) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane + 1u)) & (kRingWords - 1)] = (uint16_t)(LV(ev2) & 31u);
+    }
+    FOR_LANES
+    {
+        if (LV(fl1) & 2u) {
+            const uint32_t slot = LV(sp1) == 255u ? (uint32_t)s.bin_slot[LV(ev1) & 31u] : (tail + cnt_lt(S1, S2, LV(sp1)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd1);
+        }
+        if (LV(fl2) & 2u) {
+            const uint32_t slot = LV(sp2) == 255u ? (uint32_t)s.bin_slot[LV(ev2) & 31u] : (tail + cnt_lt(S1, S2, LV(sp2)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd2);
+        }
+    }
+    WAVE_SYNC();
+    FOR_LANES
+    {
+        if (lane < kNumBins) {
+            const uint32_t op = s.bin_open_pos[lane];
+            if (op == 254u) s.bin_slot[lane] = -1;
+            else if (op < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, op)) & (kRingWords - 1));
+        }
+        if (lane == 0) s.used = used + (uint32_t)(popc64(S1) + popc64(S2));
+    }
+    WAVE_SYNC();
+    ICER_TICK(6)
+}
+
+// drain finished words from the head of the ring, 64 per round: lengths -> prefix sum -> bit offsets,
+// code bits OR-ed into the LDS bit stage (icer_popbuf_while_avail, icer_encoding.c:114-139)
+ICER_DEV void wave_drain(CoderShared &s)
+{
+    DECL_LANE;
+    uint32_t head = s.head, used = s.used, bitpos = s.bitpos;
+    for (;;) {
+        LANEVAR(uint32_t, w); LANEVAR(uint32_t, len); LANEVAR(uint32_t, off);
+        FOR_LANES
+        {
+            LV(w) = (uint32_t)lane < used ? s.ring[(head + (uint32_t)lane) & (kRingWords - 1)] : 0u;
+        }
+        const uint64_t done = BALLOT((LV(w) & kWordDone) != 0u);
+        const uint32_t n = (uint32_t)ffs64(~done);               // leading finished words
+        if (n == 0) break;
+        FOR_LANES
+        {
+            LV(len) = (uint32_t)lane < n ? ((LV(w) >> 11) & 15u) : 0u;
+        }
+        uint32_t total;
+        WAVE_EXCL_SCAN(uint32_t, off, len, total);
+        FOR_LANES
+        {
+            if (LV(len)) {
+                const uint32_t p = bitpos + LV(off), wi = (p >> 5) & (kStageWords - 1), sh = p & 31u;
+                const uint32_t code = LV(w) & 0x3FFu;
+                LDS_OR(s.stage[wi], code << sh);
+                if (sh + LV(len) > 32u) LDS_OR(s.stage[(wi + 1) & (kStageWords - 1)], code >> (32u - sh));
+            }
+        }
+        bitpos += total;
+        head = (head + n) & (kRingWords - 1);
+        used -= n;
+        if (n < 64u) break;
+    }
+    WAVE_SYNC();
+    FOR_LANES
+    {
+        if (lane == 0) { s.head = head; s.used = used; s.bitpos = bitpos; }
+    }
+    WAVE_SYNC();
+}
+
 ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
 {
     DECL_LANE;
@@ -284,6 +546,7 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
 #pragma unroll
     for (int c = 0; c < kNumContexts; c++) { zero[c] = 2; total[c] = 4; }   // icer_context_modeller.c:607-613
 
+    ICER_TIMERS_DECL
     const uint32_t npix = a.w * a.h;
     const uint32_t lsb = (uint32_t)a.lsb;
     const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
@@ -348,13 +611,16 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
             LV(z2) = 0; LV(t2) = 0;
         }
 
+        ICER_TICK(0)
         // ---- phase 2: adaptive counts per event (C5) --------------------------------------
 #pragma unroll
         for (int c = 0; c <= 11; c++) ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == (uint32_t)c, LV(bit1) == 0u, z1, t1)
 #pragma unroll
         for (int c = 12; c <= 16; c++) ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == (uint32_t)c, LV(bit2) == 0u, z2, t2)
 
+        ICER_TICK(1)
         // ---- phase 3: fold + bin (E1) -----------------------------------------------------
+        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);           // 0x80 | bit << 5 | bin, 0 = no event
         FOR_LANES
         {
             uint32_t e1 = 0, e2 = 0;
@@ -368,26 +634,47 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
                 if (z < (t >> 1)) { z = t - z; b ^= 1u; }
                 e2 = 0x80u | (b << 5) | pick_bin(s.tab.cut, z, t);
             }
-            s.ev[2 * lane] = (uint8_t)e1;
-            s.ev[2 * lane + 1] = (uint8_t)e2;
+            LV(ev1) = e1;
+            LV(ev2) = e2;
         }
-        WAVE_SYNC();
 
-        // ---- phase 4: interleaved entropy coder, exact event order -------------------------
-        FOR_LANES
-        {
-            if (lane == 0) {
-                for (int e = 0; e < 128; e++) {
-                    const uint32_t v = s.ev[e];
-                    if (v & 0x80u) seq_put(s, (int)(v & 31u), (v >> 5) & 1u);
+        ICER_TICK(2)
+        // ---- phase 4: interleaved entropy coder ------------------------------------------
+        const uint32_t nev = (uint32_t)(popc64(BALLOT(LV(ev1) != 0u)) + popc64(BALLOT(LV(ev2) != 0u)));
+        if (s.used + nev <= (uint32_t)kRingWords) {
+            // every event could open at most one word, so the ring cannot fill up in this chunk:
+            // no forced flush (E5) is possible and word boundaries depend on each bin alone
+            fast_chunk(s, ev1, ev2 ICER_TIMER_PASS);
+            wave_drain(s);
+            ICER_TICK(7)
+            ICER_EMU_COUNT(0);
+        } else {
+            ICER_EMU_COUNT(1);
+            // ring nearly full: replay the reference state machine exactly, event by event
+            FOR_LANES
+            {
+                s.ev[2 * lane] = (uint8_t)LV(ev1);
+                s.ev[2 * lane + 1] = (uint8_t)LV(ev2);
+            }
+            WAVE_SYNC();
+            FOR_LANES
+            {
+                if (lane == 0) {
+                    for (int e = 0; e < 128; e++) {
+                        const uint32_t v = s.ev[e];
+                        if (v & 0x80u) seq_put(s, (int)(v & 31u), (v >> 5) & 1u);
+                    }
                 }
             }
+            WAVE_SYNC();
+            ICER_TICK(8)
         }
-        WAVE_SYNC();
         ok = flush_stage(s, a, false);
+        ICER_TICK(9)
     }
 
     if (!ok) return kUnitTooBig;
+    ICER_TICK(10)
     // end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455)
     FOR_LANES
     {
@@ -396,6 +683,8 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
     }
     WAVE_SYNC();
     ok = flush_stage(s, a, true);
+    ICER_TICK(11)
+    ICER_TIMERS_STORE(a.timers)
     return ok ? s.bitpos : kUnitTooBig;
 }
 

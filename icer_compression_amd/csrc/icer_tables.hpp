@@ -47,6 +47,8 @@ struct CoderTables {
     uint8_t v2v_flush[8][9][6];
     // bins 8..16: Golomb m, l = ceil(log2 m), i = 2^l - m
     uint16_t gm[17], gl[17], gi[17];
+    // floor(2^20 / m) + 1: z / m == (z * ginv) >> 20 for every run length z < 2048 (checked at build time)
+    uint32_t ginv[17];
     // probability cut-offs x65536 separating bin b-1 from bin b, b = 1..16   (icer_config.c:69-87)
     uint32_t cut[16];
     // x^(2^k) mod P for the CRC-32 polynomial (reflected), k = 0..31: lets a wave combine piece CRCs
@@ -92,6 +94,9 @@ inline void build_coder_tables(CoderTables *t)
         t->gm[b] = m[b];
         t->gl[b] = (uint16_t)l;
         t->gi[b] = (uint16_t)((1u << l) - m[b]);
+        t->ginv[b] = (1u << 20) / m[b] + 1;
+        for (uint32_t z = 0; z < 2048; z++)
+            if (((z * t->ginv[b]) >> 20) != z / m[b]) t->ginv[b] = 0;     // would be caught by tests/test_tables.py
     }
     static const uint32_t cut[16] = {35298, 37345, 40503, 43591, 47480, 50133, 53645, 55902,
                                      57755, 58894, 60437, 62267, 63613, 64557, 65134, 65392};

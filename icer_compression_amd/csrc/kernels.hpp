@@ -106,7 +106,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots, size_t slot_frame_stride,
-                  uint32_t *__restrict__ unit_bits)
+                  uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers)
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
@@ -131,6 +131,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.subband = (int)u.subband; a.lsb = (int)u.lsb;
     a.out_words = slot_words + kHeaderBytes / 4;
     a.cap_words = u.cap_words;
+    a.timers = timers;
     const uint32_t bits = code_unit_wave(s, a);
 
     if (bits != kUnitTooBig) {

@@ -34,6 +34,10 @@ static inline int mbcnt64(uint64_t m, int lane) { return __builtin_popcountll(m 
 static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }      // index of lowest set bit
 static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+static inline int clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
+#define LANEARG(T, name) T (&name)[64]
+#define LDS_OR(REF, VAL) ((REF) |= (VAL))
 // cross-lane reductions / scans over a lane variable
 #define WAVE_XOR(DST, X) { DST = 0; for (int l_ = 0; l_ < 64; ++l_) DST ^= X[l_]; }
 #define WAVE_EXCL_SCAN(T, OUT, IN, TOTAL) { T run_ = 0; for (int l_ = 0; l_ < 64; ++l_) { const T v_ = IN[l_]; OUT[l_] = run_; run_ += v_; } TOTAL = run_; }
@@ -56,6 +60,10 @@ static __device__ __forceinline__ int mbcnt64(uint64_t m, int /*lane*/)
 static __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 static __device__ __forceinline__ int ffs64(uint64_t m) { return m ? (int)__builtin_ctzll(m) : 64; }
 static __device__ __forceinline__ int clz32(uint32_t v) { return v ? (int)__builtin_clz(v) : 32; }
+static __device__ __forceinline__ int clz64(uint64_t v) { return v ? (int)__builtin_clzll(v) : 64; }
+static __device__ __forceinline__ uint32_t brev32(uint32_t v) { return __brev(v); }
+#define LANEARG(T, name) T name
+#define LDS_OR(REF, VAL) atomicOr(&(REF), (VAL))
 #define WAVE_XOR(DST, X) { uint32_t t_ = (X); for (int o_ = 32; o_ > 0; o_ >>= 1) t_ ^= (uint32_t)__shfl_xor((int)t_, o_); DST = t_; }
 #define WAVE_EXCL_SCAN(T, OUT, IN, TOTAL) { const T v_ = (IN); T s_ = v_; \
     for (int o_ = 1; o_ < 64; o_ <<= 1) { const T u_ = (T)__shfl_up(s_, o_); if (lane >= o_) s_ += u_; } \

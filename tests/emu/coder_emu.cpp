@@ -14,6 +14,8 @@
 using namespace icer;
 
 static CoderShared g_sh;
+unsigned long long g_emu_chunks[2] = {0, 0};
+extern "C" void emu_chunk_stats(unsigned long long *out, int reset) { out[0] = g_emu_chunks[0]; out[1] = g_emu_chunks[1]; if (reset) g_emu_chunks[0] = g_emu_chunks[1] = 0; }
 
 extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
                               uint8_t *out, size_t cap_bytes)

@@ -7,7 +7,7 @@ import numpy as np
 class CoderTables(C.Structure):     # mirrors icer::CoderTables
     _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
                 ("gm", C.c_uint16 * 17), ("gl", C.c_uint16 * 17), ("gi", C.c_uint16 * 17),
-                ("cut", C.c_uint32 * 16), ("x2n", C.c_uint32 * 32)]
+                ("ginv", C.c_uint32 * 17), ("cut", C.c_uint32 * 16), ("x2n", C.c_uint32 * 32)]
 
 
 def _tables(emu):
@@ -31,6 +31,7 @@ def test_tables_equal_reference(emu, reference):
                 assert (t.v2v_flush[b][pre][nb] & 15, t.v2v_flush[b][pre][nb] >> 4) == (fb, fn), (b, pre, nb)
     for b in range(8, 17):
         assert (t.gm[b], t.gl[b], t.gi[b]) == reference.golomb(b)
+        assert all(((z * t.ginv[b]) >> 20) == z // t.gm[b] for z in range(2048))     # exact reciprocal
     for i in range(16):
         assert t.cut[i] == reference.lib.ref_tap_cutoff(i)
 
