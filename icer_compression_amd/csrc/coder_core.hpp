@@ -68,7 +68,7 @@ struct CoderShared {
     uint8_t ev[128];            // events of the current chunk in coding order: 0x80 | bit << 5 | bin
     uint8_t evflag[128];        // bins 1..7, written by the walker lanes: bit0 word starts here, bit1 word ends here
     uint8_t evstart[128];       // position of the start event of the word that ends here (255: carried-in word)
-    uint16_t evword[128];       // finished ring word of an end event
+    uint8_t evacc[128];         // bins 1..7: completed input value of the word that ends here (code looked up by the event lane)
     uint8_t bin_open_pos[32];   // per bin after the chunk: 255 unchanged, 254 closed, else start position of its open word
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value
@@ -76,6 +76,7 @@ struct CoderShared {
     uint32_t head, used;        // ring state
     uint32_t bitpos;            // payload bits produced so far
     uint32_t flushed_words;     // payload words already written to HBM
+    uint32_t resume;            // exact path: event index at which the single-lane replay paused
 };
 
 struct UnitArgs {
@@ -89,31 +90,9 @@ struct UnitArgs {
 };
 
 // ------------------------------------------------------------------------------------------
-// sequential coder steps (executed by a single lane; exact restatement of E1-E6)
+// sequential coder steps (executed by a single lane; exact restatement of E1-E6 except that
+// draining is left to wave_drain)
 // ------------------------------------------------------------------------------------------
-ICER_DEV void seq_emit(CoderShared &s, uint32_t code, uint32_t n)
-{
-    const uint32_t bp = s.bitpos, wi = (bp >> 5) & (kStageWords - 1), sh = bp & 31;
-    s.stage[wi] |= code << sh;
-    if (sh + n > 32) s.stage[(wi + 1) & (kStageWords - 1)] |= code >> (32 - sh);
-    s.bitpos = bp + n;
-}
-
-// icer_popbuf_while_avail, icer_encoding.c:114-139
-ICER_DEV void seq_drain(CoderShared &s)
-{
-    uint32_t head = s.head, used = s.used;
-    while (used > 0) {
-        const uint32_t w = s.ring[head];
-        if (!(w & kWordDone)) break;
-        seq_emit(s, w & 0x3FFu, (w >> 11) & 15u);
-        head = (head + 1) & (kRingWords - 1);
-        used--;
-    }
-    s.head = head;
-    s.used = used;
-}
-
 // Golomb codeword for a run of k zeros ended by a one (icer_encoding.c:73-80)
 ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
 {
@@ -123,8 +102,9 @@ ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
     return kWordDone | (n << 11) | ((brev32(code) >> (32u - n)) & 0x3FFu);
 }
 
-// icer_flush_encode, icer_encoding.c:141-189: force-complete the oldest word, then drain
-ICER_DEV void seq_flush_head(CoderShared &s)
+// first half of icer_flush_encode (icer_encoding.c:141-189): force-complete the oldest word.
+// The caller drains afterwards (wave_drain).
+ICER_DEV void seq_complete_head(CoderShared &s)
 {
     const uint32_t w = s.ring[s.head];
     if (!(w & kWordDone)) {
@@ -148,15 +128,15 @@ ICER_DEV void seq_flush_head(CoderShared &s)
             s.bin_slot[bin] = -1;
         }
     }
-    seq_drain(s);
 }
 
-// icer_encode_bit after bin selection, icer_encoding.c:59-112
+// icer_encode_bit after bin selection (icer_encoding.c:59-112), without the drain that follows every
+// event in the reference: finished words are only *observable* through `used` when a new word is
+// allocated with the ring apparently full, which seq_run checks for (it then pauses for a drain).
 ICER_DEV void seq_put(CoderShared &s, int bin, uint32_t bit)
 {
     int slot = s.bin_slot[bin];
     if (slot < 0) {
-        if (s.used == (uint32_t)kRingWords) seq_flush_head(s);      // E5: ring full
         slot = (int)((s.head + s.used) & (kRingWords - 1));
         s.used++;
         s.ring[slot] = (uint16_t)bin;
@@ -192,7 +172,20 @@ ICER_DEV void seq_put(CoderShared &s, int bin, uint32_t bit)
         s.ring[slot] = (uint16_t)(kWordDone | (1u << 11) | bit);
         s.bin_slot[0] = -1;
     }
-    seq_drain(s);
+}
+
+// replay events [e, 128) of s.ev in order; stops BEFORE an event that needs a new word while the ring
+// holds 2048 (possibly already finished) words, returning its index; 128 when the chunk is done
+ICER_DEV uint32_t seq_run(CoderShared &s, uint32_t e)
+{
+    for (; e < 128u; e++) {
+        const uint32_t v = s.ev[e];
+        if (!(v & 0x80u)) continue;
+        const int bin = (int)(v & 31u);
+        if (s.bin_slot[bin] < 0 && s.used == (uint32_t)kRingWords) return e;
+        seq_put(s, bin, (v >> 5) & 1u);
+    }
+    return 128u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,7 +322,8 @@ ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u 
         WD = (BIT) ? golomb_word(s.tab, b, kb_) : (kWordDone | (1u << 11) | 1u);                      \
     }
 
-ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_t, ev2) ICER_TIMER_PARAMS)
+ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_t, ev2), LANEARG(uint32_t, term1),
+                         LANEARG(uint32_t, term2), LANEARG(uint32_t, term3), LANEARG(uint32_t, term4), LANEARG(uint32_t, term5) ICER_TIMER_PARAMS)
 {
     DECL_LANE;
     LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
@@ -424,10 +418,11 @@ ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_
                     if (nin == 0) { flag = 1; cur_start = pos; }
                     acc |= bit << nin;
                     nin++;
-                    const uint32_t e = s.tab.v2v[b][acc & 31u];
-                    if ((e & 15u) == nin) {
+                    // complete iff acc is a code word of exactly nin input bits (masks live in registers)
+                    const uint32_t tm = nin == 1 ? LV(term1) : nin == 2 ? LV(term2) : nin == 3 ? LV(term3) : nin == 4 ? LV(term4) : LV(term5);
+                    if ((tm >> (acc & 31u)) & 1u) {
                         flag |= 2u;
-                        s.evword[pos] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
+                        s.evacc[pos] = (uint8_t)acc;
                         s.evstart[pos] = (uint8_t)cur_start;
                         acc = 0;
                         nin = 0;
@@ -445,11 +440,19 @@ ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_
             const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
             if (b1 >= 0x81u && b1 <= 0x87u) {
                 LV(fl1) = s.evflag[2 * lane];
-                if (LV(fl1) & 2u) { LV(wd1) = s.evword[2 * lane]; LV(sp1) = s.evstart[2 * lane]; }
+                if (LV(fl1) & 2u) {
+                    const uint32_t e = s.tab.v2v[b1 & 31u][s.evacc[2 * lane] & 31u];
+                    LV(wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
+                    LV(sp1) = s.evstart[2 * lane];
+                }
             }
             if (b2 >= 0x81u && b2 <= 0x87u) {
                 LV(fl2) = s.evflag[2 * lane + 1];
-                if (LV(fl2) & 2u) { LV(wd2) = s.evword[2 * lane + 1]; LV(sp2) = s.evstart[2 * lane + 1]; }
+                if (LV(fl2) & 2u) {
+                    const uint32_t e = s.tab.v2v[b2 & 31u][s.evacc[2 * lane + 1] & 31u];
+                    LV(wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
+                    LV(sp2) = s.evstart[2 * lane + 1];
+                }
             }
         }
     }
@@ -547,30 +550,62 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
     for (int c = 0; c < kNumContexts; c++) { zero[c] = 2; total[c] = 4; }   // icer_context_modeller.c:607-613
 
     ICER_TIMERS_DECL
+    // lanes 1..7 walk bins 1..7: keep that bin's code-word termination masks in registers
+    LANEVAR(uint32_t, term1); LANEVAR(uint32_t, term2); LANEVAR(uint32_t, term3); LANEVAR(uint32_t, term4); LANEVAR(uint32_t, term5);
+    FOR_LANES
+    {
+        const int wb = lane & 7;
+        LV(term1) = s.tab.v2v_term[wb][1]; LV(term2) = s.tab.v2v_term[wb][2]; LV(term3) = s.tab.v2v_term[wb][3];
+        LV(term4) = s.tab.v2v_term[wb][4]; LV(term5) = s.tab.v2v_term[wb][5];
+    }
     const uint32_t npix = a.w * a.h;
     const uint32_t lsb = (uint32_t)a.lsb;
     const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
     bool ok = true;
 
+    // coefficient window of the NEXT chunk is fetched while the current one is coded (the loads stay in
+    // flight across the whole chunk: WAVE_SYNC does not drain vmcnt)
+    LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
+    LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
+#define ICER_FETCH_WINDOW(BASE)                                                                        \
+    FOR_LANES                                                                                          \
+    {                                                                                                  \
+        const uint32_t p_ = (BASE) + (uint32_t)lane;                                                   \
+        const uint32_t pp_ = p_ < npix ? p_ : 0u;                                                      \
+        const uint32_t r_ = pp_ / a.w, c_ = pp_ - r_ * a.w;                                            \
+        const uint16_t *q_ = a.seg + (size_t)r_ * a.stride + c_;                                       \
+        const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < a.w, hasN_ = r_ > 0, hasS_ = r_ + 1 < a.h;          \
+        LV(nC) = q_[0];                                                                                \
+        LV(nW) = hasW_ ? q_[-1] : 0u;                                                                  \
+        LV(nE) = hasE_ ? q_[1] : 0u;                                                                   \
+        LV(nN) = hasN_ ? *(q_ - a.stride) : 0u;                                                        \
+        LV(nS) = hasS_ ? *(q_ + a.stride) : 0u;                                                        \
+        LV(nNW) = (hasN_ && hasW_) ? *(q_ - a.stride - 1) : 0u;                                        \
+        LV(nNE) = (hasN_ && hasE_) ? *(q_ - a.stride + 1) : 0u;                                        \
+        LV(nSW) = (hasS_ && hasW_) ? *(q_ + a.stride - 1) : 0u;                                        \
+        LV(nSE) = (hasS_ && hasE_) ? *(q_ + a.stride + 1) : 0u;                                        \
+    }
+    if (npix) ICER_FETCH_WINDOW(0u)
+
     for (uint32_t base = 0; base < npix && ok; base += 64) {
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
         LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
+        LANEVAR(uint32_t, cC); LANEVAR(uint32_t, cW); LANEVAR(uint32_t, cE); LANEVAR(uint32_t, cN); LANEVAR(uint32_t, cS);
+        LANEVAR(uint32_t, cNW); LANEVAR(uint32_t, cNE); LANEVAR(uint32_t, cSW); LANEVAR(uint32_t, cSE);
+        FOR_LANES
+        {
+            LV(cC) = LV(nC); LV(cW) = LV(nW); LV(cE) = LV(nE); LV(cN) = LV(nN); LV(cS) = LV(nS);
+            LV(cNW) = LV(nNW); LV(cNE) = LV(nNE); LV(cSW) = LV(nSW); LV(cSE) = LV(nSE);
+        }
+        if (base + 64u < npix) ICER_FETCH_WINDOW(base + 64u)
 
         // ---- phase 1: context formation (C1-C6) -------------------------------------------
         FOR_LANES
         {
-            const uint32_t p = base + (uint32_t)lane;
-            const bool valid = p < npix;
-            const uint32_t pp = valid ? p : 0u;
-            const uint32_t r = pp / a.w, c = pp - r * a.w;
-            const uint16_t *q = a.seg + (size_t)r * a.stride + c;
-            const bool hasW = c > 0, hasE = c + 1 < a.w, hasN = r > 0, hasS = r + 1 < a.h;
-            const uint32_t x = q[0];
-            const uint32_t xW = hasW ? q[-1] : 0u, xE = hasE ? q[1] : 0u;
-            const uint32_t xN = hasN ? *(q - a.stride) : 0u, xS = hasS ? *(q + a.stride) : 0u;
-            const uint32_t xNW = (hasN && hasW) ? *(q - a.stride - 1) : 0u, xNE = (hasN && hasE) ? *(q - a.stride + 1) : 0u;
-            const uint32_t xSW = (hasS && hasW) ? *(q + a.stride - 1) : 0u, xSE = (hasS && hasE) ? *(q + a.stride + 1) : 0u;
+            const bool valid = base + (uint32_t)lane < npix;
+            const uint32_t x = LV(cC), xW = LV(cW), xE = LV(cE), xN = LV(cN), xS = LV(cS);
+            const uint32_t xNW = LV(cNW), xNE = LV(cNE), xSW = LV(cSW), xSE = LV(cSE);
 
             const uint32_t mag = x & 0x7FFFu;
             const int msb = 31 - clz32(mag | 1u);
@@ -644,7 +679,7 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
         if (s.used + nev <= (uint32_t)kRingWords) {
             // every event could open at most one word, so the ring cannot fill up in this chunk:
             // no forced flush (E5) is possible and word boundaries depend on each bin alone
-            fast_chunk(s, ev1, ev2 ICER_TIMER_PASS);
+            fast_chunk(s, ev1, ev2, term1, term2, term3, term4, term5 ICER_TIMER_PASS);
             wave_drain(s);
             ICER_TICK(7)
             ICER_EMU_COUNT(0);
@@ -657,16 +692,28 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
                 s.ev[2 * lane + 1] = (uint8_t)LV(ev2);
             }
             WAVE_SYNC();
-            FOR_LANES
-            {
-                if (lane == 0) {
-                    for (int e = 0; e < 128; e++) {
-                        const uint32_t v = s.ev[e];
-                        if (v & 0x80u) seq_put(s, (int)(v & 31u), (v >> 5) & 1u);
+            uint32_t e = 0;
+            for (;;) {
+                FOR_LANES
+                {
+                    if (lane == 0) s.resume = seq_run(s, e);
+                }
+                WAVE_SYNC();
+                e = s.resume;
+                if (e >= 128u) break;
+                // a new word is needed and the ring holds 2048 words: pop what is finished (64 lanes),
+                // and if the oldest word is still open force-complete it (E5, icer_encoding.c:59-64)
+                wave_drain(s);
+                if (s.used == (uint32_t)kRingWords) {
+                    FOR_LANES
+                    {
+                        if (lane == 0) seq_complete_head(s);
                     }
+                    WAVE_SYNC();
+                    wave_drain(s);
                 }
             }
-            WAVE_SYNC();
+            wave_drain(s);
             ICER_TICK(8)
         }
         ok = flush_stage(s, a, false);
@@ -676,12 +723,14 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
     if (!ok) return kUnitTooBig;
     ICER_TICK(10)
     // end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455)
-    FOR_LANES
-    {
-        if (lane == 0)
-            while (s.used > 0) seq_flush_head(s);
+    while (s.used > 0) {
+        FOR_LANES
+        {
+            if (lane == 0) seq_complete_head(s);
+        }
+        WAVE_SYNC();
+        wave_drain(s);
     }
-    WAVE_SYNC();
     ok = flush_stage(s, a, true);
     ICER_TICK(11)
     ICER_TIMERS_STORE(a.timers)

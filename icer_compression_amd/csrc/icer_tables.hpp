@@ -43,6 +43,8 @@ inline FilterTaps filter_taps(int filt)
 struct CoderTables {
     // bins 1..7: [bin][partial input value] -> in_bits | out_bits<<4 | out_code<<8   (0 = no entry)
     uint16_t v2v[8][32];
+    // bins 1..7: [bin][n] = set of input values that are complete code words of n input bits (bit v set)
+    uint32_t v2v_term[8][8];
     // bins 1..7: [bin][partial value 0..8][bits so far 0..5] -> appended bits | count<<4
     uint8_t v2v_flush[8][9][6];
     // bins 8..16: Golomb m, l = ceil(log2 m), i = 2^l - m
@@ -75,7 +77,10 @@ inline void build_coder_tables(CoderTables *t)
         {7, 1, 2, 3, 3},  {7, 2, 2, 5, 3},  {7, 3, 2, 31, 5},  {7, 4, 3, 1, 3},  {7, 0, 4, 0, 1},
         {7, 8, 5, 7, 4},  {7, 24, 5, 15, 5},
     };
-    for (const V &c : codes) t->v2v[c.bin][c.val] = (uint16_t)(c.nin | (c.nout << 4) | (c.code << 8));
+    for (const V &c : codes) {
+        t->v2v[c.bin][c.val] = (uint16_t)(c.nin | (c.nout << 4) | (c.code << 8));
+        t->v2v_term[c.bin][c.nin] |= 1u << c.val;
+    }
     struct F { uint8_t bin, val, nin, add, nadd; };
     static const F fl[] = {
         {1, 1, 1, 0, 1}, {1, 3, 2, 0, 1}, {1, 7, 3, 0, 1}, {1, 0, 1, 1, 1}, {1, 0, 2, 1, 1}, {1, 0, 3, 1, 1}, {1, 0, 4, 0, 1},

@@ -50,7 +50,10 @@ static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 
 #define FOR_LANES
 #define LV(x) x
 #define DECL_LANE const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))
-#define WAVE_SYNC() __syncthreads()
+// The coding-unit kernel runs ONE wavefront per workgroup: LDS traffic of a single wave is executed in
+// program order by the LDS pipeline, so cross-lane hand-offs through LDS only need the compiler not to
+// reorder or cache across the point (no s_barrier, no vmcnt drain -> global prefetches stay in flight).
+#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define BALLOT(expr) ((uint64_t)__ballot((int)(expr)))
 // number of set bits of m strictly below this lane (two v_mbcnt instructions)
 static __device__ __forceinline__ int mbcnt64(uint64_t m, int /*lane*/)

@@ -5,7 +5,7 @@ import numpy as np
 
 
 class CoderTables(C.Structure):     # mirrors icer::CoderTables
-    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
+    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
                 ("gm", C.c_uint16 * 17), ("gl", C.c_uint16 * 17), ("gi", C.c_uint16 * 17),
                 ("ginv", C.c_uint32 * 17), ("cut", C.c_uint32 * 16), ("x2n", C.c_uint32 * 32)]
 
@@ -25,6 +25,8 @@ def test_tables_equal_reference(emu, reference):
             nin, nout, code = reference.custom_code(b, pre)
             e = t.v2v[b][pre]
             assert (e & 15, (e >> 4) & 15, e >> 8) == ((nin, nout, code) if nin else (0, 0, 0)), (b, pre)
+            for n in range(1, 6):       # termination masks agree with the look-up rule of icer_encoding.c:91
+                assert ((t.v2v_term[b][n] >> pre) & 1) == (1 if nin == n else 0)
         for pre in range(9):
             for nb in range(6):
                 fb, fn = reference.flush_entry(b, pre, nb)

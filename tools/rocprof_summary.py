@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd databases into a small JSON/Markdown pair under profiles/.
+
+  python tools/rocprof_summary.py <tag> <stats.db> [<pmc_fetch.db> <pmc_write.db>]
+
+Kernel times come from the --kernel-trace --stats run; FETCH_SIZE / WRITE_SIZE from their own --pmc
+passes (they do not fit one pass: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2).  Units: the
+counters are in KiB.  Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports half
+of the bytes of a streaming read -- our own calibration point is finalize_kernel, which reads and writes
+exactly one plane set (W*H*2 bytes per plane): WRITE_SIZE matches exactly, FETCH_SIZE reads 0.50x.
+So traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.
+"""
+import json
+import os
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    n = name.split("(")[0]
+    return n.split("::")[-1] if "::" in n else n
+
+
+def main():
+    tag, stats = sys.argv[1], sys.argv[2]
+    out = {"tag": tag, "kernels": {}}
+    cur = sqlite3.connect(stats).cursor()
+    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        out["kernels"][short(name)] = {"calls": calls, "avg_us": round(avg, 3), "total_us": round(total, 3), "pct": round(pct, 4)}
+    for path, ctr in zip(sys.argv[3:5], ("FETCH_SIZE", "WRITE_SIZE")):
+        c = sqlite3.connect(path).cursor()
+        q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
+        for name, n, avg in c.execute(q, (ctr,)):
+            out["kernels"].setdefault(short(name), {})[ctr + "_KiB_per_launch"] = round(avg, 3)
+    for k, v in out["kernels"].items():
+        if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
+            v["traffic_bytes_per_launch"] = int(2 * v["FETCH_SIZE_KiB_per_launch"] * 1024 + v["WRITE_SIZE_KiB_per_launch"] * 1024)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", f"{tag}_rocprof.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    lines = [f"# rocprofv3 summary `{tag}`", "", "| kernel | calls | avg us | % | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB (2*F+W) |", "|---|---|---|---|---|---|---|"]
+    for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("total_us", 0)):
+        lines.append(f"| {k} | {v.get('calls','')} | {v.get('avg_us','')} | {v.get('pct','')} | {v.get('FETCH_SIZE_KiB_per_launch','')} | "
+                     f"{v.get('WRITE_SIZE_KiB_per_launch','')} | {round(v['traffic_bytes_per_launch']/1e6,2) if 'traffic_bytes_per_launch' in v else ''} |")
+    with open(os.path.join(root, "profiles", f"{tag}_rocprof.md"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
