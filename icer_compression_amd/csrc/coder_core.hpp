@@ -68,6 +68,8 @@ struct CoderShared {
     uint8_t ev[128];            // events of the current chunk in coding order: 0x80 | bit << 5 | bin
     uint8_t evflag[128];        // bins 1..7, written by the walker lanes: bit0 word starts here, bit1 word ends here
     uint8_t evstart[128];       // position of the start event of the word that ends here (255: carried-in word)
+    uint8_t binseq[8][128];     // bins 1..7: that bin's events in coding order, bit7 = input bit, bits 6..0 = position
+    uint32_t ctx_zero[kNumContexts], ctx_total[kNumContexts];   // adaptive model of the unit (C5)
     uint8_t evacc[128];         // bins 1..7: completed input value of the word that ends here (code looked up by the event lane)
     uint8_t bin_open_pos[32];   // per bin after the chunk: 255 unchanged, 254 closed, else start position of its open word
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
@@ -231,7 +233,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
         if (m_) {                                                                                     \
             const uint64_t zm_ = BALLOT((PRED) && (ISZERO));                                          \
             const uint32_t n_ = (uint32_t)popc64(m_), nz_ = (uint32_t)popc64(zm_);                    \
-            const uint32_t t0_ = total[C], z0_ = zero[C];                                             \
+            const uint32_t t0_ = s.ctx_total[C], z0_ = s.ctx_zero[C];                                 \
             if (t0_ + n_ < kRescaleCap) {                                                             \
                 FOR_LANES                                                                             \
                 {                                                                                     \
@@ -240,8 +242,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
                         LV(ZOUT) = z0_ + (uint32_t)mbcnt64(zm_, lane);                                \
                     }                                                                                 \
                 }                                                                                     \
-                total[C] = t0_ + n_;                                                                  \
-                zero[C] = z0_ + nz_;                                                                  \
+                FOR_LANES { if (lane == 0) { s.ctx_total[C] = t0_ + n_; s.ctx_zero[C] = z0_ + nz_; } }       \
             } else {                                                                                  \
                 const uint32_t kc_ = kRescaleCap - 1 - t0_; /* rank of the event that triggers it */  \
                 const int lc_ = ffs64(BALLOT((PRED) && (uint32_t)mbcnt64(m_, lane) == kc_));          \
@@ -256,8 +257,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
                         else { LV(TOUT) = kRescaleCap / 2 + (rk_ - kc_ - 1); LV(ZOUT) = zr_ + (zb_ - zc_); } \
                     }                                                                                 \
                 }                                                                                     \
-                total[C] = kRescaleCap / 2 + (n_ - kc_ - 1);                                          \
-                zero[C] = zr_ + (nz_ - zc_);                                                          \
+                FOR_LANES { if (lane == 0) { s.ctx_total[C] = kRescaleCap / 2 + (n_ - kc_ - 1); s.ctx_zero[C] = zr_ + (nz_ - zc_); } } \
             }                                                                                         \
         }                                                                                             \
     }
@@ -322,19 +322,17 @@ ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u 
         WD = (BIT) ? golomb_word(s.tab, b, kb_) : (kWordDone | (1u << 11) | 1u);                      \
     }
 
-ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_t, ev2), LANEARG(uint32_t, term1),
-                         LANEARG(uint32_t, term2), LANEARG(uint32_t, term3), LANEARG(uint32_t, term4), LANEARG(uint32_t, term5) ICER_TIMER_PARAMS)
+ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_t, ev2), LANEARG(uint32_t, term) ICER_TIMER_PARAMS)
 {
     DECL_LANE;
     LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
     LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
     LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
-    LANEVAR(uint64_t, wm1); LANEVAR(uint64_t, wm2); LANEVAR(uint64_t, wv1); LANEVAR(uint64_t, wv2);   // walker masks
+    LANEVAR(uint32_t, wn);                              // lanes 1..7: number of events of bin `lane` in this chunk
 
     FOR_LANES
     {
         LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
-        LV(wm1) = 0; LV(wm2) = 0; LV(wv1) = 0; LV(wv2) = 0;
         if (lane < kNumBins) s.bin_open_pos[lane] = 255;
         // bin 0 (uncoded): every event is a complete one-bit word (E3)
         if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
@@ -343,10 +341,13 @@ ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_
     WAVE_SYNC();
 
     // ---- Golomb bins 8..16: run length since the bin's previous one-event, modulo m ------------
-    for (int b = 8; b <= 16; b++) {
+    // one step per Golomb bin PRESENT in the chunk
+    for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), rem2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u); rem1 | rem2;) {
+        const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
         const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
         const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-        if (!(M1 | M2)) continue;
+        rem1 &= ~M1;
+        rem2 &= ~M2;
         const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
         const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
         const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
@@ -385,53 +386,56 @@ ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_
     }
 
     ICER_TICK(4)
-    // ---- bins 1..7 (variable-to-variable codes): lane b walks the events of bin b ---------------
+    // ---- bins 1..7 (variable-to-variable codes) ---------------------------------------------------
+    // Every event of a present bin writes (position, bit) at its rank into that bin's sequence in LDS;
+    // lane b then walks the dense sequence of bin b (all <= 7 walkers run in lockstep).
     bool any_v2v = false;
-    for (int b = 1; b <= 7; b++) {
+    FOR_LANES { LV(wn) = 0; }
+    for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), rem2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u)); rem1 | rem2;) {
+        const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
         const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
         const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-        if (!(M1 | M2)) continue;
+        rem1 &= ~M1;
+        rem2 &= ~M2;
         any_v2v = true;
-        const uint64_t V1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
-        const uint64_t V2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
+        const uint32_t n = (uint32_t)(popc64(M1) + popc64(M2));
         FOR_LANES
         {
-            if (lane == b) { LV(wm1) = M1; LV(wm2) = M2; LV(wv1) = V1; LV(wv2) = V2; }
+            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b))
+                s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane)] = (uint8_t)(2u * (uint32_t)lane | ((LV(ev1) << 2) & 0x80u));
+            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b))
+                s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane + 1u)] = (uint8_t)((2u * (uint32_t)lane + 1u) | ((LV(ev2) << 2) & 0x80u));
+            if (lane == b) LV(wn) = n;
         }
     }
     if (any_v2v) {
+        WAVE_SYNC();
         FOR_LANES
         {
-            if (lane >= 1 && lane <= 7 && (LV(wm1) | LV(wm2))) {
+            if (lane >= 1 && lane <= 7 && LV(wn)) {
                 const int b = lane;
-                uint64_t m1 = LV(wm1), m2 = LV(wm2);
-                const uint64_t v1 = LV(wv1), v2 = LV(wv2);
-                uint32_t acc = s.bin_acc[b], nin = s.bin_nin[b];
-                uint32_t cur_start = 255;                       // an unfinished word carried in from earlier chunks
-                while (m1 | m2) {
-                    const int l1 = ffs64(m1), l2 = ffs64(m2);
-                    const bool first = l1 <= l2;                // magnitude event of lane l precedes its sign event
-                    const uint32_t pos = first ? 2u * (uint32_t)l1 : 2u * (uint32_t)l2 + 1u;
-                    const uint32_t bit = first ? (uint32_t)((v1 >> l1) & 1ull) : (uint32_t)((v2 >> l2) & 1ull);
-                    if (first) m1 &= m1 - 1ull; else m2 &= m2 - 1ull;
-                    uint32_t flag = 0;
-                    if (nin == 0) { flag = 1; cur_start = pos; }
-                    acc |= bit << nin;
-                    nin++;
-                    // complete iff acc is a code word of exactly nin input bits (masks live in registers)
-                    const uint32_t tm = nin == 1 ? LV(term1) : nin == 2 ? LV(term2) : nin == 3 ? LV(term3) : nin == 4 ? LV(term4) : LV(term5);
-                    if ((tm >> (acc & 31u)) & 1u) {
-                        flag |= 2u;
-                        s.evacc[pos] = (uint8_t)acc;
-                        s.evstart[pos] = (uint8_t)cur_start;
-                        acc = 0;
-                        nin = 0;
-                    }
-                    s.evflag[pos] = (uint8_t)flag;
+                const uint32_t n = LV(wn), tmask = LV(term);
+                uint32_t acc = s.bin_acc[b], top = 1u << s.bin_nin[b];   // partial input and the weight of its next bit
+                uint32_t cur_start = 255;                                // an unfinished word carried in from earlier chunks
+                uint32_t x = s.binseq[b][0];
+                for (uint32_t r = 0; r < n; r++) {
+                    const uint32_t pos = x & 127u, bit = x >> 7;
+                    if (r + 1 < n) x = s.binseq[b][r + 1];              // next event's record is fetched early
+                    const uint32_t starts = top == 1u ? 1u : 0u;
+                    cur_start = starts ? pos : cur_start;
+                    acc |= bit ? top : 0u;
+                    top <<= 1;
+                    // (acc | top) numbers the node of the code tree; all 5-bit inputs are code words
+                    const uint32_t ends = (top == 32u || ((tmask >> (acc | top)) & 1u)) ? 1u : 0u;
+                    s.evflag[pos] = (uint8_t)(starts | (ends << 1));
+                    s.evacc[pos] = (uint8_t)acc;
+                    s.evstart[pos] = (uint8_t)cur_start;
+                    acc = ends ? 0u : acc;
+                    top = ends ? 1u : top;
                 }
                 s.bin_acc[b] = acc;
-                s.bin_nin[b] = nin;
-                s.bin_open_pos[b] = (uint8_t)(nin ? cur_start : 254u);
+                s.bin_nin[b] = 31u - (uint32_t)clz32(top);
+                s.bin_open_pos[b] = (uint8_t)(top != 1u ? cur_start : 254u);
             }
         }
         WAVE_SYNC();
@@ -541,22 +545,23 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
     {
         for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
+        if (lane < kNumContexts) { s.ctx_zero[lane] = 2; s.ctx_total[lane] = 4; }      // icer_context_modeller.c:607-613
         if (lane == 0) { s.head = 0; s.used = 0; s.bitpos = 0; s.flushed_words = 0; }
     }
     WAVE_SYNC();
 
-    uint32_t zero[kNumContexts], total[kNumContexts];         // wave-uniform (SGPR) model state
-#pragma unroll
-    for (int c = 0; c < kNumContexts; c++) { zero[c] = 2; total[c] = 4; }   // icer_context_modeller.c:607-613
 
     ICER_TIMERS_DECL
-    // lanes 1..7 walk bins 1..7: keep that bin's code-word termination masks in registers
-    LANEVAR(uint32_t, term1); LANEVAR(uint32_t, term2); LANEVAR(uint32_t, term3); LANEVAR(uint32_t, term4); LANEVAR(uint32_t, term5);
+    // lanes 1..7 walk bins 1..7: that bin's code-tree termination mask stays in a register.
+    // Node numbering: (partial input | 1 << bits so far), < 32 for inputs of up to 4 bits.
+    LANEVAR(uint32_t, term);
     FOR_LANES
     {
         const int wb = lane & 7;
-        LV(term1) = s.tab.v2v_term[wb][1]; LV(term2) = s.tab.v2v_term[wb][2]; LV(term3) = s.tab.v2v_term[wb][3];
-        LV(term4) = s.tab.v2v_term[wb][4]; LV(term5) = s.tab.v2v_term[wb][5];
+        LV(term) = 0;
+        for (uint32_t n = 1; n <= 4; n++)
+            for (uint32_t v = 0; v < (1u << n); v++)
+                if ((s.tab.v2v_term[wb][n] >> v) & 1u) LV(term) |= 1u << (v | (1u << n));
     }
     const uint32_t npix = a.w * a.h;
     const uint32_t lsb = (uint32_t)a.lsb;
@@ -648,10 +653,18 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
 
         ICER_TICK(0)
         // ---- phase 2: adaptive counts per event (C5) --------------------------------------
-#pragma unroll
-        for (int c = 0; c <= 11; c++) ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == (uint32_t)c, LV(bit1) == 0u, z1, t1)
-#pragma unroll
-        for (int c = 12; c <= 16; c++) ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == (uint32_t)c, LV(bit2) == 0u, z2, t2)
+        // one step per context PRESENT in the chunk (typically 3-8 of the 17)
+        for (uint64_t rem = BALLOT(LV(valid1) && LV(ctx1) != 31u); rem;) {
+            const uint32_t c = READLANE(ctx1, ffs64(rem));
+            ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == c, LV(bit1) == 0u, z1, t1)
+            rem &= ~BALLOT(LV(valid1) && LV(ctx1) == c);
+        }
+        for (uint64_t rem = BALLOT(LV(valid2) != 0u); rem;) {
+            const uint32_t c = READLANE(ctx2, ffs64(rem));
+            ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == c, LV(bit2) == 0u, z2, t2)
+            rem &= ~BALLOT(LV(valid2) && LV(ctx2) == c);
+        }
+        WAVE_SYNC();
 
         ICER_TICK(1)
         // ---- phase 3: fold + bin (E1) -----------------------------------------------------
@@ -679,7 +692,7 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
         if (s.used + nev <= (uint32_t)kRingWords) {
             // every event could open at most one word, so the ring cannot fill up in this chunk:
             // no forced flush (E5) is possible and word boundaries depend on each bin alone
-            fast_chunk(s, ev1, ev2, term1, term2, term3, term4, term5 ICER_TIMER_PASS);
+            fast_chunk(s, ev1, ev2, term ICER_TIMER_PASS);
             wave_drain(s);
             ICER_TICK(7)
             ICER_EMU_COUNT(0);

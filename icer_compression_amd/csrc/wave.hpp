@@ -38,6 +38,7 @@ static inline int clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
 static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
 #define LANEARG(T, name) T (&name)[64]
 #define LDS_OR(REF, VAL) ((REF) |= (VAL))
+#define READLANE(X, L) (X[L])
 // cross-lane reductions / scans over a lane variable
 #define WAVE_XOR(DST, X) { DST = 0; for (int l_ = 0; l_ < 64; ++l_) DST ^= X[l_]; }
 #define WAVE_EXCL_SCAN(T, OUT, IN, TOTAL) { T run_ = 0; for (int l_ = 0; l_ < 64; ++l_) { const T v_ = IN[l_]; OUT[l_] = run_; run_ += v_; } TOTAL = run_; }
@@ -67,6 +68,7 @@ static __device__ __forceinline__ int clz64(uint64_t v) { return v ? (int)__buil
 static __device__ __forceinline__ uint32_t brev32(uint32_t v) { return __brev(v); }
 #define LANEARG(T, name) T name
 #define LDS_OR(REF, VAL) atomicOr(&(REF), (VAL))
+#define READLANE(X, L) ((uint32_t)__builtin_amdgcn_readlane((int)(X), (int)(L)))
 #define WAVE_XOR(DST, X) { uint32_t t_ = (X); for (int o_ = 32; o_ > 0; o_ >>= 1) t_ ^= (uint32_t)__shfl_xor((int)t_, o_); DST = t_; }
 #define WAVE_EXCL_SCAN(T, OUT, IN, TOTAL) { const T v_ = (IN); T s_ = v_; \
     for (int o_ = 1; o_ < 64; o_ <<= 1) { const T u_ = (T)__shfl_up(s_, o_); if (lane >= o_) s_ += u_; } \
