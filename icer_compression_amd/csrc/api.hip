@@ -179,7 +179,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
 
     // ---- coding units
-    hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64), 0, st,
+    hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64 * kUnitWaves), 0, st,
                        reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                        e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes,
                        e->unit_bits.p, e->prof.p);

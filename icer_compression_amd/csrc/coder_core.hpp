@@ -1,4 +1,5 @@
-// coder_core.hpp -- one wavefront codes one ICER coding unit (channel, level, subband, plane, segment).
+// coder_core.hpp -- one workgroup of three wavefronts codes one ICER coding unit
+// (channel, level, subband, plane, segment).
 //
 // Replaces, for the uint16 path, the reference's per-segment chain
 //   icer_compress_bitplane_uint16   lib_icer/src/icer_context_modeller.c:312-457
@@ -6,47 +7,62 @@
 //   icer_popbuf_while_avail / icer_flush_encode   icer_encoding.c:114-189
 // and must emit the identical payload bits.
 //
-// Structure per 64-pixel chunk (raster order inside the segment):
-//   phase 1  (64 lanes)  pixel category, magnitude bit, 8-neighbour context, sign context
-//   phase 2  (64 lanes)  adaptive counts seen by every event: ballot + v_mbcnt ranks per context,
-//                        including the single rescale a context can cross inside a chunk
-//   phase 3  (64 lanes)  probability fold + bin selection (16 compare/accumulate steps)
-//   phase 4              interleaved entropy coder.  Code words are delimited per bin, allocated to
-//                        the 2048-word ring in order of their first event and emitted in that order.
-//                        Fast path (the ring cannot fill up inside this chunk): Golomb bins 8..16 in
-//                        closed form on ballot masks (run length since the bin's last one, mod m),
-//                        bins 1..7 by one walker lane per bin over that bin's events, ring slots from
-//                        a prefix count of word-start flags, finished words drained 64 at a time
-//                        with a prefix sum of their lengths.  Exact path (ring nearly full, so the
-//                        forced flush of the oldest open word, E5, may trigger; also the end-of-unit
-//                        flush): one lane replays the reference state machine event by event.
-//   drain                finished words are packed LSB-first into an LDS bit stage and whole
-//                        32-bit words are written to the unit's payload slot in HBM (coalesced).
+// The segment is coded in chunks of 64 pixels (raster order inside the segment).  The reference is a
+// sequential state machine; its state splits into three parts that only depend on their own history, so
+// three wavefronts work on consecutive chunks at the same time, handing chunks over through small LDS
+// queues (depth kQueueDepth):
+//
+//   context wave   per chunk: pixel category, magnitude bit, 8-neighbour context, sign context (64 lanes,
+//     (state: the    pure function of the 3x3 window; next chunk's window prefetched); the adaptive counts
+//      17 context    every event sees = counts at chunk start + rank among the chunk's events of the same
+//      counters)     context (ballot + v_mbcnt; the at-most-one rescale per context and chunk in closed form);
+//                    probability fold + bin selection.  Output: 128 event bytes (bin, bit).
+//   walker wave    bins 1..7 (variable-to-variable codes): events of a bin are compacted into a dense
+//     (state: the    sequence, lane b walks bin b's sequence through the code tree (termination mask in a
+//      partial       register) and marks where code words start/end.  It runs one chunk ahead of the
+//      inputs)       assembly wave's verdict (speculation, see below).
+//   assembly wave  bin 0 and the Golomb bins 8..16 in closed form on ballot masks (run length since the bin's
+//     (state: ring,  previous one-event, mod m); ring slots = prefix count of word-start flags (allocation order
+//      Golomb runs,  = order of first events, E2); finished words drained 64 at a time (ballot of done flags,
+//      bit stage)    prefix sum of lengths, ds_or into the LDS bit stage); whole 32-bit words stored to HBM.
+//
+// Exactness: word boundaries depend on each bin alone only while the 2048-word ring cannot fill up inside
+// the chunk (used + events <= 2048): then no forced flush of the oldest open word (E5) can fire.  Otherwise
+// (~0.3-2.5 % of chunks) the assembly wave replays the reference state machine event by event on one lane,
+// with draining deferred to the 64-lane drain (it is only observable through `used` when a word is allocated),
+// and the walker wave discards its speculative result and reloads its state.
+//
 // Written with the SPMD macros of wave.hpp (see there for the tests-only CPU build).
 #pragma once
 #include "icer_tables.hpp"
 #include "wave.hpp"
 
 #ifdef ICER_WAVE_EMU
+#include <assert.h>
 extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path chunks, [1] exact-path chunks
 #define ICER_EMU_COUNT(i) (g_emu_chunks[i]++)
+// cross-wave hand-off: the emulation runs the waves in an order in which every wait is already satisfied
+#define ICER_LOAD_CNT(x) (x)
+#define ICER_WAIT_UNTIL(cond) { assert(cond); }
+#define ICER_PUBLISH(x, v) { (x) = (v); }
 #else
 #define ICER_EMU_COUNT(i)
+// counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
+// LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
+#define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define ICER_WAIT_UNTIL(cond) { while (!(cond)) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+#define ICER_PUBLISH(x, v) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
-// Optional per-phase cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
+// Optional per-wave cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
 // -DICER_PHASE_TIMERS (a separate profiling build of the library, never the shipped one).
 #if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
 #define ICER_NUM_TIMERS 12
 #define ICER_TIMERS_DECL uint64_t tacc_[ICER_NUM_TIMERS] = {}; uint64_t tlast_ = __builtin_amdgcn_s_memtime();
-#define ICER_TIMER_PARAMS , uint64_t *tacc_, uint64_t &tlast_
-#define ICER_TIMER_PASS , tacc_, tlast_
 #define ICER_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc_[k] += t_ - tlast_; tlast_ = t_; }
-#define ICER_TIMERS_STORE(dst) { if (dst) { _Pragma("unroll") for (int i_ = 0; i_ < ICER_NUM_TIMERS; i_++) if (lane == 0) atomicAdd((unsigned long long *)&(dst)[i_], (unsigned long long)tacc_[i_]); } }
+#define ICER_TIMERS_STORE(dst) { if (dst) { _Pragma("unroll") for (int i_ = 0; i_ < ICER_NUM_TIMERS; i_++) if (lane == 0 && tacc_[i_]) atomicAdd((unsigned long long *)&(dst)[i_], (unsigned long long)tacc_[i_]); } }
 #else
 #define ICER_TIMERS_DECL
-#define ICER_TIMER_PARAMS
-#define ICER_TIMER_PASS
 #define ICER_TICK(k)
 #define ICER_TIMERS_STORE(dst)
 #endif
@@ -55,30 +71,46 @@ namespace icer {
 
 constexpr uint32_t kStageWords = 1024;      // LDS bit stage (circular, 32-bit words)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
+constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
+constexpr int kUnitWaves = 3;               // context, walker, assembly
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)
 constexpr uint32_t kWordDone = 0x8000u;
+
+struct EventSlot {              // context wave -> walker + assembly waves
+    uint8_t ev1[64];            // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | bin, 0 = none
+    uint8_t ev2[64];            // sign event of pixel `lane`
+    uint32_t nev;               // number of events in the chunk
+};
+struct WalkSlot {               // walker wave -> assembly wave (bins 1..7)
+    uint8_t evflag[128];        // bit0: a code word starts at this event, bit1: one ends here
+    uint8_t evacc[128];         // completed input value of the word that ends here
+    uint8_t evstart[128];       // position of that word's first event (255: it was carried into the chunk)
+    uint8_t open_pos[8];        // per bin after the chunk: 255 untouched, 254 closed, else first event of its open word
+    uint8_t post_acc[8], post_nin[8];   // walker state after the chunk
+};
 
 struct CoderShared {
     uint32_t stage[kStageWords];
     uint16_t ring[kRingWords];
     CoderTables tab;
     uint32_t crc_tab[256];
-    uint8_t ev[128];            // events of the current chunk in coding order: 0x80 | bit << 5 | bin
-    uint8_t evflag[128];        // bins 1..7, written by the walker lanes: bit0 word starts here, bit1 word ends here
-    uint8_t evstart[128];       // position of the start event of the word that ends here (255: carried-in word)
-    uint8_t binseq[8][128];     // bins 1..7: that bin's events in coding order, bit7 = input bit, bits 6..0 = position
-    uint32_t ctx_zero[kNumContexts], ctx_total[kNumContexts];   // adaptive model of the unit (C5)
-    uint8_t evacc[128];         // bins 1..7: completed input value of the word that ends here (code looked up by the event lane)
-    uint8_t bin_open_pos[32];   // per bin after the chunk: 255 unchanged, 254 closed, else start position of its open word
+    EventSlot eq[kQueueDepth];
+    WalkSlot wq[kQueueDepth];
+    uint8_t binseq[8][128];     // walker wave: events of bin b in coding order, bit7 = input bit, bits 6..0 = position
+    uint32_t ctx_zero[kNumContexts], ctx_total[kNumContexts];   // adaptive model of the unit (C5), context wave
+    uint8_t bin_open_pos[32];   // assembly wave, per bin after the chunk (same encoding as WalkSlot::open_pos)
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
-    uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value
+    uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
     uint32_t head, used;        // ring state
     uint32_t bitpos;            // payload bits produced so far
     uint32_t flushed_words;     // payload words already written to HBM
     uint32_t resume;            // exact path: event index at which the single-lane replay paused
+    // progress counters of the three waves (chunks completed) and the per-chunk verdicts
+    uint32_t a_done, c_done, b_decided, b_done, abort;
+    uint8_t exact[kQueueDepth]; // assembly wave's verdict for the chunk in this queue slot: 1 = exact path
 };
 
 struct UnitArgs {
@@ -176,12 +208,13 @@ ICER_DEV void seq_put(CoderShared &s, int bin, uint32_t bit)
     }
 }
 
-// replay events [e, 128) of s.ev in order; stops BEFORE an event that needs a new word while the ring
-// holds 2048 (possibly already finished) words, returning its index; 128 when the chunk is done
-ICER_DEV uint32_t seq_run(CoderShared &s, uint32_t e)
+// replay events [e, 128) of a chunk in coding order (event 2L = magnitude bit of pixel L, 2L+1 = its
+// sign); stops BEFORE an event that needs a new word while the ring holds 2048 (possibly already
+// finished) words, returning its index; 128 when the chunk is done
+ICER_DEV uint32_t seq_run(CoderShared &s, const EventSlot &q, uint32_t e)
 {
     for (; e < 128u; e++) {
-        const uint32_t v = s.ev[e];
+        const uint32_t v = (e & 1u) ? q.ev2[e >> 1] : q.ev1[e >> 1];
         if (!(v & 0x80u)) continue;
         const int bin = (int)(v & 31u);
         if (s.bin_slot[bin] < 0 && s.used == (uint32_t)kRingWords) return e;
@@ -221,7 +254,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
 }
 
 // ------------------------------------------------------------------------------------------
-// the unit coder.  Returns the payload length in bits, or kUnitTooBig when the slot is too small.
+// building blocks shared by the waves
 // ------------------------------------------------------------------------------------------
 // Adaptive counts for every event of context C in this chunk (phase 2).  A context is rescaled
 // when its total reaches 500 (-> 250); with at most 64 events per context and chunk that can
@@ -290,12 +323,6 @@ ICER_DEV bool flush_stage(CoderShared &s, const UnitArgs &a, bool final_partial)
     return fits && (bp >> 3) < a.cap_words * 4u;
 }
 
-// ------------------------------------------------------------------------------------------
-// phase 4, fast path: the whole chunk's events coded by 64 lanes
-// ------------------------------------------------------------------------------------------
-// Event coordinates: lane L carries the magnitude-bit event at position 2L and the sign event at
-// position 2L+1 (coding order = position order).  A set of events is a pair of 64-bit lane masks
-// (A1 for magnitude events, A2 for sign events).
 ICER_DEV uint64_t below64(uint32_t x) { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); }
 // events of the set strictly before position pos
 ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
@@ -321,179 +348,6 @@ ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u 
         FL = (kb_ == 0u ? 1u : 0u) | (((BIT) || kb_ + 1u == m) ? 2u : 0u);                            \
         WD = (BIT) ? golomb_word(s.tab, b, kb_) : (kWordDone | (1u << 11) | 1u);                      \
     }
-
-ICER_DEV void fast_chunk(CoderShared &s, LANEARG(uint32_t, ev1), LANEARG(uint32_t, ev2), LANEARG(uint32_t, term) ICER_TIMER_PARAMS)
-{
-    DECL_LANE;
-    LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
-    LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
-    LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
-    LANEVAR(uint32_t, wn);                              // lanes 1..7: number of events of bin `lane` in this chunk
-
-    FOR_LANES
-    {
-        LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
-        if (lane < kNumBins) s.bin_open_pos[lane] = 255;
-        // bin 0 (uncoded): every event is a complete one-bit word (E3)
-        if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
-        if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
-    }
-    WAVE_SYNC();
-
-    // ---- Golomb bins 8..16: run length since the bin's previous one-event, modulo m ------------
-    // one step per Golomb bin PRESENT in the chunk
-    for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), rem2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u); rem1 | rem2;) {
-        const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
-        const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
-        const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-        rem1 &= ~M1;
-        rem2 &= ~M2;
-        const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
-        const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
-        const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
-        const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = s.bin_acc[b];
-        FOR_LANES
-        {
-            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
-            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
-        }
-        const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
-        const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
-        FOR_LANES
-        {
-            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 2u)) {
-                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane);
-                LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
-            }
-            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 2u)) {
-                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane + 1u);
-                LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
-            }
-        }
-        // bin state after the chunk (wave-uniform)
-        const int lastone = last_le(O1, O2, 127u);
-        const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
-        const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : k_in + ztot;
-        const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
-        const int laststart = last_le(SB1, SB2, 127u);
-        FOR_LANES
-        {
-            if (lane == 0) {
-                s.bin_acc[b] = k_out;
-                s.bin_open_pos[b] = (uint8_t)(k_out ? (laststart >= 0 ? laststart : 255) : 254);
-            }
-        }
-    }
-
-    ICER_TICK(4)
-    // ---- bins 1..7 (variable-to-variable codes) ---------------------------------------------------
-    // Every event of a present bin writes (position, bit) at its rank into that bin's sequence in LDS;
-    // lane b then walks the dense sequence of bin b (all <= 7 walkers run in lockstep).
-    bool any_v2v = false;
-    FOR_LANES { LV(wn) = 0; }
-    for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), rem2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u)); rem1 | rem2;) {
-        const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
-        const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
-        const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-        rem1 &= ~M1;
-        rem2 &= ~M2;
-        any_v2v = true;
-        const uint32_t n = (uint32_t)(popc64(M1) + popc64(M2));
-        FOR_LANES
-        {
-            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b))
-                s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane)] = (uint8_t)(2u * (uint32_t)lane | ((LV(ev1) << 2) & 0x80u));
-            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b))
-                s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane + 1u)] = (uint8_t)((2u * (uint32_t)lane + 1u) | ((LV(ev2) << 2) & 0x80u));
-            if (lane == b) LV(wn) = n;
-        }
-    }
-    if (any_v2v) {
-        WAVE_SYNC();
-        FOR_LANES
-        {
-            if (lane >= 1 && lane <= 7 && LV(wn)) {
-                const int b = lane;
-                const uint32_t n = LV(wn), tmask = LV(term);
-                uint32_t acc = s.bin_acc[b], top = 1u << s.bin_nin[b];   // partial input and the weight of its next bit
-                uint32_t cur_start = 255;                                // an unfinished word carried in from earlier chunks
-                uint32_t x = s.binseq[b][0];
-                for (uint32_t r = 0; r < n; r++) {
-                    const uint32_t pos = x & 127u, bit = x >> 7;
-                    if (r + 1 < n) x = s.binseq[b][r + 1];              // next event's record is fetched early
-                    const uint32_t starts = top == 1u ? 1u : 0u;
-                    cur_start = starts ? pos : cur_start;
-                    acc |= bit ? top : 0u;
-                    top <<= 1;
-                    // (acc | top) numbers the node of the code tree; all 5-bit inputs are code words
-                    const uint32_t ends = (top == 32u || ((tmask >> (acc | top)) & 1u)) ? 1u : 0u;
-                    s.evflag[pos] = (uint8_t)(starts | (ends << 1));
-                    s.evacc[pos] = (uint8_t)acc;
-                    s.evstart[pos] = (uint8_t)cur_start;
-                    acc = ends ? 0u : acc;
-                    top = ends ? 1u : top;
-                }
-                s.bin_acc[b] = acc;
-                s.bin_nin[b] = 31u - (uint32_t)clz32(top);
-                s.bin_open_pos[b] = (uint8_t)(top != 1u ? cur_start : 254u);
-            }
-        }
-        WAVE_SYNC();
-        FOR_LANES
-        {
-            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
-            if (b1 >= 0x81u && b1 <= 0x87u) {
-                LV(fl1) = s.evflag[2 * lane];
-                if (LV(fl1) & 2u) {
-                    const uint32_t e = s.tab.v2v[b1 & 31u][s.evacc[2 * lane] & 31u];
-                    LV(wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(sp1) = s.evstart[2 * lane];
-                }
-            }
-            if (b2 >= 0x81u && b2 <= 0x87u) {
-                LV(fl2) = s.evflag[2 * lane + 1];
-                if (LV(fl2) & 2u) {
-                    const uint32_t e = s.tab.v2v[b2 & 31u][s.evacc[2 * lane + 1] & 31u];
-                    LV(wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(sp2) = s.evstart[2 * lane + 1];
-                }
-            }
-        }
-    }
-
-    ICER_TICK(5)
-    // ---- ring slots in allocation order = order of the words' first events (E2) ------------------
-    const uint64_t S1 = BALLOT(LV(fl1) & 1u), S2 = BALLOT(LV(fl2) & 1u);
-    const uint32_t used = s.used, tail = s.head + used;
-    FOR_LANES
-    {
-        if (LV(fl1) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane)) & (kRingWords - 1)] = (uint16_t)(LV(ev1) & 31u);
-        if (LV(fl2) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane + 1u)) & (kRingWords - 1)] = (uint16_t)(LV(ev2) & 31u);
-    }
-    FOR_LANES
-    {
-        if (LV(fl1) & 2u) {
-            const uint32_t slot = LV(sp1) == 255u ? (uint32_t)s.bin_slot[LV(ev1) & 31u] : (tail + cnt_lt(S1, S2, LV(sp1)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd1);
-        }
-        if (LV(fl2) & 2u) {
-            const uint32_t slot = LV(sp2) == 255u ? (uint32_t)s.bin_slot[LV(ev2) & 31u] : (tail + cnt_lt(S1, S2, LV(sp2)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd2);
-        }
-    }
-    WAVE_SYNC();
-    FOR_LANES
-    {
-        if (lane < kNumBins) {
-            const uint32_t op = s.bin_open_pos[lane];
-            if (op == 254u) s.bin_slot[lane] = -1;
-            else if (op < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, op)) & (kRingWords - 1));
-        }
-        if (lane == 0) s.used = used + (uint32_t)(popc64(S1) + popc64(S2));
-    }
-    WAVE_SYNC();
-    ICER_TICK(6)
-}
 
 // drain finished words from the head of the ring, 64 per round: lengths -> prefix sum -> bit offsets,
 // code bits OR-ed into the LDS bit stage (icer_popbuf_while_avail, icer_encoding.c:114-139)
@@ -538,40 +392,15 @@ ICER_DEV void wave_drain(CoderShared &s)
     WAVE_SYNC();
 }
 
-ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
-{
-    DECL_LANE;
-    FOR_LANES
-    {
-        for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
-        if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
-        if (lane < kNumContexts) { s.ctx_zero[lane] = 2; s.ctx_total[lane] = 4; }      // icer_context_modeller.c:607-613
-        if (lane == 0) { s.head = 0; s.used = 0; s.bitpos = 0; s.flushed_words = 0; }
-    }
-    WAVE_SYNC();
 
-
-    ICER_TIMERS_DECL
-    // lanes 1..7 walk bins 1..7: that bin's code-tree termination mask stays in a register.
-    // Node numbering: (partial input | 1 << bits so far), < 32 for inputs of up to 4 bits.
-    LANEVAR(uint32_t, term);
-    FOR_LANES
-    {
-        const int wb = lane & 7;
-        LV(term) = 0;
-        for (uint32_t n = 1; n <= 4; n++)
-            for (uint32_t v = 0; v < (1u << n); v++)
-                if ((s.tab.v2v_term[wb][n] >> v) & 1u) LV(term) |= 1u << (v | (1u << n));
-    }
-    const uint32_t npix = a.w * a.h;
-    const uint32_t lsb = (uint32_t)a.lsb;
-    const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
-    bool ok = true;
-
-    // coefficient window of the NEXT chunk is fetched while the current one is coded (the loads stay in
-    // flight across the whole chunk: WAVE_SYNC does not drain vmcnt)
+// ==========================================================================================
+// context wave
+// ==========================================================================================
+struct CtxWave {                // next chunk's 3x3 coefficient window, one pixel per lane
     LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
     LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
+};
+
 #define ICER_FETCH_WINDOW(BASE)                                                                        \
     FOR_LANES                                                                                          \
     {                                                                                                  \
@@ -580,19 +409,29 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
         const uint32_t r_ = pp_ / a.w, c_ = pp_ - r_ * a.w;                                            \
         const uint16_t *q_ = a.seg + (size_t)r_ * a.stride + c_;                                       \
         const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < a.w, hasN_ = r_ > 0, hasS_ = r_ + 1 < a.h;          \
-        LV(nC) = q_[0];                                                                                \
-        LV(nW) = hasW_ ? q_[-1] : 0u;                                                                  \
-        LV(nE) = hasE_ ? q_[1] : 0u;                                                                   \
-        LV(nN) = hasN_ ? *(q_ - a.stride) : 0u;                                                        \
-        LV(nS) = hasS_ ? *(q_ + a.stride) : 0u;                                                        \
-        LV(nNW) = (hasN_ && hasW_) ? *(q_ - a.stride - 1) : 0u;                                        \
-        LV(nNE) = (hasN_ && hasE_) ? *(q_ - a.stride + 1) : 0u;                                        \
-        LV(nSW) = (hasS_ && hasW_) ? *(q_ + a.stride - 1) : 0u;                                        \
-        LV(nSE) = (hasS_ && hasE_) ? *(q_ + a.stride + 1) : 0u;                                        \
+        LV(cw.nC) = q_[0];                                                                             \
+        LV(cw.nW) = hasW_ ? q_[-1] : 0u;                                                               \
+        LV(cw.nE) = hasE_ ? q_[1] : 0u;                                                                \
+        LV(cw.nN) = hasN_ ? *(q_ - a.stride) : 0u;                                                     \
+        LV(cw.nS) = hasS_ ? *(q_ + a.stride) : 0u;                                                     \
+        LV(cw.nNW) = (hasN_ && hasW_) ? *(q_ - a.stride - 1) : 0u;                                     \
+        LV(cw.nNE) = (hasN_ && hasE_) ? *(q_ - a.stride + 1) : 0u;                                     \
+        LV(cw.nSW) = (hasS_ && hasW_) ? *(q_ + a.stride - 1) : 0u;                                     \
+        LV(cw.nSE) = (hasS_ && hasE_) ? *(q_ + a.stride + 1) : 0u;                                     \
     }
-    if (npix) ICER_FETCH_WINDOW(0u)
 
-    for (uint32_t base = 0; base < npix && ok; base += 64) {
+// chunks [j0, j1) of the unit; the first call must start at chunk 0
+ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint32_t j0, uint32_t j1)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    const uint32_t npix = a.w * a.h;
+    const uint32_t lsb = (uint32_t)a.lsb;
+    const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
+    if (j0 == 0 && npix) ICER_FETCH_WINDOW(0u)
+
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t base = j * 64u;
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
         LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
@@ -600,12 +439,13 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
         LANEVAR(uint32_t, cNW); LANEVAR(uint32_t, cNE); LANEVAR(uint32_t, cSW); LANEVAR(uint32_t, cSE);
         FOR_LANES
         {
-            LV(cC) = LV(nC); LV(cW) = LV(nW); LV(cE) = LV(nE); LV(cN) = LV(nN); LV(cS) = LV(nS);
-            LV(cNW) = LV(nNW); LV(cNE) = LV(nNE); LV(cSW) = LV(nSW); LV(cSE) = LV(nSE);
+            LV(cC) = LV(cw.nC); LV(cW) = LV(cw.nW); LV(cE) = LV(cw.nE); LV(cN) = LV(cw.nN); LV(cS) = LV(cw.nS);
+            LV(cNW) = LV(cw.nNW); LV(cNE) = LV(cw.nNE); LV(cSW) = LV(cw.nSW); LV(cSE) = LV(cw.nSE);
         }
+        // the next chunk's window is fetched while this one is processed (the LDS-only fences never drain vmcnt)
         if (base + 64u < npix) ICER_FETCH_WINDOW(base + 64u)
 
-        // ---- phase 1: context formation (C1-C6) -------------------------------------------
+        // ---- context formation (C1-C6) ------------------------------------------------------------
         FOR_LANES
         {
             const bool valid = base + (uint32_t)lane < npix;
@@ -650,10 +490,9 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
             LV(bit2) = (pred ^ (x >> 15)) & 1u;
             LV(z2) = 0; LV(t2) = 0;
         }
-
         ICER_TICK(0)
-        // ---- phase 2: adaptive counts per event (C5) --------------------------------------
-        // one step per context PRESENT in the chunk (typically 3-8 of the 17)
+
+        // ---- adaptive counts per event (C5): one step per context PRESENT in the chunk ----------------
         for (uint64_t rem = BALLOT(LV(valid1) && LV(ctx1) != 31u); rem;) {
             const uint32_t c = READLANE(ctx1, ffs64(rem));
             ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == c, LV(bit1) == 0u, z1, t1)
@@ -665,10 +504,10 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
             rem &= ~BALLOT(LV(valid2) && LV(ctx2) == c);
         }
         WAVE_SYNC();
-
         ICER_TICK(1)
-        // ---- phase 3: fold + bin (E1) -----------------------------------------------------
-        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);           // 0x80 | bit << 5 | bin, 0 = no event
+
+        // ---- fold + bin (E1), hand the chunk over ------------------------------------------------------
+        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
         FOR_LANES
         {
             uint32_t e1 = 0, e2 = 0;
@@ -685,31 +524,302 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
             LV(ev1) = e1;
             LV(ev2) = e2;
         }
-
-        ICER_TICK(2)
-        // ---- phase 4: interleaved entropy coder ------------------------------------------
         const uint32_t nev = (uint32_t)(popc64(BALLOT(LV(ev1) != 0u)) + popc64(BALLOT(LV(ev2) != 0u)));
-        if (s.used + nev <= (uint32_t)kRingWords) {
-            // every event could open at most one word, so the ring cannot fill up in this chunk:
-            // no forced flush (E5) is possible and word boundaries depend on each bin alone
-            fast_chunk(s, ev1, ev2, term ICER_TIMER_PASS);
-            wave_drain(s);
-            ICER_TICK(7)
-            ICER_EMU_COUNT(0);
-        } else {
-            ICER_EMU_COUNT(1);
-            // ring nearly full: replay the reference state machine exactly, event by event
+        ICER_TICK(2)
+        // queue slot j % D is free once the assembly wave has retired chunk j - D
+        ICER_WAIT_UNTIL(j < ICER_LOAD_CNT(s.b_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_TICK(3)
+        EventSlot &q = s.eq[j % kQueueDepth];
+        FOR_LANES
+        {
+            q.ev1[lane] = (uint8_t)LV(ev1);
+            q.ev2[lane] = (uint8_t)LV(ev2);
+            if (lane == 0) q.nev = nev;
+        }
+        ICER_PUBLISH(s.a_done, j + 1u)
+    }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// ==========================================================================================
+// walker wave (bins 1..7)
+// ==========================================================================================
+struct WalkWave {
+    LANEVAR(uint32_t, acc);     // lane b (1..7): partial input of bin b
+    LANEVAR(uint32_t, top);     //                1 << (number of bits in acc)
+    LANEVAR(uint32_t, term);    //                code-tree termination mask of bin b, node = acc | top (< 32)
+};
+
+ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
+{
+    DECL_LANE;
+    FOR_LANES
+    {
+        const int wb = lane & 7;
+        LV(ww.acc) = 0;
+        LV(ww.top) = 1;
+        LV(ww.term) = 0;
+        for (uint32_t n = 1; n <= 4; n++)
+            for (uint32_t v = 0; v < (1u << n); v++)
+                if ((s.tab.v2v_term[wb][n] >> v) & 1u) LV(ww.term) |= 1u << (v | (1u << n));
+    }
+}
+
+ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uint32_t j0, uint32_t j1)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    (void)a;
+    for (uint32_t j = j0; j < j1; j++) {
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) break;
+        if (j > 0) {
+            // chunk j-1 was walked speculatively; if the assembly wave had to take the exact path for it,
+            // the partial inputs are whatever its replay left behind
+            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_decided) >= j || ICER_LOAD_CNT(s.abort))
+            if (s.exact[(j - 1u) % kQueueDepth]) {
+                ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_done) >= j || ICER_LOAD_CNT(s.abort))
+                FOR_LANES
+                {
+                    if (lane >= 1 && lane <= 7) { LV(ww.acc) = s.bin_acc[lane]; LV(ww.top) = 1u << s.bin_nin[lane]; }
+                }
+            }
+            if (ICER_LOAD_CNT(s.abort)) break;
+        }
+        ICER_TICK(4)
+        const EventSlot &q = s.eq[j % kQueueDepth];
+        WalkSlot &o = s.wq[j % kQueueDepth];
+        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2); LANEVAR(uint32_t, wn);
+        FOR_LANES
+        {
+            LV(ev1) = q.ev1[lane];
+            LV(ev2) = q.ev2[lane];
+            LV(wn) = 0;
+            if (lane < 8) o.open_pos[lane] = 255;
+        }
+        // every event of a present bin writes (position, bit) at its rank into the bin's dense sequence
+        for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), rem2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u)); rem1 | rem2;) {
+            const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
+            const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
+            const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
+            rem1 &= ~M1;
+            rem2 &= ~M2;
+            const uint32_t n = (uint32_t)(popc64(M1) + popc64(M2));
             FOR_LANES
             {
-                s.ev[2 * lane] = (uint8_t)LV(ev1);
-                s.ev[2 * lane + 1] = (uint8_t)LV(ev2);
+                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b))
+                    s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane)] = (uint8_t)(2u * (uint32_t)lane | ((LV(ev1) << 2) & 0x80u));
+                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b))
+                    s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane + 1u)] = (uint8_t)((2u * (uint32_t)lane + 1u) | ((LV(ev2) << 2) & 0x80u));
+                if (lane == b) LV(wn) = n;
             }
-            WAVE_SYNC();
+        }
+        WAVE_SYNC();
+        ICER_TICK(5)
+        // lane b walks bin b's sequence through the code tree (all <= 7 walkers in lockstep)
+        FOR_LANES
+        {
+            if (lane >= 1 && lane <= 7) {
+                const int b = lane;
+                const uint32_t n = LV(wn), tmask = LV(ww.term);
+                uint32_t acc = LV(ww.acc), top = LV(ww.top);
+                uint32_t cur_start = 255;                                // an unfinished word carried into the chunk
+                uint32_t x = n ? s.binseq[b][0] : 0u;
+                for (uint32_t r = 0; r < n; r++) {
+                    const uint32_t pos = x & 127u, bit = x >> 7;
+                    if (r + 1 < n) x = s.binseq[b][r + 1];              // next event's record is fetched early
+                    const uint32_t starts = top == 1u ? 1u : 0u;
+                    cur_start = starts ? pos : cur_start;
+                    acc |= bit ? top : 0u;
+                    top <<= 1;
+                    // (acc | top) numbers the node of the code tree; all 5-bit inputs are code words
+                    const uint32_t ends = (top == 32u || ((tmask >> (acc | top)) & 1u)) ? 1u : 0u;
+                    o.evflag[pos] = (uint8_t)(starts | (ends << 1));
+                    o.evacc[pos] = (uint8_t)acc;
+                    o.evstart[pos] = (uint8_t)cur_start;
+                    acc = ends ? 0u : acc;
+                    top = ends ? 1u : top;
+                }
+                LV(ww.acc) = acc;
+                LV(ww.top) = top;
+                if (n) o.open_pos[b] = (uint8_t)(top != 1u ? cur_start : 254u);
+                o.post_acc[b] = (uint8_t)acc;
+                o.post_nin[b] = (uint8_t)(31u - (uint32_t)clz32(top));
+            }
+        }
+        ICER_TICK(6)
+        ICER_PUBLISH(s.c_done, j + 1u)
+    }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// ==========================================================================================
+// assembly wave
+// ==========================================================================================
+
+// fast path of one chunk: bin 0 + Golomb bins from the event slot, bins 1..7 from the walker slot
+ICER_DEV void asm_fast_chunk(CoderShared &s, uint32_t j)
+{
+    DECL_LANE;
+    const EventSlot &q = s.eq[j % kQueueDepth];
+    LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
+    LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
+    LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
+    LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
+
+    FOR_LANES
+    {
+        LV(ev1) = q.ev1[lane];
+        LV(ev2) = q.ev2[lane];
+        LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
+        if (lane < kNumBins) s.bin_open_pos[lane] = 255;
+        // bin 0 (uncoded): every event is a complete one-bit word (E3)
+        if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
+        if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
+    }
+    WAVE_SYNC();
+
+    // ---- Golomb bins 8..16 present in the chunk: run length since the bin's previous one-event, modulo m
+    for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), rem2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u); rem1 | rem2;) {
+        const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
+        const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
+        const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
+        rem1 &= ~M1;
+        rem2 &= ~M2;
+        const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
+        const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
+        const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
+        const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = s.bin_acc[b];
+        FOR_LANES
+        {
+            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
+            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
+        }
+        const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
+        const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
+        FOR_LANES
+        {
+            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 2u)) {
+                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane);
+                LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+            }
+            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 2u)) {
+                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane + 1u);
+                LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
+            }
+        }
+        // bin state after the chunk (wave-uniform)
+        const int lastone = last_le(O1, O2, 127u);
+        const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
+        const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : k_in + ztot;
+        const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
+        const int laststart = last_le(SB1, SB2, 127u);
+        FOR_LANES
+        {
+            if (lane == 0) {
+                s.bin_acc[b] = k_out;
+                s.bin_open_pos[b] = (uint8_t)(k_out ? (laststart >= 0 ? laststart : 255) : 254);
+            }
+        }
+    }
+
+    // ---- bins 1..7: results of the walker wave ---------------------------------------------------------
+    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j)
+    {
+        const WalkSlot &wq = s.wq[j % kQueueDepth];
+        FOR_LANES
+        {
+            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
+            if (b1 >= 0x81u && b1 <= 0x87u) {
+                LV(fl1) = wq.evflag[2 * lane];
+                if (LV(fl1) & 2u) {
+                    const uint32_t e = s.tab.v2v[b1 & 31u][wq.evacc[2 * lane] & 31u];
+                    LV(wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
+                    LV(sp1) = wq.evstart[2 * lane];
+                }
+            }
+            if (b2 >= 0x81u && b2 <= 0x87u) {
+                LV(fl2) = wq.evflag[2 * lane + 1];
+                if (LV(fl2) & 2u) {
+                    const uint32_t e = s.tab.v2v[b2 & 31u][wq.evacc[2 * lane + 1] & 31u];
+                    LV(wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
+                    LV(sp2) = wq.evstart[2 * lane + 1];
+                }
+            }
+            if (lane >= 1 && lane <= 7) {
+                s.bin_open_pos[lane] = wq.open_pos[lane];
+                s.bin_acc[lane] = wq.post_acc[lane];          // walker state as of this (now retired) chunk
+                s.bin_nin[lane] = wq.post_nin[lane];
+            }
+        }
+    }
+    WAVE_SYNC();
+
+    // ---- ring slots in allocation order = order of the words' first events (E2) ------------------
+    const uint64_t S1 = BALLOT(LV(fl1) & 1u), S2 = BALLOT(LV(fl2) & 1u);
+    const uint32_t used = s.used, tail = s.head + used;
+    FOR_LANES
+    {
+        if (LV(fl1) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane)) & (kRingWords - 1)] = (uint16_t)(LV(ev1) & 31u);
+        if (LV(fl2) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane + 1u)) & (kRingWords - 1)] = (uint16_t)(LV(ev2) & 31u);
+    }
+    FOR_LANES
+    {
+        if (LV(fl1) & 2u) {
+            const uint32_t slot = LV(sp1) == 255u ? (uint32_t)s.bin_slot[LV(ev1) & 31u] : (tail + cnt_lt(S1, S2, LV(sp1)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd1);
+        }
+        if (LV(fl2) & 2u) {
+            const uint32_t slot = LV(sp2) == 255u ? (uint32_t)s.bin_slot[LV(ev2) & 31u] : (tail + cnt_lt(S1, S2, LV(sp2)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd2);
+        }
+    }
+    WAVE_SYNC();
+    FOR_LANES
+    {
+        if (lane < kNumBins) {
+            const uint32_t op = s.bin_open_pos[lane];
+            if (op == 254u) s.bin_slot[lane] = -1;
+            else if (op < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, op)) & (kRingWords - 1));
+        }
+        if (lane == 0) s.used = used + (uint32_t)(popc64(S1) + popc64(S2));
+    }
+    WAVE_SYNC();
+}
+
+// chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
+ICER_DEV bool asm_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    for (uint32_t j = j0; j < j1; j++) {
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j)
+        ICER_TICK(7)
+        const EventSlot &q = s.eq[j % kQueueDepth];
+        // every event could open at most one word: if the ring cannot fill up inside this chunk no forced
+        // flush (E5) is possible and word boundaries depend on each bin alone
+        const bool exact = s.used + q.nev > (uint32_t)kRingWords;
+        FOR_LANES
+        {
+            if (lane == 0) s.exact[j % kQueueDepth] = exact ? 1 : 0;
+        }
+        ICER_PUBLISH(s.b_decided, j + 1u)
+        if (!exact) {
+            asm_fast_chunk(s, j);
+            ICER_TICK(8)
+            wave_drain(s);
+            ICER_EMU_COUNT(0);
+            ICER_TICK(9)
+        } else {
+            ICER_EMU_COUNT(1);
+            // the walker wave must be past its speculative pass over this chunk before its bins are replayed
+            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j)
             uint32_t e = 0;
             for (;;) {
                 FOR_LANES
                 {
-                    if (lane == 0) s.resume = seq_run(s, e);
+                    if (lane == 0) s.resume = seq_run(s, q, e);
                 }
                 WAVE_SYNC();
                 e = s.resume;
@@ -727,15 +837,26 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
                 }
             }
             wave_drain(s);
-            ICER_TICK(8)
+            ICER_TICK(10)
         }
-        ok = flush_stage(s, a, false);
-        ICER_TICK(9)
+        const bool ok = flush_stage(s, a, false);
+        ICER_TICK(11)
+        if (!ok) {
+            ICER_PUBLISH(s.abort, 1u)
+            ICER_TIMERS_STORE(a.timers)
+            return false;
+        }
+        ICER_PUBLISH(s.b_done, j + 1u)
     }
+    ICER_TIMERS_STORE(a.timers)
+    return true;
+}
 
-    if (!ok) return kUnitTooBig;
-    ICER_TICK(10)
-    // end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455)
+// end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455);
+// returns the payload length in bits, or kUnitTooBig when the slot is too small
+ICER_DEV uint32_t asm_wave_finish(CoderShared &s, const UnitArgs &a)
+{
+    DECL_LANE;
     while (s.used > 0) {
         FOR_LANES
         {
@@ -744,10 +865,49 @@ ICER_DEV uint32_t code_unit_wave(CoderShared &s, const UnitArgs &a)
         WAVE_SYNC();
         wave_drain(s);
     }
-    ok = flush_stage(s, a, true);
-    ICER_TICK(11)
-    ICER_TIMERS_STORE(a.timers)
-    return ok ? s.bitpos : kUnitTooBig;
+    return flush_stage(s, a, true) ? s.bitpos : kUnitTooBig;
 }
+
+// state every wave relies on; run by ONE wave before the others start (a workgroup barrier follows on the GPU)
+ICER_DEV void unit_state_init(CoderShared &s)
+{
+    DECL_LANE;
+    FOR_LANES
+    {
+        for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
+        if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
+        if (lane < kNumContexts) { s.ctx_zero[lane] = 2; s.ctx_total[lane] = 4; }      // icer_context_modeller.c:607-613
+        if (lane == 0) {
+            s.head = 0; s.used = 0; s.bitpos = 0; s.flushed_words = 0;
+            s.a_done = 0; s.c_done = 0; s.b_decided = 0; s.b_done = 0; s.abort = 0;
+        }
+    }
+    WAVE_SYNC();
+}
+
+#ifdef ICER_WAVE_EMU
+// tests only: the three waves interleaved on one CPU thread.  The context wave runs as far ahead as the
+// queue allows and the walker as far as its speculation rule allows, so slot reuse and the discard/reload
+// protocol are exercised, not just the lock-step order.
+static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
+{
+    unit_state_init(s);
+    CtxWave cw;
+    WalkWave ww;
+    walk_wave_init(s, ww);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    uint32_t ja = 0, jc = 0, jb = 0;
+    while (jb < nchunks) {
+        while (ja < nchunks && ja < s.b_done + kQueueDepth) { ctx_wave_run(s, a, cw, ja, ja + 1); ja++; }
+        while (jc < ja && (jc == 0 || (s.b_decided >= jc && (!s.exact[(jc - 1) % kQueueDepth] || s.b_done >= jc)))) {
+            walk_wave_run(s, a, ww, jc, jc + 1);
+            jc++;
+        }
+        if (!asm_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+        jb++;
+    }
+    return asm_wave_finish(s, a);
+}
+#endif
 
 }  // namespace icer

@@ -100,8 +100,9 @@ finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------ coder
-// One wavefront = one coding unit of one frame.  grid = (units, frames), block = 64.
-__global__ void __launch_bounds__(64)
+// One workgroup of three wavefronts = one coding unit of one frame: context wave, walker wave, assembly
+// wave (coder_core.hpp).  grid = (units, frames), block = 192.
+__global__ void __launch_bounds__(64 * kUnitWaves)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
@@ -111,6 +112,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
     const uint32_t ui = work_order[blockIdx.x];
+    const uint32_t wave = threadIdx.x >> 6;
     if (frame_skip[frame]) {                      // DWT / mean overflow: the reference emits nothing
         if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
         return;
@@ -119,9 +121,11 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     {   // tables -> LDS
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
-        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * kUnitWaves) dst[i] = src[i];
     }
-    build_crc_table(s);
+    if (wave == 0) unit_state_init(s);
+    if (wave == 2) build_crc_table(s);
+    __syncthreads();
 
     uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
     UnitArgs a;
@@ -132,20 +136,30 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.out_words = slot_words + kHeaderBytes / 4;
     a.cap_words = u.cap_words;
     a.timers = timers;
-    const uint32_t bits = code_unit_wave(s, a);
+    const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
 
-    if (bits != kUnitTooBig) {
-        // make this wave's payload stores visible to its own loads before the CRC pass reads them
-        __threadfence();
-        FinishArgs f;
-        f.slot_words = slot_words;
-        f.bits = bits;
-        f.mean = means[(size_t)frame * channels + u.chan];
-        f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
-        f.image_w = img_w; f.image_h = img_h;
-        finish_unit_wave(s, f);
+    if (wave == 0) {
+        CtxWave cw;
+        ctx_wave_run(s, a, cw, 0, nchunks);
+    } else if (wave == 1) {
+        WalkWave ww;
+        walk_wave_init(s, ww);
+        walk_wave_run(s, a, ww, 0, nchunks);
+    } else {
+        const uint32_t bits = asm_wave_run(s, a, 0, nchunks) ? asm_wave_finish(s, a) : kUnitTooBig;
+        if (bits != kUnitTooBig) {
+            // make this wave's payload stores visible to its own loads before the CRC pass reads them
+            __threadfence();
+            FinishArgs f;
+            f.slot_words = slot_words;
+            f.bits = bits;
+            f.mean = means[(size_t)frame * channels + u.chan];
+            f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
+            f.image_w = img_w; f.image_h = img_h;
+            finish_unit_wave(s, f);
+        }
+        if ((threadIdx.x & 63) == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
     }
-    if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
 }
 
 // ------------------------------------------------------------------------------------------ assembly

@@ -28,7 +28,8 @@ extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t st
     a.cap_words = (uint32_t)(cap_bytes / 4);
     std::vector<uint32_t> words(a.cap_words + 1, 0);
     a.out_words = words.data();
-    uint32_t bits = code_unit_wave(g_sh, a);
+    a.timers = nullptr;
+    uint32_t bits = code_unit_emu(g_sh, a);
     long res = (bits == kUnitTooBig) ? -5 : (long)bits;
     if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
     return res;
@@ -114,7 +115,8 @@ extern "C" int emu_compress(uint16_t *const planes[], int channels, size_t w, si
         a.stride = (uint32_t)w; a.w = u.w; a.h = u.h; a.subband = (int)u.subband; a.lsb = (int)u.lsb;
         a.out_words = slot_words + kHeaderBytes / 4;
         a.cap_words = u.cap_words;
-        const uint32_t bits = code_unit_wave(g_sh, a);
+        a.timers = nullptr;
+        const uint32_t bits = code_unit_emu(g_sh, a);
         if (bits != kUnitTooBig) {
             FinishArgs f;
             f.slot_words = slot_words; f.bits = bits; f.mean = means[u.chan];

@@ -11,8 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from icer_compression_amd import api, build, synth  # noqa: E402
 
-NAMES = ["p1 context+loads", "p2 counts", "p3 fold+bin", "-", "p4 bin0+golomb", "p4 v2v walkers", "p4 slots+ring", "p4 drain",
-         "p4 exact path", "flush_stage", "loop exit", "end-of-unit flush"]
+NAMES = ["ctx wave: context+loads", "ctx wave: counts", "ctx wave: fold+bin", "ctx wave: wait (queue full)",
+         "walk wave: wait (events/verdict)", "walk wave: compaction", "walk wave: walk",
+         "asm wave: wait (events)", "asm wave: bin0+golomb+wait walker+slots", "asm wave: drain", "asm wave: exact path",
+         "asm wave: stage flush"]
 
 
 def main():
