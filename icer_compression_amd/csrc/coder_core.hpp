@@ -1,4 +1,4 @@
-// coder_core.hpp -- one workgroup of three wavefronts codes one ICER coding unit
+// coder_core.hpp -- one workgroup of five wavefronts codes one ICER coding unit
 // (channel, level, subband, plane, segment).
 //
 // Replaces, for the uint16 path, the reference's per-segment chain
@@ -8,29 +8,30 @@
 // and must emit the identical payload bits.
 //
 // The segment is coded in chunks of 64 pixels (raster order inside the segment).  The reference is a
-// sequential state machine; its state splits into three parts that only depend on their own history, so
-// three wavefronts work on consecutive chunks at the same time, handing chunks over through small LDS
-// queues (depth kQueueDepth):
+// sequential state machine; its state splits into parts that only depend on their own history, so five
+// wavefronts work on consecutive chunks at the same time (a software pipeline), handing chunks over
+// through small LDS queues (depth kQueueDepth):
 //
-//   context wave   per chunk: pixel category, magnitude bit, 8-neighbour context, sign context (64 lanes,
-//     (state: the    pure function of the 3x3 window; next chunk's window prefetched); the adaptive counts
-//      17 context    every event sees = counts at chunk start + rank among the chunk's events of the same
-//      counters)     context (ballot + v_mbcnt; the at-most-one rescale per context and chunk in closed form);
-//                    probability fold + bin selection.  Output: 128 event bytes (bin, bit).
+//   pixel wave     per chunk: pixel category, magnitude bit, 8-neighbour context, sign context (64 lanes,
+//     (stateless)    pure function of the 3x3 window; the next chunk's window is prefetched).
+//   count wave     the adaptive counts every event sees = counts at chunk start + rank among the chunk's
+//     (17 context    events of the same context (ballot + v_mbcnt; the at-most-one rescale per context and
+//      counters)     chunk in closed form); probability fold + bin selection.  Output: 128 event bytes.
 //   walker wave    bins 1..7 (variable-to-variable codes): events of a bin are compacted into a dense
-//     (state: the    sequence, lane b walks bin b's sequence through the code tree (termination mask in a
-//      partial       register) and marks where code words start/end.  It runs one chunk ahead of the
-//      inputs)       assembly wave's verdict (speculation, see below).
-//   assembly wave  bin 0 and the Golomb bins 8..16 in closed form on ballot masks (run length since the bin's
-//     (state: ring,  previous one-event, mod m); ring slots = prefix count of word-start flags (allocation order
-//      Golomb runs,  = order of first events, E2); finished words drained 64 at a time (ballot of done flags,
-//      bit stage)    prefix sum of lengths, ds_or into the LDS bit stage); whole 32-bit words stored to HBM.
+//     (partial       sequence, lane b walks bin b's sequence through the code tree (termination mask in a
+//      inputs)       register) and marks where code words start/end.
+//   golomb wave    bin 0 and the Golomb bins 8..16 in closed form on ballot masks: run length since the bin's
+//     (run lengths)  previous one-event, mod m, gives word starts/ends and the finished words.
+//   merge wave     ring slots = prefix count of word-start flags (allocation order = order of first events,
+//     (ring, bit     E2); finished words drained 64 at a time (ballot of done flags, prefix sum of lengths,
+//      stage)        ds_or into the LDS bit stage); whole 32-bit words stored to HBM; the exact path.
+// The walker and golomb waves run one chunk ahead of the merge wave's verdict (speculation, see below).
 //
 // Exactness: word boundaries depend on each bin alone only while the 2048-word ring cannot fill up inside
 // the chunk (used + events <= 2048): then no forced flush of the oldest open word (E5) can fire.  Otherwise
-// (~0.3-2.5 % of chunks) the assembly wave replays the reference state machine event by event on one lane,
+// (~0.3-2.5 % of chunks) the merge wave replays the reference state machine event by event on one lane,
 // with draining deferred to the 64-lane drain (it is only observable through `used` when a word is allocated),
-// and the walker wave discards its speculative result and reloads its state.
+// and the walker and golomb waves discard their speculative results and reload their state.
 //
 // Written with the SPMD macros of wave.hpp (see there for the tests-only CPU build).
 #pragma once
@@ -57,7 +58,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // Optional per-wave cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
 // -DICER_PHASE_TIMERS (a separate profiling build of the library, never the shipped one).
 #if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
-#define ICER_NUM_TIMERS 12
+#define ICER_NUM_TIMERS 24
 #define ICER_TIMERS_DECL uint64_t tacc_[ICER_NUM_TIMERS] = {}; uint64_t tlast_ = __builtin_amdgcn_s_memtime();
 #define ICER_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc_[k] += t_ - tlast_; tlast_ = t_; }
 #define ICER_TIMERS_STORE(dst) { if (dst) { _Pragma("unroll") for (int i_ = 0; i_ < ICER_NUM_TIMERS; i_++) if (lane == 0 && tacc_[i_]) atomicAdd((unsigned long long *)&(dst)[i_], (unsigned long long)tacc_[i_]); } }
@@ -72,21 +73,33 @@ namespace icer {
 constexpr uint32_t kStageWords = 1024;      // LDS bit stage (circular, 32-bit words)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
-constexpr int kUnitWaves = 3;               // context, walker, assembly
+constexpr int kUnitWaves = 5;               // pixel, count, walker, golomb, merge
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)
 constexpr uint32_t kWordDone = 0x8000u;
 
-struct EventSlot {              // context wave -> walker + assembly waves
+struct PixelSlot {              // pixel wave -> count wave
+    uint8_t c1[64];             // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | context (31 = uncoded), 0 = none
+    uint8_t c2[64];             // sign event: 0x80 | agreement bit << 5 | context
+};
+struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint8_t ev1[64];            // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | bin, 0 = none
     uint8_t ev2[64];            // sign event of pixel `lane`
     uint32_t nev;               // number of events in the chunk
 };
-struct WalkSlot {               // walker wave -> assembly wave (bins 1..7)
-    uint8_t evflag[128];        // bit0: a code word starts at this event, bit1: one ends here
-    uint8_t evacc[128];         // completed input value of the word that ends here
-    uint8_t evstart[128];       // position of that word's first event (255: it was carried into the chunk)
+struct GolombSlot {             // golomb wave -> merge wave (bins 0, 8..16)
+    uint8_t evflag[128];        // as WalkSlot::evflag
+    uint8_t evstart[128];
+    uint16_t evword[128];       // finished ring word of an end event
+    uint8_t open_pos[20];       // per bin, as WalkSlot::open_pos
+    uint16_t post_k[20];        // run lengths after the chunk
+};
+struct WalkSlot {               // walker wave -> merge wave (bins 1..7)
+    // per event of bins 1..7: bit0 a code word starts here, bit1 one ends here, bits 2..6 the completed
+    // input value of the word that ends here, bits 8..15 the position of that word's first event
+    // (255: it was carried into the chunk)
+    uint16_t rec[128];
     uint8_t open_pos[8];        // per bin after the chunk: 255 untouched, 254 closed, else first event of its open word
     uint8_t post_acc[8], post_nin[8];   // walker state after the chunk
 };
@@ -96,11 +109,11 @@ struct CoderShared {
     uint16_t ring[kRingWords];
     CoderTables tab;
     uint32_t crc_tab[256];
+    PixelSlot pq[kQueueDepth];
     EventSlot eq[kQueueDepth];
     WalkSlot wq[kQueueDepth];
-    uint8_t binseq[8][128];     // walker wave: events of bin b in coding order, bit7 = input bit, bits 6..0 = position
-    uint32_t ctx_zero[kNumContexts], ctx_total[kNumContexts];   // adaptive model of the unit (C5), context wave
-    uint8_t bin_open_pos[32];   // assembly wave, per bin after the chunk (same encoding as WalkSlot::open_pos)
+    GolombSlot gq[kQueueDepth];
+    alignas(16) uint8_t binseq[8][128];     // walker wave: events of bin b in coding order, bit7 = input bit, bits 6..0 = position
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
@@ -109,7 +122,7 @@ struct CoderShared {
     uint32_t flushed_words;     // payload words already written to HBM
     uint32_t resume;            // exact path: event index at which the single-lane replay paused
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
-    uint32_t a_done, c_done, b_decided, b_done, abort;
+    uint32_t p_done, a_done, c_done, g_done, b_decided, b_done, abort;
     uint8_t exact[kQueueDepth]; // assembly wave's verdict for the chunk in this queue slot: 1 = exact path
 };
 
@@ -266,7 +279,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
         if (m_) {                                                                                     \
             const uint64_t zm_ = BALLOT((PRED) && (ISZERO));                                          \
             const uint32_t n_ = (uint32_t)popc64(m_), nz_ = (uint32_t)popc64(zm_);                    \
-            const uint32_t t0_ = s.ctx_total[C], z0_ = s.ctx_zero[C];                                 \
+            const uint32_t t0_ = READLANE(ctot, C), z0_ = READLANE(czer, C);                          \
             if (t0_ + n_ < kRescaleCap) {                                                             \
                 FOR_LANES                                                                             \
                 {                                                                                     \
@@ -275,7 +288,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
                         LV(ZOUT) = z0_ + (uint32_t)mbcnt64(zm_, lane);                                \
                     }                                                                                 \
                 }                                                                                     \
-                FOR_LANES { if (lane == 0) { s.ctx_total[C] = t0_ + n_; s.ctx_zero[C] = z0_ + nz_; } }       \
+                FOR_LANES { if ((uint32_t)lane == (C)) { LV(ctot) = t0_ + n_; LV(czer) = z0_ + nz_; } }      \
             } else {                                                                                  \
                 const uint32_t kc_ = kRescaleCap - 1 - t0_; /* rank of the event that triggers it */  \
                 const int lc_ = ffs64(BALLOT((PRED) && (uint32_t)mbcnt64(m_, lane) == kc_));          \
@@ -290,7 +303,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
                         else { LV(TOUT) = kRescaleCap / 2 + (rk_ - kc_ - 1); LV(ZOUT) = zr_ + (zb_ - zc_); } \
                     }                                                                                 \
                 }                                                                                     \
-                FOR_LANES { if (lane == 0) { s.ctx_total[C] = kRescaleCap / 2 + (n_ - kc_ - 1); s.ctx_zero[C] = zr_ + (nz_ - zc_); } } \
+                FOR_LANES { if ((uint32_t)lane == (C)) { LV(ctot) = kRescaleCap / 2 + (n_ - kc_ - 1); LV(czer) = zr_ + (nz_ - zc_); } } \
             }                                                                                         \
         }                                                                                             \
     }
@@ -394,9 +407,9 @@ ICER_DEV void wave_drain(CoderShared &s)
 
 
 // ==========================================================================================
-// context wave
+// pixel wave
 // ==========================================================================================
-struct CtxWave {                // next chunk's 3x3 coefficient window, one pixel per lane
+struct PixelWave {                // next chunk's 3x3 coefficient window, one pixel per lane
     LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
     LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
 };
@@ -421,7 +434,7 @@ struct CtxWave {                // next chunk's 3x3 coefficient window, one pixe
     }
 
 // chunks [j0, j1) of the unit; the first call must start at chunk 0
-ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint32_t j0, uint32_t j1)
+ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -434,7 +447,6 @@ ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint3
         const uint32_t base = j * 64u;
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
-        LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
         LANEVAR(uint32_t, cC); LANEVAR(uint32_t, cW); LANEVAR(uint32_t, cE); LANEVAR(uint32_t, cN); LANEVAR(uint32_t, cS);
         LANEVAR(uint32_t, cNW); LANEVAR(uint32_t, cNE); LANEVAR(uint32_t, cSW); LANEVAR(uint32_t, cSE);
         FOR_LANES
@@ -475,7 +487,6 @@ ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint3
             LV(valid1) = valid ? 1u : 0u;
             LV(ctx1) = ctx;
             LV(bit1) = bit;
-            LV(z1) = 1; LV(t1) = 2;                               // what an uncoded event presents (C2)
 
             // sign event (C6): only negative significant neighbours count
             const bool sgn = valid && cat == 0 && bit;
@@ -488,9 +499,57 @@ ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint3
             LV(valid2) = sgn ? 1u : 0u;
             LV(ctx2) = sctx;
             LV(bit2) = (pred ^ (x >> 15)) & 1u;
-            LV(z2) = 0; LV(t2) = 0;
         }
         ICER_TICK(0)
+        // queue slot j % D is free once the count wave has consumed chunk j - D
+        ICER_WAIT_UNTIL(j < ICER_LOAD_CNT(s.a_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_TICK(1)
+        PixelSlot &o = s.pq[j % kQueueDepth];
+        FOR_LANES
+        {
+            o.c1[lane] = (uint8_t)(LV(valid1) ? (0x80u | (LV(bit1) << 5) | LV(ctx1)) : 0u);
+            o.c2[lane] = (uint8_t)(LV(valid2) ? (0x80u | (LV(bit2) << 5) | LV(ctx2)) : 0u);
+        }
+        ICER_PUBLISH(s.p_done, j + 1u)
+    }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// ==========================================================================================
+// count wave
+// ==========================================================================================
+struct CountWave {              // lane c: adaptive counts of context c (icer_context_model_typedef, icer.h:195-199)
+    LANEVAR(uint32_t, czer);
+    LANEVAR(uint32_t, ctot);
+};
+
+ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    LANEVAR(uint32_t, czer); LANEVAR(uint32_t, ctot);
+    FOR_LANES
+    {
+        LV(czer) = j0 == 0 ? 2u : LV(cs.czer);                    // icer_context_modeller.c:607-613
+        LV(ctot) = j0 == 0 ? 4u : LV(cs.ctot);
+    }
+    for (uint32_t j = j0; j < j1; j++) {
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.p_done) > j || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_TICK(2)
+        const PixelSlot &in = s.pq[j % kQueueDepth];
+        LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
+        LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
+        LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
+        FOR_LANES
+        {
+            const uint32_t c1 = in.c1[lane], c2 = in.c2[lane];
+            LV(valid1) = c1 >> 7; LV(ctx1) = c1 & 31u; LV(bit1) = (c1 >> 5) & 1u;
+            LV(valid2) = c2 >> 7; LV(ctx2) = c2 & 31u; LV(bit2) = (c2 >> 5) & 1u;
+            LV(z1) = 1; LV(t1) = 2;                               // what an uncoded event presents (C2)
+            LV(z2) = 0; LV(t2) = 0;
+        }
 
         // ---- adaptive counts per event (C5): one step per context PRESENT in the chunk ----------------
         for (uint64_t rem = BALLOT(LV(valid1) && LV(ctx1) != 31u); rem;) {
@@ -503,8 +562,7 @@ ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint3
             ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == c, LV(bit2) == 0u, z2, t2)
             rem &= ~BALLOT(LV(valid2) && LV(ctx2) == c);
         }
-        WAVE_SYNC();
-        ICER_TICK(1)
+        ICER_TICK(3)
 
         // ---- fold + bin (E1), hand the chunk over ------------------------------------------------------
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
@@ -525,11 +583,11 @@ ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint3
             LV(ev2) = e2;
         }
         const uint32_t nev = (uint32_t)(popc64(BALLOT(LV(ev1) != 0u)) + popc64(BALLOT(LV(ev2) != 0u)));
-        ICER_TICK(2)
+        ICER_TICK(4)
         // queue slot j % D is free once the assembly wave has retired chunk j - D
         ICER_WAIT_UNTIL(j < ICER_LOAD_CNT(s.b_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
         if (ICER_LOAD_CNT(s.abort)) break;
-        ICER_TICK(3)
+        ICER_TICK(5)
         EventSlot &q = s.eq[j % kQueueDepth];
         FOR_LANES
         {
@@ -539,6 +597,7 @@ ICER_DEV void ctx_wave_run(CoderShared &s, const UnitArgs &a, CtxWave &cw, uint3
         }
         ICER_PUBLISH(s.a_done, j + 1u)
     }
+    FOR_LANES { LV(cs.czer) = LV(czer); LV(cs.ctot) = LV(ctot); }
     ICER_TIMERS_STORE(a.timers)
 }
 
@@ -587,7 +646,7 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
             }
             if (ICER_LOAD_CNT(s.abort)) break;
         }
-        ICER_TICK(4)
+        ICER_TICK(6)
         const EventSlot &q = s.eq[j % kQueueDepth];
         WalkSlot &o = s.wq[j % kQueueDepth];
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2); LANEVAR(uint32_t, wn);
@@ -616,7 +675,7 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
             }
         }
         WAVE_SYNC();
-        ICER_TICK(5)
+        ICER_TICK(7)
         // lane b walks bin b's sequence through the code tree (all <= 7 walkers in lockstep)
         FOR_LANES
         {
@@ -625,22 +684,31 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
                 const uint32_t n = LV(wn), tmask = LV(ww.term);
                 uint32_t acc = LV(ww.acc), top = LV(ww.top);
                 uint32_t cur_start = 255;                                // an unfinished word carried into the chunk
-                uint32_t x = n ? s.binseq[b][0] : 0u;
-                for (uint32_t r = 0; r < n; r++) {
-                    const uint32_t pos = x & 127u, bit = x >> 7;
-                    if (r + 1 < n) x = s.binseq[b][r + 1];              // next event's record is fetched early
-                    const uint32_t starts = top == 1u ? 1u : 0u;
-                    cur_start = starts ? pos : cur_start;
-                    acc |= bit ? top : 0u;
-                    top <<= 1;
-                    // (acc | top) numbers the node of the code tree; all 5-bit inputs are code words
-                    const uint32_t ends = (top == 32u || ((tmask >> (acc | top)) & 1u)) ? 1u : 0u;
-                    o.evflag[pos] = (uint8_t)(starts | (ends << 1));
-                    o.evacc[pos] = (uint8_t)acc;
-                    o.evstart[pos] = (uint8_t)cur_start;
-                    acc = ends ? 0u : acc;
-                    top = ends ? 1u : top;
+                // one step of the walk: event record x = position | input bit << 7
+#define ICER_WALK_STEP(X)                                                                             \
+                {                                                                                     \
+                    const uint32_t pos_ = (X) & 127u;                                                 \
+                    const uint32_t starts_ = top == 1u ? 1u : 0u;                                     \
+                    cur_start = starts_ ? pos_ : cur_start;                                           \
+                    acc |= ((X) & 128u) ? top : 0u;                                                   \
+                    top <<= 1;                                                                        \
+                    /* (acc | top) numbers the node of the code tree; all 5-bit inputs are code words */ \
+                    const uint32_t ends_ = (top == 32u || ((tmask >> (acc | top)) & 1u)) ? 1u : 0u;   \
+                    o.rec[pos_] = (uint16_t)(starts_ | (ends_ << 1) | (acc << 2) | (cur_start << 8)); \
+                    acc = ends_ ? 0u : acc;                                                           \
+                    top = ends_ ? 1u : top;                                                           \
                 }
+                // the first 32 records come from registers (two 16-byte LDS reads, no per-step latency)
+                const uint32_t *seq32 = reinterpret_cast<const uint32_t *>(&s.binseq[b][0]);
+                uint32_t w[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) w[i] = (uint32_t)(4 * i) < n ? seq32[i] : 0u;
+#pragma unroll
+                for (int r = 0; r < 32; r++) {
+                    if ((uint32_t)r < n) ICER_WALK_STEP((w[r >> 2] >> (8 * (r & 3))) & 255u)
+                }
+                for (uint32_t r = 32; r < n; r++) ICER_WALK_STEP((uint32_t)s.binseq[b][r])
+#undef ICER_WALK_STEP
                 LV(ww.acc) = acc;
                 LV(ww.top) = top;
                 if (n) o.open_pos[b] = (uint8_t)(top != 1u ? cur_start : 254u);
@@ -648,18 +716,126 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
                 o.post_nin[b] = (uint8_t)(31u - (uint32_t)clz32(top));
             }
         }
-        ICER_TICK(6)
+        ICER_TICK(8)
         ICER_PUBLISH(s.c_done, j + 1u)
     }
     ICER_TIMERS_STORE(a.timers)
 }
 
-// ==========================================================================================
-// assembly wave
-// ==========================================================================================
 
-// fast path of one chunk: bin 0 + Golomb bins from the event slot, bins 1..7 from the walker slot
-ICER_DEV void asm_fast_chunk(CoderShared &s, uint32_t j)
+// ==========================================================================================
+// golomb wave (bins 0 and 8..16)
+// ==========================================================================================
+struct GolombWave {
+    LANEVAR(uint32_t, k);       // lane b (8..16): zero-run length of bin b's open word (0 = no open word)
+};
+
+ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw, uint32_t j0, uint32_t j1)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    (void)a;
+    for (uint32_t j = j0; j < j1; j++) {
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) break;
+        if (j == 0) {
+            FOR_LANES { LV(gw.k) = 0; }
+        } else {
+            // chunk j-1 was processed speculatively; after an exact-path chunk the runs are what the replay left
+            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_decided) >= j || ICER_LOAD_CNT(s.abort))
+            if (s.exact[(j - 1u) % kQueueDepth]) {
+                ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_done) >= j || ICER_LOAD_CNT(s.abort))
+                FOR_LANES
+                {
+                    if (lane >= 8 && lane <= 16) LV(gw.k) = s.bin_acc[lane];
+                }
+            }
+            if (ICER_LOAD_CNT(s.abort)) break;
+        }
+        ICER_TICK(9)
+        const EventSlot &q = s.eq[j % kQueueDepth];
+        GolombSlot &o = s.gq[j % kQueueDepth];
+        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
+        LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
+        LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
+        LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
+        FOR_LANES
+        {
+            LV(ev1) = q.ev1[lane];
+            LV(ev2) = q.ev2[lane];
+            LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
+            if (lane < 20) o.open_pos[lane] = 255;
+            // bin 0 (uncoded): every event is a complete one-bit word (E3)
+            if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
+            if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
+        }
+        WAVE_SYNC();
+        // Golomb bins present in the chunk: run length since the bin's previous one-event, modulo m
+        for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), rem2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u); rem1 | rem2;) {
+            const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
+            const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
+            const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
+            rem1 &= ~M1;
+            rem2 &= ~M2;
+            const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
+            const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
+            const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
+            const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = READLANE(gw.k, b);
+            FOR_LANES
+            {
+                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
+                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
+            }
+            const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
+            const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
+            FOR_LANES
+            {
+                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 2u)) {
+                    const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane);
+                    LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+                }
+                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 2u)) {
+                    const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane + 1u);
+                    LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
+                }
+            }
+            // bin state after the chunk (wave-uniform)
+            const int lastone = last_le(O1, O2, 127u);
+            const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
+            const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : k_in + ztot;
+            const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
+            const int laststart = last_le(SB1, SB2, 127u);
+            FOR_LANES
+            {
+                if (lane == b) {
+                    LV(gw.k) = k_out;
+                    o.open_pos[b] = (uint8_t)(k_out ? (laststart >= 0 ? laststart : 255) : 254);
+                }
+            }
+        }
+        ICER_TICK(10)
+        FOR_LANES
+        {
+            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
+            if (b1 == 0x80u || b1 >= 0x88u) {
+                o.evflag[2 * lane] = (uint8_t)LV(fl1); o.evword[2 * lane] = (uint16_t)LV(wd1); o.evstart[2 * lane] = (uint8_t)LV(sp1);
+            }
+            if (b2 == 0x80u || b2 >= 0x88u) {
+                o.evflag[2 * lane + 1] = (uint8_t)LV(fl2); o.evword[2 * lane + 1] = (uint16_t)LV(wd2); o.evstart[2 * lane + 1] = (uint8_t)LV(sp2);
+            }
+            if (lane >= 8 && lane <= 16) o.post_k[lane] = (uint16_t)LV(gw.k);
+        }
+        ICER_PUBLISH(s.g_done, j + 1u)
+        ICER_TICK(11)
+    }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// ==========================================================================================
+// merge wave
+// ==========================================================================================
+// fast path of one chunk: word starts/ends from the golomb and walker waves -> ring slots -> ring words
+ICER_DEV void merge_fast_chunk(CoderShared &s, uint32_t j)
 {
     DECL_LANE;
     const EventSlot &q = s.eq[j % kQueueDepth];
@@ -667,64 +843,27 @@ ICER_DEV void asm_fast_chunk(CoderShared &s, uint32_t j)
     LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
     LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
     LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
-
+    LANEVAR(uint32_t, op);                              // lane b: open_pos of bin b after this chunk
     FOR_LANES
     {
         LV(ev1) = q.ev1[lane];
         LV(ev2) = q.ev2[lane];
-        LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
-        if (lane < kNumBins) s.bin_open_pos[lane] = 255;
-        // bin 0 (uncoded): every event is a complete one-bit word (E3)
-        if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
-        if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
+        LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255; LV(op) = 255;
     }
-    WAVE_SYNC();
-
-    // ---- Golomb bins 8..16 present in the chunk: run length since the bin's previous one-event, modulo m
-    for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), rem2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u); rem1 | rem2;) {
-        const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
-        const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
-        const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-        rem1 &= ~M1;
-        rem2 &= ~M2;
-        const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
-        const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
-        const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
-        const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = s.bin_acc[b];
+    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.g_done) > j)
+    {
+        const GolombSlot &gq = s.gq[j % kQueueDepth];
         FOR_LANES
         {
-            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
-            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
-        }
-        const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
-        const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
-        FOR_LANES
-        {
-            if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 2u)) {
-                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane);
-                LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
-            }
-            if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 2u)) {
-                const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane + 1u);
-                LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
-            }
-        }
-        // bin state after the chunk (wave-uniform)
-        const int lastone = last_le(O1, O2, 127u);
-        const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
-        const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : k_in + ztot;
-        const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
-        const int laststart = last_le(SB1, SB2, 127u);
-        FOR_LANES
-        {
-            if (lane == 0) {
-                s.bin_acc[b] = k_out;
-                s.bin_open_pos[b] = (uint8_t)(k_out ? (laststart >= 0 ? laststart : 255) : 254);
+            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
+            if (b1 == 0x80u || b1 >= 0x88u) { LV(fl1) = gq.evflag[2 * lane]; LV(wd1) = gq.evword[2 * lane]; LV(sp1) = gq.evstart[2 * lane]; }
+            if (b2 == 0x80u || b2 >= 0x88u) { LV(fl2) = gq.evflag[2 * lane + 1]; LV(wd2) = gq.evword[2 * lane + 1]; LV(sp2) = gq.evstart[2 * lane + 1]; }
+            if (lane >= 8 && lane <= 16) {
+                LV(op) = gq.open_pos[lane];
+                s.bin_acc[lane] = gq.post_k[lane];            // run lengths as of this (now retired) chunk
             }
         }
     }
-
-    // ---- bins 1..7: results of the walker wave ---------------------------------------------------------
     ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j)
     {
         const WalkSlot &wq = s.wq[j % kQueueDepth];
@@ -732,29 +871,30 @@ ICER_DEV void asm_fast_chunk(CoderShared &s, uint32_t j)
         {
             const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
             if (b1 >= 0x81u && b1 <= 0x87u) {
-                LV(fl1) = wq.evflag[2 * lane];
-                if (LV(fl1) & 2u) {
-                    const uint32_t e = s.tab.v2v[b1 & 31u][wq.evacc[2 * lane] & 31u];
+                const uint32_t r = wq.rec[2 * lane];
+                LV(fl1) = r & 3u;
+                if (r & 2u) {
+                    const uint32_t e = s.tab.v2v[b1 & 31u][(r >> 2) & 31u];
                     LV(wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(sp1) = wq.evstart[2 * lane];
+                    LV(sp1) = r >> 8;
                 }
             }
             if (b2 >= 0x81u && b2 <= 0x87u) {
-                LV(fl2) = wq.evflag[2 * lane + 1];
-                if (LV(fl2) & 2u) {
-                    const uint32_t e = s.tab.v2v[b2 & 31u][wq.evacc[2 * lane + 1] & 31u];
+                const uint32_t r = wq.rec[2 * lane + 1];
+                LV(fl2) = r & 3u;
+                if (r & 2u) {
+                    const uint32_t e = s.tab.v2v[b2 & 31u][(r >> 2) & 31u];
                     LV(wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(sp2) = wq.evstart[2 * lane + 1];
+                    LV(sp2) = r >> 8;
                 }
             }
             if (lane >= 1 && lane <= 7) {
-                s.bin_open_pos[lane] = wq.open_pos[lane];
+                LV(op) = wq.open_pos[lane];
                 s.bin_acc[lane] = wq.post_acc[lane];          // walker state as of this (now retired) chunk
                 s.bin_nin[lane] = wq.post_nin[lane];
             }
         }
     }
-    WAVE_SYNC();
 
     // ---- ring slots in allocation order = order of the words' first events (E2) ------------------
     const uint64_t S1 = BALLOT(LV(fl1) & 1u), S2 = BALLOT(LV(fl2) & 1u);
@@ -779,9 +919,8 @@ ICER_DEV void asm_fast_chunk(CoderShared &s, uint32_t j)
     FOR_LANES
     {
         if (lane < kNumBins) {
-            const uint32_t op = s.bin_open_pos[lane];
-            if (op == 254u) s.bin_slot[lane] = -1;
-            else if (op < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, op)) & (kRingWords - 1));
+            if (LV(op) == 254u) s.bin_slot[lane] = -1;
+            else if (LV(op) < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, LV(op))) & (kRingWords - 1));
         }
         if (lane == 0) s.used = used + (uint32_t)(popc64(S1) + popc64(S2));
     }
@@ -789,13 +928,13 @@ ICER_DEV void asm_fast_chunk(CoderShared &s, uint32_t j)
 }
 
 // chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
-ICER_DEV bool asm_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
+ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     for (uint32_t j = j0; j < j1; j++) {
         ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j)
-        ICER_TICK(7)
+        ICER_TICK(12)
         const EventSlot &q = s.eq[j % kQueueDepth];
         // every event could open at most one word: if the ring cannot fill up inside this chunk no forced
         // flush (E5) is possible and word boundaries depend on each bin alone
@@ -806,15 +945,16 @@ ICER_DEV bool asm_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint3
         }
         ICER_PUBLISH(s.b_decided, j + 1u)
         if (!exact) {
-            asm_fast_chunk(s, j);
-            ICER_TICK(8)
+            merge_fast_chunk(s, j);
+            ICER_TICK(13)
             wave_drain(s);
             ICER_EMU_COUNT(0);
-            ICER_TICK(9)
+            ICER_TICK(14)
         } else {
             ICER_EMU_COUNT(1);
-            // the walker wave must be past its speculative pass over this chunk before its bins are replayed
-            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j)
+            // the walker and golomb waves must be past their speculative pass over this chunk before its
+            // bins are replayed (bin_acc / bin_nin hold their state as of the last retired chunk)
+            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j && ICER_LOAD_CNT(s.g_done) > j)
             uint32_t e = 0;
             for (;;) {
                 FOR_LANES
@@ -837,10 +977,10 @@ ICER_DEV bool asm_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint3
                 }
             }
             wave_drain(s);
-            ICER_TICK(10)
+            ICER_TICK(15)
         }
         const bool ok = flush_stage(s, a, false);
-        ICER_TICK(11)
+        ICER_TICK(16)
         if (!ok) {
             ICER_PUBLISH(s.abort, 1u)
             ICER_TIMERS_STORE(a.timers)
@@ -854,7 +994,7 @@ ICER_DEV bool asm_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint3
 
 // end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455);
 // returns the payload length in bits, or kUnitTooBig when the slot is too small
-ICER_DEV uint32_t asm_wave_finish(CoderShared &s, const UnitArgs &a)
+ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a)
 {
     DECL_LANE;
     while (s.used > 0) {
@@ -876,37 +1016,38 @@ ICER_DEV void unit_state_init(CoderShared &s)
     {
         for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
-        if (lane < kNumContexts) { s.ctx_zero[lane] = 2; s.ctx_total[lane] = 4; }      // icer_context_modeller.c:607-613
         if (lane == 0) {
             s.head = 0; s.used = 0; s.bitpos = 0; s.flushed_words = 0;
-            s.a_done = 0; s.c_done = 0; s.b_decided = 0; s.b_done = 0; s.abort = 0;
+            s.p_done = 0; s.a_done = 0; s.c_done = 0; s.g_done = 0; s.b_decided = 0; s.b_done = 0; s.abort = 0;
         }
     }
     WAVE_SYNC();
 }
 
 #ifdef ICER_WAVE_EMU
-// tests only: the three waves interleaved on one CPU thread.  The context wave runs as far ahead as the
-// queue allows and the walker as far as its speculation rule allows, so slot reuse and the discard/reload
-// protocol are exercised, not just the lock-step order.
+// tests only: the five waves interleaved on one CPU thread.  Each wave runs as far ahead as the queues and
+// the speculation rule allow, so slot reuse and the discard/reload protocol are exercised, not just the
+// lock-step order.
 static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
 {
     unit_state_init(s);
-    CtxWave cw;
+    PixelWave pw;
+    CountWave cs;
     WalkWave ww;
+    GolombWave gw;
     walk_wave_init(s, ww);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
-    uint32_t ja = 0, jc = 0, jb = 0;
+    uint32_t jp = 0, ja = 0, jc = 0, jg = 0, jb = 0;
+    auto spec_ok = [&](uint32_t j) { return j == 0 || (s.b_decided >= j && (!s.exact[(j - 1) % kQueueDepth] || s.b_done >= j)); };
     while (jb < nchunks) {
-        while (ja < nchunks && ja < s.b_done + kQueueDepth) { ctx_wave_run(s, a, cw, ja, ja + 1); ja++; }
-        while (jc < ja && (jc == 0 || (s.b_decided >= jc && (!s.exact[(jc - 1) % kQueueDepth] || s.b_done >= jc)))) {
-            walk_wave_run(s, a, ww, jc, jc + 1);
-            jc++;
-        }
-        if (!asm_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+        while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; }
+        while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; }
+        while (jc < ja && spec_ok(jc)) { walk_wave_run(s, a, ww, jc, jc + 1); jc++; }
+        while (jg < ja && spec_ok(jg)) { golomb_wave_run(s, a, gw, jg, jg + 1); jg++; }
+        if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
     }
-    return asm_wave_finish(s, a);
+    return merge_wave_finish(s, a);
 }
 #endif
 

@@ -100,8 +100,8 @@ finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------ coder
-// One workgroup of three wavefronts = one coding unit of one frame: context wave, walker wave, assembly
-// wave (coder_core.hpp).  grid = (units, frames), block = 192.
+// One workgroup of five wavefronts = one coding unit of one frame: pixel, count, walker, golomb and merge
+// waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  grid = (units, frames), block = 320.
 __global__ void __launch_bounds__(64 * kUnitWaves)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
@@ -118,13 +118,19 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         return;
     }
     const UnitDesc u = units[ui];
+    switch (u.prio) {                             // s_setprio takes an immediate
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: break;
+    }
     {   // tables -> LDS
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
         for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * kUnitWaves) dst[i] = src[i];
     }
     if (wave == 0) unit_state_init(s);
-    if (wave == 2) build_crc_table(s);
+    if (wave == 4) build_crc_table(s);
     __syncthreads();
 
     uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
@@ -135,18 +141,25 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.subband = (int)u.subband; a.lsb = (int)u.lsb;
     a.out_words = slot_words + kHeaderBytes / 4;
     a.cap_words = u.cap_words;
-    a.timers = timers;
+    // profiling build: per-wave cycle counters of the level-1 (largest) units, one row per bit plane
+    a.timers = (timers && u.level == 1) ? timers + u.lsb * 24 : nullptr;
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
 
     if (wave == 0) {
-        CtxWave cw;
-        ctx_wave_run(s, a, cw, 0, nchunks);
+        PixelWave pw;
+        pixel_wave_run(s, a, pw, 0, nchunks);
     } else if (wave == 1) {
+        CountWave cs;
+        count_wave_run(s, a, cs, 0, nchunks);
+    } else if (wave == 2) {
         WalkWave ww;
         walk_wave_init(s, ww);
         walk_wave_run(s, a, ww, 0, nchunks);
+    } else if (wave == 3) {
+        GolombWave gw;
+        golomb_wave_run(s, a, gw, 0, nchunks);
     } else {
-        const uint32_t bits = asm_wave_run(s, a, 0, nchunks) ? asm_wave_finish(s, a) : kUnitTooBig;
+        const uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (bits != kUnitTooBig) {
             // make this wave's payload stores visible to its own loads before the CRC pass reads them
             __threadfence();

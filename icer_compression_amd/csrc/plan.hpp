@@ -29,7 +29,7 @@ struct UnitDesc {
     uint32_t chan, level, subband, lsb, seg;
     uint32_t cap_words;             // payload capacity of the slot (32-bit words)
     uint32_t cap_is_bound;          // 1: capacity came from the bits-per-pixel bound, 0: from the byte quota
-    uint32_t pad_;
+    uint32_t prio;                  // wave priority (s_setprio): the largest units form the critical path of a frame
     uint64_t slot_off;              // byte offset of the slot (28-byte header + payload) in the frame's slot area
 };
 
@@ -200,6 +200,12 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
     std::stable_sort(p->work_order.begin(), p->work_order.end(), [&](uint32_t a, uint32_t b) {
         return (uint64_t)p->units[a].w * p->units[a].h > (uint64_t)p->units[b].w * p->units[b].h;
     });
+    // the launch is latency-bound by its largest units: give their waves issue priority over the small ones
+    const uint64_t biggest = p->units.empty() ? 1 : (uint64_t)p->units[p->work_order[0]].w * p->units[p->work_order[0]].h;
+    for (UnitDesc &u : p->units) {
+        const uint64_t px = (uint64_t)u.w * u.h;
+        u.prio = px * 2 >= biggest ? 3u : px * 8 >= biggest ? 2u : px * 32 >= biggest ? 1u : 0u;
+    }
     return p->error = kOk;
 }
 

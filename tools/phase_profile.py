@@ -11,10 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from icer_compression_amd import api, build, synth  # noqa: E402
 
-NAMES = ["ctx wave: context+loads", "ctx wave: counts", "ctx wave: fold+bin", "ctx wave: wait (queue full)",
+NAMES = ["pixel wave: context+loads", "pixel wave: wait (queue full)",
+         "count wave: wait (pixels)", "count wave: counts", "count wave: fold+bin", "count wave: wait (queue full)",
          "walk wave: wait (events/verdict)", "walk wave: compaction", "walk wave: walk",
-         "asm wave: wait (events)", "asm wave: bin0+golomb+wait walker+slots", "asm wave: drain", "asm wave: exact path",
-         "asm wave: stage flush"]
+         "golomb wave: wait (events/verdict)", "golomb wave: bins 0, 8-16", "golomb wave: hand-over",
+         "merge wave: wait (events)", "merge wave: wait golomb/walker + slots", "merge wave: drain", "merge wave: exact path",
+         "merge wave: stage flush"]
+NT = 24
 
 
 def main():
@@ -25,16 +28,20 @@ def main():
     enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=1)
     frame = synth.gray_frame(w, h, 12345, int(os.environ.get("MODE", "1")))[None]
     enc.encode_host(frame, 2 * w * h)
-    out = (C.c_uint64 * 12)()
+    out = (C.c_uint64 * (9 * NT))()
     lib.icerx_prof_read(enc.handle, out, 1)
     enc.timing_enable(True)
     enc.encode_host(frame, 2 * w * h)
     ms, _ = enc.timing_read()
     lib.icerx_prof_read(enc.handle, out, 1)
-    tot = sum(out)
-    print(f"{w}x{h} st={st} seg={sg}: code_units {ms['code_units']:.2f} ms; summed wave-cycles {tot/1e6:.1f} M")
-    for n, v in zip(NAMES, out):
-        print(f"  {n:22s} {v/1e6:10.1f} Mcyc  {100.0*v/max(tot,1):5.1f} %")
+    nunits = 3 * sg                                     # level-1 units per plane (HL, LH, HH x segments)
+    chunks = (w // 2) * (h // 2) * 3 / 64.0             # 64-pixel chunks per plane over those units
+    print(f"{w}x{h} st={st} seg={sg}: code_units {ms['code_units']:.2f} ms; level-1 units only, per bit plane:")
+    print("   cycles per chunk and wave (kcyc)  " + "".join(f"  lsb{p}" for p in range(9)))
+    for k, n in enumerate(NAMES):
+        print(f"  {n:40s}" + "".join(f"{out[p * NT + k] / chunks / 1e3:6.2f}" for p in range(9)))
+    tot = [sum(out[p * NT + k] for k in range(NT)) for p in range(9)]
+    print(f"  {'per-wave total (= unit latency / chunk)':40s}" + "".join(f"{t / 5 / chunks / 1e3:6.2f}" for t in tot))
 
 
 if __name__ == "__main__":
