@@ -113,7 +113,10 @@ struct CoderShared {
     EventSlot eq[kQueueDepth];
     WalkSlot wq[kQueueDepth];
     GolombSlot gq[kQueueDepth];
-    alignas(16) uint8_t binseq[8][128];     // walker wave: events of bin b in coding order, bit7 = input bit, bits 6..0 = position
+    uint8_t binseq[8][128];     // walker wave: positions of bin b's events in coding order (rank -> position)
+    uint32_t binbits[8][6];     // walker wave: input bits of bin b by rank, stored with an offset of 8 bits
+    uint32_t binstart[8][6];    // walker wave: word-start flags of bin b by rank, same offset
+    uint8_t bincarry[8], binn[8];   // walker wave: node carried into the chunk, number of events of the bin
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
@@ -605,24 +608,23 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
 // walker wave (bins 1..7)
 // ==========================================================================================
 struct WalkWave {
-    LANEVAR(uint32_t, acc);     // lane b (1..7): partial input of bin b
-    LANEVAR(uint32_t, top);     //                1 << (number of bits in acc)
-    LANEVAR(uint32_t, term);    //                code-tree termination mask of bin b, node = acc | top (< 32)
+    LANEVAR(uint32_t, node);    // lane b (1..7): code-tree node of bin b's partial input, acc | 1 << bits (1 = root)
 };
 
 ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
 {
     DECL_LANE;
-    FOR_LANES
-    {
-        const int wb = lane & 7;
-        LV(ww.acc) = 0;
-        LV(ww.top) = 1;
-        LV(ww.term) = 0;
-        for (uint32_t n = 1; n <= 4; n++)
-            for (uint32_t v = 0; v < (1u << n); v++)
-                if ((s.tab.v2v_term[wb][n] >> v) & 1u) LV(ww.term) |= 1u << (v | (1u << n));
-    }
+    (void)s;
+    FOR_LANES { LV(ww.node) = 1; }
+}
+
+// bits [start, start + 6) of a bit string stored with an offset of 8 (rank r lives at bit r + 8, so that
+// reads a few ranks before rank 0 see zeros); `start` is a rank - 4 >= -4
+ICER_DEV uint32_t window6(const uint32_t *words, int start)
+{
+    const uint32_t pos = (uint32_t)(start + 8);
+    const uint64_t two = (uint64_t)words[pos >> 5] | ((uint64_t)words[(pos >> 5) + 1] << 32);
+    return (uint32_t)(two >> (pos & 31u)) & 63u;
 }
 
 ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uint32_t j0, uint32_t j1)
@@ -634,14 +636,14 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
         ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
         if (ICER_LOAD_CNT(s.abort)) break;
         if (j > 0) {
-            // chunk j-1 was walked speculatively; if the assembly wave had to take the exact path for it,
+            // chunk j-1 was walked speculatively; if the merge wave had to take the exact path for it,
             // the partial inputs are whatever its replay left behind
             ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_decided) >= j || ICER_LOAD_CNT(s.abort))
             if (s.exact[(j - 1u) % kQueueDepth]) {
                 ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_done) >= j || ICER_LOAD_CNT(s.abort))
                 FOR_LANES
                 {
-                    if (lane >= 1 && lane <= 7) { LV(ww.acc) = s.bin_acc[lane]; LV(ww.top) = 1u << s.bin_nin[lane]; }
+                    if (lane >= 1 && lane <= 7) LV(ww.node) = s.bin_acc[lane] | (1u << s.bin_nin[lane]);
                 }
             }
             if (ICER_LOAD_CNT(s.abort)) break;
@@ -650,14 +652,18 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
         const EventSlot &q = s.eq[j % kQueueDepth];
         WalkSlot &o = s.wq[j % kQueueDepth];
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2); LANEVAR(uint32_t, wn);
+        LANEVAR(uint32_t, rk1); LANEVAR(uint32_t, rk2);         // rank of this lane's events inside their bin
         FOR_LANES
         {
             LV(ev1) = q.ev1[lane];
             LV(ev2) = q.ev2[lane];
-            LV(wn) = 0;
+            LV(wn) = 0; LV(rk1) = 0; LV(rk2) = 0;
             if (lane < 8) o.open_pos[lane] = 255;
+            if (lane < 48) (&s.binbits[0][0])[lane] = 0;
         }
-        // every event of a present bin writes (position, bit) at its rank into the bin's dense sequence
+        WAVE_SYNC();
+        // every event of a present bin puts its input bit at its rank into the bin's bit string and its
+        // position into the bin's position list
         for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), rem2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u)); rem1 | rem2;) {
             const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
             const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
@@ -667,61 +673,114 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
             const uint32_t n = (uint32_t)(popc64(M1) + popc64(M2));
             FOR_LANES
             {
-                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b))
-                    s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane)] = (uint8_t)(2u * (uint32_t)lane | ((LV(ev1) << 2) & 0x80u));
-                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b))
-                    s.binseq[b][cnt_lt(M1, M2, 2u * (uint32_t)lane + 1u)] = (uint8_t)((2u * (uint32_t)lane + 1u) | ((LV(ev2) << 2) & 0x80u));
+                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) {
+                    const uint32_t r = cnt_lt(M1, M2, 2u * (uint32_t)lane);
+                    LV(rk1) = r;
+                    s.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane);
+                    if (LV(ev1) & 0x20u) LDS_OR(s.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
+                }
+                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) {
+                    const uint32_t r = cnt_lt(M1, M2, 2u * (uint32_t)lane + 1u);
+                    LV(rk2) = r;
+                    s.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane + 1u);
+                    if (LV(ev2) & 0x20u) LDS_OR(s.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
+                }
                 if (lane == b) LV(wn) = n;
             }
         }
         WAVE_SYNC();
         ICER_TICK(7)
-        // lane b walks bin b's sequence through the code tree (all <= 7 walkers in lockstep)
+        // lane b walks bin b's bit string through the code tree, four input bits per table look-up, and
+        // records at which ranks code words start (all <= 7 walkers in lockstep)
         FOR_LANES
         {
             if (lane >= 1 && lane <= 7) {
                 const int b = lane;
-                const uint32_t n = LV(wn), tmask = LV(ww.term);
-                uint32_t acc = LV(ww.acc), top = LV(ww.top);
-                uint32_t cur_start = 255;                                // an unfinished word carried into the chunk
-                // one step of the walk: event record x = position | input bit << 7
-#define ICER_WALK_STEP(X)                                                                             \
-                {                                                                                     \
-                    const uint32_t pos_ = (X) & 127u;                                                 \
-                    const uint32_t starts_ = top == 1u ? 1u : 0u;                                     \
-                    cur_start = starts_ ? pos_ : cur_start;                                           \
-                    acc |= ((X) & 128u) ? top : 0u;                                                   \
-                    top <<= 1;                                                                        \
-                    /* (acc | top) numbers the node of the code tree; all 5-bit inputs are code words */ \
-                    const uint32_t ends_ = (top == 32u || ((tmask >> (acc | top)) & 1u)) ? 1u : 0u;   \
-                    o.rec[pos_] = (uint16_t)(starts_ | (ends_ << 1) | (acc << 2) | (cur_start << 8)); \
-                    acc = ends_ ? 0u : acc;                                                           \
-                    top = ends_ ? 1u : top;                                                           \
+                const uint32_t n = LV(wn);
+                uint32_t node = LV(ww.node);
+                s.bincarry[b] = (uint8_t)node;
+                uint64_t lo = ((uint64_t)s.binbits[b][0] | ((uint64_t)s.binbits[b][1] << 32)) >> 8;      // ranks 0..55
+                uint64_t hi = (uint64_t)s.binbits[b][2] | ((uint64_t)s.binbits[b][3] << 32);             // ranks 56..119
+                const uint32_t top8 = s.binbits[b][4];                                                     // ranks 120..127
+                lo |= hi << 56;
+                hi = (hi >> 8) | ((uint64_t)top8 << 56);                                                   // ranks 64..127
+                uint64_t st_lo = 0, st_hi = 0;                  // word-start flags by rank
+                uint32_t r = 0;
+                for (; r + 4u <= n && r < 64u; r += 4) {
+                    const uint32_t e = s.tab.v2v_step[b][node][(uint32_t)(lo >> r) & 15u];
+                    st_lo |= (uint64_t)((e >> 5) & 15u) << r;
+                    node = e & 31u;
                 }
-                // the first 32 records come from registers (two 16-byte LDS reads, no per-step latency)
-                const uint32_t *seq32 = reinterpret_cast<const uint32_t *>(&s.binseq[b][0]);
-                uint32_t w[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) w[i] = (uint32_t)(4 * i) < n ? seq32[i] : 0u;
-#pragma unroll
-                for (int r = 0; r < 32; r++) {
-                    if ((uint32_t)r < n) ICER_WALK_STEP((w[r >> 2] >> (8 * (r & 3))) & 255u)
+                for (; r + 4u <= n; r += 4) {
+                    const uint32_t e = s.tab.v2v_step[b][node][(uint32_t)(hi >> (r - 64u)) & 15u];
+                    st_hi |= (uint64_t)((e >> 5) & 15u) << (r - 64u);
+                    node = e & 31u;
                 }
-                for (uint32_t r = 32; r < n; r++) ICER_WALK_STEP((uint32_t)s.binseq[b][r])
-#undef ICER_WALK_STEP
-                LV(ww.acc) = acc;
-                LV(ww.top) = top;
-                if (n) o.open_pos[b] = (uint8_t)(top != 1u ? cur_start : 254u);
-                o.post_acc[b] = (uint8_t)acc;
-                o.post_nin[b] = (uint8_t)(31u - (uint32_t)clz32(top));
+                for (; r < n; r++) {                            // last 1..3 bits one at a time
+                    const uint32_t bit = (uint32_t)((r < 64u ? lo >> r : hi >> (r - 64u)) & 1ull);
+                    if (node == 1u) { if (r < 64u) st_lo |= 1ull << r; else st_hi |= 1ull << (r - 64u); }
+                    // one step: append the bit, back to the root when the input is a code word
+                    uint32_t nin = 31u - (uint32_t)clz32(node);
+                    uint32_t acc = (node ^ (1u << nin)) | (bit << nin);
+                    nin++;
+                    node = (nin == 5u || ((s.tab.v2v_term[b][nin] >> acc) & 1u)) ? 1u : (acc | (1u << nin));
+                }
+                LV(ww.node) = node;
+                // post: start flags with the same offset of 8 as the bit string
+                s.binstart[b][0] = (uint32_t)(st_lo << 8);
+                s.binstart[b][1] = (uint32_t)(st_lo >> 24);
+                s.binstart[b][2] = (uint32_t)(st_lo >> 56) | (uint32_t)(st_hi << 8);
+                s.binstart[b][3] = (uint32_t)(st_hi >> 24);
+                s.binstart[b][4] = (uint32_t)(st_hi >> 56);
+                s.binstart[b][5] = 0;
+                const uint32_t nin = 31u - (uint32_t)clz32(node);
+                o.post_acc[b] = (uint8_t)(node ^ (1u << nin));
+                o.post_nin[b] = (uint8_t)nin;
+                if (n) {
+                    // open word after the chunk: the last start, unless everything after it completed
+                    int last = st_hi ? 64 + 63 - clz64(st_hi) : (st_lo ? 63 - clz64(st_lo) : -1);
+                    o.open_pos[b] = (uint8_t)(node == 1u ? 254u : (last >= 0 ? (uint32_t)s.binseq[b][last] : 255u));
+                }
+                s.binn[b] = (uint8_t)n;
             }
         }
+        WAVE_SYNC();
         ICER_TICK(8)
+        // every event lane derives its own record from the start flags: does a word start / end here,
+        // and for an end: the word's input value and the position of its first event
+#define ICER_V2V_RECORD(EV, RK, POS)                                                                   \
+        if (((EV)&0x98u) == 0x80u && ((EV)&7u)) {                                                      \
+            const uint32_t b_ = (EV)&7u, r_ = (RK), n_ = s.binn[b_];                                    \
+            const uint32_t sw_ = window6(s.binstart[b_], (int)r_ - 4);      /* starts at ranks r-4 .. r+1 */ \
+            const uint32_t bw_ = window6(s.binbits[b_], (int)r_ - 4);       /* input bits, same ranks */    \
+            const uint32_t starts_ = (sw_ >> 4) & 1u;                                                   \
+            const uint32_t carry_ = s.bincarry[b_];                                                     \
+            const uint32_t ends_ = (r_ + 1u < n_) ? ((sw_ >> 5) & 1u) : (o.post_nin[b_] == 0u ? 1u : 0u); \
+            uint32_t acc_ = 0, sp_ = 255;                                                               \
+            if (ends_) {                                                                                \
+                const uint32_t back_ = sw_ & 31u;                            /* starts at r-4 .. r */   \
+                if (back_) {                                                                            \
+                    const uint32_t k_ = 31u - (uint32_t)clz32(back_);        /* start at rank r-4+k */  \
+                    acc_ = (bw_ & 31u) >> k_;                                                           \
+                    sp_ = s.binseq[b_][r_ - 4u + k_];                                                   \
+                } else {                                                     /* the carried-in word */  \
+                    const uint32_t cn_ = 31u - (uint32_t)clz32(carry_);                                 \
+                    acc_ = (carry_ ^ (1u << cn_)) | (((bw_ & 31u) >> (4u - r_)) << cn_);                \
+                }                                                                                       \
+            }                                                                                           \
+            o.rec[POS] = (uint16_t)(starts_ | (ends_ << 1) | ((acc_ & 31u) << 2) | (sp_ << 8));         \
+        }
+        FOR_LANES
+        {
+            ICER_V2V_RECORD(LV(ev1), LV(rk1), 2 * lane)
+            ICER_V2V_RECORD(LV(ev2), LV(rk2), 2 * lane + 1)
+        }
+#undef ICER_V2V_RECORD
+        ICER_TICK(9)
         ICER_PUBLISH(s.c_done, j + 1u)
     }
     ICER_TIMERS_STORE(a.timers)
 }
-
 
 // ==========================================================================================
 // golomb wave (bins 0 and 8..16)
@@ -752,7 +811,7 @@ ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw,
             }
             if (ICER_LOAD_CNT(s.abort)) break;
         }
-        ICER_TICK(9)
+        ICER_TICK(10)
         const EventSlot &q = s.eq[j % kQueueDepth];
         GolombSlot &o = s.gq[j % kQueueDepth];
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
@@ -813,7 +872,7 @@ ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw,
                 }
             }
         }
-        ICER_TICK(10)
+        ICER_TICK(11)
         FOR_LANES
         {
             const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
@@ -826,7 +885,7 @@ ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw,
             if (lane >= 8 && lane <= 16) o.post_k[lane] = (uint16_t)LV(gw.k);
         }
         ICER_PUBLISH(s.g_done, j + 1u)
-        ICER_TICK(11)
+        ICER_TICK(12)
     }
     ICER_TIMERS_STORE(a.timers)
 }
@@ -934,7 +993,7 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
     ICER_TIMERS_DECL
     for (uint32_t j = j0; j < j1; j++) {
         ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j)
-        ICER_TICK(12)
+        ICER_TICK(13)
         const EventSlot &q = s.eq[j % kQueueDepth];
         // every event could open at most one word: if the ring cannot fill up inside this chunk no forced
         // flush (E5) is possible and word boundaries depend on each bin alone
@@ -946,10 +1005,10 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         ICER_PUBLISH(s.b_decided, j + 1u)
         if (!exact) {
             merge_fast_chunk(s, j);
-            ICER_TICK(13)
+            ICER_TICK(14)
             wave_drain(s);
             ICER_EMU_COUNT(0);
-            ICER_TICK(14)
+            ICER_TICK(15)
         } else {
             ICER_EMU_COUNT(1);
             // the walker and golomb waves must be past their speculative pass over this chunk before its
@@ -977,10 +1036,10 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
                 }
             }
             wave_drain(s);
-            ICER_TICK(15)
+            ICER_TICK(16)
         }
         const bool ok = flush_stage(s, a, false);
-        ICER_TICK(16)
+        ICER_TICK(17)
         if (!ok) {
             ICER_PUBLISH(s.abort, 1u)
             ICER_TIMERS_STORE(a.timers)

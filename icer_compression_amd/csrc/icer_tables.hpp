@@ -45,6 +45,10 @@ struct CoderTables {
     uint16_t v2v[8][32];
     // bins 1..7: [bin][n] = set of input values that are complete code words of n input bits (bit v set)
     uint32_t v2v_term[8][8];
+    // bins 1..7: four input bits at a time.  A node of the code tree is numbered (partial input | 1 << bits so
+    // far), the root is 1.  [bin][node][nibble] -> node after the 4 bits | (bit k set: a code word starts at the
+    // k-th of the 4 bits) << 5
+    uint16_t v2v_step[8][32][16];
     // bins 1..7: [bin][partial value 0..8][bits so far 0..5] -> appended bits | count<<4
     uint8_t v2v_flush[8][9][6];
     // bins 8..16: Golomb m, l = ceil(log2 m), i = 2^l - m
@@ -81,6 +85,20 @@ inline void build_coder_tables(CoderTables *t)
         t->v2v[c.bin][c.val] = (uint16_t)(c.nin | (c.nout << 4) | (c.code << 8));
         t->v2v_term[c.bin][c.nin] |= 1u << c.val;
     }
+    for (int b = 1; b <= 7; b++)
+        for (uint32_t node = 1; node < 32; node++)
+            for (uint32_t nib = 0; nib < 16; nib++) {
+                uint32_t nin = 0;
+                while ((2u << nin) <= node) nin++;                 // node = acc | 1 << nin
+                uint32_t acc = node ^ (1u << nin), starts = 0;
+                for (int k = 0; k < 4; k++) {
+                    if (nin == 0) starts |= 1u << k;
+                    acc |= ((nib >> k) & 1u) << nin;
+                    nin++;
+                    if (nin == 5 || ((t->v2v_term[b][nin] >> acc) & 1u)) { acc = 0; nin = 0; }
+                }
+                t->v2v_step[b][node][nib] = (uint16_t)((acc | (1u << nin)) | (starts << 5));
+            }
     struct F { uint8_t bin, val, nin, add, nadd; };
     static const F fl[] = {
         {1, 1, 1, 0, 1}, {1, 3, 2, 0, 1}, {1, 7, 3, 0, 1}, {1, 0, 1, 1, 1}, {1, 0, 2, 1, 1}, {1, 0, 3, 1, 1}, {1, 0, 4, 0, 1},

@@ -5,7 +5,7 @@ import numpy as np
 
 
 class CoderTables(C.Structure):     # mirrors icer::CoderTables
-    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
+    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_step", ((C.c_uint16 * 16) * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
                 ("gm", C.c_uint16 * 17), ("gl", C.c_uint16 * 17), ("gi", C.c_uint16 * 17),
                 ("ginv", C.c_uint32 * 17), ("cut", C.c_uint32 * 16), ("x2n", C.c_uint32 * 32)]
 
@@ -36,6 +36,32 @@ def test_tables_equal_reference(emu, reference):
         assert all(((z * t.ginv[b]) >> 20) == z // t.gm[b] for z in range(2048))     # exact reciprocal
     for i in range(16):
         assert t.cut[i] == reference.lib.ref_tap_cutoff(i)
+
+
+def test_nibble_step_table_equals_four_single_steps(emu, reference):
+    """v2v_step[bin][node][nibble] must equal four applications of the reference's per-bit rule
+    (icer_encoding.c:87-98: a prefix is complete when the table entry's input length equals the bits consumed)."""
+    t = _tables(emu)
+    for b in range(1, 8):
+        partial = {1}                                   # reachable nodes: root + every proper prefix of a code
+        for pre in range(32):
+            nin, _, _ = reference.custom_code(b, pre)
+            for k in range(1, nin):
+                partial.add((pre & ((1 << k) - 1)) | (1 << k))
+        for node in partial:
+            for nib in range(16):
+                nin = node.bit_length() - 1
+                acc, starts = node ^ (1 << nin), 0
+                for k in range(4):
+                    if nin == 0:
+                        starts |= 1 << k
+                    acc |= ((nib >> k) & 1) << nin
+                    nin += 1
+                    if reference.custom_code(b, acc)[0] == nin:
+                        acc, nin = 0, 0
+                    assert nin < 5
+                e = t.v2v_step[b][node][nib]
+                assert (e & 31, (e >> 5) & 15) == (acc | (1 << nin), starts), (b, node, nib)
 
 
 def test_pick_bin_equals_reference(emu, reference):
