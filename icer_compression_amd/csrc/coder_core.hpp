@@ -554,17 +554,86 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             LV(z2) = 0; LV(t2) = 0;
         }
 
-        // ---- adaptive counts per event (C5): one step per context PRESENT in the chunk ----------------
-        for (uint64_t rem = BALLOT(LV(valid1) && LV(ctx1) != 31u); rem;) {
-            const uint32_t c = READLANE(ctx1, ffs64(rem));
-            ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == c, LV(bit1) == 0u, z1, t1)
-            rem &= ~BALLOT(LV(valid1) && LV(ctx1) == c);
+        // ---- adaptive counts per event (C5) --------------------------------------------------------------
+        // Lanes with the same context are found from per-bit ballots of the context number (no loop over
+        // contexts): rank inside the context group and the zeros before give the counts an event sees; lane c
+        // applies the same match to "context c" and advances its own counters.  A context that reaches the
+        // rescale point inside this chunk (total 500, at most once per chunk) is redone by ICER_CTX_STEP.
+#define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
+        ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+        {
+            // magnitude-bit events: contexts 0..11
+            const uint64_t V = BALLOT(LV(valid1) && LV(ctx1) != 31u);
+            const uint64_t B0 = BALLOT(LV(ctx1) & 1u), B1 = BALLOT(LV(ctx1) & 2u), B2 = BALLOT(LV(ctx1) & 4u), B3 = BALLOT(LV(ctx1) & 8u);
+            const uint64_t ZM = BALLOT(LV(bit1) == 0u);
+            LANEVAR(uint32_t, t0); LANEVAR(uint32_t, zz0); LANEVAR(uint32_t, idx);
+            FOR_LANES { LV(idx) = LV(ctx1) & 15u; }
+            WAVE_GATHER(t0, ctot, idx)
+            WAVE_GATHER(zz0, czer, idx)
+            LANEVAR(uint32_t, cross);
+            FOR_LANES
+            {
+                const uint64_t m = ICER_MATCH(LV(ctx1), V, B0, B1, B2, B3);
+                LV(cross) = 0;
+                if (LV(valid1) && LV(ctx1) != 31u) {
+                    LV(t1) = LV(t0) + (uint32_t)mbcnt64(m, lane);
+                    LV(z1) = LV(zz0) + (uint32_t)mbcnt64(m & ZM, lane);
+                    LV(cross) = LV(t0) + (uint32_t)popc64(m) >= kRescaleCap ? 1u : 0u;
+                }
+            }
+            const uint64_t resc = BALLOT(LV(cross) != 0u);
+            FOR_LANES
+            {
+                if (lane < 12) {                                  // lane c owns context c
+                    const uint64_t m = ICER_MATCH((uint32_t)lane, V, B0, B1, B2, B3);
+                    const uint32_t n = (uint32_t)popc64(m);
+                    if (LV(ctot) + n < kRescaleCap) { LV(ctot) += n; LV(czer) += (uint32_t)popc64(m & ZM); }
+                }
+            }
+            for (uint64_t rem = resc; rem;) {                     // rare: redo the contexts that rescale in this chunk
+                const uint32_t c = READLANE(ctx1, ffs64(rem));
+                ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == c, LV(bit1) == 0u, z1, t1)
+                rem &= ~BALLOT(LV(valid1) && LV(ctx1) == c);
+            }
         }
-        for (uint64_t rem = BALLOT(LV(valid2) != 0u); rem;) {
-            const uint32_t c = READLANE(ctx2, ffs64(rem));
-            ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == c, LV(bit2) == 0u, z2, t2)
-            rem &= ~BALLOT(LV(valid2) && LV(ctx2) == c);
+        {
+            // sign events: contexts 12..16, keyed by context - 12
+            const uint64_t V = BALLOT(LV(valid2) != 0u);
+            if (V) {
+                const uint64_t B0 = BALLOT((LV(ctx2) - 12u) & 1u), B1 = BALLOT((LV(ctx2) - 12u) & 2u), B2 = BALLOT((LV(ctx2) - 12u) & 4u);
+                const uint64_t ZM = BALLOT(LV(bit2) == 0u);
+                LANEVAR(uint32_t, t0); LANEVAR(uint32_t, zz0); LANEVAR(uint32_t, idx);
+                FOR_LANES { LV(idx) = LV(ctx2) & 31u; }
+                WAVE_GATHER(t0, ctot, idx)
+                WAVE_GATHER(zz0, czer, idx)
+                LANEVAR(uint32_t, cross);
+                FOR_LANES
+                {
+                    const uint64_t m = ICER_MATCH(LV(ctx2) - 12u, V, B0, B1, B2, 0ull);
+                    LV(cross) = 0;
+                    if (LV(valid2)) {
+                        LV(t2) = LV(t0) + (uint32_t)mbcnt64(m, lane);
+                        LV(z2) = LV(zz0) + (uint32_t)mbcnt64(m & ZM, lane);
+                        LV(cross) = LV(t0) + (uint32_t)popc64(m) >= kRescaleCap ? 1u : 0u;
+                    }
+                }
+                const uint64_t resc = BALLOT(LV(cross) != 0u);
+                FOR_LANES
+                {
+                    if (lane >= 12 && lane <= 16) {
+                        const uint64_t m = ICER_MATCH((uint32_t)lane - 12u, V, B0, B1, B2, 0ull);
+                        const uint32_t n = (uint32_t)popc64(m);
+                        if (LV(ctot) + n < kRescaleCap) { LV(ctot) += n; LV(czer) += (uint32_t)popc64(m & ZM); }
+                    }
+                }
+                for (uint64_t rem = resc; rem;) {
+                    const uint32_t c = READLANE(ctx2, ffs64(rem));
+                    ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == c, LV(bit2) == 0u, z2, t2)
+                    rem &= ~BALLOT(LV(valid2) && LV(ctx2) == c);
+                }
+            }
         }
+#undef ICER_MATCH
         ICER_TICK(3)
 
         // ---- fold + bin (E1), hand the chunk over ------------------------------------------------------
@@ -893,34 +962,35 @@ ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw,
 // ==========================================================================================
 // merge wave
 // ==========================================================================================
-// fast path of one chunk: word starts/ends from the golomb and walker waves -> ring slots -> ring words
-ICER_DEV void merge_fast_chunk(CoderShared &s, uint32_t j)
-{
-    DECL_LANE;
-    const EventSlot &q = s.eq[j % kQueueDepth];
+struct MergeChunk {             // one chunk's events with their code-word roles, one pixel per lane
     LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
     LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
     LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
     LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
     LANEVAR(uint32_t, op);                              // lane b: open_pos of bin b after this chunk
+    uint64_t S1, S2;                                    // word-start flags of the chunk
+};
+
+// collect the (speculative) results of the golomb and walker waves for chunk j
+ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j)
+{
+    DECL_LANE;
+    const EventSlot &q = s.eq[j % kQueueDepth];
     FOR_LANES
     {
-        LV(ev1) = q.ev1[lane];
-        LV(ev2) = q.ev2[lane];
-        LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255; LV(op) = 255;
+        LV(c.ev1) = q.ev1[lane];
+        LV(c.ev2) = q.ev2[lane];
+        LV(c.fl1) = 0; LV(c.fl2) = 0; LV(c.wd1) = 0; LV(c.wd2) = 0; LV(c.sp1) = 255; LV(c.sp2) = 255; LV(c.op) = 255;
     }
     ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.g_done) > j)
     {
         const GolombSlot &gq = s.gq[j % kQueueDepth];
         FOR_LANES
         {
-            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
-            if (b1 == 0x80u || b1 >= 0x88u) { LV(fl1) = gq.evflag[2 * lane]; LV(wd1) = gq.evword[2 * lane]; LV(sp1) = gq.evstart[2 * lane]; }
-            if (b2 == 0x80u || b2 >= 0x88u) { LV(fl2) = gq.evflag[2 * lane + 1]; LV(wd2) = gq.evword[2 * lane + 1]; LV(sp2) = gq.evstart[2 * lane + 1]; }
-            if (lane >= 8 && lane <= 16) {
-                LV(op) = gq.open_pos[lane];
-                s.bin_acc[lane] = gq.post_k[lane];            // run lengths as of this (now retired) chunk
-            }
+            const uint32_t b1 = LV(c.ev1) & 0x9Fu, b2 = LV(c.ev2) & 0x9Fu;
+            if (b1 == 0x80u || b1 >= 0x88u) { LV(c.fl1) = gq.evflag[2 * lane]; LV(c.wd1) = gq.evword[2 * lane]; LV(c.sp1) = gq.evstart[2 * lane]; }
+            if (b2 == 0x80u || b2 >= 0x88u) { LV(c.fl2) = gq.evflag[2 * lane + 1]; LV(c.wd2) = gq.evword[2 * lane + 1]; LV(c.sp2) = gq.evstart[2 * lane + 1]; }
+            if (lane >= 8 && lane <= 16) LV(c.op) = gq.open_pos[lane];
         }
     }
     ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j)
@@ -928,59 +998,66 @@ ICER_DEV void merge_fast_chunk(CoderShared &s, uint32_t j)
         const WalkSlot &wq = s.wq[j % kQueueDepth];
         FOR_LANES
         {
-            const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
+            const uint32_t b1 = LV(c.ev1) & 0x9Fu, b2 = LV(c.ev2) & 0x9Fu;
             if (b1 >= 0x81u && b1 <= 0x87u) {
                 const uint32_t r = wq.rec[2 * lane];
-                LV(fl1) = r & 3u;
+                LV(c.fl1) = r & 3u;
                 if (r & 2u) {
                     const uint32_t e = s.tab.v2v[b1 & 31u][(r >> 2) & 31u];
-                    LV(wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(sp1) = r >> 8;
+                    LV(c.wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
+                    LV(c.sp1) = r >> 8;
                 }
             }
             if (b2 >= 0x81u && b2 <= 0x87u) {
                 const uint32_t r = wq.rec[2 * lane + 1];
-                LV(fl2) = r & 3u;
+                LV(c.fl2) = r & 3u;
                 if (r & 2u) {
                     const uint32_t e = s.tab.v2v[b2 & 31u][(r >> 2) & 31u];
-                    LV(wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(sp2) = r >> 8;
+                    LV(c.wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
+                    LV(c.sp2) = r >> 8;
                 }
             }
-            if (lane >= 1 && lane <= 7) {
-                LV(op) = wq.open_pos[lane];
-                s.bin_acc[lane] = wq.post_acc[lane];          // walker state as of this (now retired) chunk
-                s.bin_nin[lane] = wq.post_nin[lane];
-            }
+            if (lane >= 1 && lane <= 7) LV(c.op) = wq.open_pos[lane];
         }
     }
+    c.S1 = BALLOT(LV(c.fl1) & 1u);
+    c.S2 = BALLOT(LV(c.fl2) & 1u);
+}
 
-    // ---- ring slots in allocation order = order of the words' first events (E2) ------------------
-    const uint64_t S1 = BALLOT(LV(fl1) & 1u), S2 = BALLOT(LV(fl2) & 1u);
+// fast path: ring slots in allocation order = order of the words' first events (E2), finished words into
+// their slots, bin states as of this (now retired) chunk
+ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
+{
+    DECL_LANE;
+    const uint64_t S1 = c.S1, S2 = c.S2;
     const uint32_t used = s.used, tail = s.head + used;
+    const GolombSlot &gq = s.gq[j % kQueueDepth];
+    const WalkSlot &wq = s.wq[j % kQueueDepth];
     FOR_LANES
     {
-        if (LV(fl1) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane)) & (kRingWords - 1)] = (uint16_t)(LV(ev1) & 31u);
-        if (LV(fl2) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane + 1u)) & (kRingWords - 1)] = (uint16_t)(LV(ev2) & 31u);
+        if (LV(c.fl1) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev1) & 31u);
+        if (LV(c.fl2) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane + 1u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev2) & 31u);
     }
     FOR_LANES
     {
-        if (LV(fl1) & 2u) {
-            const uint32_t slot = LV(sp1) == 255u ? (uint32_t)s.bin_slot[LV(ev1) & 31u] : (tail + cnt_lt(S1, S2, LV(sp1)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd1);
+        if (LV(c.fl1) & 2u) {
+            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1) & 31u] : (tail + cnt_lt(S1, S2, LV(c.sp1)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd1);
         }
-        if (LV(fl2) & 2u) {
-            const uint32_t slot = LV(sp2) == 255u ? (uint32_t)s.bin_slot[LV(ev2) & 31u] : (tail + cnt_lt(S1, S2, LV(sp2)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(wd2);
+        if (LV(c.fl2) & 2u) {
+            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2) & 31u] : (tail + cnt_lt(S1, S2, LV(c.sp2)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd2);
         }
     }
     WAVE_SYNC();
     FOR_LANES
     {
         if (lane < kNumBins) {
-            if (LV(op) == 254u) s.bin_slot[lane] = -1;
-            else if (LV(op) < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, LV(op))) & (kRingWords - 1));
+            if (LV(c.op) == 254u) s.bin_slot[lane] = -1;
+            else if (LV(c.op) < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, LV(c.op))) & (kRingWords - 1));
         }
+        if (lane >= 8 && lane <= 16) s.bin_acc[lane] = gq.post_k[lane];
+        if (lane >= 1 && lane <= 7) { s.bin_acc[lane] = wq.post_acc[lane]; s.bin_nin[lane] = wq.post_nin[lane]; }
         if (lane == 0) s.used = used + (uint32_t)(popc64(S1) + popc64(S2));
     }
     WAVE_SYNC();
@@ -995,25 +1072,33 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j)
         ICER_TICK(13)
         const EventSlot &q = s.eq[j % kQueueDepth];
-        // every event could open at most one word: if the ring cannot fill up inside this chunk no forced
-        // flush (E5) is possible and word boundaries depend on each bin alone
-        const bool exact = s.used + q.nev > (uint32_t)kRingWords;
+        // Every event could open at most one word: if the ring cannot fill up inside this chunk no forced flush
+        // (E5) is possible and word boundaries depend on each bin alone.  When that quick test fails, the exact
+        // number of new words decides: the speculative results say how many words the chunk opens *if* no flush
+        // happens, and if they all fit none happens.
+        MergeChunk c;
+        bool exact = false;
+        const bool doubtful = s.used + q.nev > (uint32_t)kRingWords;
+        if (doubtful) {
+            merge_gather(s, c, j);
+            exact = s.used + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
+        }
         FOR_LANES
         {
             if (lane == 0) s.exact[j % kQueueDepth] = exact ? 1 : 0;
         }
         ICER_PUBLISH(s.b_decided, j + 1u)
         if (!exact) {
-            merge_fast_chunk(s, j);
+            if (!doubtful) merge_gather(s, c, j);
+            merge_commit(s, c, j);
             ICER_TICK(14)
             wave_drain(s);
             ICER_EMU_COUNT(0);
             ICER_TICK(15)
         } else {
             ICER_EMU_COUNT(1);
-            // the walker and golomb waves must be past their speculative pass over this chunk before its
-            // bins are replayed (bin_acc / bin_nin hold their state as of the last retired chunk)
-            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j && ICER_LOAD_CNT(s.g_done) > j)
+            // (merge_gather has waited for the walker and golomb waves: they are past their speculative pass
+            // over this chunk; bin_acc / bin_nin hold their state as of the last retired chunk)
             uint32_t e = 0;
             for (;;) {
                 FOR_LANES
