@@ -46,13 +46,17 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_LOAD_CNT(x) (x)
 #define ICER_WAIT_UNTIL(cond) { assert(cond); }
 #define ICER_PUBLISH(x, v) { (x) = (v); }
+#define ICER_ACQUIRE()
+#define ICER_IDLE() break;     /* the emulation never waits: hand control back to the scheduler */
 #else
 #define ICER_EMU_COUNT(i)
 // counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ICER_WAIT_UNTIL(cond) { while (!(cond)) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
-#define ICER_PUBLISH(x, v) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), pv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define ICER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#define ICER_IDLE() __builtin_amdgcn_s_sleep(1);
 #endif
 
 // Optional per-wave cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
@@ -60,10 +64,14 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
 #define ICER_NUM_TIMERS 24
 #define ICER_TIMERS_DECL uint64_t tacc_[ICER_NUM_TIMERS] = {}; uint64_t tlast_ = __builtin_amdgcn_s_memtime();
+#define ICER_TIMER_PARAMS , uint64_t *tacc_, uint64_t &tlast_
+#define ICER_TIMER_PASS , tacc_, tlast_
 #define ICER_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc_[k] += t_ - tlast_; tlast_ = t_; }
 #define ICER_TIMERS_STORE(dst) { if (dst) { _Pragma("unroll") for (int i_ = 0; i_ < ICER_NUM_TIMERS; i_++) if (lane == 0 && tacc_[i_]) atomicAdd((unsigned long long *)&(dst)[i_], (unsigned long long)tacc_[i_]); } }
 #else
 #define ICER_TIMERS_DECL
+#define ICER_TIMER_PARAMS
+#define ICER_TIMER_PASS
 #define ICER_TICK(k)
 #define ICER_TIMERS_STORE(dst)
 #endif
@@ -94,6 +102,7 @@ struct GolombSlot {             // golomb wave -> merge wave (bins 0, 8..16)
     uint16_t evword[128];       // finished ring word of an end event
     uint8_t open_pos[20];       // per bin, as WalkSlot::open_pos
     uint16_t post_k[20];        // run lengths after the chunk
+    uint32_t tag;               // (chunk << 8 | generation) + 1 once the slot holds that chunk's results
 };
 struct WalkSlot {               // walker wave -> merge wave (bins 1..7)
     // per event of bins 1..7: bit0 a code word starts here, bit1 one ends here, bits 2..6 the completed
@@ -102,6 +111,7 @@ struct WalkSlot {               // walker wave -> merge wave (bins 1..7)
     uint16_t rec[128];
     uint8_t open_pos[8];        // per bin after the chunk: 255 untouched, 254 closed, else first event of its open word
     uint8_t post_acc[8], post_nin[8];   // walker state after the chunk
+    uint32_t tag;               // as GolombSlot::tag
 };
 
 struct CoderShared {
@@ -125,8 +135,10 @@ struct CoderShared {
     uint32_t flushed_words;     // payload words already written to HBM
     uint32_t resume;            // exact path: event index at which the single-lane replay paused
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
-    uint32_t p_done, a_done, c_done, g_done, b_decided, b_done, abort;
-    uint8_t exact[kQueueDepth]; // assembly wave's verdict for the chunk in this queue slot: 1 = exact path
+    uint32_t p_done, a_done, b_done, abort;
+    // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
+    // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
+    uint32_t exact_seq, last_exact;
 };
 
 struct UnitArgs {
@@ -678,6 +690,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
 // ==========================================================================================
 struct WalkWave {
     LANEVAR(uint32_t, node);    // lane b (1..7): code-tree node of bin b's partial input, acc | 1 << bits (1 = root)
+    uint32_t next, gen;         // next chunk to walk; generation (= number of exact-path chunks seen)
 };
 
 ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
@@ -685,6 +698,8 @@ ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
     DECL_LANE;
     (void)s;
     FOR_LANES { LV(ww.node) = 1; }
+    ww.next = 0;
+    ww.gen = 0;
 }
 
 // bits [start, start + 6) of a bit string stored with an offset of 8 (rank r lives at bit r + 8, so that
@@ -696,27 +711,39 @@ ICER_DEV uint32_t window6(const uint32_t *words, int start)
     return (uint32_t)(two >> (pos & 31u)) & 63u;
 }
 
-ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uint32_t j0, uint32_t j1)
+ICER_DEV uint32_t chunk_tag(uint32_t j, uint32_t gen) { return ((j << 8) | (gen & 255u)) + 1u; }
+
+// Processes chunks speculatively (assuming the merge wave takes the fast path) for as long as events are
+// available; rolls back to the chunk after the last exact-path chunk whenever the merge wave reports one.
+// `max_chunks` bounds the work of one call (the emulation interleaves the waves; the GPU passes ~0u).
+// Returns the number of chunks walked.
+ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uint32_t nchunks, uint32_t max_chunks)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     (void)a;
-    for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
+    uint32_t done = 0;
+    for (;;) {
         if (ICER_LOAD_CNT(s.abort)) break;
-        if (j > 0) {
-            // chunk j-1 was walked speculatively; if the merge wave had to take the exact path for it,
-            // the partial inputs are whatever its replay left behind
-            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_decided) >= j || ICER_LOAD_CNT(s.abort))
-            if (s.exact[(j - 1u) % kQueueDepth]) {
-                ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_done) >= j || ICER_LOAD_CNT(s.abort))
-                FOR_LANES
-                {
-                    if (lane >= 1 && lane <= 7) LV(ww.node) = s.bin_acc[lane] | (1u << s.bin_nin[lane]);
-                }
+        const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
+        if (seq != ww.gen) {
+            // everything walked after chunk last_exact is void; the replay left the bins' partial inputs in LDS
+            ICER_ACQUIRE()
+            ww.gen = seq;
+            ww.next = s.last_exact + 1u;
+            FOR_LANES
+            {
+                if (lane >= 1 && lane <= 7) LV(ww.node) = s.bin_acc[lane] | (1u << s.bin_nin[lane]);
             }
-            if (ICER_LOAD_CNT(s.abort)) break;
         }
+        const uint32_t j = ww.next;
+        if (j >= nchunks || ICER_LOAD_CNT(s.a_done) <= j) {
+            if (ICER_LOAD_CNT(s.b_done) >= nchunks || done >= max_chunks) break;
+            ICER_IDLE()
+            continue;
+        }
+        if (done >= max_chunks) break;
+        ICER_ACQUIRE()
         ICER_TICK(6)
         const EventSlot &q = s.eq[j % kQueueDepth];
         WalkSlot &o = s.wq[j % kQueueDepth];
@@ -846,9 +873,12 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
         }
 #undef ICER_V2V_RECORD
         ICER_TICK(9)
-        ICER_PUBLISH(s.c_done, j + 1u)
+        ICER_PUBLISH(o.tag, chunk_tag(j, ww.gen))
+        ww.next = j + 1u;
+        done++;
     }
     ICER_TIMERS_STORE(a.timers)
+    return done;
 }
 
 // ==========================================================================================
@@ -856,30 +886,44 @@ ICER_DEV void walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww, uin
 // ==========================================================================================
 struct GolombWave {
     LANEVAR(uint32_t, k);       // lane b (8..16): zero-run length of bin b's open word (0 = no open word)
+    uint32_t next, gen;         // as WalkWave
 };
 
-ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw, uint32_t j0, uint32_t j1)
+ICER_DEV void golomb_wave_init(GolombWave &gw)
+{
+    DECL_LANE;
+    FOR_LANES { LV(gw.k) = 0; }
+    gw.next = 0;
+    gw.gen = 0;
+}
+
+// same speculation / roll-back scheme as walk_wave_run
+ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw, uint32_t nchunks, uint32_t max_chunks)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     (void)a;
-    for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
+    uint32_t done = 0;
+    for (;;) {
         if (ICER_LOAD_CNT(s.abort)) break;
-        if (j == 0) {
-            FOR_LANES { LV(gw.k) = 0; }
-        } else {
-            // chunk j-1 was processed speculatively; after an exact-path chunk the runs are what the replay left
-            ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_decided) >= j || ICER_LOAD_CNT(s.abort))
-            if (s.exact[(j - 1u) % kQueueDepth]) {
-                ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.b_done) >= j || ICER_LOAD_CNT(s.abort))
-                FOR_LANES
-                {
-                    if (lane >= 8 && lane <= 16) LV(gw.k) = s.bin_acc[lane];
-                }
+        const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
+        if (seq != gw.gen) {
+            ICER_ACQUIRE()
+            gw.gen = seq;
+            gw.next = s.last_exact + 1u;
+            FOR_LANES
+            {
+                if (lane >= 8 && lane <= 16) LV(gw.k) = s.bin_acc[lane];
             }
-            if (ICER_LOAD_CNT(s.abort)) break;
         }
+        const uint32_t j = gw.next;
+        if (j >= nchunks || ICER_LOAD_CNT(s.a_done) <= j) {
+            if (ICER_LOAD_CNT(s.b_done) >= nchunks || done >= max_chunks) break;
+            ICER_IDLE()
+            continue;
+        }
+        if (done >= max_chunks) break;
+        ICER_ACQUIRE()
         ICER_TICK(10)
         const EventSlot &q = s.eq[j % kQueueDepth];
         GolombSlot &o = s.gq[j % kQueueDepth];
@@ -953,10 +997,13 @@ ICER_DEV void golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw,
             }
             if (lane >= 8 && lane <= 16) o.post_k[lane] = (uint16_t)LV(gw.k);
         }
-        ICER_PUBLISH(s.g_done, j + 1u)
+        ICER_PUBLISH(o.tag, chunk_tag(j, gw.gen))
+        gw.next = j + 1u;
+        done++;
         ICER_TICK(12)
     }
     ICER_TIMERS_STORE(a.timers)
+    return done;
 }
 
 // ==========================================================================================
@@ -972,7 +1019,7 @@ struct MergeChunk {             // one chunk's events with their code-word roles
 };
 
 // collect the (speculative) results of the golomb and walker waves for chunk j
-ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j)
+ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_PARAMS)
 {
     DECL_LANE;
     const EventSlot &q = s.eq[j % kQueueDepth];
@@ -982,7 +1029,8 @@ ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j)
         LV(c.ev2) = q.ev2[lane];
         LV(c.fl1) = 0; LV(c.fl2) = 0; LV(c.wd1) = 0; LV(c.wd2) = 0; LV(c.sp1) = 255; LV(c.sp2) = 255; LV(c.op) = 255;
     }
-    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.g_done) > j)
+    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.gq[j % kQueueDepth].tag) == chunk_tag(j, s.exact_seq))
+    ICER_TICK(18)
     {
         const GolombSlot &gq = s.gq[j % kQueueDepth];
         FOR_LANES
@@ -993,7 +1041,8 @@ ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j)
             if (lane >= 8 && lane <= 16) LV(c.op) = gq.open_pos[lane];
         }
     }
-    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.c_done) > j)
+    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.wq[j % kQueueDepth].tag) == chunk_tag(j, s.exact_seq))
+    ICER_TICK(19)
     {
         const WalkSlot &wq = s.wq[j % kQueueDepth];
         FOR_LANES
@@ -1080,16 +1129,11 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         bool exact = false;
         const bool doubtful = s.used + q.nev > (uint32_t)kRingWords;
         if (doubtful) {
-            merge_gather(s, c, j);
+            merge_gather(s, c, j ICER_TIMER_PASS);
             exact = s.used + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
         }
-        FOR_LANES
-        {
-            if (lane == 0) s.exact[j % kQueueDepth] = exact ? 1 : 0;
-        }
-        ICER_PUBLISH(s.b_decided, j + 1u)
         if (!exact) {
-            if (!doubtful) merge_gather(s, c, j);
+            if (!doubtful) merge_gather(s, c, j ICER_TIMER_PASS);
             merge_commit(s, c, j);
             ICER_TICK(14)
             wave_drain(s);
@@ -1121,6 +1165,12 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
                 }
             }
             wave_drain(s);
+            // results the walker / golomb waves produced for later chunks assumed the fast path here: void them
+            FOR_LANES
+            {
+                if (lane == 0) s.last_exact = j;
+            }
+            ICER_PUBLISH(s.exact_seq, s.exact_seq + 1u)
             ICER_TICK(16)
         }
         const bool ok = flush_stage(s, a, false);
@@ -1162,7 +1212,8 @@ ICER_DEV void unit_state_init(CoderShared &s)
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
         if (lane == 0) {
             s.head = 0; s.used = 0; s.bitpos = 0; s.flushed_words = 0;
-            s.p_done = 0; s.a_done = 0; s.c_done = 0; s.g_done = 0; s.b_decided = 0; s.b_done = 0; s.abort = 0;
+            s.p_done = 0; s.a_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
+            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.gq[i].tag = 0; }
         }
     }
     WAVE_SYNC();
@@ -1181,13 +1232,14 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
     GolombWave gw;
     walk_wave_init(s, ww);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
-    uint32_t jp = 0, ja = 0, jc = 0, jg = 0, jb = 0;
-    auto spec_ok = [&](uint32_t j) { return j == 0 || (s.b_decided >= j && (!s.exact[(j - 1) % kQueueDepth] || s.b_done >= j)); };
+    golomb_wave_init(gw);
+    uint32_t jp = 0, ja = 0, jb = 0;
     while (jb < nchunks) {
         while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; }
         while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; }
-        while (jc < ja && spec_ok(jc)) { walk_wave_run(s, a, ww, jc, jc + 1); jc++; }
-        while (jg < ja && spec_ok(jg)) { golomb_wave_run(s, a, gw, jg, jg + 1); jg++; }
+        // both speculating waves run as far ahead as events allow (and roll back when told to)
+        walk_wave_run(s, a, ww, nchunks, kQueueDepth);
+        golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
         if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
     }

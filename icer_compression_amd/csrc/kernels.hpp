@@ -154,10 +154,11 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     } else if (wave == 2) {
         WalkWave ww;
         walk_wave_init(s, ww);
-        walk_wave_run(s, a, ww, 0, nchunks);
+        walk_wave_run(s, a, ww, nchunks, ~0u);
     } else if (wave == 3) {
         GolombWave gw;
-        golomb_wave_run(s, a, gw, 0, nchunks);
+        golomb_wave_init(gw);
+        golomb_wave_run(s, a, gw, nchunks, ~0u);
     } else {
         const uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (bits != kUnitTooBig) {

@@ -15,8 +15,8 @@ NAMES = ["pixel wave: context+loads", "pixel wave: wait (queue full)",
          "count wave: wait (pixels)", "count wave: counts", "count wave: fold+bin", "count wave: wait (queue full)",
          "walk wave: wait (events/verdict)", "walk wave: compaction", "walk wave: walk", "walk wave: records",
          "golomb wave: wait (events/verdict)", "golomb wave: bins 0, 8-16", "golomb wave: hand-over",
-         "merge wave: wait (events)", "merge wave: wait golomb/walker + slots", "merge wave: drain", "merge wave: exact path",
-         "merge wave: stage flush"]
+         "merge wave: wait (events)", "merge wave: walker reads + ring slots", "merge wave: drain", "merge wave: exact path",
+         "merge wave: stage flush", "merge wave: event reads + wait golomb", "merge wave: golomb reads + wait walker"]
 NT = 24
 
 
