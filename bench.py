@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="frames per rank per step (default 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-probe", type=int, default=8,
+                    help="also report throughput with this many frames per launch (secondary figure, 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +123,30 @@ def main():
 
     elapsed_max = shard.max_over_ranks(elapsed, dev)
 
+    # secondary figure: the same frame geometry with several frames per launch (what BASELINE configs[3]/[4]
+    # do); one frame alone cannot fill 256 CUs because its largest coding units form a serial chain
+    batched = None
+    if args.batched_probe > 1:
+        PB = args.batched_probe
+        bf = torch.from_numpy(np.stack([synth.gray_frame(W, H, s, 1) for s in shard.frame_seeds(synth.DEFAULT_SEED, rank, world, PB)]).view(np.int16)).to(dev)
+        bout = torch.empty((PB, QUOTA), dtype=torch.uint8, device=dev)
+        bsizes = torch.zeros(PB, dtype=torch.int64, device=dev)
+        brcs = torch.zeros(PB, dtype=torch.int32, device=dev)
+        benc = api.Encoder(W, H, 1, STAGES, FILT, SEGMENTS, max_frames=PB, device=local_rank)
+        benc.encode_torch(bf, QUOTA, bout, bsizes, brcs)
+        barrier()
+        tb = time.perf_counter()
+        nb = max(2, args.steps // 2)
+        for _ in range(nb):
+            benc.encode_torch(bf, QUOTA, bout, bsizes, brcs)
+        barrier()
+        tb = shard.max_over_ranks(time.perf_counter() - tb, dev)
+        ok = bool((brcs.cpu().numpy() == 0).all()) and (rank != 0 or int(bsizes[0]) == gold["size"])
+        batched = {"frames_per_gpu_per_launch": PB, "value": round(world * PB * W * H * nb / tb / 1e6, 3), "unit": "Mpixels/s",
+                   "ms_per_launch": round(tb / nb * 1e3, 3), "parity": ok}
+        benc.close()
+        del bf, bout
+
     if rank == 0:
         n_pix = world * B * W * H * args.steps
         value = n_pix / elapsed_max / 1e6
@@ -142,6 +168,14 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 4)},
             "stage_ms_per_step": {k: round(v / max(calls, 1), 4) for k, v in stage_ms.items()},
         }
+        if batched:
+            line["batched"] = batched
+        pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
+        if os.path.exists(pmc):                      # HBM traffic of code_units_kernel from the committed PMC passes
+            with open(pmc) as fh:
+                t = json.load(fh)
+            line["roofline"]["traffic"] = t.get("traffic_bytes_per_launch")
+            line["roofline"]["traffic_source"] = t.get("source")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_frames[0], gold["crc32"])
             line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)

@@ -116,8 +116,8 @@ ICER_DEV void finish_unit_wave(CoderShared &s, const FinishArgs &f)
 // Rule (P3): walking units in priority order with `used` bytes so far, a unit is kept iff
 // 28 header bytes fit and floor(bits/8) < quota - used - 28; the first failing unit stops everything.
 // ------------------------------------------------------------------------------------------
-ICER_DEV int scan_frame_wave(const uint32_t *bits, const uint32_t *final_order, uint32_t n_units, uint64_t quota,
-                             uint64_t *final_off, uint32_t *kept, uint64_t *size_used)
+// index of the first unit (priority order) that does not fit the quota, n_units if all fit
+ICER_DEV uint32_t quota_cut_wave(const uint32_t *bits, uint32_t n_units, uint64_t quota)
 {
     DECL_LANE;
     uint64_t used = 0;
@@ -140,6 +140,14 @@ ICER_DEV int scan_frame_wave(const uint32_t *bits, const uint32_t *final_order, 
         if (fail) K = base + (uint32_t)ffs64(fail);
         else used += total;
     }
+    return K;
+}
+
+ICER_DEV int scan_frame_wave(const uint32_t *bits, const uint32_t *final_order, uint32_t n_units, uint64_t quota,
+                             uint64_t *final_off, uint32_t *kept, uint64_t *size_used)
+{
+    DECL_LANE;
+    const uint32_t K = quota_cut_wave(bits, n_units, quota);
     // final stream offsets
     uint64_t off = 0;
     for (uint32_t base = 0; base < n_units; base += 64) {

@@ -106,14 +106,16 @@ __global__ void __launch_bounds__(64 * kUnitWaves)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
-                  const int *__restrict__ frame_skip, uint8_t *__restrict__ slots, size_t slot_frame_stride,
-                  uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers)
+                  const int *__restrict__ frame_skip, const int *__restrict__ quota_hit, uint8_t *__restrict__ slots,
+                  size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers)
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
     const uint32_t ui = work_order[blockIdx.x];
     const uint32_t wave = threadIdx.x >> 6;
-    if (frame_skip[frame]) {                      // DWT / mean overflow: the reference emits nothing
+    // DWT / mean overflow: the reference emits nothing.  Progressive mode: an earlier priority range already
+    // exhausted this frame's byte quota, so this unit can not be part of the stream.
+    if (frame_skip[frame] || quota_hit[frame]) {
         if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
         return;
     }
@@ -200,6 +202,17 @@ scan_kernel(const uint32_t *__restrict__ unit_bits, const uint32_t *__restrict__
     if (kept < n_units && threadIdx.x == 0 && bits[kept] == kUnitTooBig && units[kept].cap_is_bound)
         atomicOr(bound_overflow, 1);
     if (threadIdx.x == 0) { sizes[frame] = used; rcs[frame] = rc; }
+}
+
+// progressive mode, between two priority ranges: has the quota walk over the units coded so far (priority
+// order, the first n_coded of them) already hit the cut?  grid = frames, block = 64.
+__global__ void __launch_bounds__(64)
+quota_probe_kernel(const uint32_t *__restrict__ unit_bits, uint32_t n_units, uint32_t n_coded, uint64_t quota,
+                   int *__restrict__ quota_hit)
+{
+    const uint32_t frame = blockIdx.x;
+    if (quota_hit[frame]) return;
+    if (quota_cut_wave(unit_bits + (size_t)frame * n_units, n_coded, quota) < n_coded && threadIdx.x == 0) quota_hit[frame] = 1;
 }
 
 // copy every kept unit (header + payload) to its place in the final stream.  grid = (units, frames)
