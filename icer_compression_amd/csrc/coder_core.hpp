@@ -67,12 +67,14 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_TIMER_PARAMS , uint64_t *tacc_, uint64_t &tlast_
 #define ICER_TIMER_PASS , tacc_, tlast_
 #define ICER_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc_[k] += t_ - tlast_; tlast_ = t_; }
+#define ICER_COUNT(k) { tacc_[k] += 1; }
 #define ICER_TIMERS_STORE(dst) { if (dst) { _Pragma("unroll") for (int i_ = 0; i_ < ICER_NUM_TIMERS; i_++) if (lane == 0 && tacc_[i_]) atomicAdd((unsigned long long *)&(dst)[i_], (unsigned long long)tacc_[i_]); } }
 #else
 #define ICER_TIMERS_DECL
 #define ICER_TIMER_PARAMS
 #define ICER_TIMER_PASS
 #define ICER_TICK(k)
+#define ICER_COUNT(k)
 #define ICER_TIMERS_STORE(dst)
 #endif
 
@@ -133,7 +135,6 @@ struct CoderShared {
     uint32_t head, used;        // ring state
     uint32_t bitpos;            // payload bits produced so far
     uint32_t flushed_words;     // payload words already written to HBM
-    uint32_t resume;            // exact path: event index at which the single-lane replay paused
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
     uint32_t p_done, a_done, b_done, abort;
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
@@ -152,8 +153,7 @@ struct UnitArgs {
 };
 
 // ------------------------------------------------------------------------------------------
-// sequential coder steps (executed by a single lane; exact restatement of E1-E6 except that
-// draining is left to wave_drain)
+// exact coder steps (restatement of E1-E6; draining is left to wave_drain)
 // ------------------------------------------------------------------------------------------
 // Golomb codeword for a run of k zeros ended by a one (icer_encoding.c:73-80)
 ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
@@ -190,65 +190,6 @@ ICER_DEV void seq_complete_head(CoderShared &s)
             s.bin_slot[bin] = -1;
         }
     }
-}
-
-// icer_encode_bit after bin selection (icer_encoding.c:59-112), without the drain that follows every
-// event in the reference: finished words are only *observable* through `used` when a new word is
-// allocated with the ring apparently full, which seq_run checks for (it then pauses for a drain).
-ICER_DEV void seq_put(CoderShared &s, int bin, uint32_t bit)
-{
-    int slot = s.bin_slot[bin];
-    if (slot < 0) {
-        slot = (int)((s.head + s.used) & (kRingWords - 1));
-        s.used++;
-        s.ring[slot] = (uint16_t)bin;
-        s.bin_slot[bin] = slot;
-    }
-    if (bin >= 8) {
-        if (bit) {
-            s.ring[slot] = (uint16_t)golomb_word(s.tab, bin, s.bin_acc[bin]);
-            s.bin_acc[bin] = 0;
-            s.bin_slot[bin] = -1;
-        } else {
-            const uint32_t k = s.bin_acc[bin] + 1;
-            if (k >= s.tab.gm[bin]) {
-                s.ring[slot] = (uint16_t)(kWordDone | (1u << 11) | 1u);
-                s.bin_acc[bin] = 0;
-                s.bin_slot[bin] = -1;
-            } else s.bin_acc[bin] = k;
-        }
-    } else if (bin >= 1) {
-        const uint32_t nin = s.bin_nin[bin] + 1;
-        const uint32_t pre = s.bin_acc[bin] | (bit << (nin - 1));
-        const uint32_t e = s.tab.v2v[bin][pre & 31u];
-        if ((e & 15u) == nin) {
-            s.ring[slot] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
-            s.bin_acc[bin] = 0;
-            s.bin_nin[bin] = 0;
-            s.bin_slot[bin] = -1;
-        } else {
-            s.bin_acc[bin] = pre;
-            s.bin_nin[bin] = nin;
-        }
-    } else {
-        s.ring[slot] = (uint16_t)(kWordDone | (1u << 11) | bit);
-        s.bin_slot[0] = -1;
-    }
-}
-
-// replay events [e, 128) of a chunk in coding order (event 2L = magnitude bit of pixel L, 2L+1 = its
-// sign); stops BEFORE an event that needs a new word while the ring holds 2048 (possibly already
-// finished) words, returning its index; 128 when the chunk is done
-ICER_DEV uint32_t seq_run(CoderShared &s, const EventSlot &q, uint32_t e)
-{
-    for (; e < 128u; e++) {
-        const uint32_t v = (e & 1u) ? q.ev2[e >> 1] : q.ev1[e >> 1];
-        if (!(v & 0x80u)) continue;
-        const int bin = (int)(v & 31u);
-        if (s.bin_slot[bin] < 0 && s.used == (uint32_t)kRingWords) return e;
-        seq_put(s, bin, (v >> 5) & 1u);
-    }
-    return 128u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,6 +298,11 @@ ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
 {
     return (uint32_t)(popc64(A1 & below64((pos + 1u) >> 1)) + popc64(A2 & below64(pos >> 1)));
 }
+// the same for this lane's own events (position 2 * lane + slot): two v_mbcnt pairs instead of 64-bit shifts
+ICER_DEV uint32_t cnt_lt_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
+{
+    return (uint32_t)(mbcnt64(A1, lane) + mbcnt64(A2, lane)) + (slot ? (uint32_t)((A1 >> lane) & 1ull) : 0u);
+}
 // latest position <= pos in the set, -1 if none
 ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
 {
@@ -367,9 +313,9 @@ ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
 ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u ? -1 : last_le(A1, A2, pos - 1u); }
 
 // one Golomb-bin event at position POS with bit BIT (lane-local); Z*/O* = zero/one events of the bin
-#define ICER_GOLOMB_EVENT(POS, BIT, FL, WD)                                                           \
+#define ICER_GOLOMB_EVENT(POS, SLOT, BIT, FL, WD)                                                           \
     {                                                                                                 \
-        const uint32_t zb_ = cnt_lt(Z1, Z2, (POS));                                                   \
+        const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                                   \
         const int lo_ = last_lt(O1, O2, (POS));                                                       \
         const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : k_in + zb_;              \
         const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                             \
@@ -758,31 +704,35 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
             if (lane < 48) (&s.binbits[0][0])[lane] = 0;
         }
         WAVE_SYNC();
-        // every event of a present bin puts its input bit at its rank into the bin's bit string and its
-        // position into the bin's position list
-        for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), rem2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u)); rem1 | rem2;) {
-            const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
-            const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
-            const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-            rem1 &= ~M1;
-            rem2 &= ~M2;
-            const uint32_t n = (uint32_t)(popc64(M1) + popc64(M2));
+        // every event of bins 1..7 puts its input bit at its rank into the bin's bit string and its position
+        // into the bin's position list.  Rank = number of earlier events of the same bin; the lanes of a bin
+        // are found from per-bit ballots of the bin number (no loop over bins).
+        {
+#define ICER_MATCH3(KEY, V, B0, B1, B2) ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)))
+            const uint64_t V1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), V2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u));
+            const uint64_t P0 = BALLOT(LV(ev1) & 1u), P1 = BALLOT(LV(ev1) & 2u), P2 = BALLOT(LV(ev1) & 4u);
+            const uint64_t Q0 = BALLOT(LV(ev2) & 1u), Q1 = BALLOT(LV(ev2) & 2u), Q2 = BALLOT(LV(ev2) & 4u);
             FOR_LANES
             {
-                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) {
-                    const uint32_t r = cnt_lt(M1, M2, 2u * (uint32_t)lane);
+                if ((V1 >> lane) & 1ull) {
+                    const uint32_t b = LV(ev1) & 7u;
+                    const uint32_t r = (uint32_t)(mbcnt64(ICER_MATCH3(b, V1, P0, P1, P2), lane) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
                     LV(rk1) = r;
                     s.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane);
                     if (LV(ev1) & 0x20u) LDS_OR(s.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
                 }
-                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) {
-                    const uint32_t r = cnt_lt(M1, M2, 2u * (uint32_t)lane + 1u);
+                if ((V2 >> lane) & 1ull) {
+                    const uint32_t b = LV(ev2) & 7u;
+                    const uint64_t m1 = ICER_MATCH3(b, V1, P0, P1, P2);          // this lane's own magnitude event comes first
+                    const uint32_t r = (uint32_t)(mbcnt64(m1, lane) + (int)((m1 >> lane) & 1ull) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
                     LV(rk2) = r;
                     s.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane + 1u);
                     if (LV(ev2) & 0x20u) LDS_OR(s.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
                 }
-                if (lane == b) LV(wn) = n;
+                if (lane >= 1 && lane <= 7)
+                    LV(wn) = (uint32_t)(popc64(ICER_MATCH3((uint32_t)lane, V1, P0, P1, P2)) + popc64(ICER_MATCH3((uint32_t)lane, V2, Q0, Q1, Q2)));
             }
+#undef ICER_MATCH3
         }
         WAVE_SYNC();
         ICER_TICK(7)
@@ -955,8 +905,8 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = READLANE(gw.k, b);
             FOR_LANES
             {
-                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
-                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
+                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, 0u, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
+                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
             }
             const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
             const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
@@ -1084,8 +1034,8 @@ ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
     const WalkSlot &wq = s.wq[j % kQueueDepth];
     FOR_LANES
     {
-        if (LV(c.fl1) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev1) & 31u);
-        if (LV(c.fl2) & 1u) s.ring[(tail + cnt_lt(S1, S2, 2u * (uint32_t)lane + 1u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev2) & 31u);
+        if (LV(c.fl1) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev1) & 31u);
+        if (LV(c.fl2) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev2) & 31u);
     }
     FOR_LANES
     {
@@ -1112,6 +1062,104 @@ ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
     WAVE_SYNC();
 }
 
+// Exact replay of one chunk, event by event in coding order (icer_encode_bit, icer_encoding.c:37-112), for
+// chunks in which the ring may fill up.  Wave-uniform control flow; the per-bin coder state lives in lane
+// registers for the duration (lane b = bin b: open slot, Golomb run / partial input, input bits), events are
+// fetched with v_readlane, so the only LDS traffic is table look-ups and ring stores.  Finished words are
+// NOT drained after every event as in the reference: draining is only observable through `used` when a new
+// word is allocated with the ring apparently full -- then, and only then, the 64-lane drain runs and, if the
+// oldest word is still open, it is force-completed (E5, icer_flush_encode icer_encoding.c:141-189).
+ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
+{
+    DECL_LANE;
+    LANEVAR(uint32_t, bslot); LANEVAR(uint32_t, bacc); LANEVAR(uint32_t, bnin);
+    FOR_LANES
+    {
+        const int b = lane < kNumBins ? lane : 0;
+        LV(bslot) = (uint32_t)s.bin_slot[b];
+        LV(bacc) = s.bin_acc[b];
+        LV(bnin) = s.bin_nin[b];
+    }
+    uint32_t head = s.head, used = s.used;
+    for (uint32_t e = 0; e < 128u; e++) {
+        const uint32_t v = (e & 1u) ? READLANE(c.ev2, e >> 1) : READLANE(c.ev1, e >> 1);
+        if (!(v & 0x80u)) continue;
+        const uint32_t bin = v & 31u, bit = (v >> 5) & 1u;
+        uint32_t slot = READLANE(bslot, bin);
+        if (slot == 0xFFFFFFFFu) {                                   // the bin has no open word: allocate one
+            if (used == (uint32_t)kRingWords) {
+                // pop what is finished; if the oldest word is still open, force-complete it
+                FOR_LANES
+                {
+                    if (lane == 0) { s.head = head; s.used = used; }
+                }
+                WAVE_SYNC();
+                wave_drain(s);
+                head = s.head;
+                used = s.used;
+                if (used == (uint32_t)kRingWords) {
+                    const uint32_t hb = s.ring[head] & 31u;          // owner bin of the (open) head word
+                    const uint32_t hacc = READLANE(bacc, hb), hnin = READLANE(bnin, hb);
+                    uint32_t word;
+                    if (hb >= 8u) {
+                        word = (hacc == (uint32_t)s.tab.gm[hb] - 1u) ? (kWordDone | (1u << 11) | 1u) : golomb_word(s.tab, (int)hb, hacc);
+                    } else {
+                        const uint32_t f = s.tab.v2v_flush[hb][hacc > 8u ? 8u : hacc][hnin > 5u ? 5u : hnin];
+                        const uint32_t en = s.tab.v2v[hb][(hacc | ((f & 15u) << hnin)) & 31u];
+                        word = kWordDone | (((en >> 4) & 15u) << 11) | (en >> 8);   // QUIRK (kept): not checked to be a code word
+                    }
+                    FOR_LANES
+                    {
+                        if ((uint32_t)lane == hb) { LV(bslot) = 0xFFFFFFFFu; LV(bacc) = 0; LV(bnin) = 0; }
+                        if (lane == 0) s.ring[head] = (uint16_t)word;
+                    }
+                    WAVE_SYNC();
+                    wave_drain(s);
+                    head = s.head;
+                    used = s.used;
+                }
+            }
+            slot = (head + used) & (kRingWords - 1);
+            used++;
+            FOR_LANES
+            {
+                if ((uint32_t)lane == bin) LV(bslot) = slot;
+                if (lane == 0) s.ring[slot] = (uint16_t)bin;
+            }
+        }
+        const uint32_t acc = READLANE(bacc, bin), nin = READLANE(bnin, bin);
+        uint32_t word = 0, nacc = acc, nnin = nin;
+        bool close = false;
+        if (bin >= 8u) {
+            if (bit) { word = golomb_word(s.tab, (int)bin, acc); close = true; }
+            else if (acc + 1u >= s.tab.gm[bin]) { word = kWordDone | (1u << 11) | 1u; close = true; }
+            else nacc = acc + 1u;
+        } else if (bin >= 1u) {
+            nnin = nin + 1u;
+            nacc = acc | (bit << nin);
+            const uint32_t en = s.tab.v2v[bin][nacc & 31u];
+            if ((en & 15u) == nnin) { word = kWordDone | (((en >> 4) & 15u) << 11) | (en >> 8); close = true; }
+        } else {
+            word = kWordDone | (1u << 11) | bit;
+            close = true;
+        }
+        FOR_LANES
+        {
+            if ((uint32_t)lane == bin) {
+                if (close) { LV(bslot) = 0xFFFFFFFFu; LV(bacc) = 0; LV(bnin) = 0; }
+                else { LV(bacc) = nacc; LV(bnin) = nnin; }
+            }
+            if (lane == 0 && close) s.ring[slot] = (uint16_t)word;
+        }
+    }
+    FOR_LANES
+    {
+        if (lane < kNumBins) { s.bin_slot[lane] = (int32_t)LV(bslot); s.bin_acc[lane] = LV(bacc); s.bin_nin[lane] = LV(bnin); }
+        if (lane == 0) { s.head = head; s.used = used; }
+    }
+    WAVE_SYNC();
+}
+
 // chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
 ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
 {
@@ -1128,7 +1176,9 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         MergeChunk c;
         bool exact = false;
         const bool doubtful = s.used + q.nev > (uint32_t)kRingWords;
+        ICER_COUNT(22)
         if (doubtful) {
+            ICER_COUNT(21)
             merge_gather(s, c, j ICER_TIMER_PASS);
             exact = s.used + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
         }
@@ -1141,29 +1191,10 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             ICER_TICK(15)
         } else {
             ICER_EMU_COUNT(1);
+            ICER_COUNT(20)
             // (merge_gather has waited for the walker and golomb waves: they are past their speculative pass
             // over this chunk; bin_acc / bin_nin hold their state as of the last retired chunk)
-            uint32_t e = 0;
-            for (;;) {
-                FOR_LANES
-                {
-                    if (lane == 0) s.resume = seq_run(s, q, e);
-                }
-                WAVE_SYNC();
-                e = s.resume;
-                if (e >= 128u) break;
-                // a new word is needed and the ring holds 2048 words: pop what is finished (64 lanes),
-                // and if the oldest word is still open force-complete it (E5, icer_encoding.c:59-64)
-                wave_drain(s);
-                if (s.used == (uint32_t)kRingWords) {
-                    FOR_LANES
-                    {
-                        if (lane == 0) seq_complete_head(s);
-                    }
-                    WAVE_SYNC();
-                    wave_drain(s);
-                }
-            }
+            exact_chunk_wave(s, c);
             wave_drain(s);
             // results the walker / golomb waves produced for later chunks assumed the fast path here: void them
             FOR_LANES

@@ -40,7 +40,9 @@ def main():
     print("   cycles per chunk and wave (kcyc)  " + "".join(f"  lsb{p}" for p in range(9)))
     for k, n in enumerate(NAMES):
         print(f"  {n:40s}" + "".join(f"{out[p * NT + k] / chunks / 1e3:6.2f}" for p in range(9)))
-    tot = [sum(out[p * NT + k] for k in range(NT)) for p in range(9)]
+    print(f"  {'exact-path chunks %':40s}" + "".join(f"{100.0 * out[p * NT + 20] / max(out[p * NT + 22], 1):6.2f}" for p in range(9)))
+    print(f"  {'doubtful chunks % (quick test failed)':40s}" + "".join(f"{100.0 * out[p * NT + 21] / max(out[p * NT + 22], 1):6.2f}" for p in range(9)))
+    tot = [sum(out[p * NT + k] for k in range(20)) for p in range(9)]
     print(f"  {'per-wave total (= unit latency / chunk)':40s}" + "".join(f"{t / 5 / chunks / 1e3:6.2f}" for t in tot))
 
 
