@@ -99,9 +99,9 @@ struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint32_t nev;               // number of events in the chunk
 };
 struct GolombSlot {             // golomb wave -> merge wave (bins 0, 8..16)
-    uint8_t evflag[128];        // as WalkSlot::evflag
-    uint8_t evstart[128];
-    uint16_t evword[128];       // finished ring word of an end event
+    // per event of bins 0, 8..16: bit0 a code word starts here, bit1 one ends here, bits 8..15 the position of
+    // that word's first event (255: carried in), bits 16..31 the finished ring word of an end event
+    uint32_t rec[128];
     uint8_t open_pos[20];       // per bin, as WalkSlot::open_pos
     uint16_t post_k[20];        // run lengths after the chunk
     uint32_t tag;               // (chunk << 8 | generation) + 1 once the slot holds that chunk's results
@@ -373,14 +373,16 @@ ICER_DEV void wave_drain(CoderShared &s)
 struct PixelWave {                // next chunk's 3x3 coefficient window, one pixel per lane
     LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
     LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
+    LANEVAR(uint32_t, row); LANEVAR(uint32_t, col);     // raster coordinates of this lane's pixel in the next chunk
 };
 
+// fetch the 3x3 windows of the 64 pixels starting at BASE; (cw.row, cw.col) = raster coordinates of pixel
+// BASE + lane, advanced by 64 pixels per chunk without a division when the segment is at least 64 wide
 #define ICER_FETCH_WINDOW(BASE)                                                                        \
     FOR_LANES                                                                                          \
     {                                                                                                  \
-        const uint32_t p_ = (BASE) + (uint32_t)lane;                                                   \
-        const uint32_t pp_ = p_ < npix ? p_ : 0u;                                                      \
-        const uint32_t r_ = pp_ / a.w, c_ = pp_ - r_ * a.w;                                            \
+        const bool in_ = (BASE) + (uint32_t)lane < npix;                                               \
+        const uint32_t r_ = in_ ? LV(cw.row) : 0u, c_ = in_ ? LV(cw.col) : 0u;                          \
         const uint16_t *q_ = a.seg + (size_t)r_ * a.stride + c_;                                       \
         const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < a.w, hasN_ = r_ > 0, hasS_ = r_ + 1 < a.h;          \
         LV(cw.nC) = q_[0];                                                                             \
@@ -392,6 +394,16 @@ struct PixelWave {                // next chunk's 3x3 coefficient window, one pi
         LV(cw.nNE) = (hasN_ && hasE_) ? *(q_ - a.stride + 1) : 0u;                                     \
         LV(cw.nSW) = (hasS_ && hasW_) ? *(q_ + a.stride - 1) : 0u;                                     \
         LV(cw.nSE) = (hasS_ && hasE_) ? *(q_ + a.stride + 1) : 0u;                                     \
+        /* advance to the same lane of the next chunk */                                               \
+        if (a.w >= 64u) {                                                                              \
+            uint32_t nc_ = LV(cw.col) + 64u;                                                           \
+            if (nc_ >= a.w) { nc_ -= a.w; LV(cw.row)++; }                                              \
+            LV(cw.col) = nc_;                                                                          \
+        } else {                                                                                       \
+            const uint32_t np_ = (BASE) + 64u + (uint32_t)lane;                                        \
+            LV(cw.row) = np_ / a.w;                                                                    \
+            LV(cw.col) = np_ - LV(cw.row) * a.w;                                                       \
+        }                                                                                              \
     }
 
 // chunks [j0, j1) of the unit; the first call must start at chunk 0
@@ -402,7 +414,10 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
     const uint32_t npix = a.w * a.h;
     const uint32_t lsb = (uint32_t)a.lsb;
     const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
-    if (j0 == 0 && npix) ICER_FETCH_WINDOW(0u)
+    if (j0 == 0 && npix) {
+        FOR_LANES { LV(cw.row) = (uint32_t)lane / a.w; LV(cw.col) = (uint32_t)lane - LV(cw.row) * a.w; }
+        ICER_FETCH_WINDOW(0u)
+    }
 
     for (uint32_t j = j0; j < j1; j++) {
         const uint32_t base = j * 64u;
@@ -940,10 +955,10 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         {
             const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
             if (b1 == 0x80u || b1 >= 0x88u) {
-                o.evflag[2 * lane] = (uint8_t)LV(fl1); o.evword[2 * lane] = (uint16_t)LV(wd1); o.evstart[2 * lane] = (uint8_t)LV(sp1);
+                o.rec[2 * lane] = LV(fl1) | (LV(sp1) << 8) | (LV(wd1) << 16);
             }
             if (b2 == 0x80u || b2 >= 0x88u) {
-                o.evflag[2 * lane + 1] = (uint8_t)LV(fl2); o.evword[2 * lane + 1] = (uint16_t)LV(wd2); o.evstart[2 * lane + 1] = (uint8_t)LV(sp2);
+                o.rec[2 * lane + 1] = LV(fl2) | (LV(sp2) << 8) | (LV(wd2) << 16);
             }
             if (lane >= 8 && lane <= 16) o.post_k[lane] = (uint16_t)LV(gw.k);
         }
@@ -986,8 +1001,8 @@ ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_
         FOR_LANES
         {
             const uint32_t b1 = LV(c.ev1) & 0x9Fu, b2 = LV(c.ev2) & 0x9Fu;
-            if (b1 == 0x80u || b1 >= 0x88u) { LV(c.fl1) = gq.evflag[2 * lane]; LV(c.wd1) = gq.evword[2 * lane]; LV(c.sp1) = gq.evstart[2 * lane]; }
-            if (b2 == 0x80u || b2 >= 0x88u) { LV(c.fl2) = gq.evflag[2 * lane + 1]; LV(c.wd2) = gq.evword[2 * lane + 1]; LV(c.sp2) = gq.evstart[2 * lane + 1]; }
+            if (b1 == 0x80u || b1 >= 0x88u) { const uint32_t r = gq.rec[2 * lane]; LV(c.fl1) = r & 3u; LV(c.sp1) = (r >> 8) & 255u; LV(c.wd1) = r >> 16; }
+            if (b2 == 0x80u || b2 >= 0x88u) { const uint32_t r = gq.rec[2 * lane + 1]; LV(c.fl2) = r & 3u; LV(c.sp2) = (r >> 8) & 255u; LV(c.wd2) = r >> 16; }
             if (lane >= 8 && lane <= 16) LV(c.op) = gq.open_pos[lane];
         }
     }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Randomised parity stress on a GPU (not collected by pytest): random geometries, filters, segment counts,
+quotas and content, HIP path through the C ABI vs the oracle.  Meant to shake out rare cross-wave races.
+   python tests/stress_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from icer_compression_amd import api, synth  # noqa: E402
+from oracle.binding import Oracle  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    orc = Oracle()
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        w, h = int(rng.integers(5, 700)), int(rng.integers(5, 700))
+        st = int(rng.integers(1, 7))
+        while ((w + (1 << st) - 1) >> st) < 3 or ((h + (1 << st) - 1) >> st) < 3:
+            st -= 1
+        filt, sg = int(rng.integers(0, 7)), int(rng.integers(1, 33))
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            img = synth.gray_frame(w, h, int(rng.integers(1, 1 << 30)), 0)
+        elif kind == 1:
+            img = synth.gray_frame(w, h, int(rng.integers(1, 1 << 30)), 1)
+        elif kind == 2:
+            img = rng.integers(0, int(rng.choice([2, 16, 1024, 4096])), (h, w)).astype(np.uint16)
+        elif kind == 3:
+            img = (rng.integers(0, 256, (h, w)) * (rng.random((h, w)) < rng.choice([0.01, 0.1, 0.5]))).astype(np.uint16)
+        else:
+            img = np.full((h, w), int(rng.integers(0, 256)), np.uint16)
+        quota = int(rng.choice([2 * w * h + 64, max(64, w * h // 3), max(40, w * h // 20), 100 + int(rng.integers(0, 3000))]))
+        color = rng.random() < 0.2
+        planes = [img] if not color else [img, np.roll(img, 3, 0), np.roll(img, 5, 1)]
+        try:
+            a = api.compress(planes, st, filt, sg, quota)
+        except Exception as exc:                                   # noqa: BLE001
+            print("EXCEPTION", w, h, st, filt, sg, quota, exc)
+            bad += 1
+            continue
+        b = orc.compress(planes, st, filt, sg, quota)
+        same = a[0] == b[0] and a[1] == b[1] and (a[0] not in (0, -5) or all(np.array_equal(p, q) for p, q in zip(a[2], b[2])))
+        n += 1
+        if not same:
+            bad += 1
+            print("MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color)),
+                  "rc", a[0], b[0], "len", len(a[1]), len(b[1]), flush=True)
+    print(f"stress: {n} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
