@@ -97,6 +97,11 @@ struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint8_t ev1[64];            // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | bin, 0 = none
     uint8_t ev2[64];            // sign event of pixel `lane`
     uint32_t nev;               // number of events in the chunk
+    // bins 1..7, compacted per bin in coding order (rank = number of earlier events of the same bin):
+    uint8_t rk1[64], rk2[64];   // rank of this lane's events inside their bin
+    uint8_t binseq[8][128];     // rank -> position of the event
+    uint32_t binbits[8][6];     // rank -> input bit, stored with an offset of 8 bits
+    uint8_t binn[8];            // number of events of the bin
 };
 struct GolombSlot {             // golomb wave -> merge wave (bins 0, 8..16)
     // per event of bins 0, 8..16: bit0 a code word starts here, bit1 one ends here, bits 8..15 the position of
@@ -125,10 +130,8 @@ struct CoderShared {
     EventSlot eq[kQueueDepth];
     WalkSlot wq[kQueueDepth];
     GolombSlot gq[kQueueDepth];
-    uint8_t binseq[8][128];     // walker wave: positions of bin b's events in coding order (rank -> position)
-    uint32_t binbits[8][6];     // walker wave: input bits of bin b by rank, stored with an offset of 8 bits
     uint32_t binstart[8][6];    // walker wave: word-start flags of bin b by rank, same offset
-    uint8_t bincarry[8], binn[8];   // walker wave: node carried into the chunk, number of events of the bin
+    uint8_t bincarry[8];        // walker wave: node carried into the chunk
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
@@ -639,6 +642,38 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             q.ev1[lane] = (uint8_t)LV(ev1);
             q.ev2[lane] = (uint8_t)LV(ev2);
             if (lane == 0) q.nev = nev;
+            if (lane < 48) (&q.binbits[0][0])[lane] = 0;
+        }
+        WAVE_SYNC();
+        // every event of bins 1..7 puts its input bit at its rank into the bin's bit string and its position
+        // into the bin's position list.  Rank = number of earlier events of the same bin; the lanes of a bin
+        // are found from per-bit ballots of the bin number (no loop over bins).
+        {
+#define ICER_MATCH3(KEY, V, B0, B1, B2) ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)))
+            const uint64_t V1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), V2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u));
+            const uint64_t P0 = BALLOT(LV(ev1) & 1u), P1 = BALLOT(LV(ev1) & 2u), P2 = BALLOT(LV(ev1) & 4u);
+            const uint64_t Q0 = BALLOT(LV(ev2) & 1u), Q1 = BALLOT(LV(ev2) & 2u), Q2 = BALLOT(LV(ev2) & 4u);
+            FOR_LANES
+            {
+                if ((V1 >> lane) & 1ull) {
+                    const uint32_t b = LV(ev1) & 7u;
+                    const uint32_t r = (uint32_t)(mbcnt64(ICER_MATCH3(b, V1, P0, P1, P2), lane) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
+                    q.rk1[lane] = (uint8_t)r;
+                    q.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane);
+                    if (LV(ev1) & 0x20u) LDS_OR(q.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
+                }
+                if ((V2 >> lane) & 1ull) {
+                    const uint32_t b = LV(ev2) & 7u;
+                    const uint64_t m1 = ICER_MATCH3(b, V1, P0, P1, P2);          // this lane's own magnitude event comes first
+                    const uint32_t r = (uint32_t)(mbcnt64(m1, lane) + (int)((m1 >> lane) & 1ull) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
+                    q.rk2[lane] = (uint8_t)r;
+                    q.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane + 1u);
+                    if (LV(ev2) & 0x20u) LDS_OR(q.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
+                }
+                if (lane < 8)
+                    q.binn[lane] = (uint8_t)(popc64(ICER_MATCH3((uint32_t)lane, V1, P0, P1, P2)) + popc64(ICER_MATCH3((uint32_t)lane, V2, Q0, Q1, Q2)));
+            }
+#undef ICER_MATCH3
         }
         ICER_PUBLISH(s.a_done, j + 1u)
     }
@@ -714,40 +749,10 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
         {
             LV(ev1) = q.ev1[lane];
             LV(ev2) = q.ev2[lane];
-            LV(wn) = 0; LV(rk1) = 0; LV(rk2) = 0;
+            LV(rk1) = q.rk1[lane];
+            LV(rk2) = q.rk2[lane];
+            LV(wn) = lane < 8 ? q.binn[lane] : 0u;
             if (lane < 8) o.open_pos[lane] = 255;
-            if (lane < 48) (&s.binbits[0][0])[lane] = 0;
-        }
-        WAVE_SYNC();
-        // every event of bins 1..7 puts its input bit at its rank into the bin's bit string and its position
-        // into the bin's position list.  Rank = number of earlier events of the same bin; the lanes of a bin
-        // are found from per-bit ballots of the bin number (no loop over bins).
-        {
-#define ICER_MATCH3(KEY, V, B0, B1, B2) ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)))
-            const uint64_t V1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), V2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u));
-            const uint64_t P0 = BALLOT(LV(ev1) & 1u), P1 = BALLOT(LV(ev1) & 2u), P2 = BALLOT(LV(ev1) & 4u);
-            const uint64_t Q0 = BALLOT(LV(ev2) & 1u), Q1 = BALLOT(LV(ev2) & 2u), Q2 = BALLOT(LV(ev2) & 4u);
-            FOR_LANES
-            {
-                if ((V1 >> lane) & 1ull) {
-                    const uint32_t b = LV(ev1) & 7u;
-                    const uint32_t r = (uint32_t)(mbcnt64(ICER_MATCH3(b, V1, P0, P1, P2), lane) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
-                    LV(rk1) = r;
-                    s.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane);
-                    if (LV(ev1) & 0x20u) LDS_OR(s.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
-                }
-                if ((V2 >> lane) & 1ull) {
-                    const uint32_t b = LV(ev2) & 7u;
-                    const uint64_t m1 = ICER_MATCH3(b, V1, P0, P1, P2);          // this lane's own magnitude event comes first
-                    const uint32_t r = (uint32_t)(mbcnt64(m1, lane) + (int)((m1 >> lane) & 1ull) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
-                    LV(rk2) = r;
-                    s.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane + 1u);
-                    if (LV(ev2) & 0x20u) LDS_OR(s.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
-                }
-                if (lane >= 1 && lane <= 7)
-                    LV(wn) = (uint32_t)(popc64(ICER_MATCH3((uint32_t)lane, V1, P0, P1, P2)) + popc64(ICER_MATCH3((uint32_t)lane, V2, Q0, Q1, Q2)));
-            }
-#undef ICER_MATCH3
         }
         WAVE_SYNC();
         ICER_TICK(7)
@@ -760,9 +765,9 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 const uint32_t n = LV(wn);
                 uint32_t node = LV(ww.node);
                 s.bincarry[b] = (uint8_t)node;
-                uint64_t lo = ((uint64_t)s.binbits[b][0] | ((uint64_t)s.binbits[b][1] << 32)) >> 8;      // ranks 0..55
-                uint64_t hi = (uint64_t)s.binbits[b][2] | ((uint64_t)s.binbits[b][3] << 32);             // ranks 56..119
-                const uint32_t top8 = s.binbits[b][4];                                                     // ranks 120..127
+                uint64_t lo = ((uint64_t)q.binbits[b][0] | ((uint64_t)q.binbits[b][1] << 32)) >> 8;      // ranks 0..55
+                uint64_t hi = (uint64_t)q.binbits[b][2] | ((uint64_t)q.binbits[b][3] << 32);             // ranks 56..119
+                const uint32_t top8 = q.binbits[b][4];                                                     // ranks 120..127
                 lo |= hi << 56;
                 hi = (hi >> 8) | ((uint64_t)top8 << 56);                                                   // ranks 64..127
                 uint64_t st_lo = 0, st_hi = 0;                  // word-start flags by rank
@@ -800,9 +805,8 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 if (n) {
                     // open word after the chunk: the last start, unless everything after it completed
                     int last = st_hi ? 64 + 63 - clz64(st_hi) : (st_lo ? 63 - clz64(st_lo) : -1);
-                    o.open_pos[b] = (uint8_t)(node == 1u ? 254u : (last >= 0 ? (uint32_t)s.binseq[b][last] : 255u));
+                    o.open_pos[b] = (uint8_t)(node == 1u ? 254u : (last >= 0 ? (uint32_t)q.binseq[b][last] : 255u));
                 }
-                s.binn[b] = (uint8_t)n;
             }
         }
         WAVE_SYNC();
@@ -811,9 +815,9 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
         // and for an end: the word's input value and the position of its first event
 #define ICER_V2V_RECORD(EV, RK, POS)                                                                   \
         if (((EV)&0x98u) == 0x80u && ((EV)&7u)) {                                                      \
-            const uint32_t b_ = (EV)&7u, r_ = (RK), n_ = s.binn[b_];                                    \
+            const uint32_t b_ = (EV)&7u, r_ = (RK), n_ = q.binn[b_];                                    \
             const uint32_t sw_ = window6(s.binstart[b_], (int)r_ - 4);      /* starts at ranks r-4 .. r+1 */ \
-            const uint32_t bw_ = window6(s.binbits[b_], (int)r_ - 4);       /* input bits, same ranks */    \
+            const uint32_t bw_ = window6(q.binbits[b_], (int)r_ - 4);       /* input bits, same ranks */    \
             const uint32_t starts_ = (sw_ >> 4) & 1u;                                                   \
             const uint32_t carry_ = s.bincarry[b_];                                                     \
             const uint32_t ends_ = (r_ + 1u < n_) ? ((sw_ >> 5) & 1u) : (o.post_nin[b_] == 0u ? 1u : 0u); \
@@ -823,7 +827,7 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 if (back_) {                                                                            \
                     const uint32_t k_ = 31u - (uint32_t)clz32(back_);        /* start at rank r-4+k */  \
                     acc_ = (bw_ & 31u) >> k_;                                                           \
-                    sp_ = s.binseq[b_][r_ - 4u + k_];                                                   \
+                    sp_ = q.binseq[b_][r_ - 4u + k_];                                                   \
                 } else {                                                     /* the carried-in word */  \
                     const uint32_t cn_ = 31u - (uint32_t)clz32(carry_);                                 \
                     acc_ = (carry_ ^ (1u << cn_)) | (((bw_ & 31u) >> (4u - r_)) << cn_);                \
