@@ -45,6 +45,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // cross-wave hand-off: the emulation runs the waves in an order in which every wait is already satisfied
 #define ICER_LOAD_CNT(x) (x)
 #define ICER_WAIT_UNTIL(cond) { assert(cond); }
+#define ICER_WAIT_RELAXED(cond) { assert(cond); }
 #define ICER_PUBLISH(x, v) { (x) = (v); }
 #define ICER_ACQUIRE()
 #define ICER_IDLE() break;     /* the emulation never waits: hand control back to the scheduler */
@@ -54,6 +55,8 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ICER_WAIT_UNTIL(cond) { while (!(cond)) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+// for waits of a wave that runs AHEAD of the pipeline (its queue is full): poll rarely, leave the issue slots to others
+#define ICER_WAIT_RELAXED(cond) { while (!(cond)) __builtin_amdgcn_s_sleep(6); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 #define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), pv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define ICER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #define ICER_IDLE() __builtin_amdgcn_s_sleep(1);
@@ -481,7 +484,7 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         }
         ICER_TICK(0)
         // queue slot j % D is free once the count wave has consumed chunk j - D
-        ICER_WAIT_UNTIL(j < ICER_LOAD_CNT(s.a_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
+        ICER_WAIT_RELAXED(j < ICER_LOAD_CNT(s.a_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
         if (ICER_LOAD_CNT(s.abort)) break;
         ICER_TICK(1)
         PixelSlot &o = s.pq[j % kQueueDepth];
@@ -633,7 +636,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         const uint32_t nev = (uint32_t)(popc64(BALLOT(LV(ev1) != 0u)) + popc64(BALLOT(LV(ev2) != 0u)));
         ICER_TICK(4)
         // queue slot j % D is free once the assembly wave has retired chunk j - D
-        ICER_WAIT_UNTIL(j < ICER_LOAD_CNT(s.b_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
+        ICER_WAIT_RELAXED(j < ICER_LOAD_CNT(s.b_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
         if (ICER_LOAD_CNT(s.abort)) break;
         ICER_TICK(5)
         EventSlot &q = s.eq[j % kQueueDepth];
