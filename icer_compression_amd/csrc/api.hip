@@ -281,8 +281,8 @@ int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, in
     }
     HIP_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
 #ifdef ICER_PHASE_TIMERS
-    if (e->prof.ensure(9 * 24)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
-    HIP_TRY(hipMemset(e->prof.p, 0, 9 * 24 * sizeof(uint64_t)));
+    if (e->prof.ensure(9 * 32)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
+    HIP_TRY(hipMemset(e->prof.p, 0, 9 * 32 * sizeof(uint64_t)));
 #endif
     for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     *out = e;
@@ -413,11 +413,11 @@ int icerx_info(icerx_encoder *e, uint32_t *units_per_frame, uint32_t *slot_bits_
 
 #ifdef ICER_PHASE_TIMERS
 // profiling build only: summed s_memtime cycles per coder phase over all units since the last reset
-int icerx_prof_read(icerx_encoder *e, uint64_t out[9 * 24], int reset)
+int icerx_prof_read(icerx_encoder *e, uint64_t out[9 * 32], int reset)
 {
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpy(out, e->prof.p, 9 * 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(e->prof.p, 0, 9 * 24 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(out, e->prof.p, 9 * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(e->prof.p, 0, 9 * 32 * sizeof(uint64_t)));
     return 0;
 }
 #endif

@@ -1,4 +1,4 @@
-// coder_core.hpp -- one workgroup of five wavefronts codes one ICER coding unit
+// coder_core.hpp -- one workgroup of six wavefronts codes one ICER coding unit
 // (channel, level, subband, plane, segment).
 //
 // Replaces, for the uint16 path, the reference's per-segment chain
@@ -8,7 +8,7 @@
 // and must emit the identical payload bits.
 //
 // The segment is coded in chunks of 64 pixels (raster order inside the segment).  The reference is a
-// sequential state machine; its state splits into parts that only depend on their own history, so five
+// sequential state machine; its state splits into parts that only depend on their own history, so six
 // wavefronts work on consecutive chunks at the same time (a software pipeline), handing chunks over
 // through small LDS queues (depth kQueueDepth):
 //
@@ -23,8 +23,11 @@
 //   golomb wave    bin 0 and the Golomb bins 8..16 in closed form on ballot masks: run length since the bin's
 //     (run lengths)  previous one-event, mod m, gives word starts/ends and the finished words.
 //   merge wave     ring slots = prefix count of word-start flags (allocation order = order of first events,
-//     (ring, bit     E2); finished words drained 64 at a time (ballot of done flags, prefix sum of lengths,
-//      stage)        ds_or into the LDS bit stage); whole 32-bit words stored to HBM; the exact path.
+//     (ring tail,    E2); end events write the finished word into the slot of the word's first event; the exact
+//      open slots)   path.
+//   drain wave     finished words popped from the head of the ring 64 at a time (ballot of done flags, prefix
+//     (ring head,    sum of lengths, ds_or into the LDS bit stage); whole 32-bit words stored to HBM.  Parks on
+//      bit stage)    request when the merge wave needs the exact ring occupancy (exact path, end of unit).
 // The walker and golomb waves run one chunk ahead of the merge wave's verdict (speculation, see below).
 //
 // Exactness: word boundaries depend on each bin alone only while the 2048-word ring cannot fill up inside
@@ -65,7 +68,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // Optional per-wave cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
 // -DICER_PHASE_TIMERS (a separate profiling build of the library, never the shipped one).
 #if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
-#define ICER_NUM_TIMERS 24
+#define ICER_NUM_TIMERS 32
 #define ICER_TIMERS_DECL uint64_t tacc_[ICER_NUM_TIMERS] = {}; uint64_t tlast_ = __builtin_amdgcn_s_memtime();
 #define ICER_TIMER_PARAMS , uint64_t *tacc_, uint64_t &tlast_
 #define ICER_TIMER_PASS , tacc_, tlast_
@@ -86,7 +89,7 @@ namespace icer {
 constexpr uint32_t kStageWords = 1024;      // LDS bit stage (circular, 32-bit words)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
-constexpr int kUnitWaves = 5;               // pixel, count, walker, golomb, merge
+constexpr int kUnitWaves = 6;               // pixel, count, walker, golomb, merge, drain
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)
@@ -138,9 +141,13 @@ struct CoderShared {
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
-    uint32_t head, used;        // ring state
-    uint32_t bitpos;            // payload bits produced so far
+    // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
+    uint32_t alloc;             // words allocated so far          (merge wave)
+    uint32_t popped;            // words popped so far             (drain wave, or the merge wave while it holds the drain)
+    uint32_t bitpos;            // payload bits produced so far    (same owner as popped)
     uint32_t flushed_words;     // payload words already written to HBM
+    // merge -> drain wave: odd = "park, I need the drain state", even = released; the drain wave answers in hold_ack
+    uint32_t hold_seq, hold_ack, drain_exit;
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
     uint32_t p_done, a_done, b_done, abort;
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
@@ -174,12 +181,13 @@ ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
 // The caller drains afterwards (wave_drain).
 ICER_DEV void seq_complete_head(CoderShared &s)
 {
-    const uint32_t w = s.ring[s.head];
+    const uint32_t head = s.popped & (kRingWords - 1);
+    const uint32_t w = s.ring[head];
     if (!(w & kWordDone)) {
         const int bin = (int)(w & 31u);
         if (bin >= 8) {
             const uint32_t k = s.bin_acc[bin];
-            s.ring[s.head] = (uint16_t)((k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u)
+            s.ring[head] = (uint16_t)((k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u)
                                                                             : golomb_word(s.tab, bin, k));
             s.bin_acc[bin] = 0;
             s.bin_slot[bin] = -1;
@@ -190,7 +198,7 @@ ICER_DEV void seq_complete_head(CoderShared &s)
             const uint32_t pre = (s.bin_acc[bin] | ((f & 15u) << nin)) & 31u;
             const uint32_t e = s.tab.v2v[bin][pre];
             // QUIRK (kept): the completed input is not checked to be a real code word
-            s.ring[s.head] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
+            s.ring[head] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
             s.bin_acc[bin] = 0;
             s.bin_nin[bin] = 0;
             s.bin_slot[bin] = -1;
@@ -331,10 +339,13 @@ ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u 
 
 // drain finished words from the head of the ring, 64 per round: lengths -> prefix sum -> bit offsets,
 // code bits OR-ed into the LDS bit stage (icer_popbuf_while_avail, icer_encoding.c:114-139)
-ICER_DEV void wave_drain(CoderShared &s)
+// `limit` = allocation count up to which ring slots are valid.  Returns the number of words popped.
+ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit)
 {
     DECL_LANE;
-    uint32_t head = s.head, used = s.used, bitpos = s.bitpos;
+    const uint32_t popped0 = s.popped;
+    uint32_t head = popped0 & (kRingWords - 1), used = limit - popped0, bitpos = s.bitpos;
+    uint32_t npop = 0;
     for (;;) {
         LANEVAR(uint32_t, w); LANEVAR(uint32_t, len); LANEVAR(uint32_t, off);
         FOR_LANES
@@ -362,14 +373,17 @@ ICER_DEV void wave_drain(CoderShared &s)
         bitpos += total;
         head = (head + n) & (kRingWords - 1);
         used -= n;
+        npop += n;
         if (n < 64u) break;
     }
     WAVE_SYNC();
     FOR_LANES
     {
-        if (lane == 0) { s.head = head; s.used = used; s.bitpos = bitpos; }
+        if (lane == 0) s.bitpos = bitpos;
     }
+    ICER_PUBLISH(s.popped, popped0 + npop)
     WAVE_SYNC();
+    return npop;
 }
 
 
@@ -1051,7 +1065,7 @@ ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
 {
     DECL_LANE;
     const uint64_t S1 = c.S1, S2 = c.S2;
-    const uint32_t used = s.used, tail = s.head + used;
+    const uint32_t tail = s.alloc;
     const GolombSlot &gq = s.gq[j % kQueueDepth];
     const WalkSlot &wq = s.wq[j % kQueueDepth];
     FOR_LANES
@@ -1079,8 +1093,9 @@ ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
         }
         if (lane >= 8 && lane <= 16) s.bin_acc[lane] = gq.post_k[lane];
         if (lane >= 1 && lane <= 7) { s.bin_acc[lane] = wq.post_acc[lane]; s.bin_nin[lane] = wq.post_nin[lane]; }
-        if (lane == 0) s.used = used + (uint32_t)(popc64(S1) + popc64(S2));
     }
+    // the new words (and the finished ones) become visible to the drain wave
+    ICER_PUBLISH(s.alloc, tail + (uint32_t)(popc64(S1) + popc64(S2)))
     WAVE_SYNC();
 }
 
@@ -1102,24 +1117,20 @@ ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
         LV(bacc) = s.bin_acc[b];
         LV(bnin) = s.bin_nin[b];
     }
-    uint32_t head = s.head, used = s.used;
+    uint32_t alloc = s.alloc, popped = s.popped;
     for (uint32_t e = 0; e < 128u; e++) {
         const uint32_t v = (e & 1u) ? READLANE(c.ev2, e >> 1) : READLANE(c.ev1, e >> 1);
         if (!(v & 0x80u)) continue;
         const uint32_t bin = v & 31u, bit = (v >> 5) & 1u;
         uint32_t slot = READLANE(bslot, bin);
         if (slot == 0xFFFFFFFFu) {                                   // the bin has no open word: allocate one
-            if (used == (uint32_t)kRingWords) {
+            if (alloc - popped == (uint32_t)kRingWords) {
                 // pop what is finished; if the oldest word is still open, force-complete it
-                FOR_LANES
-                {
-                    if (lane == 0) { s.head = head; s.used = used; }
-                }
                 WAVE_SYNC();
-                wave_drain(s);
-                head = s.head;
-                used = s.used;
-                if (used == (uint32_t)kRingWords) {
+                wave_drain(s, alloc);
+                popped = s.popped;
+                if (alloc - popped == (uint32_t)kRingWords) {
+                    const uint32_t head = popped & (kRingWords - 1);
                     const uint32_t hb = s.ring[head] & 31u;          // owner bin of the (open) head word
                     const uint32_t hacc = READLANE(bacc, hb), hnin = READLANE(bnin, hb);
                     uint32_t word;
@@ -1136,13 +1147,12 @@ ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
                         if (lane == 0) s.ring[head] = (uint16_t)word;
                     }
                     WAVE_SYNC();
-                    wave_drain(s);
-                    head = s.head;
-                    used = s.used;
+                    wave_drain(s, alloc);
+                    popped = s.popped;
                 }
             }
-            slot = (head + used) & (kRingWords - 1);
-            used++;
+            slot = alloc & (kRingWords - 1);
+            alloc++;
             FOR_LANES
             {
                 if ((uint32_t)lane == bin) LV(bslot) = slot;
@@ -1177,47 +1187,101 @@ ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
     FOR_LANES
     {
         if (lane < kNumBins) { s.bin_slot[lane] = (int32_t)LV(bslot); s.bin_acc[lane] = LV(bacc); s.bin_nin[lane] = LV(bnin); }
-        if (lane == 0) { s.head = head; s.used = used; }
+        if (lane == 0) s.alloc = alloc;
     }
     WAVE_SYNC();
 }
 
 // chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
+// ==========================================================================================
+// drain wave + the merge wave's hand-shake with it
+// ==========================================================================================
+// Pops finished words and writes the payload until told to park (hold_seq odd) or to exit.
+// `max_passes` bounds one call in the emulation (the GPU passes ~0u).
+ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_passes)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    for (uint32_t pass = 0;; pass++) {
+        if (ICER_LOAD_CNT(s.abort)) break;
+        const uint32_t hs = ICER_LOAD_CNT(s.hold_seq);
+        if (hs & 1u) {
+            // parked: the merge wave owns popped / bitpos / the bit stage until it releases the hold
+            ICER_PUBLISH(s.hold_ack, hs)
+            if (ICER_LOAD_CNT(s.drain_exit) || pass >= max_passes) break;
+            ICER_IDLE()
+            continue;
+        }
+        if (pass >= max_passes) break;
+        const uint32_t limit = ICER_LOAD_CNT(s.alloc);
+        ICER_ACQUIRE()
+        ICER_TICK(20)
+        if (limit == s.popped || wave_drain(s, limit) == 0u) {
+            ICER_TICK(21)
+            ICER_IDLE()
+            continue;
+        }
+        ICER_TICK(21)
+        if (!flush_stage(s, a, false)) {                 // payload slot too small: abandon the unit
+            ICER_PUBLISH(s.abort, 1u)
+            break;
+        }
+        ICER_TICK(22)
+    }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// merge wave: take over / give back the drain state
+#ifdef ICER_WAVE_EMU
+#define ICER_DRAIN_HOLD(S, A) { (S).hold_seq |= 1u; drain_wave_run((S), (A), 0u); assert((S).hold_ack == (S).hold_seq); }
+#else
+#define ICER_DRAIN_HOLD(S, A) { const uint32_t hs_ = (S).hold_seq | 1u; ICER_PUBLISH((S).hold_seq, hs_) ICER_WAIT_UNTIL(ICER_LOAD_CNT((S).hold_ack) == hs_ || ICER_LOAD_CNT((S).abort)) }
+#endif
+#define ICER_DRAIN_RELEASE(S) { ICER_PUBLISH((S).hold_seq, ((S).hold_seq | 1u) + 1u) }
+
+// chunks [j0, j1); returns false when the unit was abandoned (payload slot too small)
 ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j)
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
         ICER_TICK(13)
         const EventSlot &q = s.eq[j % kQueueDepth];
         // Every event could open at most one word: if the ring cannot fill up inside this chunk no forced flush
-        // (E5) is possible and word boundaries depend on each bin alone.  When that quick test fails, the exact
-        // number of new words decides: the speculative results say how many words the chunk opens *if* no flush
-        // happens, and if they all fit none happens.
+        // (E5) is possible and word boundaries depend on each bin alone.  The drain wave's pop count may lag, which
+        // only over-estimates the occupancy.  When that quick test fails the drain wave is parked, everything
+        // finished is popped (the reference's state) and the test repeated; if it still fails the exact number of new
+        // words decides: the speculative results say how many words the chunk opens *if* no flush happens, and if
+        // they all fit none happens.
         MergeChunk c;
-        bool exact = false;
-        const bool doubtful = s.used + q.nev > (uint32_t)kRingWords;
-        ICER_COUNT(22)
-        if (doubtful) {
-            ICER_COUNT(21)
-            merge_gather(s, c, j ICER_TIMER_PASS);
-            exact = s.used + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
+        bool exact = false, held = false, gathered = false;
+        ICER_COUNT(31)
+        if (s.alloc - ICER_LOAD_CNT(s.popped) + q.nev > (uint32_t)kRingWords) {
+            ICER_DRAIN_HOLD(s, a)
+            if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+            held = true;
+            wave_drain(s, s.alloc);
+            if (s.alloc - s.popped + q.nev > (uint32_t)kRingWords) {
+                ICER_COUNT(30)
+                merge_gather(s, c, j ICER_TIMER_PASS);
+                gathered = true;
+                exact = s.alloc - s.popped + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
+            }
         }
         if (!exact) {
-            if (!doubtful) merge_gather(s, c, j ICER_TIMER_PASS);
+            if (!gathered) merge_gather(s, c, j ICER_TIMER_PASS);
             merge_commit(s, c, j);
-            ICER_TICK(14)
-            wave_drain(s);
             ICER_EMU_COUNT(0);
-            ICER_TICK(15)
+            ICER_TICK(14)
         } else {
             ICER_EMU_COUNT(1);
-            ICER_COUNT(20)
+            ICER_COUNT(29)
             // (merge_gather has waited for the walker and golomb waves: they are past their speculative pass
             // over this chunk; bin_acc / bin_nin hold their state as of the last retired chunk)
             exact_chunk_wave(s, c);
-            wave_drain(s);
+            wave_drain(s, s.alloc);
             // results the walker / golomb waves produced for later chunks assumed the fast path here: void them
             FOR_LANES
             {
@@ -1226,31 +1290,39 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             ICER_PUBLISH(s.exact_seq, s.exact_seq + 1u)
             ICER_TICK(16)
         }
-        const bool ok = flush_stage(s, a, false);
-        ICER_TICK(17)
-        if (!ok) {
-            ICER_PUBLISH(s.abort, 1u)
-            ICER_TIMERS_STORE(a.timers)
-            return false;
+        if (held) {
+            // what this wave drained while holding goes out now (the drain wave only flushes after its own pops)
+            if (!flush_stage(s, a, false)) {
+                ICER_PUBLISH(s.abort, 1u)
+                ICER_TIMERS_STORE(a.timers)
+                return false;
+            }
+            ICER_PUBLISH(s.alloc, s.alloc)               // (the exact path advanced it with plain stores)
+            ICER_DRAIN_RELEASE(s)
         }
         ICER_PUBLISH(s.b_done, j + 1u)
+        ICER_TICK(17)
     }
     ICER_TIMERS_STORE(a.timers)
     return true;
 }
 
-// end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455);
-// returns the payload length in bits, or kUnitTooBig when the slot is too small
+// end of unit: park the drain wave for good, force-complete whatever is still open (C8,
+// icer_context_modeller.c:452-455); returns the payload length in bits, or kUnitTooBig
 ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a)
 {
     DECL_LANE;
-    while (s.used > 0) {
+    ICER_PUBLISH(s.drain_exit, 1u)
+    ICER_DRAIN_HOLD(s, a)
+    if (ICER_LOAD_CNT(s.abort)) return kUnitTooBig;
+    wave_drain(s, s.alloc);
+    while (s.alloc != s.popped) {
         FOR_LANES
         {
             if (lane == 0) seq_complete_head(s);
         }
         WAVE_SYNC();
-        wave_drain(s);
+        wave_drain(s, s.alloc);
     }
     return flush_stage(s, a, true) ? s.bitpos : kUnitTooBig;
 }
@@ -1264,7 +1336,7 @@ ICER_DEV void unit_state_init(CoderShared &s)
         for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
         if (lane == 0) {
-            s.head = 0; s.used = 0; s.bitpos = 0; s.flushed_words = 0;
+            s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
             s.p_done = 0; s.a_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
             for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.gq[i].tag = 0; }
         }
@@ -1295,6 +1367,8 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
         golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
         if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
+        if ((jb & 3u) == 3u) drain_wave_run(s, a, 1u + (jb & 4u) / 4u);      // lags behind the merge wave on purpose
+        if (s.abort) return kUnitTooBig;
     }
     return merge_wave_finish(s, a);
 }

@@ -100,8 +100,8 @@ finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------ coder
-// One workgroup of five wavefronts = one coding unit of one frame: pixel, count, walker, golomb and merge
-// waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  grid = (units, frames), block = 320.
+// One workgroup of six wavefronts = one coding unit of one frame: pixel, count, walker, golomb, merge and
+// drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  grid = (units, frames), block = 384.
 __global__ void __launch_bounds__(64 * kUnitWaves)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
@@ -144,7 +144,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.out_words = slot_words + kHeaderBytes / 4;
     a.cap_words = u.cap_words;
     // profiling build: per-wave cycle counters of the level-1 (largest) units, one row per bit plane
-    a.timers = (timers && u.level == 1) ? timers + u.lsb * 24 : nullptr;
+    a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
 
     if (wave == 0) {
@@ -161,6 +161,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         GolombWave gw;
         golomb_wave_init(gw);
         golomb_wave_run(s, a, gw, nchunks, ~0u);
+    } else if (wave == 5) {
+        drain_wave_run(s, a, ~0u);
     } else {
         const uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (bits != kUnitTooBig) {
