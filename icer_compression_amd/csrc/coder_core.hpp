@@ -52,17 +52,26 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_PUBLISH(x, v) { (x) = (v); }
 #define ICER_ACQUIRE()
 #define ICER_IDLE() break;     /* the emulation never waits: hand control back to the scheduler */
+#define ICER_IDLE_DECL
+#define ICER_IDLE_RESET
 #else
 #define ICER_EMU_COUNT(i)
 // counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define ICER_WAIT_UNTIL(cond) { while (!(cond)) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+// Every spin is bounded (kSpinLimit polls, seconds of wall time): a wave that would wait longer declares the unit
+// failed (abort = 2), which every other wait observes; the host then reports ICER_FATAL_ERROR instead of hanging.
+#define ICER_SPIN(cond, SLEEP) { uint32_t spins_ = 0; while (!(cond)) { __builtin_amdgcn_s_sleep(SLEEP); \
+        if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } } \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+#define ICER_WAIT_UNTIL(cond) ICER_SPIN(cond, 1)
 // for waits of a wave that runs AHEAD of the pipeline (its queue is full): poll rarely, leave the issue slots to others
-#define ICER_WAIT_RELAXED(cond) { while (!(cond)) __builtin_amdgcn_s_sleep(6); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+#define ICER_WAIT_RELAXED(cond) ICER_SPIN(cond, 6)
 #define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), pv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define ICER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#define ICER_IDLE() __builtin_amdgcn_s_sleep(1);
+#define ICER_IDLE() { __builtin_amdgcn_s_sleep(1); if (++idle_spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } }
+#define ICER_IDLE_DECL uint32_t idle_spins_ = 0;
+#define ICER_IDLE_RESET idle_spins_ = 0;
 #endif
 
 // Optional per-wave cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
@@ -88,8 +97,10 @@ namespace icer {
 
 constexpr uint32_t kStageWords = 1024;      // LDS bit stage (circular, 32-bit words)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
+constexpr uint32_t kUnitFailed = 0xFFFFFFFEu;    // internal error (a bounded spin expired): reported as ICER_FATAL_ERROR
+constexpr uint32_t kSpinLimit = 1u << 25;
 constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
-constexpr int kUnitWaves = 6;               // pixel, count, walker, golomb, merge, drain
+constexpr int kUnitWaves = 6;               // pixel, count, walker, golomb, merge, helper
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)
@@ -118,10 +129,13 @@ struct GolombSlot {             // golomb wave -> merge wave (bins 0, 8..16)
     uint32_t tag;               // (chunk << 8 | generation) + 1 once the slot holds that chunk's results
 };
 struct WalkSlot {               // walker wave -> merge wave (bins 1..7)
-    // per event of bins 1..7: bit0 a code word starts here, bit1 one ends here, bits 2..6 the completed
-    // input value of the word that ends here, bits 8..15 the position of that word's first event
-    // (255: it was carried into the chunk)
-    uint16_t rec[128];
+    // walker wave: word-start flags of bin b by rank (offset of 8 bits like EventSlot::binbits), node carried in
+    uint32_t binstart[8][6];
+    uint8_t bincarry[8];
+    // helper wave, per event of bins 1..7 (same layout as GolombSlot::rec): bit0 a code word starts here, bit1 one
+    // ends here, bits 8..15 the position of that word's first event (255: carried in), bits 16..31 the finished word
+    uint32_t rec[128];
+    uint32_t rtag;              // as tag, once rec[] holds that chunk's records
     uint8_t open_pos[8];        // per bin after the chunk: 255 untouched, 254 closed, else first event of its open word
     uint8_t post_acc[8], post_nin[8];   // walker state after the chunk
     uint32_t tag;               // as GolombSlot::tag
@@ -136,8 +150,6 @@ struct CoderShared {
     EventSlot eq[kQueueDepth];
     WalkSlot wq[kQueueDepth];
     GolombSlot gq[kQueueDepth];
-    uint32_t binstart[8][6];    // walker wave: word-start flags of bin b by rank, same offset
-    uint8_t bincarry[8];        // walker wave: node carried into the chunk
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
     uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
@@ -148,6 +160,7 @@ struct CoderShared {
     uint32_t flushed_words;     // payload words already written to HBM
     // merge -> drain wave: odd = "park, I need the drain state", even = released; the drain wave answers in hold_ack
     uint32_t hold_seq, hold_ack, drain_exit;
+    uint32_t helper_next, helper_gen, nchunks;   // helper wave's record cursor / generation; chunks of the unit
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
     uint32_t p_done, a_done, b_done, abort;
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
@@ -734,6 +747,7 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
 {
     DECL_LANE;
     ICER_TIMERS_DECL
+    ICER_IDLE_DECL
     (void)a;
     uint32_t done = 0;
     for (;;) {
@@ -760,18 +774,12 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
         ICER_TICK(6)
         const EventSlot &q = s.eq[j % kQueueDepth];
         WalkSlot &o = s.wq[j % kQueueDepth];
-        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2); LANEVAR(uint32_t, wn);
-        LANEVAR(uint32_t, rk1); LANEVAR(uint32_t, rk2);         // rank of this lane's events inside their bin
+        LANEVAR(uint32_t, wn);
         FOR_LANES
         {
-            LV(ev1) = q.ev1[lane];
-            LV(ev2) = q.ev2[lane];
-            LV(rk1) = q.rk1[lane];
-            LV(rk2) = q.rk2[lane];
             LV(wn) = lane < 8 ? q.binn[lane] : 0u;
             if (lane < 8) o.open_pos[lane] = 255;
         }
-        WAVE_SYNC();
         ICER_TICK(7)
         // lane b walks bin b's bit string through the code tree, four input bits per table look-up, and
         // records at which ranks code words start (all <= 7 walkers in lockstep)
@@ -781,7 +789,7 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 const int b = lane;
                 const uint32_t n = LV(wn);
                 uint32_t node = LV(ww.node);
-                s.bincarry[b] = (uint8_t)node;
+                o.bincarry[b] = (uint8_t)node;
                 uint64_t lo = ((uint64_t)q.binbits[b][0] | ((uint64_t)q.binbits[b][1] << 32)) >> 8;      // ranks 0..55
                 uint64_t hi = (uint64_t)q.binbits[b][2] | ((uint64_t)q.binbits[b][3] << 32);             // ranks 56..119
                 const uint32_t top8 = q.binbits[b][4];                                                     // ranks 120..127
@@ -810,12 +818,12 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 }
                 LV(ww.node) = node;
                 // post: start flags with the same offset of 8 as the bit string
-                s.binstart[b][0] = (uint32_t)(st_lo << 8);
-                s.binstart[b][1] = (uint32_t)(st_lo >> 24);
-                s.binstart[b][2] = (uint32_t)(st_lo >> 56) | (uint32_t)(st_hi << 8);
-                s.binstart[b][3] = (uint32_t)(st_hi >> 24);
-                s.binstart[b][4] = (uint32_t)(st_hi >> 56);
-                s.binstart[b][5] = 0;
+                o.binstart[b][0] = (uint32_t)(st_lo << 8);
+                o.binstart[b][1] = (uint32_t)(st_lo >> 24);
+                o.binstart[b][2] = (uint32_t)(st_lo >> 56) | (uint32_t)(st_hi << 8);
+                o.binstart[b][3] = (uint32_t)(st_hi >> 24);
+                o.binstart[b][4] = (uint32_t)(st_hi >> 56);
+                o.binstart[b][5] = 0;
                 const uint32_t nin = 31u - (uint32_t)clz32(node);
                 o.post_acc[b] = (uint8_t)(node ^ (1u << nin));
                 o.post_nin[b] = (uint8_t)nin;
@@ -826,42 +834,11 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 }
             }
         }
-        WAVE_SYNC();
         ICER_TICK(8)
-        // every event lane derives its own record from the start flags: does a word start / end here,
-        // and for an end: the word's input value and the position of its first event
-#define ICER_V2V_RECORD(EV, RK, POS)                                                                   \
-        if (((EV)&0x98u) == 0x80u && ((EV)&7u)) {                                                      \
-            const uint32_t b_ = (EV)&7u, r_ = (RK), n_ = q.binn[b_];                                    \
-            const uint32_t sw_ = window6(s.binstart[b_], (int)r_ - 4);      /* starts at ranks r-4 .. r+1 */ \
-            const uint32_t bw_ = window6(q.binbits[b_], (int)r_ - 4);       /* input bits, same ranks */    \
-            const uint32_t starts_ = (sw_ >> 4) & 1u;                                                   \
-            const uint32_t carry_ = s.bincarry[b_];                                                     \
-            const uint32_t ends_ = (r_ + 1u < n_) ? ((sw_ >> 5) & 1u) : (o.post_nin[b_] == 0u ? 1u : 0u); \
-            uint32_t acc_ = 0, sp_ = 255;                                                               \
-            if (ends_) {                                                                                \
-                const uint32_t back_ = sw_ & 31u;                            /* starts at r-4 .. r */   \
-                if (back_) {                                                                            \
-                    const uint32_t k_ = 31u - (uint32_t)clz32(back_);        /* start at rank r-4+k */  \
-                    acc_ = (bw_ & 31u) >> k_;                                                           \
-                    sp_ = q.binseq[b_][r_ - 4u + k_];                                                   \
-                } else {                                                     /* the carried-in word */  \
-                    const uint32_t cn_ = 31u - (uint32_t)clz32(carry_);                                 \
-                    acc_ = (carry_ ^ (1u << cn_)) | (((bw_ & 31u) >> (4u - r_)) << cn_);                \
-                }                                                                                       \
-            }                                                                                           \
-            o.rec[POS] = (uint16_t)(starts_ | (ends_ << 1) | ((acc_ & 31u) << 2) | (sp_ << 8));         \
-        }
-        FOR_LANES
-        {
-            ICER_V2V_RECORD(LV(ev1), LV(rk1), 2 * lane)
-            ICER_V2V_RECORD(LV(ev2), LV(rk2), 2 * lane + 1)
-        }
-#undef ICER_V2V_RECORD
-        ICER_TICK(9)
         ICER_PUBLISH(o.tag, chunk_tag(j, ww.gen))
         ww.next = j + 1u;
         done++;
+        ICER_IDLE_RESET
     }
     ICER_TIMERS_STORE(a.timers)
     return done;
@@ -888,6 +865,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
 {
     DECL_LANE;
     ICER_TIMERS_DECL
+    ICER_IDLE_DECL
     (void)a;
     uint32_t done = 0;
     for (;;) {
@@ -986,6 +964,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         ICER_PUBLISH(o.tag, chunk_tag(j, gw.gen))
         gw.next = j + 1u;
         done++;
+        ICER_IDLE_RESET
         ICER_TICK(12)
     }
     ICER_TIMERS_STORE(a.timers)
@@ -1015,7 +994,9 @@ ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_
         LV(c.ev2) = q.ev2[lane];
         LV(c.fl1) = 0; LV(c.fl2) = 0; LV(c.wd1) = 0; LV(c.wd2) = 0; LV(c.sp1) = 255; LV(c.sp2) = 255; LV(c.op) = 255;
     }
-    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.gq[j % kQueueDepth].tag) == chunk_tag(j, s.exact_seq))
+    // (every wait of the merge wave also ends when the unit is abandoned: the helper wave may have found the
+    // payload slot too small and left)
+    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.gq[j % kQueueDepth].tag) == chunk_tag(j, s.exact_seq) || ICER_LOAD_CNT(s.abort))
     ICER_TICK(18)
     {
         const GolombSlot &gq = s.gq[j % kQueueDepth];
@@ -1027,31 +1008,15 @@ ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_
             if (lane >= 8 && lane <= 16) LV(c.op) = gq.open_pos[lane];
         }
     }
-    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.wq[j % kQueueDepth].tag) == chunk_tag(j, s.exact_seq))
+    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.wq[j % kQueueDepth].rtag) == chunk_tag(j, s.exact_seq) || ICER_LOAD_CNT(s.abort))
     ICER_TICK(19)
     {
         const WalkSlot &wq = s.wq[j % kQueueDepth];
         FOR_LANES
         {
             const uint32_t b1 = LV(c.ev1) & 0x9Fu, b2 = LV(c.ev2) & 0x9Fu;
-            if (b1 >= 0x81u && b1 <= 0x87u) {
-                const uint32_t r = wq.rec[2 * lane];
-                LV(c.fl1) = r & 3u;
-                if (r & 2u) {
-                    const uint32_t e = s.tab.v2v[b1 & 31u][(r >> 2) & 31u];
-                    LV(c.wd1) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(c.sp1) = r >> 8;
-                }
-            }
-            if (b2 >= 0x81u && b2 <= 0x87u) {
-                const uint32_t r = wq.rec[2 * lane + 1];
-                LV(c.fl2) = r & 3u;
-                if (r & 2u) {
-                    const uint32_t e = s.tab.v2v[b2 & 31u][(r >> 2) & 31u];
-                    LV(c.wd2) = kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8);
-                    LV(c.sp2) = r >> 8;
-                }
-            }
+            if (b1 >= 0x81u && b1 <= 0x87u) { const uint32_t r = wq.rec[2 * lane]; LV(c.fl1) = r & 3u; LV(c.sp1) = (r >> 8) & 255u; LV(c.wd1) = r >> 16; }
+            if (b2 >= 0x81u && b2 <= 0x87u) { const uint32_t r = wq.rec[2 * lane + 1]; LV(c.fl2) = r & 3u; LV(c.sp2) = (r >> 8) & 255u; LV(c.wd2) = r >> 16; }
             if (lane >= 1 && lane <= 7) LV(c.op) = wq.open_pos[lane];
         }
     }
@@ -1194,46 +1159,118 @@ ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
 
 // chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
 // ==========================================================================================
-// drain wave + the merge wave's hand-shake with it
+// helper wave (records + drain) and the merge wave's hand-shake with it
 // ==========================================================================================
-// Pops finished words and writes the payload until told to park (hold_seq odd) or to exit.
-// `max_passes` bounds one call in the emulation (the GPU passes ~0u).
-ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_passes)
+// Helper wave, two duties:
+//  (1) records: once the walker wave has walked chunk r, every event lane of bins 1..7 derives from the bin's
+//      start flags whether a code word starts / ends at its event and, for an end, the finished ring word and the
+//      position of the word's first event (on the merge wave's critical path, so it comes first);
+//  (2) drain: pop finished words from the head of the ring and write the payload, until told to park
+//      (hold_seq odd) or to exit.
+// `max_steps` bounds one call in the emulation (the GPU passes ~0u).
+ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_steps)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
-    for (uint32_t pass = 0;; pass++) {
+    ICER_IDLE_DECL
+    const uint32_t nchunks = s.nchunks;
+    uint32_t idle = 0;
+    for (uint32_t step = 0;;) {
         if (ICER_LOAD_CNT(s.abort)) break;
+        const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
+        if (seq != s.helper_gen) {                      // records for chunks after last_exact are void
+            ICER_ACQUIRE()
+            FOR_LANES
+            {
+                if (lane == 0) { s.helper_gen = seq; s.helper_next = s.last_exact + 1u; }
+            }
+            WAVE_SYNC();
+        }
+        const uint32_t r = s.helper_next, gen = s.helper_gen;
+        if (r < nchunks && ICER_LOAD_CNT(s.wq[r % kQueueDepth].tag) == chunk_tag(r, gen)) {
+            if (step >= max_steps) break;
+            ICER_ACQUIRE()
+            ICER_TICK(20)
+            const EventSlot &q = s.eq[r % kQueueDepth];
+            WalkSlot &o = s.wq[r % kQueueDepth];
+#define ICER_V2V_RECORD(EV, RK, POS)                                                                   \
+            if (((EV)&0x98u) == 0x80u && ((EV)&7u)) {                                                  \
+                const uint32_t b_ = (EV)&7u, r_ = (RK), n_ = q.binn[b_];                                \
+                const uint32_t sw_ = window6(o.binstart[b_], (int)r_ - 4);  /* starts at ranks r-4 .. r+1 */ \
+                const uint32_t bw_ = window6(q.binbits[b_], (int)r_ - 4);   /* input bits, same ranks */    \
+                const uint32_t starts_ = (sw_ >> 4) & 1u;                                               \
+                const uint32_t carry_ = o.bincarry[b_];                                                 \
+                const uint32_t ends_ = (r_ + 1u < n_) ? ((sw_ >> 5) & 1u) : (o.post_nin[b_] == 0u ? 1u : 0u); \
+                uint32_t wd_ = 0, sp_ = 255;                                                            \
+                if (ends_) {                                                                            \
+                    const uint32_t back_ = sw_ & 31u;                        /* starts at r-4 .. r */   \
+                    uint32_t acc_;                                                                      \
+                    if (back_) {                                                                        \
+                        const uint32_t k_ = 31u - (uint32_t)clz32(back_);    /* start at rank r-4+k */  \
+                        acc_ = (bw_ & 31u) >> k_;                                                       \
+                        sp_ = q.binseq[b_][r_ - 4u + k_];                                               \
+                    } else {                                                 /* the carried-in word */  \
+                        const uint32_t cn_ = 31u - (uint32_t)clz32(carry_);                             \
+                        acc_ = (carry_ ^ (1u << cn_)) | (((bw_ & 31u) >> (4u - r_)) << cn_);            \
+                    }                                                                                   \
+                    const uint32_t e_ = s.tab.v2v[b_][acc_ & 31u];                                      \
+                    wd_ = kWordDone | (((e_ >> 4) & 15u) << 11) | (e_ >> 8);                            \
+                }                                                                                       \
+                o.rec[POS] = starts_ | (ends_ << 1) | (sp_ << 8) | (wd_ << 16);                         \
+            }
+            FOR_LANES
+            {
+                const uint32_t e1 = q.ev1[lane], e2 = q.ev2[lane];
+                ICER_V2V_RECORD(e1, (uint32_t)q.rk1[lane], 2 * lane)
+                ICER_V2V_RECORD(e2, (uint32_t)q.rk2[lane], 2 * lane + 1)
+            }
+#undef ICER_V2V_RECORD
+            ICER_PUBLISH(o.rtag, chunk_tag(r, gen))
+            FOR_LANES
+            {
+                if (lane == 0) s.helper_next = r + 1u;
+            }
+            WAVE_SYNC();
+            ICER_TICK(21)
+            step++;
+            idle = 0;
+            ICER_IDLE_RESET
+            continue;
+        }
         const uint32_t hs = ICER_LOAD_CNT(s.hold_seq);
         if (hs & 1u) {
             // parked: the merge wave owns popped / bitpos / the bit stage until it releases the hold
             ICER_PUBLISH(s.hold_ack, hs)
-            if (ICER_LOAD_CNT(s.drain_exit) || pass >= max_passes) break;
+            if (ICER_LOAD_CNT(s.drain_exit) || step >= max_steps) break;
             ICER_IDLE()
             continue;
         }
-        if (pass >= max_passes) break;
+        if (step >= max_steps) break;
         const uint32_t limit = ICER_LOAD_CNT(s.alloc);
-        ICER_ACQUIRE()
-        ICER_TICK(20)
-        if (limit == s.popped || wave_drain(s, limit) == 0u) {
-            ICER_TICK(21)
-            ICER_IDLE()
+        // a drain pass has a fixed cost: run one when enough words have piled up or nothing else happened for a while
+        if (limit - s.popped >= 64u || (limit != s.popped && idle >= 8u)) {
+            ICER_ACQUIRE()
+            const uint32_t npop = wave_drain(s, limit);
+            ICER_TICK(22)
+            if (npop && !flush_stage(s, a, false)) {     // payload slot too small: abandon the unit
+                ICER_PUBLISH(s.abort, 1u)
+                break;
+            }
+            ICER_TICK(23)
+            idle = 0;
+            ICER_IDLE_RESET
+            step++;
             continue;
         }
-        ICER_TICK(21)
-        if (!flush_stage(s, a, false)) {                 // payload slot too small: abandon the unit
-            ICER_PUBLISH(s.abort, 1u)
-            break;
-        }
-        ICER_TICK(22)
+        idle++;
+        ICER_IDLE()
     }
     ICER_TIMERS_STORE(a.timers)
 }
 
 // merge wave: take over / give back the drain state
 #ifdef ICER_WAVE_EMU
-#define ICER_DRAIN_HOLD(S, A) { (S).hold_seq |= 1u; drain_wave_run((S), (A), 0u); assert((S).hold_ack == (S).hold_seq); }
+#define ICER_DRAIN_HOLD(S, A) { (S).hold_seq |= 1u; helper_wave_run((S), (A), 0u); assert((S).hold_ack == (S).hold_seq); }
 #else
 #define ICER_DRAIN_HOLD(S, A) { const uint32_t hs_ = (S).hold_seq | 1u; ICER_PUBLISH((S).hold_seq, hs_) ICER_WAIT_UNTIL(ICER_LOAD_CNT((S).hold_ack) == hs_ || ICER_LOAD_CNT((S).abort)) }
 #endif
@@ -1267,11 +1304,13 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
                 ICER_COUNT(30)
                 merge_gather(s, c, j ICER_TIMER_PASS);
                 gathered = true;
+                if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
                 exact = s.alloc - s.popped + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
             }
         }
         if (!exact) {
             if (!gathered) merge_gather(s, c, j ICER_TIMER_PASS);
+            if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             merge_commit(s, c, j);
             ICER_EMU_COUNT(0);
             ICER_TICK(14)
@@ -1338,7 +1377,8 @@ ICER_DEV void unit_state_init(CoderShared &s)
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
             s.p_done = 0; s.a_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
-            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.gq[i].tag = 0; }
+            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.wq[i].rtag = 0; s.gq[i].tag = 0; }
+            s.helper_next = 0; s.helper_gen = 0;
         }
     }
     WAVE_SYNC();
@@ -1365,9 +1405,10 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
         // both speculating waves run as far ahead as events allow (and roll back when told to)
         walk_wave_run(s, a, ww, nchunks, kQueueDepth);
         golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
+        helper_wave_run(s, a, kQueueDepth);
         if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
-        if ((jb & 3u) == 3u) drain_wave_run(s, a, 1u + (jb & 4u) / 4u);      // lags behind the merge wave on purpose
+        helper_wave_run(s, a, 1u + (jb & 3u));      // records first; the drain lags behind the merge wave on purpose
         if (s.abort) return kUnitTooBig;
     }
     return merge_wave_finish(s, a);

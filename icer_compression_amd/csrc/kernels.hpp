@@ -132,6 +132,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * kUnitWaves) dst[i] = src[i];
     }
     if (wave == 0) unit_state_init(s);
+    if (threadIdx.x == 64) s.nchunks = (u.w * u.h + 63u) / 64u;
     if (wave == 4) build_crc_table(s);
     __syncthreads();
 
@@ -162,10 +163,11 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         golomb_wave_init(gw);
         golomb_wave_run(s, a, gw, nchunks, ~0u);
     } else if (wave == 5) {
-        drain_wave_run(s, a, ~0u);
+        helper_wave_run(s, a, ~0u);
     } else {
-        const uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
-        if (bits != kUnitTooBig) {
+        uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
+        if (s.abort == 2u) bits = kUnitFailed;        // a bounded spin expired: internal error, never a silent hang
+        if (bits != kUnitTooBig && bits != kUnitFailed) {
             // make this wave's payload stores visible to its own loads before the CRC pass reads them
             __threadfence();
             FinishArgs f;
@@ -196,6 +198,15 @@ scan_kernel(const uint32_t *__restrict__ unit_bits, const uint32_t *__restrict__
         return;
     }
     const uint32_t *bits = unit_bits + (size_t)frame * n_units;
+    {   // any unit that reported an internal error makes the frame fail loudly
+        int failed = 0;
+        for (uint32_t i = threadIdx.x; i < n_units; i += 64) failed |= bits[i] == kUnitFailed;
+        if (__ballot(failed)) {
+            for (uint32_t i = threadIdx.x; i < n_units; i += 64) foff[i] = ~0ull;
+            if (threadIdx.x == 0) { sizes[frame] = 0; rcs[frame] = kFatalError; }
+            return;
+        }
+    }
     uint32_t kept;
     uint64_t used;
     const int rc = scan_frame_wave(bits, final_order, n_units, quota, foff, &kept, &used);
