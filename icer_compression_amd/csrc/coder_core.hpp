@@ -1090,10 +1090,13 @@ ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
         uint32_t slot = READLANE(bslot, bin);
         if (slot == 0xFFFFFFFFu) {                                   // the bin has no open word: allocate one
             if (alloc - popped == (uint32_t)kRingWords) {
-                // pop what is finished; if the oldest word is still open, force-complete it
+                // pop what is finished (nothing can be popped while the oldest word is open: skip the drain pass
+                // then); if the oldest word is still open, force-complete it
                 WAVE_SYNC();
-                wave_drain(s, alloc);
-                popped = s.popped;
+                if (s.ring[popped & (kRingWords - 1)] & kWordDone) {
+                    wave_drain(s, alloc);
+                    popped = s.popped;
+                }
                 if (alloc - popped == (uint32_t)kRingWords) {
                     const uint32_t head = popped & (kRingWords - 1);
                     const uint32_t hb = s.ring[head] & 31u;          // owner bin of the (open) head word
@@ -1248,7 +1251,7 @@ ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_st
         if (step >= max_steps) break;
         const uint32_t limit = ICER_LOAD_CNT(s.alloc);
         // a drain pass has a fixed cost: run one when enough words have piled up or nothing else happened for a while
-        if (limit - s.popped >= 64u || (limit != s.popped && idle >= 8u)) {
+        if (limit - s.popped >= 256u || (limit != s.popped && idle >= 16u)) {
             ICER_ACQUIRE()
             const uint32_t npop = wave_drain(s, limit);
             ICER_TICK(22)
