@@ -18,6 +18,7 @@
 
 namespace icer {
 
+constexpr int kXcds = 8;             // MI355X: 8 XCDs, workgroup b of a launch is placed on XCD b % 8
 constexpr int kQuotaRanges = 12;     // progressive mode: launches per frame batch (each followed by a quota probe)
 
 struct Packet {
@@ -200,11 +201,33 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
                         const int64_t u = where[key(ch, lv, sb, lsb, sg)];
                         if (u >= 0) p->final_order.push_back((uint32_t)u);
                     }
-    p->work_order.resize(p->units.size());
-    for (size_t i = 0; i < p->units.size(); i++) p->work_order[i] = (uint32_t)i;
-    std::stable_sort(p->work_order.begin(), p->work_order.end(), [&](uint32_t a, uint32_t b) {
-        return (uint64_t)p->units[a].w * p->units[a].h > (uint64_t)p->units[b].w * p->units[b].h;
-    });
+    // Launch order.  Largest units first (they form the critical path); and XCD-aware: workgroup b of a launch
+    // runs on XCD b % 8 (observed placement, used for speed only), each XCD has its own 4 MiB L2, and the 9 bit
+    // planes of one (channel, level, subband, segment) read the same coefficients.  So units are dealt to 8 lists
+    // by family -- all planes of a family to the same list -- and the lists are interleaved: position 8k + x holds
+    // the k-th unit of list x.
+    {
+        const size_t n = p->units.size();
+        std::vector<uint32_t> by_size(n);
+        for (size_t i = 0; i < n; i++) by_size[i] = (uint32_t)i;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) {
+            return (uint64_t)p->units[a].w * p->units[a].h > (uint64_t)p->units[b].w * p->units[b].h;
+        });
+        auto family = [&](const UnitDesc &u) { return ((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg; };
+        std::vector<int> xcd_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
+        std::vector<std::vector<uint32_t>> lists(kXcds);
+        int next_xcd = 0;
+        for (uint32_t u : by_size) {                                 // families meet their XCD in size order
+            int &x = xcd_of_family[family(p->units[u])];
+            if (x < 0) { x = next_xcd; next_xcd = (next_xcd + 1) % kXcds; }
+            lists[x].push_back(u);
+        }
+        p->work_order.clear();
+        for (size_t k = 0; p->work_order.size() < n; k++)
+            for (int x = 0; x < kXcds; x++)
+                if (k < lists[x].size()) p->work_order.push_back(lists[x][k]);
+                // (a shorter list simply stops contributing; the tail then drifts off the b % 8 pattern, harmless)
+    }
     // progressive mode: priority ranges of about n/kQuotaRanges units each, aligned to whole packets
     {
         const size_t n = p->units.size(), per = (size_t)segments;
