@@ -176,6 +176,16 @@ def main():
                 t = json.load(fh)
             line["roofline"]["traffic"] = t.get("traffic_bytes_per_launch")
             line["roofline"]["traffic_source"] = t.get("source")
+        if world == 1:
+            # PCIe-inclusive figure of the host-buffer entry point (never `value`): H2D frame + kernels + D2H stream
+            t0h = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                (hrc, hstream), = enc.encode_host(host_frames[:1], QUOTA)
+            th = (time.perf_counter() - t0h) / reps
+            line["host_buffers"] = {"ms_per_frame": round(th * 1e3, 3), "value": round(W * H / th / 1e6, 3), "unit": "Mpixels/s",
+                                    "note": "icerx_encode_host: pageable H2D of the frame, all kernels, D2H of size/rc/stream",
+                                    "parity": hrc == 0 and ("%08x" % zlib.crc32(hstream)) == gold["crc32"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_frames[0], gold["crc32"])
             line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)

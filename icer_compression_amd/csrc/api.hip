@@ -152,17 +152,28 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     HIP_TRY(hipMemsetAsync(e->sums.p, 0, (size_t)P * sizeof(unsigned long long), st));
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
 
-    // ---- DWT: rows (src -> tmp), columns (tmp -> coef); stage 1 reads the caller's frames
-    size_t cw = W, ch = H;
+    // ---- DWT: one fused tile pass per stage.  Stage 0 reads the caller's frames; every stage writes HL/LH/HH
+    // to their final place in `coef` and its LL band to a compact side buffer in `tmp` that the next stage
+    // reads (the last stage writes LL into `coef`), so no workgroup reads what another one of the same
+    // stage writes.
+    size_t cw = W, ch = H, ll_off = 0;
+    DwtStageArgs da;
+    da.f = ft;
+    da.coef = e->coef.p; da.coef_stride = (uint32_t)W;
+    da.src = reinterpret_cast<const int16_t *>(d_frames); da.src_stride = (uint32_t)W;
+    size_t src_plane = plane;
     for (int s = 0; s < e->stages; s++) {
-        const int16_t *src = s == 0 ? reinterpret_cast<const int16_t *>(d_frames) : e->coef.p;
         const int nlw = (int)((cw + 1) / 2), nlh = (int)((ch + 1) / 2);
-        hipLaunchKernelGGL(dwt_rows_kernel, dim3((nlw + 255) / 256, (unsigned)ch, P), dim3(256), 0, st, src, plane,
-                           (uint32_t)W, e->tmp.p, plane, (uint32_t)W, (int)cw, ft, dwt_ovf);
-        hipLaunchKernelGGL(dwt_cols_kernel, dim3((unsigned)((cw + 63) / 64), (nlh + 3) / 4, P), dim3(64, 4), 0, st,
-                           e->tmp.p, plane, (uint32_t)W, e->coef.p, plane, (uint32_t)W, (int)cw, (int)ch, ft, dwt_ovf);
-        cw = (cw + 1) / 2;
-        ch = (ch + 1) / 2;
+        da.cw = (int)cw; da.ch = (int)ch;
+        size_t ll_plane;
+        if (s == e->stages - 1) { da.ll = e->coef.p; da.ll_stride = (uint32_t)W; ll_plane = plane; }
+        else { da.ll = e->tmp.p + ll_off; da.ll_stride = (uint32_t)nlw; ll_plane = plane; }
+        hipLaunchKernelGGL(dwt_tile_kernel, dim3((nlw + kTileKX - 1) / kTileKX, (nlh + kTileKY - 1) / kTileKY, P),
+                           dim3(kTileThreads), 0, st, da, src_plane, plane, ll_plane, dwt_ovf);
+        da.src = da.ll; da.src_stride = da.ll_stride; src_plane = ll_plane;
+        ll_off += (size_t)nlw * nlh;
+        cw = nlw;
+        ch = nlh;
     }
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 

@@ -1,6 +1,6 @@
 // kernels.hpp -- gfx950 kernels of the ICER encoder (included once by api.hip).
 //
-//   dwt_rows_kernel / dwt_cols_kernel   one lifting pass over the current LL region (a-1..a-4)
+//   dwt_tile_kernel                     one stage of the 2-D lifting transform, fused LDS tile pass (a-1..a-4)
 //   ll_sum_kernel / ll_mean_kernel      LL mean (a-5)
 //   finalize_kernel                     LL mean removal + sign-magnitude (a-5, a-6)
 //   code_units_kernel                   context modeller + entropy coder + framing (a-9..a-15)
@@ -13,46 +13,29 @@
 #include "assemble_core.hpp"
 #include "coder_core.hpp"
 #include "dwt_core.hpp"
+#include "dwt_tile.hpp"
 #include "plan.hpp"
 
 namespace icer {
 
 // ------------------------------------------------------------------------------------------ DWT
-// One thread per output pair (low_k, high_k) of a row.  grid = (ceil(nl/256), rows, planes).
-__global__ void __launch_bounds__(256)
-dwt_rows_kernel(const int16_t *__restrict__ src, size_t src_plane, uint32_t src_stride,
-                int16_t *__restrict__ dst, size_t dst_plane, uint32_t dst_stride,
-                int cw, FilterTaps f, int *__restrict__ ovf)
+// One stage of the 2-D lifting transform, fused and LDS-staged (dwt_tile.hpp): a workgroup loads its input window
+// (tile + filter halo) with coalesced row reads, lifts the rows, lifts the columns, and stores the four bands.
+// grid = (ceil(nlw / 64), ceil(nlh / 16), planes), block = 256.
+__global__ void __launch_bounds__(kTileThreads)
+dwt_tile_kernel(DwtStageArgs a, size_t src_plane, size_t coef_plane, size_t ll_plane, int *__restrict__ ovf)
 {
-    const int nl = (cw + 1) >> 1;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nl) return;
-    const int16_t *line = src + blockIdx.z * src_plane + (size_t)blockIdx.y * src_stride;
-    const DwtPair p = dwt_pair([line](int i) { return line[i]; }, cw, k, f.am1, f.a0, f.a1, f.be);
-    int16_t *out = dst + blockIdx.z * dst_plane + (size_t)blockIdx.y * dst_stride;
-    out[k] = p.low;
-    if (p.has_high) out[nl + k] = p.high;
-    if (p.overflow) atomicOr(&ovf[blockIdx.z], 1);
-}
-
-// One thread per output pair of a column; consecutive threads take consecutive columns so every
-// row access is a coalesced 128-byte line.  block = (64, 4); grid = (ceil(cw/64), ceil(nl/4), planes).
-__global__ void __launch_bounds__(256)
-dwt_cols_kernel(const int16_t *__restrict__ src, size_t src_plane, uint32_t src_stride,
-                int16_t *__restrict__ dst, size_t dst_plane, uint32_t dst_stride,
-                int cw, int ch, FilterTaps f, int *__restrict__ ovf)
-{
-    const int nl = (ch + 1) >> 1;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const int k = blockIdx.y * 4 + threadIdx.y;
-    if (c >= cw || k >= nl) return;
-    const int16_t *col = src + blockIdx.z * src_plane + c;
-    const uint32_t ss = src_stride;
-    const DwtPair p = dwt_pair([col, ss](int i) { return col[(size_t)i * ss]; }, ch, k, f.am1, f.a0, f.a1, f.be);
-    int16_t *out = dst + blockIdx.z * dst_plane + c;
-    out[(size_t)k * dst_stride] = p.low;
-    if (p.has_high) out[(size_t)(nl + k) * dst_stride] = p.high;
-    if (p.overflow) atomicOr(&ovf[blockIdx.z], 1);
+    __shared__ DwtTileShared sh;
+    a.src += blockIdx.z * src_plane;
+    a.coef += blockIdx.z * coef_plane;
+    a.ll += blockIdx.z * ll_plane;
+    const int tx = blockIdx.x, ty = blockIdx.y, t = threadIdx.x;
+    dwt_tile_load(sh, a, tx, ty, t);
+    __syncthreads();
+    bool o = dwt_tile_rows(sh, a, tx, ty, t);
+    __syncthreads();
+    o |= dwt_tile_cols(sh, a, tx, ty, t);
+    if (o) atomicOr(&ovf[blockIdx.z], 1);
 }
 
 // ------------------------------------------------------------------------------------------ LL mean

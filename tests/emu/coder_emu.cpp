@@ -6,6 +6,7 @@
 #include "../../icer_compression_amd/csrc/assemble_core.hpp"
 #include "../../icer_compression_amd/csrc/coder_core.hpp"
 #include "../../icer_compression_amd/csrc/dwt_core.hpp"
+#include "../../icer_compression_amd/csrc/dwt_tile.hpp"
 #include "../../icer_compression_amd/csrc/plan.hpp"
 #include <stdlib.h>
 #include <string.h>
@@ -35,35 +36,35 @@ extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t st
     return res;
 }
 
-// forward DWT through dwt_pair with the same pass structure as the kernels (rows src->tmp, cols tmp->dst)
+// forward DWT with the structure of the product: one fused LDS-tile pass per stage (csrc/dwt_tile.hpp), the LL
+// band handed from stage to stage through a side buffer, the three detail bands written in place
 extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt)
 {
     if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return kTooManyStages;
-    const FilterTaps f = filter_taps(filt);
-    std::vector<int16_t> tmp(w * h);
+    std::vector<int16_t> src((int16_t *)img, (int16_t *)img + w * h), tmp(w * h);
     int16_t *coef = (int16_t *)img;
-    size_t cw = w, ch = h;
+    static DwtTileShared sh;
+    DwtStageArgs a;
+    a.f = filter_taps(filt);
+    a.coef = coef; a.coef_stride = (uint32_t)w;
+    a.src = src.data(); a.src_stride = (uint32_t)w;
+    size_t cw = w, ch = h, off = 0;
     bool ovf = false;
     for (int s = 0; s < stages; s++) {
         const int nlw = (int)((cw + 1) / 2), nlh = (int)((ch + 1) / 2);
-        for (size_t r = 0; r < ch; r++)
-            for (int k = 0; k < nlw; k++) {
-                const int16_t *line = coef + r * w;
-                DwtPair p = dwt_pair([line](int i) { return line[i]; }, (int)cw, k, f.am1, f.a0, f.a1, f.be);
-                tmp[r * w + k] = p.low;
-                if (p.has_high) tmp[r * w + nlw + k] = p.high;
-                ovf |= p.overflow;
+        a.cw = (int)cw; a.ch = (int)ch;
+        if (s == stages - 1) { a.ll = coef; a.ll_stride = (uint32_t)w; }
+        else { a.ll = tmp.data() + off; a.ll_stride = (uint32_t)nlw; }
+        for (int ty = 0; ty < (nlh + kTileKY - 1) / kTileKY; ty++)
+            for (int tx = 0; tx < (nlw + kTileKX - 1) / kTileKX; tx++) {
+                memset(&sh, 0x5A, sizeof sh);
+                for (int t = 0; t < kTileThreads; t++) dwt_tile_load(sh, a, tx, ty, t);
+                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_rows(sh, a, tx, ty, t);
+                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_cols(sh, a, tx, ty, t);
             }
-        for (size_t c = 0; c < cw; c++)
-            for (int k = 0; k < nlh; k++) {
-                const int16_t *col = tmp.data() + c;
-                DwtPair p = dwt_pair([col, w](int i) { return col[(size_t)i * w]; }, (int)ch, k, f.am1, f.a0, f.a1, f.be);
-                coef[(size_t)k * w + c] = p.low;
-                if (p.has_high) coef[(size_t)(nlh + k) * w + c] = p.high;
-                ovf |= p.overflow;
-            }
-        cw = (cw + 1) / 2;
-        ch = (ch + 1) / 2;
+        a.src = a.ll; a.src_stride = a.ll_stride;
+        off += (size_t)nlw * nlh;
+        cw = nlw; ch = nlh;
     }
     return ovf ? kIntegerOverflow : kOk;
 }
