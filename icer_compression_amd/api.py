@@ -74,6 +74,8 @@ def load_library() -> C.CDLL:
     L.icerx_encoder_destroy.restype = None
     L.icerx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
+    L.icerx_encode_device_u8.argtypes = L.icerx_encode_device.argtypes
+    L.icerx_encode_device_rgb8.argtypes = L.icerx_encode_device.argtypes
     L.icerx_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.icerx_get_coefficients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.icerx_timing_enable.argtypes = [C.c_void_p, C.c_int]
@@ -169,6 +171,17 @@ class Encoder:
         st = torch.cuda.current_stream(frames.device).cuda_stream
         self.encode_device_ptrs(frames.data_ptr(), n, byte_quota, out.data_ptr(), out.stride(0), sizes.data_ptr(),
                                 rcs.data_ptr(), st)
+
+    def encode_torch_frontend(self, raw, byte_quota: int, out, sizes, rcs) -> None:
+        """raw: cuda uint8 tensor, (n, h, w) gray for a 1-channel encoder or (n, h, w, 3) packed RGB for a
+        3-channel one; converted on the device (icerx_encode_device_u8 / _rgb8)."""
+        import torch
+        fn = self.lib.icerx_encode_device_u8 if self.channels == 1 else self.lib.icerx_encode_device_rgb8
+        st = torch.cuda.current_stream(raw.device).cuda_stream
+        rc = fn(self.handle, raw.data_ptr(), raw.shape[0], byte_quota, out.data_ptr(), out.stride(0), sizes.data_ptr(),
+                rcs.data_ptr(), st)
+        if rc != 0:
+            raise IcerHipError(f"front-end encode rc={rc}: {self.lib.icerx_last_error().decode()}")
 
     def encode_host(self, frames: np.ndarray, byte_quota: int):
         """frames: uint16 array (n, channels, h, w) or (n, h, w).  Returns list of (rc, stream bytes)."""

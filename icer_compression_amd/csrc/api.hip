@@ -4,6 +4,7 @@
 // -> sign-magnitude -> one launch that codes every (frame, unit) -> quota scan -> gather.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
@@ -105,6 +106,31 @@ __global__ void frame_status_kernel(const int *dwt_ovf, const int *mean_ovf, int
     int s = 0;
     for (int c = 0; c < channels; c++) s |= dwt_ovf[f * channels + c] | mean_ovf[f * channels + c];
     skip[f] = s;
+}
+
+// 8-bit gray -> uint16 (what the reference's CLI does on the host, example/src/icer_util.c:163-168)
+__global__ void __launch_bounds__(256) widen_u8_kernel(const uint8_t *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// packed RGB888 -> Y, Cb, Cr planes, integer formulas of the reference's callers (color_util.h:8,27-29)
+__global__ void __launch_bounds__(256)
+rgb8_to_ycbcr_kernel(const uint8_t *__restrict__ rgb, uint16_t *__restrict__ planes, size_t npix, int n_frames)
+{
+    const size_t total = npix * (size_t)n_frames;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t f = i / npix, p = i - f * npix;
+        const int r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        auto clip = [](int v) { return v > 255 ? 255 : (v < 0 ? 0 : v); };
+        const int y = clip((19595 * r + 38470 * g + 7471 * b) >> 16);
+        const int cb = clip(((36962 * (b - y)) >> 16) + 128);
+        const int cr = clip(((46727 * (r - y)) >> 16) + 128);
+        uint16_t *o = planes + f * 3 * npix + p;
+        o[0] = (uint16_t)y;
+        o[npix] = (uint16_t)cb;
+        o[2 * npix] = (uint16_t)cr;
+    }
 }
 
 int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
@@ -355,6 +381,36 @@ int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames
                         size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
 {
     return encode_device_impl(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream, nullptr);
+}
+
+int icerx_encode_device_u8(icerx_encoder *e, const uint8_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                           size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+{
+    if (!e || !d_frames || e->channels != 1 || n_frames < 1 || n_frames > e->max_frames) {
+        set_error("icerx_encode_device_u8: invalid arguments (needs a 1-channel encoder)");
+        return ICER_INVALID_INPUT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)n_frames * e->w * e->h;
+    if (e->in.ensure((size_t)e->max_frames * e->w * e->h)) return ICER_FATAL_ERROR;
+    hipLaunchKernelGGL(widen_u8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       d_frames, e->in.p, n);
+    return icerx_encode_device(e, e->in.p, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream);
+}
+
+int icerx_encode_device_rgb8(icerx_encoder *e, const uint8_t *d_rgb, int n_frames, size_t byte_quota, uint8_t *d_out,
+                             size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+{
+    if (!e || !d_rgb || e->channels != 3 || n_frames < 1 || n_frames > e->max_frames) {
+        set_error("icerx_encode_device_rgb8: invalid arguments (needs a 3-channel encoder)");
+        return ICER_INVALID_INPUT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t npix = e->w * e->h;
+    if (e->in.ensure((size_t)e->max_frames * 3 * npix)) return ICER_FATAL_ERROR;
+    hipLaunchKernelGGL(rgb8_to_ycbcr_kernel, dim3((unsigned)std::min<size_t>((npix * n_frames + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, d_rgb, e->in.p, npix, n_frames);
+    return icerx_encode_device(e, e->in.p, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream);
 }
 
 int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, size_t byte_quota, uint8_t *out,

@@ -99,11 +99,26 @@ void icerx_encoder_destroy(icerx_encoder *enc);
  *              (out_stride >= byte_quota)
  *   d_sizes    device pointer, n_frames uint64: stream lengths
  *   d_rcs      device pointer, n_frames int32: per-frame reference return codes
- *   stream     hipStream_t (as void*), NULL = default stream.  The call is asynchronous unless a
- *              slot-capacity retry is needed (rare), in which case it synchronises.
+ *   stream     hipStream_t (as void*), NULL = default stream.  All work is enqueued on it; the call returns
+ *              after it has completed there (it has to read back one word: whether a coding unit outgrew
+ *              its provisioned slot, in which case the batch is redone with larger slots).
  * Returns 0 or ICER_FATAL_ERROR (HIP failure) / ICER_INVALID_INPUT. */
 int icerx_encode_device(icerx_encoder *enc, const uint16_t *d_frames, int n_frames, size_t byte_quota,
                         uint8_t *d_out, size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
+
+/* Front-end fusion: inputs as the reference's callers hold them BEFORE their app-side conversion,
+ * converted on the device, so only 1 byte per sample crosses PCIe.
+ *   icerx_encode_device_u8    8-bit gray frames (n_frames * w*h bytes), widened to the uint16 planes the uint16 API
+ *                             takes -- what example/src/icer_util.c:163-168 does on the host.  channels must be 1.
+ *   icerx_encode_device_rgb8  packed RGB888 frames (n_frames * w*h*3 bytes), converted to Y, Cb, Cr planes with the
+ *                             integer formulas of the reference's callers (rgb888_packed_to_yuv,
+ *                             example/src/icer_util.c:69-94 with CRGB2Y/Cb/Cr of example/inc/color_util.h:27-29).
+ *                             channels must be 3.
+ * Same outputs and return values as icerx_encode_device on the converted planes. */
+int icerx_encode_device_u8(icerx_encoder *enc, const uint8_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                           size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
+int icerx_encode_device_rgb8(icerx_encoder *enc, const uint8_t *d_rgb, int n_frames, size_t byte_quota, uint8_t *d_out,
+                             size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
 
 /* Host-buffer convenience wrapper: H2D, icerx_encode_device, D2H, synchronous. */
 int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, size_t byte_quota,

@@ -96,6 +96,39 @@ def test_batch_color(oracle):
     enc.close()
 
 
+def test_frontend_fusion_u8_and_rgb8(oracle):
+    """next-3: 8-bit gray widening and packed RGB888 -> YCbCr on the device give the same streams as the
+    reference callers' host-side conversion followed by the uint16 encoders."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h, st, sg, quota = 192, 160, 3, 5, 2 * 192 * 160
+    gray = synth.gray_batch(2, w, h, 21, 0).astype(np.uint8)
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=2)
+    out = torch.empty((2, quota), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros(2, dtype=torch.int64, device=dev)
+    rcs = torch.zeros(2, dtype=torch.int32, device=dev)
+    enc.encode_torch_frontend(torch.from_numpy(gray).to(dev), quota, out, sizes, rcs)
+    for k in range(2):
+        rc, stream, _ = oracle.compress([gray[k].astype(np.uint16)], st, 0, sg, quota)
+        assert int(rcs[k]) == rc and out[k, : int(sizes[k])].cpu().numpy().tobytes() == stream
+    enc.close()
+
+    rng = np.random.default_rng(4)
+    rgb = rng.integers(0, 256, (2, h, w, 3)).astype(np.uint8)
+    rgb[1] = (np.linspace(0, 255, w)[None, :, None] * np.ones((h, 1, 3))).astype(np.uint8)      # smooth ramp
+    enc = api.Encoder(w, h, 3, st, 0, sg, max_frames=2)
+    enc.encode_torch_frontend(torch.from_numpy(rgb).to(dev), 20000, out, sizes, rcs)
+    for k in range(2):
+        r, g, b = (rgb[k, :, :, c].astype(np.int64) for c in range(3))
+        clip = lambda v: np.clip(v, 0, 255)
+        y = clip((19595 * r + 38470 * g + 7471 * b) >> 16)
+        cb = clip(((36962 * (b - y)) >> 16) + 128)
+        cr = clip(((46727 * (r - y)) >> 16) + 128)
+        rc, stream, _ = oracle.compress([p.astype(np.uint16) for p in (y, cb, cr)], st, 0, sg, 20000)
+        assert int(rcs[k]) == rc and out[k, : int(sizes[k])].cpu().numpy().tobytes() == stream
+    enc.close()
+
+
 def test_slot_bound_retry(oracle, monkeypatch):
     """Per-unit payload slots are provisioned at a bits-per-pixel bound; a unit that needs more must be
     noticed and the batch redone with larger slots.  Forced here by starting from 1 bit/pixel on noise."""
