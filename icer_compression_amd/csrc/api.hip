@@ -420,7 +420,6 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
     HIP_TRY(hipSetDevice(e->device));
     const size_t plane = e->w * e->h, P = (size_t)n_frames * e->channels;
     if (upload_units(e, byte_quota, nullptr)) return ICER_FATAL_ERROR;
-    const size_t dstride = byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes;
     if (e->in.ensure((size_t)e->max_frames * e->channels * plane)) return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpy(e->in.p, frames, P * plane * 2, hipMemcpyHostToDevice));
     for (;;) {   // the device stride depends on the slot bound, which a retry may enlarge
@@ -438,7 +437,6 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
             break;
         }
     }
-    (void)dstride;
     return 0;
 }
 
