@@ -90,6 +90,9 @@ struct icerx_encoder {
     DevBuf<int32_t> rcs;
     DevBuf<uint64_t> prof;              // profiling build only (-DICER_PHASE_TIMERS): per-phase cycle sums
 
+    int *h_flag = nullptr;              // pinned host word: slot-bound overflow flag of the last batch
+    hipEvent_t done = nullptr;          // end of the last batch on its stream
+
     bool timing = false;
     hipEvent_t ev[ICERX_NUM_STAGES + 1] = {};
     double ms[ICERX_NUM_STAGES] = {};
@@ -322,6 +325,8 @@ int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, in
     HIP_TRY(hipMemset(e->prof.p, 0, 9 * 32 * sizeof(uint64_t)));
 #endif
     for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipHostMalloc((void **)&e->h_flag, sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
     *out = e;
     return 0;
 }
@@ -335,6 +340,8 @@ void icerx_encoder_destroy(icerx_encoder *e)
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->done) (void)hipEventDestroy(e->done);
+    if (e->h_flag) (void)hipHostFree(e->h_flag);
     delete e;
 }
 
@@ -361,9 +368,18 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
         }
         if (enqueue(e, d_frames, n_frames, byte_quota, d_out, out_stride, (unsigned long long *)d_sizes, d_rcs, st))
             return ICER_FATAL_ERROR;
-        int ovf = 0;
-        HIP_TRY(hipMemcpyAsync(&ovf, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // One word comes back: did a coding unit outgrow its provisioned slot?  The wait spins on an event query
+        // instead of blocking in hipStreamSynchronize: an encode call is tens of milliseconds and the wake-up
+        // latency of a blocking wait (measured: up to 3 ms per call on a busy host) would be charged to every frame.
+        HIP_TRY(hipMemcpyAsync(e->h_flag, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(e->done, st));
+        for (;;) {
+            const hipError_t q = hipEventQuery(e->done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return ICER_FATAL_ERROR; }
+            __builtin_ia32_pause();
+        }
+        const int ovf = *e->h_flag;
         if (!ovf) break;
         if (e->bits_per_pixel >= 24) {
             set_error("coding-unit slot overflow at the theoretical bound");
