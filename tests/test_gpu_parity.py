@@ -96,6 +96,31 @@ def test_batch_color(oracle):
     enc.close()
 
 
+def test_plain_c_program_links_and_matches(oracle, tmp_path):
+    """A C program written against the lib_icer call sequence, compiled with gcc against include/icer_hip.h and
+    linked with libicer_hip.so (tests/c_abi/dropin_example.c): streams, return codes and the in-place side effect
+    on the planes equal the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dropin_example")
+    libdir = os.path.join(root, "icer_compression_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "dropin_example.c"),
+                           "-L", libdir, "-licer_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    for planes, st, f, sg, q in [([synth.gray_frame(320, 200, 5, 1)], 3, 0, 7, 2 * 320 * 200),
+                                 ([synth.gray_frame(128, 128, 6, 0)], 4, 2, 16, 6000),
+                                 (list(synth.color_frame_yuv(160, 120, 7)), 3, 1, 4, 15000)]:
+        h, w = planes[0].shape
+        np.stack(planes).astype("<u2").tofile(tmp_path / "in.raw")
+        r = subprocess.run([exe, str(tmp_path / "in.raw"), str(w), str(h), str(len(planes)), str(st), str(f), str(sg), str(q),
+                            str(tmp_path / "out.bin"), str(tmp_path / "coef.raw")], capture_output=True, text=True)
+        rc, stream, left = oracle.compress(planes, st, f, sg, q)
+        assert r.returncode == (0 if rc == 0 else 5), r.stdout + r.stderr
+        assert f"rc={rc} size_used={len(stream)}" in r.stdout
+        assert (tmp_path / "out.bin").read_bytes() == stream
+        assert np.array_equal(np.fromfile(tmp_path / "coef.raw", "<u2").reshape(len(planes), h, w), np.stack(left))
+
+
 def test_frontend_fusion_u8_and_rgb8(oracle):
     """next-3: 8-bit gray widening and packed RGB888 -> YCbCr on the device give the same streams as the
     reference callers' host-side conversion followed by the uint16 encoders."""
