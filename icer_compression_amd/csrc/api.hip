@@ -321,8 +321,8 @@ int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, in
     }
     HIP_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
 #ifdef ICER_PHASE_TIMERS
-    if (e->prof.ensure(9 * 32)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
-    HIP_TRY(hipMemset(e->prof.p, 0, 9 * 32 * sizeof(uint64_t)));
+    if (e->prof.ensure(kProfWords)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
+    HIP_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
 #endif
     for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(hipHostMalloc((void **)&e->h_flag, sizeof(int), hipHostMallocDefault));
@@ -498,8 +498,16 @@ int icerx_prof_read(icerx_encoder *e, uint64_t out[9 * 32], int reset)
 {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpy(out, e->prof.p, 9 * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(e->prof.p, 0, 9 * 32 * sizeof(uint64_t)));
+    if (reset) HIP_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
     return 0;
+}
+// per workgroup of frame 0 (launch position b < kTraceUnits): start / end (100 MHz wall clock), HW_ID | XCC_ID << 32, unit index
+int icerx_prof_trace(icerx_encoder *e, uint64_t *out, int n_blocks)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    if (n_blocks > kTraceUnits) n_blocks = kTraceUnits;
+    HIP_TRY(hipMemcpy(out, e->prof.p + 9 * 32, (size_t)n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return n_blocks;
 }
 #endif
 

@@ -101,6 +101,8 @@ constexpr uint32_t kUnitFailed = 0xFFFFFFFEu;    // internal error (a bounded sp
 constexpr uint32_t kSpinLimit = 1u << 25;
 constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
 constexpr int kUnitWaves = 6;               // pixel, count, walker, golomb, merge, helper
+constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
+constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits;
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)

@@ -94,6 +94,14 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
+#ifdef ICER_PHASE_TIMERS
+    uint64_t *trace = (timers && frame == 0 && blockIdx.x < (uint32_t)kTraceUnits) ? timers + 9 * 32 + 4 * blockIdx.x : nullptr;
+    if (trace && threadIdx.x == 0) {
+        trace[0] = wall_clock64();
+        trace[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+        trace[3] = work_order[blockIdx.x];
+    }
+#endif
     const uint32_t ui = work_order[blockIdx.x];
     const uint32_t wave = threadIdx.x >> 6;
     // DWT / mean overflow: the reference emits nothing.  Progressive mode: an earlier priority range already
@@ -162,6 +170,9 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
             finish_unit_wave(s, f);
         }
         if ((threadIdx.x & 63) == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
+#ifdef ICER_PHASE_TIMERS
+        if (trace && (threadIdx.x & 63) == 0) trace[1] = wall_clock64();
+#endif
     }
 }
 

@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "icer_tables.hpp"
@@ -150,6 +151,15 @@ struct Plan {
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
 };
 
+// quarter-octave size class of a unit (launch order treats units of one class as equally large)
+inline int size_class(uint64_t pixels)
+{
+    int c = 0;
+    while ((pixels >> (c + 1)) != 0) c++;                            // floor(log2)
+    const uint64_t frac = c >= 2 ? (pixels >> (c - 2)) & 3u : 0u;    // next two bits
+    return 4 * c + (int)frac;
+}
+
 inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int segments)
 {
     p->w = w; p->h = h; p->channels = channels; p->stages = stages; p->segments = segments;
@@ -210,8 +220,16 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
         const size_t n = p->units.size();
         std::vector<uint32_t> by_size(n);
         for (size_t i = 0; i < n; i++) by_size[i] = (uint32_t)i;
+        // (equal sizes: low bit planes first -- they are the dense, slow ones, and when a launch has more large units
+        // than the chip has CUs the ones that double up should be the cheap high planes)
+        const bool lsb_first = !getenv("ICER_HIP_OLD_ORDER");
         std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) {
-            return (uint64_t)p->units[a].w * p->units[a].h > (uint64_t)p->units[b].w * p->units[b].h;
+            const uint64_t pa = (uint64_t)p->units[a].w * p->units[a].h, pb = (uint64_t)p->units[b].w * p->units[b].h;
+            if (!lsb_first) return pa > pb;
+            const int ca = size_class(pa), cb = size_class(pb);        // "equal" = within about 20 %
+            if (ca != cb) return ca > cb;
+            if (p->units[a].lsb != p->units[b].lsb) return p->units[a].lsb < p->units[b].lsb;
+            return pa > pb;
         });
         auto family = [&](const UnitDesc &u) { return ((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg; };
         std::vector<int> xcd_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
