@@ -1066,101 +1066,171 @@ ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
     WAVE_SYNC();
 }
 
-// Exact replay of one chunk, event by event in coding order (icer_encode_bit, icer_encoding.c:37-112), for
-// chunks in which the ring may fill up.  Wave-uniform control flow; the per-bin coder state lives in lane
-// registers for the duration (lane b = bin b: open slot, Golomb run / partial input, input bits), events are
-// fetched with v_readlane, so the only LDS traffic is table look-ups and ring stores.  Finished words are
-// NOT drained after every event as in the reference: draining is only observable through `used` when a new
-// word is allocated with the ring apparently full -- then, and only then, the 64-lane drain runs and, if the
-// oldest word is still open, it is force-completed (E5, icer_flush_encode icer_encoding.c:141-189).
-ICER_DEV void exact_chunk_wave(CoderShared &s, MergeChunk &c)
+// ring stores for the chunk's events at positions [lo, hi): open markers of the words that start there, finished
+// words of the ones that end there (slot of a word = tail0 + number of word starts before its first event, E2)
+ICER_DEV void commit_range(CoderShared &s, MergeChunk &c, uint32_t tail0, uint32_t lo, uint32_t hi)
 {
     DECL_LANE;
-    LANEVAR(uint32_t, bslot); LANEVAR(uint32_t, bacc); LANEVAR(uint32_t, bnin);
+    const uint64_t S1 = c.S1, S2 = c.S2;
     FOR_LANES
     {
-        const int b = lane < kNumBins ? lane : 0;
-        LV(bslot) = (uint32_t)s.bin_slot[b];
-        LV(bacc) = s.bin_acc[b];
-        LV(bnin) = s.bin_nin[b];
-    }
-    uint32_t alloc = s.alloc, popped = s.popped;
-    for (uint32_t e = 0; e < 128u; e++) {
-        const uint32_t v = (e & 1u) ? READLANE(c.ev2, e >> 1) : READLANE(c.ev1, e >> 1);
-        if (!(v & 0x80u)) continue;
-        const uint32_t bin = v & 31u, bit = (v >> 5) & 1u;
-        uint32_t slot = READLANE(bslot, bin);
-        if (slot == 0xFFFFFFFFu) {                                   // the bin has no open word: allocate one
-            if (alloc - popped == (uint32_t)kRingWords) {
-                // pop what is finished (nothing can be popped while the oldest word is open: skip the drain pass
-                // then); if the oldest word is still open, force-complete it
-                WAVE_SYNC();
-                if (s.ring[popped & (kRingWords - 1)] & kWordDone) {
-                    wave_drain(s, alloc);
-                    popped = s.popped;
-                }
-                if (alloc - popped == (uint32_t)kRingWords) {
-                    const uint32_t head = popped & (kRingWords - 1);
-                    const uint32_t hb = s.ring[head] & 31u;          // owner bin of the (open) head word
-                    const uint32_t hacc = READLANE(bacc, hb), hnin = READLANE(bnin, hb);
-                    uint32_t word;
-                    if (hb >= 8u) {
-                        word = (hacc == (uint32_t)s.tab.gm[hb] - 1u) ? (kWordDone | (1u << 11) | 1u) : golomb_word(s.tab, (int)hb, hacc);
-                    } else {
-                        const uint32_t f = s.tab.v2v_flush[hb][hacc > 8u ? 8u : hacc][hnin > 5u ? 5u : hnin];
-                        const uint32_t en = s.tab.v2v[hb][(hacc | ((f & 15u) << hnin)) & 31u];
-                        word = kWordDone | (((en >> 4) & 15u) << 11) | (en >> 8);   // QUIRK (kept): not checked to be a code word
-                    }
-                    FOR_LANES
-                    {
-                        if ((uint32_t)lane == hb) { LV(bslot) = 0xFFFFFFFFu; LV(bacc) = 0; LV(bnin) = 0; }
-                        if (lane == 0) s.ring[head] = (uint16_t)word;
-                    }
-                    WAVE_SYNC();
-                    wave_drain(s, alloc);
-                    popped = s.popped;
-                }
-            }
-            slot = alloc & (kRingWords - 1);
-            alloc++;
-            FOR_LANES
-            {
-                if ((uint32_t)lane == bin) LV(bslot) = slot;
-                if (lane == 0) s.ring[slot] = (uint16_t)bin;
-            }
-        }
-        const uint32_t acc = READLANE(bacc, bin), nin = READLANE(bnin, bin);
-        uint32_t word = 0, nacc = acc, nnin = nin;
-        bool close = false;
-        if (bin >= 8u) {
-            if (bit) { word = golomb_word(s.tab, (int)bin, acc); close = true; }
-            else if (acc + 1u >= s.tab.gm[bin]) { word = kWordDone | (1u << 11) | 1u; close = true; }
-            else nacc = acc + 1u;
-        } else if (bin >= 1u) {
-            nnin = nin + 1u;
-            nacc = acc | (bit << nin);
-            const uint32_t en = s.tab.v2v[bin][nacc & 31u];
-            if ((en & 15u) == nnin) { word = kWordDone | (((en >> 4) & 15u) << 11) | (en >> 8); close = true; }
-        } else {
-            word = kWordDone | (1u << 11) | bit;
-            close = true;
-        }
-        FOR_LANES
-        {
-            if ((uint32_t)lane == bin) {
-                if (close) { LV(bslot) = 0xFFFFFFFFu; LV(bacc) = 0; LV(bnin) = 0; }
-                else { LV(bacc) = nacc; LV(bnin) = nnin; }
-            }
-            if (lane == 0 && close) s.ring[slot] = (uint16_t)word;
-        }
+        const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
+        if ((LV(c.fl1) & 1u) && p1 >= lo && p1 < hi) s.ring[(tail0 + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev1) & 31u);
+        if ((LV(c.fl2) & 1u) && p2 >= lo && p2 < hi) s.ring[(tail0 + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev2) & 31u);
     }
     FOR_LANES
     {
-        if (lane < kNumBins) { s.bin_slot[lane] = (int32_t)LV(bslot); s.bin_acc[lane] = LV(bacc); s.bin_nin[lane] = LV(bnin); }
-        if (lane == 0) s.alloc = alloc;
+        const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
+        if ((LV(c.fl1) & 2u) && p1 >= lo && p1 < hi) {
+            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp1)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd1);
+        }
+        if ((LV(c.fl2) & 2u) && p2 >= lo && p2 < hi) {
+            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp2)));
+            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd2);
+        }
     }
     WAVE_SYNC();
 }
+
+// next event of a bin: lowest position in (Q1: even positions 2 * lane, Q2: odd positions 2 * lane + 1); removes it
+#define ICER_NEXT_EVENT(Q1, Q2, POS, V)                                                                    \
+    {                                                                                                      \
+        const uint32_t q1_ = (Q1) ? 2u * (uint32_t)ffs64(Q1) : 999u, q2_ = (Q2) ? 2u * (uint32_t)ffs64(Q2) + 1u : 999u; \
+        if (q1_ < q2_) { POS = q1_; V = READLANE(c.ev1, q1_ >> 1); (Q1) &= (Q1) - 1ull; }                  \
+        else { POS = q2_; V = READLANE(c.ev2, q2_ >> 1); (Q2) &= (Q2) - 1ull; }                             \
+    }
+
+// A chunk inside which the ring may fill up.  The speculative results (c) are right up to the first word start that
+// finds the ring full -- position P, known from the ring occupancy alone -- so events before P are committed as in
+// the fast path.  Then everything finished is popped (the reference pops after every event; popping is only
+// observable through `used` when a word is allocated) and, if the ring is still full, the oldest word is
+// force-completed (E5, icer_flush_encode icer_encoding.c:141-189: it belongs to bin hb, whose state at P follows
+// from hb's events since the word's start).  A forced flush changes the word boundaries of bin hb only: hb's
+// events from P on are replayed one by one (icer_encode_bit, icer_encoding.c:37-112) with the bin starting afresh,
+// all other results stay valid, and the scheme repeats from P.  Returns true if a word was force-completed (the
+// results the walker / golomb / helper waves have produced for later chunks are then void for bin hb).
+ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j)
+{
+    DECL_LANE;
+    const uint32_t tail0 = s.alloc;
+    uint32_t base = 0;
+    bool flushed = false;
+    LANEVAR(uint32_t, ovr); LANEVAR(uint32_t, oacc); LANEVAR(uint32_t, onin);     // lane b: bin b's state after the chunk, if replayed
+    FOR_LANES { LV(ovr) = 0; LV(oacc) = 0; LV(onin) = 0; }
+    for (;;) {
+        const uint64_t S1 = c.S1, S2 = c.S2;
+        const uint32_t t = (uint32_t)kRingWords - (tail0 - s.popped);           // rank of the first word start that finds the ring full
+        if (t >= (uint32_t)(popc64(S1) + popc64(S2))) break;
+        const uint64_t h1 = BALLOT((LV(c.fl1) & 1u) && cnt_lt_own(S1, S2, lane, 0u) == t);
+        const uint64_t h2 = BALLOT((LV(c.fl2) & 1u) && cnt_lt_own(S1, S2, lane, 1u) == t);
+        const uint32_t P = h1 ? 2u * (uint32_t)ffs64(h1) : 2u * (uint32_t)ffs64(h2) + 1u;
+        commit_range(s, c, tail0, base, P);
+        const uint32_t alloc = tail0 + t;
+        FOR_LANES
+        {
+            if (lane == 0) s.alloc = alloc;
+        }
+        WAVE_SYNC();
+        wave_drain(s, alloc);
+        if (alloc - s.popped == (uint32_t)kRingWords) {
+            // still full: the head word is open.  Its bin, and that bin's state just before P:
+            const uint32_t head = s.popped & (kRingWords - 1);
+            const uint32_t hb = s.ring[head] & 31u;
+            const uint64_t E1 = BALLOT((LV(c.ev1) & 0x9Fu) == (0x80u | hb)), E2 = BALLOT((LV(c.ev2) & 0x9Fu) == (0x80u | hb));
+            const int x = last_lt(S1 & E1, S2 & E2, P);                           // first event of the open word, -1: carried in
+            const uint32_t lo = x < 0 ? 0u : (uint32_t)x;
+            uint64_t R1 = E1 & below64((P + 1u) >> 1) & ~below64((lo + 1u) >> 1);   // hb's events in [lo, P)
+            uint64_t R2 = E2 & below64(P >> 1) & ~below64(lo >> 1);
+            uint32_t hacc = x < 0 ? s.bin_acc[hb] : 0u, hnin = x < 0 ? s.bin_nin[hb] : 0u;
+            uint32_t word;
+            if (hb >= 8u) {
+                hacc += (uint32_t)(popc64(R1) + popc64(R2));                       // all zeros, or the word would have ended
+                word = (hacc == (uint32_t)s.tab.gm[hb] - 1u) ? (kWordDone | (1u << 11) | 1u) : golomb_word(s.tab, (int)hb, hacc);
+            } else {
+                while (R1 | R2) {
+                    uint32_t q, v;
+                    ICER_NEXT_EVENT(R1, R2, q, v)
+                    (void)q;
+                    hacc |= ((v >> 5) & 1u) << hnin;
+                    hnin++;
+                }
+                const uint32_t f = s.tab.v2v_flush[hb][hacc > 8u ? 8u : hacc][hnin > 5u ? 5u : hnin];
+                const uint32_t en = s.tab.v2v[hb][(hacc | ((f & 15u) << hnin)) & 31u];
+                word = kWordDone | (((en >> 4) & 15u) << 11) | (en >> 8);       // QUIRK (kept): not checked to be a code word
+            }
+            FOR_LANES
+            {
+                if (lane == 0) s.ring[head] = (uint16_t)word;
+            }
+            WAVE_SYNC();
+            // bin hb starts afresh at P: replay its remaining events of the chunk
+            uint64_t Q1 = E1 & ~below64((P + 1u) >> 1), Q2 = E2 & ~below64(P >> 1);
+            bool open = false;
+            uint32_t acc = 0, nin = 0, spos = 255;
+            while (Q1 | Q2) {
+                uint32_t q, v;
+                ICER_NEXT_EVENT(Q1, Q2, q, v)
+                const uint32_t bit = (v >> 5) & 1u;
+                const uint32_t starts = open ? 0u : 1u;
+                if (!open) { open = true; spos = q; }
+                uint32_t wd = 0;
+                bool close = false;
+                if (hb >= 8u) {
+                    if (bit) { wd = golomb_word(s.tab, (int)hb, acc); close = true; }
+                    else if (acc + 1u >= s.tab.gm[hb]) { wd = kWordDone | (1u << 11) | 1u; close = true; }
+                    else acc++;
+                } else if (hb >= 1u) {
+                    acc |= bit << nin;
+                    nin++;
+                    const uint32_t en = s.tab.v2v[hb][acc & 31u];
+                    if ((en & 15u) == nin) { wd = kWordDone | (((en >> 4) & 15u) << 11) | (en >> 8); close = true; }
+                } else {
+                    wd = kWordDone | (1u << 11) | bit;
+                    close = true;
+                }
+                const uint32_t fl = starts | (close ? 2u : 0u), sp = close ? spos : 255u;
+                FOR_LANES
+                {
+                    if ((uint32_t)lane == (q >> 1)) {
+                        if (q & 1u) { LV(c.fl2) = fl; LV(c.sp2) = sp; LV(c.wd2) = wd; }
+                        else { LV(c.fl1) = fl; LV(c.sp1) = sp; LV(c.wd1) = wd; }
+                    }
+                }
+                if (close) { open = false; acc = 0; nin = 0; }
+            }
+            FOR_LANES
+            {
+                if ((uint32_t)lane == hb) { LV(c.op) = open ? spos : 254u; LV(ovr) = 1; LV(oacc) = acc; LV(onin) = nin; }
+            }
+            c.S1 = BALLOT(LV(c.fl1) & 1u);
+            c.S2 = BALLOT(LV(c.fl2) & 1u);
+            flushed = true;
+            wave_drain(s, alloc);
+        }
+        base = P;
+    }
+    commit_range(s, c, tail0, base, 128u);
+    const uint64_t S1 = c.S1, S2 = c.S2;
+    const GolombSlot &gq = s.gq[j % kQueueDepth];
+    const WalkSlot &wq = s.wq[j % kQueueDepth];
+    FOR_LANES
+    {
+        if (lane < kNumBins) {
+            if (LV(c.op) == 254u) s.bin_slot[lane] = -1;
+            else if (LV(c.op) < 128u) s.bin_slot[lane] = (int32_t)((tail0 + cnt_lt(S1, S2, LV(c.op))) & (kRingWords - 1));
+        }
+        if (lane >= 8 && lane <= 16) s.bin_acc[lane] = LV(ovr) ? LV(oacc) : (uint32_t)gq.post_k[lane];
+        if (lane >= 1 && lane <= 7) {
+            s.bin_acc[lane] = LV(ovr) ? LV(oacc) : (uint32_t)wq.post_acc[lane];
+            s.bin_nin[lane] = LV(ovr) ? LV(onin) : (uint32_t)wq.post_nin[lane];
+        }
+        if (lane == 0) s.alloc = tail0 + (uint32_t)(popc64(S1) + popc64(S2));
+    }
+    WAVE_SYNC();
+    return flushed;
+}
+#undef ICER_NEXT_EVENT
 
 // chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
 // ==========================================================================================
@@ -1298,40 +1368,38 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         // words decides: the speculative results say how many words the chunk opens *if* no flush happens, and if
         // they all fit none happens.
         MergeChunk c;
-        bool exact = false, held = false, gathered = false;
+        bool held = false, fast = true;
         ICER_COUNT(31)
         if (s.alloc - ICER_LOAD_CNT(s.popped) + q.nev > (uint32_t)kRingWords) {
             ICER_DRAIN_HOLD(s, a)
             if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             held = true;
             wave_drain(s, s.alloc);
-            if (s.alloc - s.popped + q.nev > (uint32_t)kRingWords) {
-                ICER_COUNT(30)
-                merge_gather(s, c, j ICER_TIMER_PASS);
-                gathered = true;
-                if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
-                exact = s.alloc - s.popped + (uint32_t)(popc64(c.S1) + popc64(c.S2)) > (uint32_t)kRingWords;
-            }
+            fast = s.alloc - s.popped + q.nev <= (uint32_t)kRingWords;
         }
-        if (!exact) {
-            if (!gathered) merge_gather(s, c, j ICER_TIMER_PASS);
-            if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+        merge_gather(s, c, j ICER_TIMER_PASS);
+        if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+        if (fast) {
             merge_commit(s, c, j);
             ICER_EMU_COUNT(0);
             ICER_TICK(14)
         } else {
-            ICER_EMU_COUNT(1);
-            ICER_COUNT(29)
-            // (merge_gather has waited for the walker and golomb waves: they are past their speculative pass
-            // over this chunk; bin_acc / bin_nin hold their state as of the last retired chunk)
-            exact_chunk_wave(s, c);
-            wave_drain(s, s.alloc);
-            // results the walker / golomb waves produced for later chunks assumed the fast path here: void them
-            FOR_LANES
-            {
-                if (lane == 0) s.last_exact = j;
+            ICER_COUNT(30)
+            // (merge_gather has waited for the walker, golomb and helper waves: they are past their speculative pass
+            // over this chunk; bin_acc / bin_nin hold the bins' state as of the last retired chunk)
+            if (hybrid_chunk(s, c, j)) {
+                ICER_EMU_COUNT(1);
+                ICER_COUNT(29)
+                wave_drain(s, s.alloc);
+                // results produced for later chunks assumed no forced flush here: void them
+                FOR_LANES
+                {
+                    if (lane == 0) s.last_exact = j;
+                }
+                ICER_PUBLISH(s.exact_seq, s.exact_seq + 1u)
+            } else {
+                ICER_EMU_COUNT(0);
             }
-            ICER_PUBLISH(s.exact_seq, s.exact_seq + 1u)
             ICER_TICK(16)
         }
         if (held) {
