@@ -507,6 +507,11 @@ int icerx_prof_trace(icerx_encoder *e, uint64_t *out, int n_blocks)
     HIP_TRY(hipSetDevice(e->device));
     if (n_blocks > kTraceUnits) n_blocks = kTraceUnits;
     HIP_TRY(hipMemcpy(out, e->prof.p + 9 * 32, (size_t)n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t hw[16];
+    HIP_TRY(hipMemcpy(hw, e->prof.p + 9 * 32 + 4 * kTraceUnits, sizeof hw, hipMemcpyDeviceToHost));
+    fprintf(stderr, "workgroup 0, wave -> SIMD:");
+    for (int w = 0; w < kUnitWaves; w++) fprintf(stderr, " %d->%d", w, (int)((hw[w] >> 4) & 3));
+    fprintf(stderr, "\n");
     return n_blocks;
 }
 #endif

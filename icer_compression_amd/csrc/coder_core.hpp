@@ -50,6 +50,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_WAIT_UNTIL(cond) { assert(cond); }
 #define ICER_WAIT_RELAXED(cond) { assert(cond); }
 #define ICER_PUBLISH(x, v) { (x) = (v); }
+#define ICER_PUBLISH2(x1, v1, x2, v2) { (x1) = (v1); (x2) = (v2); }
 #define ICER_ACQUIRE()
 #define ICER_IDLE() break;     /* the emulation never waits: hand control back to the scheduler */
 #define ICER_IDLE_DECL
@@ -68,6 +69,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // for waits of a wave that runs AHEAD of the pipeline (its queue is full): poll rarely, leave the issue slots to others
 #define ICER_WAIT_RELAXED(cond) ICER_SPIN(cond, 6)
 #define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), pv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) { __hip_atomic_store(&(x1), pv1_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&(x2), pv2_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } }
 #define ICER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #define ICER_IDLE() { __builtin_amdgcn_s_sleep(1); if (++idle_spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } }
 #define ICER_IDLE_DECL uint32_t idle_spins_ = 0;
@@ -100,17 +102,21 @@ constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kUnitFailed = 0xFFFFFFFEu;    // internal error (a bounded spin expired): reported as ICER_FATAL_ERROR
 constexpr uint32_t kSpinLimit = 1u << 25;
 constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
-constexpr int kUnitWaves = 6;               // pixel, count, walker, golomb, merge, helper
+constexpr int kUnitWaves = 8;               // pixel, count, compaction, walker, golomb, merge, records, drain
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
-constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits;
+constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits + 16;     // + HW_ID of each wave of workgroup 0
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)
 constexpr uint32_t kWordDone = 0x8000u;
 
 struct PixelSlot {              // pixel wave -> count wave
-    uint8_t c1[64];             // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | context (31 = uncoded), 0 = none
-    uint8_t c2[64];             // sign event: 0x80 | agreement bit << 5 | context
+    // per pixel `lane`, word 0 the magnitude-bit event, word 1 the sign event:
+    //   bits 0..7   0x80 | bit << 5 | context (31 = uncoded), 0 = none; the sign event's bit is the agreement bit
+    //   bits 8..15  rank of the event among the chunk's events of the same context (coding order)
+    //   bits 16..23 how many of those earlier ones were zeros
+    uint32_t e[64][2];
+    uint16_t cn[32];            // per context: events in the chunk | zeros among them << 8
 };
 struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint8_t ev1[64];            // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | bin, 0 = none
@@ -122,25 +128,24 @@ struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint32_t binbits[8][6];     // rank -> input bit, stored with an offset of 8 bits
     uint8_t binn[8];            // number of events of the bin
 };
-struct GolombSlot {             // golomb wave -> merge wave (bins 0, 8..16)
-    // per event of bins 0, 8..16: bit0 a code word starts here, bit1 one ends here, bits 8..15 the position of
-    // that word's first event (255: carried in), bits 16..31 the finished ring word of an end event
+struct RecSlot {                // golomb, walker and records waves -> merge wave
+    // per event position (2 * lane + slot): bit0 a code word starts at this event, bit1 one ends here, bits 2..6 the
+    // event's bin, bits 8..15 the position of that word's first event (255: carried in), bits 16..31 the finished
+    // ring word of an end event; 0 where there is no event.  Bins 1..7 are written by the records wave, everything
+    // else by the golomb wave.
     uint32_t rec[128];
-    uint8_t open_pos[20];       // per bin, as WalkSlot::open_pos
-    uint16_t post_k[20];        // run lengths after the chunk
-    uint32_t tag;               // (chunk << 8 | generation) + 1 once the slot holds that chunk's results
+    // per bin after the chunk (bins 1..7: walker wave, the others: golomb wave): bits 0..7 open_pos -- 255 untouched,
+    // 254 closed, else the first event of its open word --, bits 8..23 Golomb run length / partial input value,
+    // bits 24..31 input bits accumulated
+    uint32_t binst[20];
+    uint32_t gtag, rtag;        // (chunk << 8 | generation) + 1 once the golomb / records wave has written its part
 };
-struct WalkSlot {               // walker wave -> merge wave (bins 1..7)
-    // walker wave: word-start flags of bin b by rank (offset of 8 bits like EventSlot::binbits), node carried in
+struct WalkSlot {               // walker wave -> records wave (bins 1..7)
+    // word-start flags of bin b by rank (offset of 8 bits like EventSlot::binbits), node carried in
     uint32_t binstart[8][6];
     uint8_t bincarry[8];
-    // helper wave, per event of bins 1..7 (same layout as GolombSlot::rec): bit0 a code word starts here, bit1 one
-    // ends here, bits 8..15 the position of that word's first event (255: carried in), bits 16..31 the finished word
-    uint32_t rec[128];
-    uint32_t rtag;              // as tag, once rec[] holds that chunk's records
-    uint8_t open_pos[8];        // per bin after the chunk: 255 untouched, 254 closed, else first event of its open word
-    uint8_t post_acc[8], post_nin[8];   // walker state after the chunk
-    uint32_t tag;               // as GolombSlot::tag
+    uint8_t post_nin[8];        // input bits of the bin's open word after the chunk
+    uint32_t tag;               // as RecSlot::gtag
 };
 
 struct CoderShared {
@@ -151,10 +156,9 @@ struct CoderShared {
     PixelSlot pq[kQueueDepth];
     EventSlot eq[kQueueDepth];
     WalkSlot wq[kQueueDepth];
-    GolombSlot gq[kQueueDepth];
+    RecSlot rq[kQueueDepth];
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
-    uint32_t bin_acc[kNumBins]; // Golomb: zero-run length so far; bins 1..7: partial input value (as of the last retired chunk)
-    uint32_t bin_nin[kNumBins]; // bins 1..7: input bits accumulated
+    uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
     uint32_t alloc;             // words allocated so far          (merge wave)
     uint32_t popped;            // words popped so far             (drain wave, or the merge wave while it holds the drain)
@@ -162,9 +166,9 @@ struct CoderShared {
     uint32_t flushed_words;     // payload words already written to HBM
     // merge -> drain wave: odd = "park, I need the drain state", even = released; the drain wave answers in hold_ack
     uint32_t hold_seq, hold_ack, drain_exit;
-    uint32_t helper_next, helper_gen, nchunks;   // helper wave's record cursor / generation; chunks of the unit
+    uint32_t helper_next, helper_gen, nchunks;   // records wave's cursor / generation; chunks of the unit
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
-    uint32_t p_done, a_done, b_done, abort;
+    uint32_t p_done, a_done, c_done, b_done, abort;
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
     // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
     uint32_t exact_seq, last_exact;
@@ -192,6 +196,11 @@ ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
     return kWordDone | (n << 11) | ((brev32(code) >> (32u - n)) & 0x3FFu);
 }
 
+// packed per-bin coder state (RecSlot::binst, CoderShared::bin_state)
+ICER_DEV uint32_t st_acc(uint32_t st) { return (st >> 8) & 0xFFFFu; }
+ICER_DEV uint32_t st_nin(uint32_t st) { return st >> 24; }
+ICER_DEV uint32_t st_pack(uint32_t op, uint32_t acc, uint32_t nin) { return op | (acc << 8) | (nin << 24); }
+
 // first half of icer_flush_encode (icer_encoding.c:141-189): force-complete the oldest word.
 // The caller drains afterwards (wave_drain).
 ICER_DEV void seq_complete_head(CoderShared &s)
@@ -201,21 +210,20 @@ ICER_DEV void seq_complete_head(CoderShared &s)
     if (!(w & kWordDone)) {
         const int bin = (int)(w & 31u);
         if (bin >= 8) {
-            const uint32_t k = s.bin_acc[bin];
+            const uint32_t k = st_acc(s.bin_state[bin]);
             s.ring[head] = (uint16_t)((k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u)
                                                                             : golomb_word(s.tab, bin, k));
-            s.bin_acc[bin] = 0;
+            s.bin_state[bin] = 0;
             s.bin_slot[bin] = -1;
         } else if (bin >= 1) {
-            const uint32_t nin = s.bin_nin[bin];
-            const uint32_t pv = s.bin_acc[bin] > 8u ? 8u : s.bin_acc[bin];          // partial values are <= 8
+            const uint32_t nin = st_nin(s.bin_state[bin]), acc = st_acc(s.bin_state[bin]);
+            const uint32_t pv = acc > 8u ? 8u : acc;                                // partial values are <= 8
             const uint32_t f = s.tab.v2v_flush[bin][pv][nin > 5u ? 5u : nin];
-            const uint32_t pre = (s.bin_acc[bin] | ((f & 15u) << nin)) & 31u;
+            const uint32_t pre = (acc | ((f & 15u) << nin)) & 31u;
             const uint32_t e = s.tab.v2v[bin][pre];
             // QUIRK (kept): the completed input is not checked to be a real code word
             s.ring[head] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
-            s.bin_acc[bin] = 0;
-            s.bin_nin[bin] = 0;
+            s.bin_state[bin] = 0;
             s.bin_slot[bin] = -1;
         }
     }
@@ -241,14 +249,23 @@ ICER_DEV uint32_t ctx_hh(uint32_t hv, uint32_t d)
 }
 
 // pick the coder bin from a folded (zero >= total/2) probability estimate: the number of
-// cut-offs not above zero/total (icer_compute_bin, icer_util.c:48-56; cut-offs are ascending)
-ICER_DEV uint32_t pick_bin(const uint32_t *cut, uint32_t zero, uint32_t total)
+// cut-offs not above zero/total (icer_compute_bin, icer_util.c:48-56; cut-offs are ascending).
+// zero * 65536 >= total * cut  <=>  floor(zero * 65536 / total) >= cut, so one exact division (total <= 500: a
+// float reciprocal estimate is within 1 of the quotient, then corrected) and one table look-up replace the 16 compares.
+ICER_DEV uint32_t pick_bin(const uint32_t *binlut, uint32_t zero, uint32_t total)
 {
-    const uint32_t lhs = zero << 16;
-    uint32_t bin = 0;
-#pragma unroll
-    for (int b = 0; b < 16; b++) bin += (lhs >= total * cut[b]) ? 1u : 0u;
-    return bin;
+    const uint32_t a = zero << 16;
+#ifdef ICER_WAVE_EMU
+    uint32_t q = (uint32_t)((float)a * (1.0f / (float)total));
+    int32_t rem = (int32_t)a - (int32_t)(q * total);
+#else
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)total));
+    int32_t rem = (int32_t)a - (int32_t)__umul24(q, total);                  // q <= 2^16 + 1, total <= 500
+#endif
+    if (rem < 0) { q--; rem += (int32_t)total; }
+    if (rem >= (int32_t)total) q++;
+    const uint32_t e = binlut[q >> 8];
+    return (e & 255u) + (q >= (e >> 8) ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -511,6 +528,46 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             LV(ctx2) = sctx;
             LV(bit2) = (pred ^ (x >> 15)) & 1u;
         }
+        // ---- context groups --------------------------------------------------------------------------
+        // What the adaptive counts (C5) need from the chunk depends on the coefficients alone and is prepared
+        // here, off the serial path: an event sees the counts at chunk start + its rank among the chunk's events
+        // of the same context (+ the zeros among those).  Lanes with the same context are found from per-bit
+        // ballots of the context number (no loop over contexts); lane c applies the same match to "context c".
+        LANEVAR(uint32_t, w1); LANEVAR(uint32_t, w2); LANEVAR(uint32_t, cnw);
+#define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
+        ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+        {
+            // magnitude-bit events: contexts 0..11; sign events: contexts 12..16, keyed by context - 12
+            const uint64_t V = BALLOT(LV(valid1) && LV(ctx1) != 31u);
+            const uint64_t B0 = BALLOT(LV(ctx1) & 1u), B1 = BALLOT(LV(ctx1) & 2u), B2 = BALLOT(LV(ctx1) & 4u), B3 = BALLOT(LV(ctx1) & 8u);
+            const uint64_t ZM = BALLOT(LV(bit1) == 0u);
+            const uint64_t U = BALLOT(LV(valid2) != 0u);
+            const uint64_t C0 = BALLOT((LV(ctx2) - 12u) & 1u), C1 = BALLOT((LV(ctx2) - 12u) & 2u), C2 = BALLOT((LV(ctx2) - 12u) & 4u);
+            const uint64_t ZN = BALLOT(LV(bit2) == 0u);
+            FOR_LANES
+            {
+                LV(w1) = 0; LV(w2) = 0; LV(cnw) = 0;
+                if (LV(valid1)) {
+                    LV(w1) = 0x80u | (LV(bit1) << 5) | LV(ctx1);
+                    if (LV(ctx1) != 31u) {
+                        const uint64_t m = ICER_MATCH(LV(ctx1), V, B0, B1, B2, B3);
+                        LV(w1) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZM, lane) << 16);
+                    }
+                }
+                if (LV(valid2)) {
+                    const uint64_t m = ICER_MATCH(LV(ctx2) - 12u, U, C0, C1, C2, 0ull);
+                    LV(w2) = 0x80u | (LV(bit2) << 5) | LV(ctx2) | ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZN, lane) << 16);
+                }
+                if (lane < 12) {
+                    const uint64_t m = ICER_MATCH((uint32_t)lane, V, B0, B1, B2, B3);
+                    LV(cnw) = (uint32_t)popc64(m) | ((uint32_t)popc64(m & ZM) << 8);
+                } else if (lane <= 16) {
+                    const uint64_t m = ICER_MATCH((uint32_t)lane - 12u, U, C0, C1, C2, 0ull);
+                    LV(cnw) = (uint32_t)popc64(m) | ((uint32_t)popc64(m & ZN) << 8);
+                }
+            }
+        }
+#undef ICER_MATCH
         ICER_TICK(0)
         // queue slot j % D is free once the count wave has consumed chunk j - D
         ICER_WAIT_RELAXED(j < ICER_LOAD_CNT(s.a_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
@@ -519,8 +576,9 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         PixelSlot &o = s.pq[j % kQueueDepth];
         FOR_LANES
         {
-            o.c1[lane] = (uint8_t)(LV(valid1) ? (0x80u | (LV(bit1) << 5) | LV(ctx1)) : 0u);
-            o.c2[lane] = (uint8_t)(LV(valid2) ? (0x80u | (LV(bit2) << 5) | LV(ctx2)) : 0u);
+            o.e[lane][0] = LV(w1);
+            o.e[lane][1] = LV(w2);
+            if (lane < 17) o.cn[lane] = (uint16_t)LV(cnw);
         }
         ICER_PUBLISH(s.p_done, j + 1u)
     }
@@ -553,95 +611,51 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
         LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
+        LANEVAR(uint32_t, rk1); LANEVAR(uint32_t, zb1); LANEVAR(uint32_t, rk2); LANEVAR(uint32_t, zb2);
+        LANEVAR(uint32_t, cn); LANEVAR(uint32_t, cnz);
         FOR_LANES
         {
-            const uint32_t c1 = in.c1[lane], c2 = in.c2[lane];
-            LV(valid1) = c1 >> 7; LV(ctx1) = c1 & 31u; LV(bit1) = (c1 >> 5) & 1u;
-            LV(valid2) = c2 >> 7; LV(ctx2) = c2 & 31u; LV(bit2) = (c2 >> 5) & 1u;
+            const uint32_t c1 = in.e[lane][0], c2 = in.e[lane][1];
+            LV(valid1) = (c1 >> 7) & 1u; LV(ctx1) = c1 & 31u; LV(bit1) = (c1 >> 5) & 1u; LV(rk1) = (c1 >> 8) & 255u; LV(zb1) = (c1 >> 16) & 255u;
+            LV(valid2) = (c2 >> 7) & 1u; LV(ctx2) = c2 & 31u; LV(bit2) = (c2 >> 5) & 1u; LV(rk2) = (c2 >> 8) & 255u; LV(zb2) = (c2 >> 16) & 255u;
+            const uint32_t w = lane < 17 ? (uint32_t)in.cn[lane] : 0u;
+            LV(cn) = w & 255u; LV(cnz) = w >> 8;
             LV(z1) = 1; LV(t1) = 2;                               // what an uncoded event presents (C2)
             LV(z2) = 0; LV(t2) = 0;
         }
 
         // ---- adaptive counts per event (C5) --------------------------------------------------------------
-        // Lanes with the same context are found from per-bit ballots of the context number (no loop over
-        // contexts): rank inside the context group and the zeros before give the counts an event sees; lane c
-        // applies the same match to "context c" and advances its own counters.  A context that reaches the
-        // rescale point inside this chunk (total 500, at most once per chunk) is redone by ICER_CTX_STEP.
-#define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
-        ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+        // counts an event sees = its context's counts at chunk start + the ranks the pixel wave prepared; lane c
+        // owns context c and advances its counters by the chunk's totals.  A context that reaches the rescale
+        // point inside this chunk (total 500, at most once per chunk) is redone by ICER_CTX_STEP.
         {
-            // magnitude-bit events: contexts 0..11
-            const uint64_t V = BALLOT(LV(valid1) && LV(ctx1) != 31u);
-            const uint64_t B0 = BALLOT(LV(ctx1) & 1u), B1 = BALLOT(LV(ctx1) & 2u), B2 = BALLOT(LV(ctx1) & 4u), B3 = BALLOT(LV(ctx1) & 8u);
-            const uint64_t ZM = BALLOT(LV(bit1) == 0u);
             LANEVAR(uint32_t, t0); LANEVAR(uint32_t, zz0); LANEVAR(uint32_t, idx);
             FOR_LANES { LV(idx) = LV(ctx1) & 15u; }
+            WAVE_GATHER(t0, ctot, idx)
+            WAVE_GATHER(zz0, czer, idx)
+            FOR_LANES
+            {
+                if (LV(valid1) && LV(ctx1) != 31u) { LV(t1) = LV(t0) + LV(rk1); LV(z1) = LV(zz0) + LV(zb1); }
+                LV(idx) = LV(ctx2);
+            }
             WAVE_GATHER(t0, ctot, idx)
             WAVE_GATHER(zz0, czer, idx)
             LANEVAR(uint32_t, cross);
             FOR_LANES
             {
-                const uint64_t m = ICER_MATCH(LV(ctx1), V, B0, B1, B2, B3);
+                if (LV(valid2)) { LV(t2) = LV(t0) + LV(rk2); LV(z2) = LV(zz0) + LV(zb2); }
                 LV(cross) = 0;
-                if (LV(valid1) && LV(ctx1) != 31u) {
-                    LV(t1) = LV(t0) + (uint32_t)mbcnt64(m, lane);
-                    LV(z1) = LV(zz0) + (uint32_t)mbcnt64(m & ZM, lane);
-                    LV(cross) = LV(t0) + (uint32_t)popc64(m) >= kRescaleCap ? 1u : 0u;
+                if (lane < 17) {
+                    if (LV(ctot) + LV(cn) < kRescaleCap) { LV(ctot) += LV(cn); LV(czer) += LV(cnz); }
+                    else LV(cross) = 1;
                 }
             }
-            const uint64_t resc = BALLOT(LV(cross) != 0u);
-            FOR_LANES
-            {
-                if (lane < 12) {                                  // lane c owns context c
-                    const uint64_t m = ICER_MATCH((uint32_t)lane, V, B0, B1, B2, B3);
-                    const uint32_t n = (uint32_t)popc64(m);
-                    if (LV(ctot) + n < kRescaleCap) { LV(ctot) += n; LV(czer) += (uint32_t)popc64(m & ZM); }
-                }
-            }
-            for (uint64_t rem = resc; rem;) {                     // rare: redo the contexts that rescale in this chunk
-                const uint32_t c = READLANE(ctx1, ffs64(rem));
-                ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == c, LV(bit1) == 0u, z1, t1)
-                rem &= ~BALLOT(LV(valid1) && LV(ctx1) == c);
+            for (uint64_t rem = BALLOT(LV(cross) != 0u); rem; rem &= rem - 1ull) {     // rare: contexts that rescale in this chunk
+                const uint32_t c = (uint32_t)ffs64(rem);
+                if (c < 12u) ICER_CTX_STEP(c, LV(valid1) && LV(ctx1) == c, LV(bit1) == 0u, z1, t1)
+                else ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == c, LV(bit2) == 0u, z2, t2)
             }
         }
-        {
-            // sign events: contexts 12..16, keyed by context - 12
-            const uint64_t V = BALLOT(LV(valid2) != 0u);
-            if (V) {
-                const uint64_t B0 = BALLOT((LV(ctx2) - 12u) & 1u), B1 = BALLOT((LV(ctx2) - 12u) & 2u), B2 = BALLOT((LV(ctx2) - 12u) & 4u);
-                const uint64_t ZM = BALLOT(LV(bit2) == 0u);
-                LANEVAR(uint32_t, t0); LANEVAR(uint32_t, zz0); LANEVAR(uint32_t, idx);
-                FOR_LANES { LV(idx) = LV(ctx2) & 31u; }
-                WAVE_GATHER(t0, ctot, idx)
-                WAVE_GATHER(zz0, czer, idx)
-                LANEVAR(uint32_t, cross);
-                FOR_LANES
-                {
-                    const uint64_t m = ICER_MATCH(LV(ctx2) - 12u, V, B0, B1, B2, 0ull);
-                    LV(cross) = 0;
-                    if (LV(valid2)) {
-                        LV(t2) = LV(t0) + (uint32_t)mbcnt64(m, lane);
-                        LV(z2) = LV(zz0) + (uint32_t)mbcnt64(m & ZM, lane);
-                        LV(cross) = LV(t0) + (uint32_t)popc64(m) >= kRescaleCap ? 1u : 0u;
-                    }
-                }
-                const uint64_t resc = BALLOT(LV(cross) != 0u);
-                FOR_LANES
-                {
-                    if (lane >= 12 && lane <= 16) {
-                        const uint64_t m = ICER_MATCH((uint32_t)lane - 12u, V, B0, B1, B2, 0ull);
-                        const uint32_t n = (uint32_t)popc64(m);
-                        if (LV(ctot) + n < kRescaleCap) { LV(ctot) += n; LV(czer) += (uint32_t)popc64(m & ZM); }
-                    }
-                }
-                for (uint64_t rem = resc; rem;) {
-                    const uint32_t c = READLANE(ctx2, ffs64(rem));
-                    ICER_CTX_STEP(c, LV(valid2) && LV(ctx2) == c, LV(bit2) == 0u, z2, t2)
-                    rem &= ~BALLOT(LV(valid2) && LV(ctx2) == c);
-                }
-            }
-        }
-#undef ICER_MATCH
         ICER_TICK(3)
 
         // ---- fold + bin (E1), hand the chunk over ------------------------------------------------------
@@ -652,12 +666,12 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             if (LV(valid1)) {
                 uint32_t z = LV(z1), t = LV(t1), b = LV(bit1);
                 if (z < (t >> 1)) { z = t - z; b ^= 1u; }
-                e1 = 0x80u | (b << 5) | pick_bin(s.tab.cut, z, t);
+                e1 = 0x80u | (b << 5) | pick_bin(s.tab.binlut, z, t);
             }
             if (LV(valid2)) {
                 uint32_t z = LV(z2), t = LV(t2), b = LV(bit2);
                 if (z < (t >> 1)) { z = t - z; b ^= 1u; }
-                e2 = 0x80u | (b << 5) | pick_bin(s.tab.cut, z, t);
+                e2 = 0x80u | (b << 5) | pick_bin(s.tab.binlut, z, t);
             }
             LV(ev1) = e1;
             LV(ev2) = e2;
@@ -674,6 +688,31 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             q.ev1[lane] = (uint8_t)LV(ev1);
             q.ev2[lane] = (uint8_t)LV(ev2);
             if (lane == 0) q.nev = nev;
+        }
+        ICER_PUBLISH(s.a_done, j + 1u)
+    }
+    FOR_LANES { LV(cs.czer) = LV(czer); LV(cs.ctot) = LV(ctot); }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// ==========================================================================================
+// compaction wave (bins 1..7): the chunk's events grouped per bin, for the walker and records waves
+// ==========================================================================================
+ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    for (uint32_t j = j0; j < j1; j++) {
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_ACQUIRE()
+        ICER_TICK(25)
+        EventSlot &q = s.eq[j % kQueueDepth];
+        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
+        FOR_LANES
+        {
+            LV(ev1) = q.ev1[lane];
+            LV(ev2) = q.ev2[lane];
             if (lane < 48) (&q.binbits[0][0])[lane] = 0;
         }
         WAVE_SYNC();
@@ -707,9 +746,9 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             }
 #undef ICER_MATCH3
         }
-        ICER_PUBLISH(s.a_done, j + 1u)
+        ICER_PUBLISH(s.c_done, j + 1u)
+        ICER_TICK(26)
     }
-    FOR_LANES { LV(cs.czer) = LV(czer); LV(cs.ctot) = LV(ctot); }
     ICER_TIMERS_STORE(a.timers)
 }
 
@@ -718,14 +757,20 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
 // ==========================================================================================
 struct WalkWave {
     LANEVAR(uint32_t, node);    // lane b (1..7): code-tree node of bin b's partial input, acc | 1 << bits (1 = root)
+    LANEVAR(uint32_t, cb);      // this lane's bin: lane b for b = 1..7, CoderTables::cand_bin for the candidate lanes, else 0
+    LANEVAR(uint32_t, ce);      // candidate lanes: the node they assume
     uint32_t next, gen;         // next chunk to walk; generation (= number of exact-path chunks seen)
 };
 
 ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
 {
     DECL_LANE;
-    (void)s;
-    FOR_LANES { LV(ww.node) = 1; }
+    FOR_LANES
+    {
+        LV(ww.node) = 1;
+        LV(ww.cb) = (lane >= 1 && lane <= 7) ? (uint32_t)lane : (uint32_t)s.tab.cand_bin[lane];
+        LV(ww.ce) = s.tab.cand_node[lane];
+    }
     ww.next = 0;
     ww.gen = 0;
 }
@@ -762,11 +807,11 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
             ww.next = s.last_exact + 1u;
             FOR_LANES
             {
-                if (lane >= 1 && lane <= 7) LV(ww.node) = s.bin_acc[lane] | (1u << s.bin_nin[lane]);
+                if (lane >= 1 && lane <= 7) LV(ww.node) = st_acc(s.bin_state[lane]) | (1u << st_nin(s.bin_state[lane]));
             }
         }
         const uint32_t j = ww.next;
-        if (j >= nchunks || ICER_LOAD_CNT(s.a_done) <= j) {
+        if (j >= nchunks || ICER_LOAD_CNT(s.c_done) <= j) {
             if (ICER_LOAD_CNT(s.b_done) >= nchunks || done >= max_chunks) break;
             ICER_IDLE()
             continue;
@@ -776,48 +821,74 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
         ICER_TICK(6)
         const EventSlot &q = s.eq[j % kQueueDepth];
         WalkSlot &o = s.wq[j % kQueueDepth];
-        LANEVAR(uint32_t, wn);
+        RecSlot &ro = s.rq[j % kQueueDepth];
+        // A bin's walk is a chain of dependent table look-ups, four input bits each.  To halve the chain the bin's
+        // n ranks are cut at h (a multiple of 4): lane b (1..7) walks [0, h) from the node carried in, and one lane
+        // per node of the bin's code tree (CoderTables::cand_*) walks [h, n) as if entered at that node; when the
+        // first half is done its end node says which of them was right.
+        LANEVAR(uint32_t, stl0); LANEVAR(uint32_t, stl1);       // start flags by rank, relative to the segment (a segment has <= 64 ranks)
+        LANEVAR(uint32_t, wnode); LANEVAR(uint32_t, wh); LANEVAR(uint32_t, wn);
         FOR_LANES
         {
-            LV(wn) = lane < 8 ? q.binn[lane] : 0u;
-            if (lane < 8) o.open_pos[lane] = 255;
-        }
-        ICER_TICK(7)
-        // lane b walks bin b's bit string through the code tree, four input bits per table look-up, and
-        // records at which ranks code words start (all <= 7 walkers in lockstep)
-        FOR_LANES
-        {
-            if (lane >= 1 && lane <= 7) {
-                const int b = lane;
-                const uint32_t n = LV(wn);
-                uint32_t node = LV(ww.node);
-                o.bincarry[b] = (uint8_t)node;
+            const uint32_t b = LV(ww.cb);
+            const bool first = lane >= 1 && lane <= 7;
+            const uint32_t n = b ? (uint32_t)q.binn[b] : 0u;
+            const uint32_t h = n >= 16u ? (((n >> 1) + 3u) & ~3u) : n;          // (short walks are not worth splitting)
+            const uint32_t r0 = first ? 0u : h, len = first ? h : n - h;
+            uint32_t node = first ? LV(ww.node) : LV(ww.ce);
+            uint64_t st_lo = 0;
+            if (b && len) {
                 uint64_t lo = ((uint64_t)q.binbits[b][0] | ((uint64_t)q.binbits[b][1] << 32)) >> 8;      // ranks 0..55
                 uint64_t hi = (uint64_t)q.binbits[b][2] | ((uint64_t)q.binbits[b][3] << 32);             // ranks 56..119
                 const uint32_t top8 = q.binbits[b][4];                                                     // ranks 120..127
                 lo |= hi << 56;
                 hi = (hi >> 8) | ((uint64_t)top8 << 56);                                                   // ranks 64..127
-                uint64_t st_lo = 0, st_hi = 0;                  // word-start flags by rank
+                if (r0 == 64u) { lo = hi; hi = 0; }
+                else if (r0) { lo = (lo >> r0) | (hi << (64u - r0)); hi >>= r0; }                            // the segment starts at bit 0
                 uint32_t r = 0;
-                for (; r + 4u <= n && r < 64u; r += 4) {
+                for (; r + 4u <= len; r += 4) {
                     const uint32_t e = s.tab.v2v_step[b][node][(uint32_t)(lo >> r) & 15u];
                     st_lo |= (uint64_t)((e >> 5) & 15u) << r;
                     node = e & 31u;
                 }
-                for (; r + 4u <= n; r += 4) {
-                    const uint32_t e = s.tab.v2v_step[b][node][(uint32_t)(hi >> (r - 64u)) & 15u];
-                    st_hi |= (uint64_t)((e >> 5) & 15u) << (r - 64u);
-                    node = e & 31u;
-                }
-                for (; r < n; r++) {                            // last 1..3 bits one at a time
-                    const uint32_t bit = (uint32_t)((r < 64u ? lo >> r : hi >> (r - 64u)) & 1ull);
-                    if (node == 1u) { if (r < 64u) st_lo |= 1ull << r; else st_hi |= 1ull << (r - 64u); }
+                for (; r < len; r++) {                          // last 1..3 bits one at a time (only where the segment ends at n)
+                    const uint32_t bit = (uint32_t)((lo >> r) & 1ull);
+                    if (node == 1u) st_lo |= 1ull << r;
                     // one step: append the bit, back to the root when the input is a code word
                     uint32_t nin = 31u - (uint32_t)clz32(node);
                     uint32_t acc = (node ^ (1u << nin)) | (bit << nin);
                     nin++;
                     node = (nin == 5u || ((s.tab.v2v_term[b][nin] >> acc) & 1u)) ? 1u : (acc | (1u << nin));
                 }
+            }
+            LV(stl0) = (uint32_t)st_lo; LV(stl1) = (uint32_t)(st_lo >> 32);
+            LV(wnode) = node; LV(wh) = h; LV(wn) = n;
+        }
+        ICER_TICK(7)
+        // lane b fetches the second half from the lane that started at the node the first half ended in
+        LANEVAR(uint32_t, src); LANEVAR(uint32_t, g0); LANEVAR(uint32_t, g1); LANEVAR(uint32_t, gnode);
+        FOR_LANES
+        {
+            LV(src) = (uint32_t)lane;
+            if (lane >= 1 && lane <= 7 && LV(wh) < LV(wn)) LV(src) = s.tab.cand_lane[lane][LV(wnode)];
+        }
+        WAVE_GATHER(g0, stl0, src)
+        WAVE_GATHER(g1, stl1, src)
+        WAVE_GATHER(gnode, wnode, src)
+        FOR_LANES
+        {
+            if (lane >= 1 && lane <= 7) {
+                const int b = lane;
+                const uint32_t n = LV(wn), h = LV(wh);
+                uint64_t st_lo = (uint64_t)LV(stl0) | ((uint64_t)LV(stl1) << 32), st_hi = 0;
+                uint32_t node = LV(wnode);
+                if (h < n) {                                    // 8 <= h <= 64: the second half's flags move up by h ranks
+                    const uint64_t s2 = (uint64_t)LV(g0) | ((uint64_t)LV(g1) << 32);
+                    if (h == 64u) st_hi = s2;
+                    else { st_lo |= s2 << h; st_hi = s2 >> (64u - h); }
+                    node = LV(gnode);
+                }
+                o.bincarry[b] = (uint8_t)LV(ww.node);
                 LV(ww.node) = node;
                 // post: start flags with the same offset of 8 as the bit string
                 o.binstart[b][0] = (uint32_t)(st_lo << 8);
@@ -827,13 +898,14 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 o.binstart[b][4] = (uint32_t)(st_hi >> 56);
                 o.binstart[b][5] = 0;
                 const uint32_t nin = 31u - (uint32_t)clz32(node);
-                o.post_acc[b] = (uint8_t)(node ^ (1u << nin));
                 o.post_nin[b] = (uint8_t)nin;
+                uint32_t op = 255;
                 if (n) {
                     // open word after the chunk: the last start, unless everything after it completed
                     int last = st_hi ? 64 + 63 - clz64(st_hi) : (st_lo ? 63 - clz64(st_lo) : -1);
-                    o.open_pos[b] = (uint8_t)(node == 1u ? 254u : (last >= 0 ? (uint32_t)q.binseq[b][last] : 255u));
+                    op = node == 1u ? 254u : (last >= 0 ? (uint32_t)q.binseq[b][last] : 255u);
                 }
+                ro.binst[b] = st_pack(op, node ^ (1u << nin), nin);
             }
         }
         ICER_TICK(8)
@@ -879,7 +951,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             gw.next = s.last_exact + 1u;
             FOR_LANES
             {
-                if (lane >= 8 && lane <= 16) LV(gw.k) = s.bin_acc[lane];
+                if (lane >= 8 && lane <= 16) LV(gw.k) = st_acc(s.bin_state[lane]);
             }
         }
         const uint32_t j = gw.next;
@@ -892,7 +964,8 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         ICER_ACQUIRE()
         ICER_TICK(10)
         const EventSlot &q = s.eq[j % kQueueDepth];
-        GolombSlot &o = s.gq[j % kQueueDepth];
+        RecSlot &o = s.rq[j % kQueueDepth];
+        LANEVAR(uint32_t, opv);                             // lane b: open_pos of bin b
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
         LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
         LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
@@ -902,7 +975,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             LV(ev1) = q.ev1[lane];
             LV(ev2) = q.ev2[lane];
             LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
-            if (lane < 20) o.open_pos[lane] = 255;
+            LV(opv) = 255;
             // bin 0 (uncoded): every event is a complete one-bit word (E3)
             if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
             if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
@@ -947,23 +1020,24 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             {
                 if (lane == b) {
                     LV(gw.k) = k_out;
-                    o.open_pos[b] = (uint8_t)(k_out ? (laststart >= 0 ? laststart : 255) : 254);
+                    LV(opv) = k_out ? (laststart >= 0 ? (uint32_t)laststart : 255u) : 254u;
                 }
             }
         }
         ICER_TICK(11)
         FOR_LANES
         {
+            // (everything but the events of bins 1..7, which the records wave fills in; empty positions read 0)
             const uint32_t b1 = LV(ev1) & 0x9Fu, b2 = LV(ev2) & 0x9Fu;
-            if (b1 == 0x80u || b1 >= 0x88u) {
-                o.rec[2 * lane] = LV(fl1) | (LV(sp1) << 8) | (LV(wd1) << 16);
+            if (!(b1 >= 0x81u && b1 <= 0x87u)) {
+                o.rec[2 * lane] = (b1 & 0x80u) ? (LV(fl1) | ((b1 & 31u) << 2) | (LV(sp1) << 8) | (LV(wd1) << 16)) : 0u;
             }
-            if (b2 == 0x80u || b2 >= 0x88u) {
-                o.rec[2 * lane + 1] = LV(fl2) | (LV(sp2) << 8) | (LV(wd2) << 16);
+            if (!(b2 >= 0x81u && b2 <= 0x87u)) {
+                o.rec[2 * lane + 1] = (b2 & 0x80u) ? (LV(fl2) | ((b2 & 31u) << 2) | (LV(sp2) << 8) | (LV(wd2) << 16)) : 0u;
             }
-            if (lane >= 8 && lane <= 16) o.post_k[lane] = (uint16_t)LV(gw.k);
+            if (lane == 0 || (lane >= 8 && lane <= 16)) o.binst[lane] = st_pack(LV(opv), LV(gw.k), 0u);
         }
-        ICER_PUBLISH(o.tag, chunk_tag(j, gw.gen))
+        ICER_PUBLISH(o.gtag, chunk_tag(j, gw.gen))
         gw.next = j + 1u;
         done++;
         ICER_IDLE_RESET
@@ -977,93 +1051,77 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
 // merge wave
 // ==========================================================================================
 struct MergeChunk {             // one chunk's events with their code-word roles, one pixel per lane
-    LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
+    LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);     // bin of the event (bits 0..4); hybrid_chunk also loads the raw event bytes
     LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
     LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
     LANEVAR(uint32_t, sp1); LANEVAR(uint32_t, sp2);     // start position of the word an end event closes (255: carried in)
-    LANEVAR(uint32_t, op);                              // lane b: open_pos of bin b after this chunk
+    LANEVAR(uint32_t, st);                              // lane b: RecSlot::binst of bin b
     uint64_t S1, S2;                                    // word-start flags of the chunk
 };
 
-// collect the (speculative) results of the golomb and walker waves for chunk j
+// wait for the (speculative) results of the golomb, walker and records waves for chunk j and unpack them.
+// (Every wait of the merge wave also ends when the unit is abandoned: the drain wave may have found the payload
+// slot too small and left.)
 ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_PARAMS)
 {
     DECL_LANE;
-    const EventSlot &q = s.eq[j % kQueueDepth];
+    const RecSlot &rq = s.rq[j % kQueueDepth];
+    const uint32_t tag = chunk_tag(j, s.exact_seq);
+    ICER_WAIT_UNTIL((ICER_LOAD_CNT(rq.gtag) == tag && ICER_LOAD_CNT(rq.rtag) == tag) || ICER_LOAD_CNT(s.abort))
+    ICER_ACQUIRE()
+    ICER_TICK(18)
     FOR_LANES
     {
-        LV(c.ev1) = q.ev1[lane];
-        LV(c.ev2) = q.ev2[lane];
-        LV(c.fl1) = 0; LV(c.fl2) = 0; LV(c.wd1) = 0; LV(c.wd2) = 0; LV(c.sp1) = 255; LV(c.sp2) = 255; LV(c.op) = 255;
-    }
-    // (every wait of the merge wave also ends when the unit is abandoned: the helper wave may have found the
-    // payload slot too small and left)
-    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.gq[j % kQueueDepth].tag) == chunk_tag(j, s.exact_seq) || ICER_LOAD_CNT(s.abort))
-    ICER_TICK(18)
-    {
-        const GolombSlot &gq = s.gq[j % kQueueDepth];
-        FOR_LANES
-        {
-            const uint32_t b1 = LV(c.ev1) & 0x9Fu, b2 = LV(c.ev2) & 0x9Fu;
-            if (b1 == 0x80u || b1 >= 0x88u) { const uint32_t r = gq.rec[2 * lane]; LV(c.fl1) = r & 3u; LV(c.sp1) = (r >> 8) & 255u; LV(c.wd1) = r >> 16; }
-            if (b2 == 0x80u || b2 >= 0x88u) { const uint32_t r = gq.rec[2 * lane + 1]; LV(c.fl2) = r & 3u; LV(c.sp2) = (r >> 8) & 255u; LV(c.wd2) = r >> 16; }
-            if (lane >= 8 && lane <= 16) LV(c.op) = gq.open_pos[lane];
-        }
-    }
-    ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.wq[j % kQueueDepth].rtag) == chunk_tag(j, s.exact_seq) || ICER_LOAD_CNT(s.abort))
-    ICER_TICK(19)
-    {
-        const WalkSlot &wq = s.wq[j % kQueueDepth];
-        FOR_LANES
-        {
-            const uint32_t b1 = LV(c.ev1) & 0x9Fu, b2 = LV(c.ev2) & 0x9Fu;
-            if (b1 >= 0x81u && b1 <= 0x87u) { const uint32_t r = wq.rec[2 * lane]; LV(c.fl1) = r & 3u; LV(c.sp1) = (r >> 8) & 255u; LV(c.wd1) = r >> 16; }
-            if (b2 >= 0x81u && b2 <= 0x87u) { const uint32_t r = wq.rec[2 * lane + 1]; LV(c.fl2) = r & 3u; LV(c.sp2) = (r >> 8) & 255u; LV(c.wd2) = r >> 16; }
-            if (lane >= 1 && lane <= 7) LV(c.op) = wq.open_pos[lane];
-        }
+        const uint32_t r1 = rq.rec[2 * lane], r2 = rq.rec[2 * lane + 1];
+        LV(c.fl1) = r1 & 3u; LV(c.ev1) = (r1 >> 2) & 31u; LV(c.sp1) = (r1 >> 8) & 255u; LV(c.wd1) = r1 >> 16;
+        LV(c.fl2) = r2 & 3u; LV(c.ev2) = (r2 >> 2) & 31u; LV(c.sp2) = (r2 >> 8) & 255u; LV(c.wd2) = r2 >> 16;
+        LV(c.st) = lane < kNumBins ? rq.binst[lane] : 255u;
     }
     c.S1 = BALLOT(LV(c.fl1) & 1u);
     c.S2 = BALLOT(LV(c.fl2) & 1u);
+    ICER_TICK(19)
 }
 
-// fast path: ring slots in allocation order = order of the words' first events (E2), finished words into
-// their slots, bin states as of this (now retired) chunk
-ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t j)
+// the bins' open words and coder state after the chunk
+ICER_DEV void commit_bins(CoderShared &s, MergeChunk &c, uint32_t tail)
 {
     DECL_LANE;
     const uint64_t S1 = c.S1, S2 = c.S2;
-    const uint32_t tail = s.alloc;
-    const GolombSlot &gq = s.gq[j % kQueueDepth];
-    const WalkSlot &wq = s.wq[j % kQueueDepth];
     FOR_LANES
     {
-        if (LV(c.fl1) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev1) & 31u);
-        if (LV(c.fl2) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev2) & 31u);
+        if (lane >= 1 && lane < kNumBins) {
+            const uint32_t op = LV(c.st) & 255u;
+            if (op == 254u) s.bin_slot[lane] = -1;
+            else if (op < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, op)) & (kRingWords - 1));
+            s.bin_state[lane] = LV(c.st);
+        }
+    }
+}
+
+// fast path: ring slots in allocation order = order of the words' first events (E2), finished words into
+// their slots, bin states as of this (now retired) chunk.  `tail` = allocation count before the chunk.
+ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t tail)
+{
+    DECL_LANE;
+    const uint64_t S1 = c.S1, S2 = c.S2;
+    FOR_LANES
+    {
+        if (LV(c.fl1) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1)] = (uint16_t)LV(c.ev1);
+        if (LV(c.fl2) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1)] = (uint16_t)LV(c.ev2);
     }
     FOR_LANES
     {
         if (LV(c.fl1) & 2u) {
-            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1) & 31u] : (tail + cnt_lt(S1, S2, LV(c.sp1)));
+            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1)] : (tail + cnt_lt(S1, S2, LV(c.sp1)));
             s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd1);
         }
         if (LV(c.fl2) & 2u) {
-            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2) & 31u] : (tail + cnt_lt(S1, S2, LV(c.sp2)));
+            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2)] : (tail + cnt_lt(S1, S2, LV(c.sp2)));
             s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd2);
         }
     }
     WAVE_SYNC();
-    FOR_LANES
-    {
-        if (lane < kNumBins) {
-            if (LV(c.op) == 254u) s.bin_slot[lane] = -1;
-            else if (LV(c.op) < 128u) s.bin_slot[lane] = (int32_t)((tail + cnt_lt(S1, S2, LV(c.op))) & (kRingWords - 1));
-        }
-        if (lane >= 8 && lane <= 16) s.bin_acc[lane] = gq.post_k[lane];
-        if (lane >= 1 && lane <= 7) { s.bin_acc[lane] = wq.post_acc[lane]; s.bin_nin[lane] = wq.post_nin[lane]; }
-    }
-    // the new words (and the finished ones) become visible to the drain wave
-    ICER_PUBLISH(s.alloc, tail + (uint32_t)(popc64(S1) + popc64(S2)))
-    WAVE_SYNC();
+    commit_bins(s, c, tail);
 }
 
 // ring stores for the chunk's events at positions [lo, hi): open markers of the words that start there, finished
@@ -1109,15 +1167,20 @@ ICER_DEV void commit_range(CoderShared &s, MergeChunk &c, uint32_t tail0, uint32
 // from hb's events since the word's start).  A forced flush changes the word boundaries of bin hb only: hb's
 // events from P on are replayed one by one (icer_encode_bit, icer_encoding.c:37-112) with the bin starting afresh,
 // all other results stay valid, and the scheme repeats from P.  Returns true if a word was force-completed (the
-// results the walker / golomb / helper waves have produced for later chunks are then void for bin hb).
-ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j)
+// results the walker / golomb / records waves have produced for later chunks are then void for bin hb).
+ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t tail0)
 {
     DECL_LANE;
-    const uint32_t tail0 = s.alloc;
     uint32_t base = 0;
     bool flushed = false;
-    LANEVAR(uint32_t, ovr); LANEVAR(uint32_t, oacc); LANEVAR(uint32_t, onin);     // lane b: bin b's state after the chunk, if replayed
-    FOR_LANES { LV(ovr) = 0; LV(oacc) = 0; LV(onin) = 0; }
+    {
+        const EventSlot &q = s.eq[j % kQueueDepth];        // the raw events: 0x80 | bit << 5 | bin
+        FOR_LANES
+        {
+            LV(c.ev1) = q.ev1[lane];
+            LV(c.ev2) = q.ev2[lane];
+        }
+    }
     for (;;) {
         const uint64_t S1 = c.S1, S2 = c.S2;
         const uint32_t t = (uint32_t)kRingWords - (tail0 - s.popped);           // rank of the first word start that finds the ring full
@@ -1127,11 +1190,6 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j)
         const uint32_t P = h1 ? 2u * (uint32_t)ffs64(h1) : 2u * (uint32_t)ffs64(h2) + 1u;
         commit_range(s, c, tail0, base, P);
         const uint32_t alloc = tail0 + t;
-        FOR_LANES
-        {
-            if (lane == 0) s.alloc = alloc;
-        }
-        WAVE_SYNC();
         wave_drain(s, alloc);
         if (alloc - s.popped == (uint32_t)kRingWords) {
             // still full: the head word is open.  Its bin, and that bin's state just before P:
@@ -1142,7 +1200,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j)
             const uint32_t lo = x < 0 ? 0u : (uint32_t)x;
             uint64_t R1 = E1 & below64((P + 1u) >> 1) & ~below64((lo + 1u) >> 1);   // hb's events in [lo, P)
             uint64_t R2 = E2 & below64(P >> 1) & ~below64(lo >> 1);
-            uint32_t hacc = x < 0 ? s.bin_acc[hb] : 0u, hnin = x < 0 ? s.bin_nin[hb] : 0u;
+            uint32_t hacc = x < 0 ? st_acc(s.bin_state[hb]) : 0u, hnin = x < 0 ? st_nin(s.bin_state[hb]) : 0u;
             uint32_t word;
             if (hb >= 8u) {
                 hacc += (uint32_t)(popc64(R1) + popc64(R2));                       // all zeros, or the word would have ended
@@ -1201,7 +1259,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j)
             }
             FOR_LANES
             {
-                if ((uint32_t)lane == hb) { LV(c.op) = open ? spos : 254u; LV(ovr) = 1; LV(oacc) = acc; LV(onin) = nin; }
+                if ((uint32_t)lane == hb) LV(c.st) = st_pack(open ? spos : 254u, acc, nin);
             }
             c.S1 = BALLOT(LV(c.fl1) & 1u);
             c.S2 = BALLOT(LV(c.fl2) & 1u);
@@ -1211,45 +1269,24 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j)
         base = P;
     }
     commit_range(s, c, tail0, base, 128u);
-    const uint64_t S1 = c.S1, S2 = c.S2;
-    const GolombSlot &gq = s.gq[j % kQueueDepth];
-    const WalkSlot &wq = s.wq[j % kQueueDepth];
-    FOR_LANES
-    {
-        if (lane < kNumBins) {
-            if (LV(c.op) == 254u) s.bin_slot[lane] = -1;
-            else if (LV(c.op) < 128u) s.bin_slot[lane] = (int32_t)((tail0 + cnt_lt(S1, S2, LV(c.op))) & (kRingWords - 1));
-        }
-        if (lane >= 8 && lane <= 16) s.bin_acc[lane] = LV(ovr) ? LV(oacc) : (uint32_t)gq.post_k[lane];
-        if (lane >= 1 && lane <= 7) {
-            s.bin_acc[lane] = LV(ovr) ? LV(oacc) : (uint32_t)wq.post_acc[lane];
-            s.bin_nin[lane] = LV(ovr) ? LV(onin) : (uint32_t)wq.post_nin[lane];
-        }
-        if (lane == 0) s.alloc = tail0 + (uint32_t)(popc64(S1) + popc64(S2));
-    }
+    commit_bins(s, c, tail0);
     WAVE_SYNC();
     return flushed;
 }
 #undef ICER_NEXT_EVENT
 
-// chunks [j0, j1); returns false when the payload slot is too small (the unit is then abandoned)
 // ==========================================================================================
-// helper wave (records + drain) and the merge wave's hand-shake with it
+// records wave and drain wave; the merge wave's hand-shake with the drain wave
 // ==========================================================================================
-// Helper wave, two duties:
-//  (1) records: once the walker wave has walked chunk r, every event lane of bins 1..7 derives from the bin's
-//      start flags whether a code word starts / ends at its event and, for an end, the finished ring word and the
-//      position of the word's first event (on the merge wave's critical path, so it comes first);
-//  (2) drain: pop finished words from the head of the ring and write the payload, until told to park
-//      (hold_seq odd) or to exit.
-// `max_steps` bounds one call in the emulation (the GPU passes ~0u).
-ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_steps)
+// Records wave: once the walker wave has walked chunk r, every event lane of bins 1..7 derives from the bin's
+// start flags whether a code word starts / ends at its event and, for an end, the finished ring word and the
+// position of the word's first event.  `max_steps` bounds one call in the emulation (the GPU passes ~0u).
+ICER_DEV void records_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_steps)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     ICER_IDLE_DECL
     const uint32_t nchunks = s.nchunks;
-    uint32_t idle = 0;
     for (uint32_t step = 0;;) {
         if (ICER_LOAD_CNT(s.abort)) break;
         const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
@@ -1262,12 +1299,17 @@ ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_st
             WAVE_SYNC();
         }
         const uint32_t r = s.helper_next, gen = s.helper_gen;
-        if (r < nchunks && ICER_LOAD_CNT(s.wq[r % kQueueDepth].tag) == chunk_tag(r, gen)) {
-            if (step >= max_steps) break;
-            ICER_ACQUIRE()
-            ICER_TICK(20)
-            const EventSlot &q = s.eq[r % kQueueDepth];
-            WalkSlot &o = s.wq[r % kQueueDepth];
+        if (r >= nchunks || ICER_LOAD_CNT(s.wq[r % kQueueDepth].tag) != chunk_tag(r, gen)) {
+            if (ICER_LOAD_CNT(s.b_done) >= nchunks || step >= max_steps) break;
+            ICER_IDLE()
+            continue;
+        }
+        if (step >= max_steps) break;
+        ICER_ACQUIRE()
+        ICER_TICK(20)
+        const EventSlot &q = s.eq[r % kQueueDepth];
+        const WalkSlot &o = s.wq[r % kQueueDepth];
+        RecSlot &ro = s.rq[r % kQueueDepth];
 #define ICER_V2V_RECORD(EV, RK, POS)                                                                   \
             if (((EV)&0x98u) == 0x80u && ((EV)&7u)) {                                                  \
                 const uint32_t b_ = (EV)&7u, r_ = (RK), n_ = q.binn[b_];                                \
@@ -1291,7 +1333,7 @@ ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_st
                     const uint32_t e_ = s.tab.v2v[b_][acc_ & 31u];                                      \
                     wd_ = kWordDone | (((e_ >> 4) & 15u) << 11) | (e_ >> 8);                            \
                 }                                                                                       \
-                o.rec[POS] = starts_ | (ends_ << 1) | (sp_ << 8) | (wd_ << 16);                         \
+                ro.rec[POS] = starts_ | (ends_ << 1) | (b_ << 2) | (sp_ << 8) | (wd_ << 16);            \
             }
             FOR_LANES
             {
@@ -1300,18 +1342,29 @@ ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_st
                 ICER_V2V_RECORD(e2, (uint32_t)q.rk2[lane], 2 * lane + 1)
             }
 #undef ICER_V2V_RECORD
-            ICER_PUBLISH(o.rtag, chunk_tag(r, gen))
-            FOR_LANES
-            {
-                if (lane == 0) s.helper_next = r + 1u;
-            }
-            WAVE_SYNC();
-            ICER_TICK(21)
-            step++;
-            idle = 0;
-            ICER_IDLE_RESET
-            continue;
+        ICER_PUBLISH(ro.rtag, chunk_tag(r, gen))
+        FOR_LANES
+        {
+            if (lane == 0) s.helper_next = r + 1u;
         }
+        WAVE_SYNC();
+        ICER_TICK(21)
+        step++;
+        ICER_IDLE_RESET
+    }
+    ICER_TIMERS_STORE(a.timers)
+}
+
+// Drain wave: pops finished words from the head of the ring and writes the payload, until told to park (hold_seq
+// odd) or to exit.
+ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_steps)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    ICER_IDLE_DECL
+    uint32_t idle = 0;
+    for (uint32_t step = 0;;) {
+        if (ICER_LOAD_CNT(s.abort)) break;
         const uint32_t hs = ICER_LOAD_CNT(s.hold_seq);
         if (hs & 1u) {
             // parked: the merge wave owns popped / bitpos / the bit stage until it releases the hold
@@ -1323,8 +1376,9 @@ ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_st
         if (step >= max_steps) break;
         const uint32_t limit = ICER_LOAD_CNT(s.alloc);
         // a drain pass has a fixed cost: run one when enough words have piled up or nothing else happened for a while
-        if (limit - s.popped >= 256u || (limit != s.popped && idle >= 16u)) {
+        if (limit - s.popped >= 128u || (limit != s.popped && idle >= 16u)) {
             ICER_ACQUIRE()
+            ICER_TICK(24)
             const uint32_t npop = wave_drain(s, limit);
             ICER_TICK(22)
             if (npop && !flush_stage(s, a, false)) {     // payload slot too small: abandon the unit
@@ -1345,7 +1399,7 @@ ICER_DEV void helper_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_st
 
 // merge wave: take over / give back the drain state
 #ifdef ICER_WAVE_EMU
-#define ICER_DRAIN_HOLD(S, A) { (S).hold_seq |= 1u; helper_wave_run((S), (A), 0u); assert((S).hold_ack == (S).hold_seq); }
+#define ICER_DRAIN_HOLD(S, A) { (S).hold_seq |= 1u; drain_wave_run((S), (A), 0u); assert((S).hold_ack == (S).hold_seq); }
 #else
 #define ICER_DRAIN_HOLD(S, A) { const uint32_t hs_ = (S).hold_seq | 1u; ICER_PUBLISH((S).hold_seq, hs_) ICER_WAIT_UNTIL(ICER_LOAD_CNT((S).hold_ack) == hs_ || ICER_LOAD_CNT((S).abort)) }
 #endif
@@ -1356,41 +1410,41 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
 {
     DECL_LANE;
     ICER_TIMERS_DECL
+    uint32_t tail = s.alloc;                                // allocation count (this wave owns it)
     for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
-        if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
-        ICER_TICK(13)
-        const EventSlot &q = s.eq[j % kQueueDepth];
-        // Every event could open at most one word: if the ring cannot fill up inside this chunk no forced flush
-        // (E5) is possible and word boundaries depend on each bin alone.  The drain wave's pop count may lag, which
-        // only over-estimates the occupancy.  When that quick test fails the drain wave is parked, everything
-        // finished is popped (the reference's state) and the test repeated; if it still fails the exact number of new
-        // words decides: the speculative results say how many words the chunk opens *if* no flush happens, and if
-        // they all fit none happens.
         MergeChunk c;
+        merge_gather(s, c, j ICER_TIMER_PASS);
+        if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+        // If the ring cannot fill up inside this chunk no forced flush (E5) is possible and word boundaries depend
+        // on each bin alone: the speculative results say how many words the chunk opens *if* no flush happens, and
+        // if they all fit none happens.  The drain wave's pop count may lag, which only over-estimates the
+        // occupancy; when the test fails with it the drain wave is parked, everything finished is popped (the
+        // reference's state) and the test repeated.
+        const uint32_t nstarts = (uint32_t)(popc64(c.S1) + popc64(c.S2));
         bool held = false, fast = true;
         ICER_COUNT(31)
-        if (s.alloc - ICER_LOAD_CNT(s.popped) + q.nev > (uint32_t)kRingWords) {
+        if (tail - ICER_LOAD_CNT(s.popped) + nstarts > (uint32_t)kRingWords) {
             ICER_DRAIN_HOLD(s, a)
             if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             held = true;
-            wave_drain(s, s.alloc);
-            fast = s.alloc - s.popped + q.nev <= (uint32_t)kRingWords;
+            wave_drain(s, tail);
+            fast = tail - s.popped + nstarts <= (uint32_t)kRingWords;
+            ICER_COUNT(30)
         }
-        merge_gather(s, c, j ICER_TIMER_PASS);
-        if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
         if (fast) {
-            merge_commit(s, c, j);
+            merge_commit(s, c, tail);
+            tail += nstarts;
             ICER_EMU_COUNT(0);
             ICER_TICK(14)
         } else {
-            ICER_COUNT(30)
-            // (merge_gather has waited for the walker, golomb and helper waves: they are past their speculative pass
-            // over this chunk; bin_acc / bin_nin hold the bins' state as of the last retired chunk)
-            if (hybrid_chunk(s, c, j)) {
+            // (merge_gather has waited for the walker, golomb and records waves: they are past their speculative pass
+            // over this chunk; bin_state holds the bins' state as of the last retired chunk)
+            const bool flushed = hybrid_chunk(s, c, j, tail);
+            tail += (uint32_t)(popc64(c.S1) + popc64(c.S2));
+            if (flushed) {
                 ICER_EMU_COUNT(1);
                 ICER_COUNT(29)
-                wave_drain(s, s.alloc);
+                wave_drain(s, tail);
                 // results produced for later chunks assumed no forced flush here: void them
                 FOR_LANES
                 {
@@ -1409,10 +1463,13 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
                 ICER_TIMERS_STORE(a.timers)
                 return false;
             }
-            ICER_PUBLISH(s.alloc, s.alloc)               // (the exact path advanced it with plain stores)
+            ICER_PUBLISH(s.alloc, tail)
             ICER_DRAIN_RELEASE(s)
+            ICER_PUBLISH(s.b_done, j + 1u)
+        } else {
+            // the new words (and the finished ones) become visible to the drain wave; the chunk's queue slots are free
+            ICER_PUBLISH2(s.alloc, tail, s.b_done, j + 1u)
         }
-        ICER_PUBLISH(s.b_done, j + 1u)
         ICER_TICK(17)
     }
     ICER_TIMERS_STORE(a.timers)
@@ -1446,11 +1503,11 @@ ICER_DEV void unit_state_init(CoderShared &s)
     FOR_LANES
     {
         for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
-        if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_acc[lane] = 0; s.bin_nin[lane] = 0; }
+        if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; }
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
-            s.p_done = 0; s.a_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
-            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.wq[i].rtag = 0; s.gq[i].tag = 0; }
+            s.p_done = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
+            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; }
             s.helper_next = 0; s.helper_gen = 0;
         }
     }
@@ -1458,7 +1515,7 @@ ICER_DEV void unit_state_init(CoderShared &s)
 }
 
 #ifdef ICER_WAVE_EMU
-// tests only: the five waves interleaved on one CPU thread.  Each wave runs as far ahead as the queues and
+// tests only: the seven waves interleaved on one CPU thread.  Each wave runs as far ahead as the queues and
 // the speculation rule allow, so slot reuse and the discard/reload protocol are exercised, not just the
 // lock-step order.
 static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
@@ -1471,17 +1528,18 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
     walk_wave_init(s, ww);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
     golomb_wave_init(gw);
-    uint32_t jp = 0, ja = 0, jb = 0;
+    uint32_t jp = 0, ja = 0, jc = 0, jb = 0;
     while (jb < nchunks) {
         while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; }
         while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; }
+        while (jc < ja) { compact_wave_run(s, a, jc, jc + 1); jc++; }
         // both speculating waves run as far ahead as events allow (and roll back when told to)
         walk_wave_run(s, a, ww, nchunks, kQueueDepth);
         golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
-        helper_wave_run(s, a, kQueueDepth);
+        records_wave_run(s, a, kQueueDepth);
         if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
-        helper_wave_run(s, a, 1u + (jb & 3u));      // records first; the drain lags behind the merge wave on purpose
+        drain_wave_run(s, a, jb & 1u);              // the drain lags behind the merge wave on purpose
         if (s.abort) return kUnitTooBig;
     }
     return merge_wave_finish(s, a);

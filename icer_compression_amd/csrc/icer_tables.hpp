@@ -49,6 +49,10 @@ struct CoderTables {
     // far), the root is 1.  [bin][node][nibble] -> node after the 4 bits | (bit k set: a code word starts at the
     // k-th of the 4 bits) << 5
     uint16_t v2v_step[8][32][16];
+    // the walker wave splits a bin's walk in two: lanes 1..7 walk the first half from the known node, lane L >= 8
+    // walks the second half of bin cand_bin[L] assuming it is entered at node cand_node[L] (one lane per node of
+    // the bin's code tree, 46 in all; cand_bin = 0: lane unused); cand_lane[bin][node] = that lane
+    uint8_t cand_bin[64], cand_node[64], cand_lane[8][32];
     // bins 1..7: [bin][partial value 0..8][bits so far 0..5] -> appended bits | count<<4
     uint8_t v2v_flush[8][9][6];
     // bins 8..16: Golomb m, l = ceil(log2 m), i = 2^l - m
@@ -57,6 +61,10 @@ struct CoderTables {
     uint32_t ginv[17];
     // probability cut-offs x65536 separating bin b-1 from bin b, b = 1..16   (icer_config.c:69-87)
     uint32_t cut[16];
+    // the same as a look-up: for r = floor(zero * 65536 / total), entry r >> 8 holds the number of cut-offs below
+    // 256 * (r >> 8) in bits 0..7 and, in bits 8..31, the one cut-off inside [256 * (r >> 8), +256) if there is one
+    // (0xFFFFFF otherwise; the cut-offs are more than 256 apart, checked at build time): bin = base + (r >= that)
+    uint32_t binlut[257];
     // x^(2^k) mod P for the CRC-32 polynomial (reflected), k = 0..31: lets a wave combine piece CRCs
     uint32_t x2n[32];
 };
@@ -99,6 +107,24 @@ inline void build_coder_tables(CoderTables *t)
                 }
                 t->v2v_step[b][node][nib] = (uint16_t)((acc | (1u << nin)) | (starts << 5));
             }
+    {
+        uint32_t lane = 8;
+        for (uint32_t b = 1; b <= 7; b++)
+            for (uint32_t node = 1; node < 32; node++) {
+                uint32_t nin = 0;
+                while ((2u << nin) <= node) nin++;
+                const uint32_t acc = node ^ (1u << nin);
+                bool is_node = node == 1;                        // proper prefix of some code word's input?
+                for (const V &c : codes)
+                    if (c.bin == b && nin && nin < c.nin && (c.val & ((1u << nin) - 1u)) == acc) is_node = true;
+                if (is_node && lane < 64) {
+                    t->cand_bin[lane] = (uint8_t)b;
+                    t->cand_node[lane] = (uint8_t)node;
+                    t->cand_lane[b][node] = (uint8_t)lane;
+                    lane++;
+                }
+            }
+    }
     struct F { uint8_t bin, val, nin, add, nadd; };
     static const F fl[] = {
         {1, 1, 1, 0, 1}, {1, 3, 2, 0, 1}, {1, 7, 3, 0, 1}, {1, 0, 1, 1, 1}, {1, 0, 2, 1, 1}, {1, 0, 3, 1, 1}, {1, 0, 4, 0, 1},
@@ -124,6 +150,14 @@ inline void build_coder_tables(CoderTables *t)
     static const uint32_t cut[16] = {35298, 37345, 40503, 43591, 47480, 50133, 53645, 55902,
                                      57755, 58894, 60437, 62267, 63613, 64557, 65134, 65392};
     memcpy(t->cut, cut, sizeof cut);
+    for (uint32_t k = 0; k <= 256; k++) {
+        uint32_t base = 0, inside = 0xFFFFFFu, n_inside = 0;
+        for (int b = 0; b < 16; b++) {
+            if (cut[b] < 256u * k) base++;
+            else if (cut[b] < 256u * (k + 1)) { inside = cut[b]; n_inside++; }
+        }
+        t->binlut[k] = n_inside <= 1 ? (base | (inside << 8)) : 0xFFFFFFFFu;   // (two in one bucket: caught by tests/test_tables.py)
+    }
     // x2n[0] = x^1; squaring chain (bit 31 = x^0 in the reflected representation)
     auto mulmod = [](uint32_t a, uint32_t b) {
         uint32_t p = 0;

@@ -83,8 +83,8 @@ finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------ coder
-// One workgroup of six wavefronts = one coding unit of one frame: pixel, count, walker, golomb, merge and
-// drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  grid = (units, frames), block = 384.
+// One workgroup of eight wavefronts = one coding unit of one frame: pixel, count, compaction, walker, golomb, merge, records and
+// drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  grid = (units, frames), block = 512.
 __global__ void __launch_bounds__(64 * kUnitWaves)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
@@ -101,6 +101,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         trace[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
         trace[3] = work_order[blockIdx.x];
     }
+    if (timers && frame == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        timers[9 * 32 + 4 * kTraceUnits + (threadIdx.x >> 6)] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
     const uint32_t ui = work_order[blockIdx.x];
     const uint32_t wave = threadIdx.x >> 6;
@@ -122,9 +124,13 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
         for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * kUnitWaves) dst[i] = src[i];
     }
+    // Role of each wavefront.  Waves w and w + 4 of a workgroup share a SIMD (observed placement, used for speed
+    // only): the count wave, which issues the most vector instructions per chunk, gets a SIMD to itself and the
+    // other issue-heavy roles are paired with latency-bound ones.
+    constexpr uint32_t kPixel = 0, kGolomb = 1, kWalker = 2, kCount = 3, kMerge = 4, kDrain = 5, kRecords = 6, kCompact = 7;
     if (wave == 0) unit_state_init(s);
     if (threadIdx.x == 64) s.nchunks = (u.w * u.h + 63u) / 64u;
-    if (wave == 4) build_crc_table(s);
+    if (wave == kMerge) build_crc_table(s);
     __syncthreads();
 
     uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
@@ -139,22 +145,26 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
 
-    if (wave == 0) {
+    if (wave == kPixel) {
         PixelWave pw;
         pixel_wave_run(s, a, pw, 0, nchunks);
-    } else if (wave == 1) {
+    } else if (wave == kCount) {
         CountWave cs;
         count_wave_run(s, a, cs, 0, nchunks);
-    } else if (wave == 2) {
+    } else if (wave == kWalker) {
         WalkWave ww;
         walk_wave_init(s, ww);
         walk_wave_run(s, a, ww, nchunks, ~0u);
-    } else if (wave == 3) {
+    } else if (wave == kGolomb) {
         GolombWave gw;
         golomb_wave_init(gw);
         golomb_wave_run(s, a, gw, nchunks, ~0u);
-    } else if (wave == 5) {
-        helper_wave_run(s, a, ~0u);
+    } else if (wave == kRecords) {
+        records_wave_run(s, a, ~0u);
+    } else if (wave == kDrain) {
+        drain_wave_run(s, a, ~0u);
+    } else if (wave == kCompact) {
+        compact_wave_run(s, a, 0, nchunks);
     } else {
         uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (s.abort == 2u) bits = kUnitFailed;        // a bounded spin expired: internal error, never a silent hang

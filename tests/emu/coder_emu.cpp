@@ -166,7 +166,8 @@ extern "C" size_t emu_get_tables(void *dst, size_t cap)
 }
 extern "C" int emu_pick_bin(uint32_t zero, uint32_t total)
 {
-    CoderTables t;
-    build_coder_tables(&t);
-    return (int)pick_bin(t.cut, zero, total);
+    static CoderTables t;
+    static bool built = false;
+    if (!built) { build_coder_tables(&t); built = true; }
+    return (int)pick_bin(t.binlut, zero, total);
 }

@@ -5,9 +5,11 @@ import numpy as np
 
 
 class CoderTables(C.Structure):     # mirrors icer::CoderTables
-    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_step", ((C.c_uint16 * 16) * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
+    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_step", ((C.c_uint16 * 16) * 32) * 8),
+                ("cand_bin", C.c_uint8 * 64), ("cand_node", C.c_uint8 * 64), ("cand_lane", (C.c_uint8 * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
                 ("gm", C.c_uint16 * 17), ("gl", C.c_uint16 * 17), ("gi", C.c_uint16 * 17),
-                ("ginv", C.c_uint32 * 17), ("cut", C.c_uint32 * 16), ("x2n", C.c_uint32 * 32)]
+                ("ginv", C.c_uint32 * 17), ("cut", C.c_uint32 * 16), ("binlut", C.c_uint32 * 257),
+                ("x2n", C.c_uint32 * 32)]
 
 
 def _tables(emu):
@@ -64,9 +66,29 @@ def test_nibble_step_table_equals_four_single_steps(emu, reference):
                 assert (e & 31, (e >> 5) & 15) == (acc | (1 << nin), starts), (b, node, nib)
 
 
+def test_walker_candidate_lanes_cover_every_tree_node(emu):
+    """Every node the nibble-step table can land on has exactly one candidate lane (the split walk relies on it)."""
+    t = _tables(emu)
+    for b in range(1, 8):
+        reach, todo = {1}, [1]
+        while todo:
+            node = todo.pop()
+            for nib in range(16):
+                nxt = t.v2v_step[b][node][nib] & 31
+                if nxt not in reach:
+                    reach.add(nxt)
+                    todo.append(nxt)
+        lanes = {node: t.cand_lane[b][node] for node in reach}
+        assert all(8 <= ln < 64 for ln in lanes.values()) and len(set(lanes.values())) == len(reach), (b, lanes)
+        assert all(t.cand_bin[ln] == b and t.cand_node[ln] == node for node, ln in lanes.items())
+    assert sum(1 for ln in range(64) if t.cand_bin[ln]) == 46
+
+
 def test_pick_bin_equals_reference(emu, reference):
-    for total in list(range(1, 64)) + [100, 249, 250, 251, 400, 498, 499, 500]:
-        for zero in range((total + 1) // 2 if total > 1 else 0, total + 1):
+    t = _tables(emu)
+    assert all(e != 0xFFFFFFFF for e in t.binlut)          # at most one cut-off per bucket of 256
+    for total in range(1, 640):                            # (counts are rescaled at 500)
+        for zero in range(total // 2, total + 1):
             assert emu.lib.emu_pick_bin(zero, total) == reference.lib.icer_compute_bin(zero, total), (zero, total)
 
 

@@ -17,7 +17,8 @@ NAMES = ["pixel wave: context+loads", "pixel wave: wait (queue full)",
          "golomb wave: wait (events/verdict)", "golomb wave: bins 0, 8-16", "golomb wave: hand-over",
          "merge wave: wait (events)", "merge wave: walker reads + ring slots", "merge wave: drain", "merge wave: exact path",
          "merge wave: retire", "merge wave: event reads + wait golomb", "merge wave: golomb reads + wait walker",
-         "helper wave: idle / poll", "helper wave: v2v records", "helper wave: pop + pack", "helper wave: store payload"]
+         "records wave: idle / poll", "records wave: v2v records", "drain wave: pop + pack", "drain wave: store payload",
+         "drain wave: idle / poll", "compaction wave: wait (events)", "compaction wave: ranks + bit strings"]
 NT = 32
 
 
@@ -74,8 +75,8 @@ def main():
         print(f"  {n:40s}" + "".join(f"{out[p * NT + k] / chunks / 1e3:6.2f}" for p in range(9)))
     print(f"  {'exact-path chunks %':40s}" + "".join(f"{100.0 * out[p * NT + 29] / max(out[p * NT + 31], 1):6.2f}" for p in range(9)))
     print(f"  {'doubtful chunks % (quick test failed)':40s}" + "".join(f"{100.0 * out[p * NT + 30] / max(out[p * NT + 31], 1):6.2f}" for p in range(9)))
-    tot = [sum(out[p * NT + k] for k in range(24)) for p in range(9)]
-    print(f"  {'per-wave total (= unit latency / chunk)':40s}" + "".join(f"{t / 6 / chunks / 1e3:6.2f}" for t in tot))
+    tot = [sum(out[p * NT + k] for k in range(27)) for p in range(9)]
+    print(f"  {'per-wave total (= unit latency / chunk)':40s}" + "".join(f"{t / 8 / chunks / 1e3:6.2f}" for t in tot))
 
 
 if __name__ == "__main__":
