@@ -358,27 +358,17 @@ ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
 }
 ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u ? -1 : last_le(A1, A2, pos - 1u); }
 
-// one Golomb-bin event at position POS with bit BIT (lane-local); Z*/O* = zero/one events of the bin
-#define ICER_GOLOMB_EVENT(POS, SLOT, BIT, FL, WD)                                                           \
-    {                                                                                                 \
-        const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                                   \
-        const int lo_ = last_lt(O1, O2, (POS));                                                       \
-        const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : k_in + zb_;              \
-        const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                             \
-        FL = (kb_ == 0u ? 1u : 0u) | (((BIT) || kb_ + 1u == m) ? 2u : 0u);                            \
-        WD = (BIT) ? golomb_word(s.tab, b, kb_) : (kWordDone | (1u << 11) | 1u);                      \
-    }
-
 // drain finished words from the head of the ring, 64 per round: lengths -> prefix sum -> bit offsets,
 // code bits OR-ed into the LDS bit stage (icer_popbuf_while_avail, icer_encoding.c:114-139)
-// `limit` = allocation count up to which ring slots are valid.  Returns the number of words popped.
-ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit)
+// `limit` = allocation count up to which ring slots are valid; at most `max_rounds` rounds of 64 words.  Returns the
+// number of words popped.
+ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit, uint32_t max_rounds)
 {
     DECL_LANE;
     const uint32_t popped0 = s.popped;
     uint32_t head = popped0 & (kRingWords - 1), used = limit - popped0, bitpos = s.bitpos;
     uint32_t npop = 0;
-    for (;;) {
+    for (uint32_t round = 0; round < max_rounds; round++) {
         LANEVAR(uint32_t, w); LANEVAR(uint32_t, len); LANEVAR(uint32_t, off);
         FOR_LANES
         {
@@ -391,8 +381,13 @@ ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit)
         {
             LV(len) = (uint32_t)lane < n ? ((LV(w) >> 11) & 15u) : 0u;
         }
-        uint32_t total;
-        WAVE_EXCL_SCAN(uint32_t, off, len, total);
+        // exclusive prefix sum of the lengths (< 16): one ballot per bit of the length, lane-masked popcounts
+        const uint64_t L0 = BALLOT(LV(len) & 1u), L1 = BALLOT(LV(len) & 2u), L2 = BALLOT(LV(len) & 4u), L3 = BALLOT(LV(len) & 8u);
+        const uint32_t total = (uint32_t)(popc64(L0) + 2 * popc64(L1) + 4 * popc64(L2) + 8 * popc64(L3));
+        FOR_LANES
+        {
+            LV(off) = (uint32_t)(mbcnt64(L0, lane) + 2 * mbcnt64(L1, lane) + 4 * mbcnt64(L2, lane) + 8 * mbcnt64(L3, lane));
+        }
         FOR_LANES
         {
             if (LV(len)) {
@@ -980,50 +975,79 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
             if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
         }
-        WAVE_SYNC();
-        // Golomb bins present in the chunk: run length since the bin's previous one-event, modulo m
-        for (uint64_t rem1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), rem2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u); rem1 | rem2;) {
-            const int b = (int)(rem1 ? READLANE(ev1, ffs64(rem1)) & 31u : READLANE(ev2, ffs64(rem2)) & 31u);
-            const uint64_t M1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b));
-            const uint64_t M2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b));
-            rem1 &= ~M1;
-            rem2 &= ~M2;
-            const uint64_t O1 = BALLOT((LV(ev1) & 0xBFu) == (0xA0u | (uint32_t)b));
-            const uint64_t O2 = BALLOT((LV(ev2) & 0xBFu) == (0xA0u | (uint32_t)b));
-            const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
-            const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = READLANE(gw.k, b);
-            FOR_LANES
-            {
-                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane, 0u, (LV(ev1) >> 5) & 1u, LV(fl1), LV(wd1))
-                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b)) ICER_GOLOMB_EVENT(2u * (uint32_t)lane + 1u, 1u, (LV(ev2) >> 5) & 1u, LV(fl2), LV(wd2))
-            }
-            const uint64_t SB1 = BALLOT((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 1u));
-            const uint64_t SB2 = BALLOT((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 1u));
-            FOR_LANES
-            {
-                if ((LV(ev1) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl1) & 2u)) {
-                    const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane);
-                    LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+        // Golomb bins 8..16, no loop over bins: the lanes of one bin are found from per-bit ballots of (bin - 8); an
+        // event's run length = zeros of its bin since the bin's previous one-event (or since the chunk start, plus the
+        // run carried in), modulo m; a word starts where that is 0 and ends at a one or when the run reaches m - 1.
+#define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
+        ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+        {
+            const uint64_t G1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), G2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u);
+            if (G1 | G2) {
+                const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u);
+                const uint64_t J0 = BALLOT(LV(ev2) & 1u), J1 = BALLOT(LV(ev2) & 2u), J2 = BALLOT(LV(ev2) & 4u), J3 = BALLOT((LV(ev2) & 31u) == 16u);
+                const uint64_t O1 = G1 & BALLOT(LV(ev1) & 0x20u), O2 = G2 & BALLOT(LV(ev2) & 0x20u);       // one-events
+                LANEVAR(uint32_t, kin1); LANEVAR(uint32_t, kin2); LANEVAR(uint32_t, idx);
+                FOR_LANES { LV(idx) = LV(ev1) & 31u; }
+                WAVE_GATHER(kin1, gw.k, idx)
+                FOR_LANES { LV(idx) = LV(ev2) & 31u; }
+                WAVE_GATHER(kin2, gw.k, idx)
+                // key of a bin: bin - 8 = 0..8, i.e. the low three bits of the bin number and "bin == 16"
+                LANEVAR(uint64_t, ma1); LANEVAR(uint64_t, mb1); LANEVAR(uint64_t, ma2); LANEVAR(uint64_t, mb2);   // events of this lane's bins
+#define ICER_GOLOMB_LANE(EV, SLOT, KIN, FL, WD, MA, MB)                                                       \
+                if (((EV) & 0x98u) >= 0x88u) {                                                                \
+                    const uint32_t b_ = (EV) & 31u, key_ = (b_ & 7u) | (b_ == 16u ? 8u : 0u);                  \
+                    const uint64_t m1_ = ICER_MATCH(key_, G1, K0, K1, K2, K3), m2_ = ICER_MATCH(key_, G2, J0, J1, J2, J3); \
+                    MA = m1_; MB = m2_;                                                                         \
+                    const uint64_t Z1 = m1_ & ~O1, Z2 = m2_ & ~O2;                                              \
+                    const uint32_t pos_ = 2u * (uint32_t)lane + (SLOT);                                         \
+                    const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                      \
+                    const int lo_ = last_lt(m1_ & O1, m2_ & O2, pos_);                                          \
+                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : (KIN) + zb_;           \
+                    const uint32_t m = s.tab.gm[b_], inv = s.tab.ginv[b_];                                      \
+                    const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
+                    const uint32_t bit_ = ((EV) >> 5) & 1u;                                                     \
+                    FL = (kb_ == 0u ? 1u : 0u) | ((bit_ || kb_ + 1u == m) ? 2u : 0u);                           \
+                    WD = bit_ ? golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);               \
                 }
-                if ((LV(ev2) & 0x9Fu) == (0x80u | (uint32_t)b) && (LV(fl2) & 2u)) {
-                    const int sp = last_le(SB1, SB2, 2u * (uint32_t)lane + 1u);
-                    LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
+                FOR_LANES
+                {
+                    LV(ma1) = 0; LV(mb1) = 0; LV(ma2) = 0; LV(mb2) = 0;
+                    ICER_GOLOMB_LANE(LV(ev1), 0u, LV(kin1), LV(fl1), LV(wd1), LV(ma1), LV(mb1))
+                    ICER_GOLOMB_LANE(LV(ev2), 1u, LV(kin2), LV(fl2), LV(wd2), LV(ma2), LV(mb2))
                 }
-            }
-            // bin state after the chunk (wave-uniform)
-            const int lastone = last_le(O1, O2, 127u);
-            const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
-            const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : k_in + ztot;
-            const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
-            const int laststart = last_le(SB1, SB2, 127u);
-            FOR_LANES
-            {
-                if (lane == b) {
-                    LV(gw.k) = k_out;
-                    LV(opv) = k_out ? (laststart >= 0 ? (uint32_t)laststart : 255u) : 254u;
+#undef ICER_GOLOMB_LANE
+                // word starts of the Golomb bins; an end event's word began at its bin's latest start
+                const uint64_t SB1 = G1 & BALLOT(LV(fl1) & 1u), SB2 = G2 & BALLOT(LV(fl2) & 1u);
+                FOR_LANES
+                {
+                    if ((LV(ev1) & 0x98u) >= 0x88u && (LV(fl1) & 2u)) {
+                        const int sp = last_le(SB1 & LV(ma1), SB2 & LV(mb1), 2u * (uint32_t)lane);
+                        LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+                    }
+                    if ((LV(ev2) & 0x98u) >= 0x88u && (LV(fl2) & 2u)) {
+                        const int sp = last_le(SB1 & LV(ma2), SB2 & LV(mb2), 2u * (uint32_t)lane + 1u);
+                        LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
+                    }
+                    // lane b = 8..16: bin b's state after the chunk
+                    if (lane >= 8 && lane <= 16) {
+                        const uint32_t key = (uint32_t)lane - 8u;
+                        const uint64_t M1 = ICER_MATCH(key, G1, K0, K1, K2, K3), M2 = ICER_MATCH(key, G2, J0, J1, J2, J3);
+                        if (M1 | M2) {
+                            const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
+                            const int lastone = last_le(M1 & O1, M2 & O2, 127u);
+                            const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
+                            const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : LV(gw.k) + ztot;
+                            const uint32_t m = s.tab.gm[lane], inv = s.tab.ginv[lane];
+                            const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
+                            const int laststart = last_le(SB1 & M1, SB2 & M2, 127u);
+                            LV(gw.k) = k_out;
+                            LV(opv) = k_out ? (laststart >= 0 ? (uint32_t)laststart : 255u) : 254u;
+                        }
+                    }
                 }
             }
         }
+#undef ICER_MATCH
         ICER_TICK(11)
         FOR_LANES
         {
@@ -1190,7 +1214,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t t
         const uint32_t P = h1 ? 2u * (uint32_t)ffs64(h1) : 2u * (uint32_t)ffs64(h2) + 1u;
         commit_range(s, c, tail0, base, P);
         const uint32_t alloc = tail0 + t;
-        wave_drain(s, alloc);
+        wave_drain(s, alloc, 2u);
         if (alloc - s.popped == (uint32_t)kRingWords) {
             // still full: the head word is open.  Its bin, and that bin's state just before P:
             const uint32_t head = s.popped & (kRingWords - 1);
@@ -1264,7 +1288,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t t
             c.S1 = BALLOT(LV(c.fl1) & 1u);
             c.S2 = BALLOT(LV(c.fl2) & 1u);
             flushed = true;
-            wave_drain(s, alloc);
+            wave_drain(s, alloc, 2u);
         }
         base = P;
     }
@@ -1379,7 +1403,7 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
         if (limit - s.popped >= 128u || (limit != s.popped && idle >= 16u)) {
             ICER_ACQUIRE()
             ICER_TICK(24)
-            const uint32_t npop = wave_drain(s, limit);
+            const uint32_t npop = wave_drain(s, limit, 4u);     // bounded, so that a hold request is answered soon
             ICER_TICK(22)
             if (npop && !flush_stage(s, a, false)) {     // payload slot too small: abandon the unit
                 ICER_PUBLISH(s.abort, 1u)
@@ -1427,7 +1451,8 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             ICER_DRAIN_HOLD(s, a)
             if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             held = true;
-            wave_drain(s, tail);
+            // (two rounds = 128 words is all a chunk can need; whatever else is finished is left to the drain wave)
+            wave_drain(s, tail, 2u);
             fast = tail - s.popped + nstarts <= (uint32_t)kRingWords;
             ICER_COUNT(30)
         }
@@ -1444,7 +1469,6 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             if (flushed) {
                 ICER_EMU_COUNT(1);
                 ICER_COUNT(29)
-                wave_drain(s, tail);
                 // results produced for later chunks assumed no forced flush here: void them
                 FOR_LANES
                 {
@@ -1484,14 +1508,14 @@ ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a)
     ICER_PUBLISH(s.drain_exit, 1u)
     ICER_DRAIN_HOLD(s, a)
     if (ICER_LOAD_CNT(s.abort)) return kUnitTooBig;
-    wave_drain(s, s.alloc);
+    wave_drain(s, s.alloc, ~0u);
     while (s.alloc != s.popped) {
         FOR_LANES
         {
             if (lane == 0) seq_complete_head(s);
         }
         WAVE_SYNC();
-        wave_drain(s, s.alloc);
+        wave_drain(s, s.alloc, ~0u);
     }
     return flush_stage(s, a, true) ? s.bitpos : kUnitTooBig;
 }
