@@ -68,14 +68,18 @@ def load_library() -> C.CDLL:
                                              C.POINTER(icer_output_data_buf_typedef)]
     L.icer_compress_image_yuv_uint16.argtypes = [u16, u16, u16, C.c_size_t, C.c_size_t, C.c_uint8, C.c_int, C.c_uint8,
                                                  C.POINTER(icer_output_data_buf_typedef)]
+    L.icer_compress_image_uint8.argtypes = L.icer_compress_image_uint16.argtypes
+    L.icer_compress_image_yuv_uint8.argtypes = L.icer_compress_image_yuv_uint16.argtypes
     L.icerx_encoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int]
+    L.icerx_encoder_create_ex.argtypes = L.icerx_encoder_create.argtypes + [C.c_int]
     L.icerx_encoder_destroy.argtypes = [C.c_void_p]
     L.icerx_encoder_destroy.restype = None
     L.icerx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
     L.icerx_encode_device_u8.argtypes = L.icerx_encode_device.argtypes
     L.icerx_encode_device_rgb8.argtypes = L.icerx_encode_device.argtypes
+    L.icerx_encode_device_s8.argtypes = L.icerx_encode_device.argtypes
     L.icerx_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.icerx_get_coefficients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.icerx_timing_enable.argtypes = [C.c_void_p, C.c_int]
@@ -95,9 +99,9 @@ def icer_init_output_struct(out: icer_output_data_buf_typedef, data: np.ndarray,
     return load_library().icer_init_output_struct(C.byref(out), data.ctypes.data, buf_len, byte_quota)
 
 
-def _check_plane(a: np.ndarray, w: int, h: int) -> None:
-    if a.dtype != np.uint16 or not a.flags["C_CONTIGUOUS"] or a.size != w * h:
-        raise ValueError("image planes must be C-contiguous uint16 arrays of w*h elements")
+def _check_plane(a: np.ndarray, w: int, h: int, dtype=np.uint16) -> None:
+    if a.dtype != dtype or not a.flags["C_CONTIGUOUS"] or a.size != w * h:
+        raise ValueError(f"image planes must be C-contiguous {np.dtype(dtype).name} arrays of w*h elements")
 
 
 def icer_compress_image_uint16(image: np.ndarray, image_w: int, image_h: int, stages: int, filt: int, segments: int,
@@ -113,6 +117,38 @@ def icer_compress_image_yuv_uint16(y: np.ndarray, u: np.ndarray, v: np.ndarray, 
         _check_plane(p, image_w, image_h)
     return load_library().icer_compress_image_yuv_uint16(y.ctypes.data, u.ctypes.data, v.ctypes.data, image_w, image_h,
                                                          stages, filt, segments, C.byref(output_data))
+
+
+def icer_compress_image_uint8(image: np.ndarray, image_w: int, image_h: int, stages: int, filt: int, segments: int,
+                              output_data: icer_output_data_buf_typedef) -> int:
+    _check_plane(image, image_w, image_h, np.uint8)
+    return load_library().icer_compress_image_uint8(image.ctypes.data, image_w, image_h, stages, filt, segments,
+                                                    C.byref(output_data))
+
+
+def icer_compress_image_yuv_uint8(y: np.ndarray, u: np.ndarray, v: np.ndarray, image_w: int, image_h: int, stages: int,
+                                  filt: int, segments: int, output_data: icer_output_data_buf_typedef) -> int:
+    for p in (y, u, v):
+        _check_plane(p, image_w, image_h, np.uint8)
+    return load_library().icer_compress_image_yuv_uint8(y.ctypes.data, u.ctypes.data, v.ctypes.data, image_w, image_h,
+                                                        stages, filt, segments, C.byref(output_data))
+
+
+def compress_u8(planes, stages: int, filt: int, segments: int, byte_quota: int):
+    """As compress(), through the uint8 twins (planes: (h, w) uint8 arrays, int8 storage)."""
+    icer_init()
+    work = [np.ascontiguousarray(p, dtype=np.uint8).copy() for p in planes]
+    h, w = work[0].shape
+    buf = np.zeros(2 * byte_quota + 64, dtype=np.uint8)
+    out = icer_output_data_buf_typedef()
+    rc = icer_init_output_struct(out, buf, buf.size, byte_quota)
+    if rc != ICER_RESULT_OK:
+        return rc, b"", work
+    if len(work) == 1:
+        rc = icer_compress_image_uint8(work[0], w, h, stages, filt, segments, out)
+    else:
+        rc = icer_compress_image_yuv_uint8(work[0], work[1], work[2], w, h, stages, filt, segments, out)
+    return rc, bytes(buf[byte_quota: byte_quota + out.size_used]), work
 
 
 def compress(planes, stages: int, filt: int, segments: int, byte_quota: int):
@@ -138,11 +174,13 @@ class Encoder:
     """icerx_encoder: frames of one geometry, many per call, buffers resident on one GPU."""
 
     def __init__(self, w: int, h: int, channels: int = 1, stages: int = 4, filt: int = ICER_FILTER_A, segments: int = 10,
-                 max_frames: int = 1, device: int = 0):
+                 max_frames: int = 1, device: int = 0, sample_bits: int = 16):
         self.lib = load_library()
         self.w, self.h, self.channels, self.max_frames, self.device = w, h, channels, max_frames, device
+        self.sample_bits = sample_bits
         self.handle = C.c_void_p()
-        rc = self.lib.icerx_encoder_create(C.byref(self.handle), device, w, h, channels, stages, filt, segments, max_frames)
+        rc = self.lib.icerx_encoder_create_ex(C.byref(self.handle), device, w, h, channels, stages, filt, segments, max_frames,
+                                              sample_bits)
         self.create_rc = rc
         if rc != 0:
             self.handle = C.c_void_p()
@@ -171,6 +209,23 @@ class Encoder:
         st = torch.cuda.current_stream(frames.device).cuda_stream
         self.encode_device_ptrs(frames.data_ptr(), n, byte_quota, out.data_ptr(), out.stride(0), sizes.data_ptr(),
                                 rcs.data_ptr(), st)
+
+    def encode_torch_s8(self, planes, byte_quota: int):
+        """uint8 twins: planes = cuda uint8 tensor (n, h, w) or (n, channels, h, w), int8 storage; the encoder must have
+        been created with sample_bits=8.  Returns [(rc, stream bytes)] per frame."""
+        import torch
+        n = planes.shape[0]
+        stride = byte_quota + 64
+        out = torch.empty((n, stride), dtype=torch.uint8, device=planes.device)
+        sizes = torch.empty(n, dtype=torch.int64, device=planes.device)
+        rcs = torch.empty(n, dtype=torch.int32, device=planes.device)
+        st = torch.cuda.current_stream(planes.device).cuda_stream
+        rc = self.lib.icerx_encode_device_s8(self.handle, planes.data_ptr(), n, byte_quota, out.data_ptr(), stride,
+                                             sizes.data_ptr(), rcs.data_ptr(), st)
+        if rc != 0:
+            raise IcerHipError(f"icerx_encode_device_s8 rc={rc}: {self.lib.icerx_last_error().decode()}")
+        sz, rr, host = sizes.cpu().numpy(), rcs.cpu().numpy(), out.cpu().numpy()
+        return [(int(rr[k]), bytes(host[k, : int(sz[k])])) for k in range(n)]
 
     def encode_torch_frontend(self, raw, byte_quota: int, out, sizes, rcs) -> None:
         """raw: cuda uint8 tensor, (n, h, w) gray for a 1-channel encoder or (n, h, w, 3) packed RGB for a

@@ -69,6 +69,7 @@ struct icerx_encoder {
     int device = 0;
     size_t w = 0, h = 0;
     int channels = 1, stages = 0, filt = 0, segments = 0, max_frames = 0;
+    int sample_bits = 16;               // 8: the uint8 twins (int8 storage, 7 bit planes)
     Plan plan;
     size_t slot_quota = (size_t)-1;     // quota the current slot table was built for
     unsigned bits_per_pixel = 3;        // slot bound; doubled on overflow
@@ -85,6 +86,7 @@ struct icerx_encoder {
     DevBuf<CoderTables> tables;
     // host-API staging
     DevBuf<uint16_t> in;
+    DevBuf<uint8_t> in8;
     DevBuf<uint8_t> out;
     DevBuf<unsigned long long> sizes;
     DevBuf<int32_t> rcs;
@@ -109,6 +111,13 @@ __global__ void frame_status_kernel(const int *dwt_ovf, const int *mean_ovf, int
     int s = 0;
     for (int c = 0; c < channels; c++) s |= dwt_ovf[f * channels + c] | mean_ovf[f * channels + c];
     skip[f] = s;
+}
+
+// uint8 twins: the samples are int8 storage (icer_wavelet.c:231 `int8_t *signed_data = (int8_t *) data`); the kernels
+// work on them sign-extended to int16
+__global__ void __launch_bounds__(256) widen_s8_kernel(const uint8_t *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (uint16_t)(int16_t)(int8_t)src[i];
 }
 
 // 8-bit gray -> uint16 (what the reference's CLI does on the host, example/src/icer_util.c:163-168)
@@ -188,6 +197,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     size_t cw = W, ch = H, ll_off = 0;
     DwtStageArgs da;
     da.f = ft;
+    da.lim = e->sample_bits == 8 ? 127 : 32767;
     da.coef = e->coef.p; da.coef_stride = (uint32_t)W;
     da.src = reinterpret_cast<const int16_t *>(d_frames); da.src_stride = (uint32_t)W;
     size_t src_plane = plane;
@@ -211,12 +221,12 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     unsigned sum_blocks = (llw * llh + 255) / 256;
     if (sum_blocks > 64) sum_blocks = 64;
     hipLaunchKernelGGL(ll_sum_kernel, dim3(sum_blocks, P), dim3(256), 0, st, reinterpret_cast<const uint16_t *>(e->coef.p),
-                       plane, (uint32_t)W, llw, llh, e->sums.p);
+                       plane, (uint32_t)W, llw, llh, e->sums.p, e->sample_bits == 8 ? 0xFFu : 0xFFFFu);
     hipLaunchKernelGGL(ll_mean_kernel, dim3((P + 63) / 64), dim3(64), 0, st, e->sums.p, (uint32_t)P, llw * llh,
-                       e->means.p, mean_ovf);
+                       e->means.p, mean_ovf, e->sample_bits);
     hipLaunchKernelGGL(frame_status_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, dwt_ovf, mean_ovf, C, n_frames, skip);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, P), dim3(256), 0, st,
-                       reinterpret_cast<uint16_t *>(e->coef.p), plane, (uint32_t)W, llw, llh, e->means.p, skip, C);
+                       reinterpret_cast<uint16_t *>(e->coef.p), plane, (uint32_t)W, llw, llh, e->means.p, skip, C, e->sample_bits);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
 
     // ---- coding units
@@ -288,13 +298,19 @@ int icer_init_output_struct(icer_output_data_buf_typedef *out, uint8_t *data, si
 int icerx_encoder_create(icerx_encoder **out, int device, size_t w, size_t h, int channels, int stages, int filt,
                          int segments, int max_frames)
 {
+    return icerx_encoder_create_ex(out, device, w, h, channels, stages, filt, segments, max_frames, 16);
+}
+
+int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h, int channels, int stages, int filt,
+                            int segments, int max_frames, int sample_bits)
+{
     *out = nullptr;
     icer_init();
-    if (filt < 0 || filt > 6 || max_frames < 1) return ICER_INVALID_INPUT;
+    if (filt < 0 || filt > 6 || max_frames < 1 || (sample_bits != 8 && sample_bits != 16)) return ICER_INVALID_INPUT;
     icerx_encoder *e = new icerx_encoder();
     e->device = device; e->w = w; e->h = h; e->channels = channels; e->stages = stages; e->filt = filt;
-    e->segments = segments; e->max_frames = max_frames;
-    const int rc = build_plan(&e->plan, w, h, channels, stages, segments);
+    e->segments = segments; e->max_frames = max_frames; e->sample_bits = sample_bits;
+    const int rc = build_plan(&e->plan, w, h, channels, stages, segments, sample_bits);
     if (rc != kOk) { delete e; return rc; }
     // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
@@ -337,7 +353,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
     e->units.release(); e->work_order.release(); e->split_order.release(); e->final_order.release(); e->unit_bits.release();
-    e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->out.release();
+    e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->done) (void)hipEventDestroy(e->done);
@@ -396,6 +412,10 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
 int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
                         size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
 {
+    if (e && e->sample_bits != 16) {
+        set_error("icerx_encode_device: this encoder was created for 8-bit samples (use icerx_encode_device_s8)");
+        return ICER_INVALID_INPUT;
+    }
     return encode_device_impl(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream, nullptr);
 }
 
@@ -412,6 +432,21 @@ int icerx_encode_device_u8(icerx_encoder *e, const uint8_t *d_frames, int n_fram
     hipLaunchKernelGGL(widen_u8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                        d_frames, e->in.p, n);
     return icerx_encode_device(e, e->in.p, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream);
+}
+
+int icerx_encode_device_s8(icerx_encoder *e, const uint8_t *d_planes, int n_frames, size_t byte_quota, uint8_t *d_out,
+                           size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+{
+    if (!e || !d_planes || e->sample_bits != 8 || n_frames < 1 || n_frames > e->max_frames) {
+        set_error("icerx_encode_device_s8: invalid arguments (needs an encoder created with sample_bits = 8)");
+        return ICER_INVALID_INPUT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)n_frames * e->channels * e->w * e->h;
+    if (e->in.ensure((size_t)e->max_frames * e->channels * e->w * e->h)) return ICER_FATAL_ERROR;
+    hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       d_planes, e->in.p, n);
+    return encode_device_impl(e, e->in.p, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream, nullptr);
 }
 
 int icerx_encode_device_rgb8(icerx_encoder *e, const uint8_t *d_rgb, int n_frames, size_t byte_quota, uint8_t *d_out,
@@ -519,24 +554,64 @@ int icerx_prof_trace(icerx_encoder *e, uint64_t *out, int n_blocks)
 // ---- lib_icer drop-in entry points -------------------------------------------------------------
 static icerx_encoder *g_cached = nullptr;
 
-static int compress_planes(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt, int segments,
-                           icer_output_data_buf_typedef *od)
+// `planes` are uint16_t* (sample_bits 16) or uint8_t* (sample_bits 8) host pointers
+static int compress_planes(void *const planes[], int channels, size_t w, size_t h, int stages, int filt, int segments,
+                           icer_output_data_buf_typedef *od, int sample_bits)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mutex);
     if (!od) return ICER_INVALID_INPUT;
     icerx_encoder *e = g_cached;
     if (!e || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt ||
-        e->segments != segments) {
+        e->segments != segments || e->sample_bits != sample_bits) {
         if (e) { icerx_encoder_destroy(e); g_cached = nullptr; }
         const char *dev = getenv("ICER_HIP_DEVICE");
-        const int rc = icerx_encoder_create(&e, dev ? atoi(dev) : 0, w, h, channels, stages, filt, segments, 1);
+        const int rc = icerx_encoder_create_ex(&e, dev ? atoi(dev) : 0, w, h, channels, stages, filt, segments, 1, sample_bits);
+        if (rc == ICER_PACKET_COUNT_EXCEEDED && sample_bits == 8) {
+            // The reference finds its packet table too small only after the transform and the LL-mean check
+            // (icer_color.c:31-131): an integer overflow there is what it reports.  Run those on the three planes as
+            // three gray frames (112 packets) and look at their return codes.
+            icerx_encoder *t = nullptr;
+            if (icerx_encoder_create_ex(&t, dev ? atoi(dev) : 0, w, h, 1, stages, filt, 1, channels, 8) == 0) {
+                const size_t plane = w * h;
+                std::vector<uint8_t> host((size_t)channels * plane), out((size_t)channels * 128);
+                std::vector<uint64_t> sizes(channels);
+                std::vector<int32_t> rcs(channels, 0);
+                for (int c = 0; c < channels; c++) memcpy(host.data() + (size_t)c * plane, planes[c], plane);
+                int r = 0;
+                if (t->in8.ensure(host.size()) || t->in.ensure(host.size())) r = ICER_FATAL_ERROR;
+                if (!r && hipMemcpy(t->in8.p, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) r = ICER_FATAL_ERROR;
+                if (!r) {
+                    hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((host.size() + 255) / 256, 4096)), dim3(256), 0, nullptr,
+                                       t->in8.p, t->in.p, host.size());
+                    // (icerx_encode_host takes uint16 frames: the widened planes are already on the device, so go below it)
+                    for (;;) {
+                        if (upload_units(t, 64, nullptr) || t->out.ensure((size_t)channels * 128)) { r = ICER_FATAL_ERROR; break; }
+                        bool regrow = false;
+                        r = encode_device_impl(t, t->in.p, channels, 64, t->out.p, 128, (uint64_t *)t->sizes.p, t->rcs.p, nullptr, &regrow);
+                        if (r || !regrow) break;
+                    }
+                    if (!r && hipMemcpy(rcs.data(), t->rcs.p, sizeof(int32_t) * channels, hipMemcpyDeviceToHost) != hipSuccess) r = ICER_FATAL_ERROR;
+                }
+                icerx_encoder_destroy(t);
+                if (r) return r;
+                for (int c = 0; c < channels; c++) if (rcs[c] == ICER_INTEGER_OVERFLOW) return ICER_INTEGER_OVERFLOW;
+            }
+        }
         if (rc) return rc;
         g_cached = e;
     }
     const size_t plane = w * h, quota = od->size_allocated;
     if (e->in.ensure((size_t)channels * plane)) return ICER_FATAL_ERROR;
-    for (int c = 0; c < channels; c++)
-        HIP_TRY(hipMemcpy(e->in.p + (size_t)c * plane, planes[c], plane * 2, hipMemcpyHostToDevice));
+    if (sample_bits == 16) {
+        for (int c = 0; c < channels; c++)
+            HIP_TRY(hipMemcpy(e->in.p + (size_t)c * plane, planes[c], plane * 2, hipMemcpyHostToDevice));
+    } else {
+        if (e->in8.ensure((size_t)channels * plane)) return ICER_FATAL_ERROR;
+        for (int c = 0; c < channels; c++)
+            HIP_TRY(hipMemcpy(e->in8.p + (size_t)c * plane, planes[c], plane, hipMemcpyHostToDevice));
+        const size_t n = (size_t)channels * plane;
+        hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, nullptr, e->in8.p, e->in.p, n);
+    }
     uint64_t size = 0;
     int32_t rc = 0;
     for (;;) {
@@ -553,7 +628,9 @@ static int compress_planes(uint16_t *const planes[], int channels, size_t w, siz
     if (rc == ICER_INTEGER_OVERFLOW) {
         // The reference aborts before any output; it leaves transformed (not sign-magnitude) data in
         // the planes it had already processed: channels up to the first DWT overflow, or all of them
-        // when only the LL-mean check failed (icer_color.c:347-381).
+        // when only the LL-mean check failed (icer_color.c:347-381).  (uint8 twins: that data went through
+        // truncating int8 stores after the overflow; we leave the caller's planes untouched instead.)
+        if (sample_bits == 8) return rc;
         std::vector<int> fl(2 * (size_t)channels);
         HIP_TRY(hipMemcpy(fl.data(), e->flags.p, sizeof(int) * channels, hipMemcpyDeviceToHost));
         int last = channels - 1;
@@ -563,8 +640,18 @@ static int compress_planes(uint16_t *const planes[], int channels, size_t w, siz
         return rc;
     }
     if (size) HIP_TRY(hipMemcpy(od->rearrange_start, e->out.p, size, hipMemcpyDeviceToHost));
-    for (int c = 0; c < channels; c++)
-        HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
+    if (sample_bits == 16) {
+        for (int c = 0; c < channels; c++)
+            HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
+    } else {
+        // what the reference leaves in the caller's image: int8 sign-magnitude bytes (icer_wavelet.c:852-858)
+        std::vector<uint16_t> tmp(plane);
+        for (int c = 0; c < channels; c++) {
+            HIP_TRY(hipMemcpy(tmp.data(), e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
+            uint8_t *dst = static_cast<uint8_t *>(planes[c]);
+            for (size_t i = 0; i < plane; i++) dst[i] = (uint8_t)(((tmp[i] >> 8) & 0x80u) | (tmp[i] & 0x7Fu));
+        }
+    }
     od->size_used = size;
     return rc;
 }
@@ -572,16 +659,31 @@ static int compress_planes(uint16_t *const planes[], int channels, size_t w, siz
 int icer_compress_image_uint16(uint16_t *image, size_t image_w, size_t image_h, uint8_t stages,
                                enum icer_filter_types filt, uint8_t segments, icer_output_data_buf_typedef *output_data)
 {
-    uint16_t *planes[1] = {image};
-    return compress_planes(planes, 1, image_w, image_h, stages, (int)filt, segments, output_data);
+    void *planes[1] = {image};
+    return compress_planes(planes, 1, image_w, image_h, stages, (int)filt, segments, output_data, 16);
 }
 
 int icer_compress_image_yuv_uint16(uint16_t *y_channel, uint16_t *u_channel, uint16_t *v_channel, size_t image_w,
                                    size_t image_h, uint8_t stages, enum icer_filter_types filt, uint8_t segments,
                                    icer_output_data_buf_typedef *output_data)
 {
-    uint16_t *planes[3] = {y_channel, u_channel, v_channel};
-    return compress_planes(planes, 3, image_w, image_h, stages, (int)filt, segments, output_data);
+    void *planes[3] = {y_channel, u_channel, v_channel};
+    return compress_planes(planes, 3, image_w, image_h, stages, (int)filt, segments, output_data, 16);
+}
+
+int icer_compress_image_uint8(uint8_t *image, size_t image_w, size_t image_h, uint8_t stages, enum icer_filter_types filt,
+                              uint8_t segments, icer_output_data_buf_typedef *output_data)
+{
+    void *planes[1] = {image};
+    return compress_planes(planes, 1, image_w, image_h, stages, (int)filt, segments, output_data, 8);
+}
+
+int icer_compress_image_yuv_uint8(uint8_t *y_channel, uint8_t *u_channel, uint8_t *v_channel, size_t image_w, size_t image_h,
+                                  uint8_t stages, enum icer_filter_types filt, uint8_t segments,
+                                  icer_output_data_buf_typedef *output_data)
+{
+    void *planes[3] = {y_channel, u_channel, v_channel};
+    return compress_planes(planes, 3, image_w, image_h, stages, (int)filt, segments, output_data, 8);
 }
 
 }  // extern "C"

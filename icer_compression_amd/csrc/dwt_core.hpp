@@ -30,12 +30,14 @@ struct DwtPair {
     bool overflow;
 };
 
-DWT_HD bool fits_i16(int32_t v) { return v >= -32768 && v <= 32767; }
-
 // `X(i)` returns sample i (0 <= i < n) of the line as int16.  k in [0, ceil(n/2)).
+// `lim` = largest storable value: 32767, or 127 for the int8 twin (icer_wavelet_transform_1d_uint8,
+// icer_wavelet.c:215-296) whose samples live sign-extended in int16 -- an out-of-range store only matters through
+// the overflow flag there (the frame is refused), so the values themselves are formed exactly as for int16.
 template <class Load>
-DWT_HD DwtPair dwt_pair(const Load &X, int n, int k, int am1, int a0, int a1, int be)
+DWT_HD DwtPair dwt_pair(const Load &X, int n, int k, int am1, int a0, int a1, int be, int32_t lim = 32767)
 {
+    const auto fits_i16 = [lim](int32_t v) { return v >= -lim - 1 && v <= lim; };
     const int nl = (n + 1) >> 1, nh = n >> 1;
     const bool odd = (n & 1) != 0;
     DwtPair out;

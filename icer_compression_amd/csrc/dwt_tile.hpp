@@ -37,6 +37,7 @@ struct DwtStageArgs {
     int16_t *ll;                        // where this stage's LL goes (next stage's source, or the plane itself)
     uint32_t ll_stride;
     FilterTaps f;
+    int32_t lim;                        // largest storable sample: 32767, or 127 for the uint8 twins
 };
 
 // window origin of the tile (tx, ty) in region coordinates (may be negative: clamped on load)
@@ -65,7 +66,7 @@ DWT_HD bool dwt_tile_rows(DwtTileShared &sh, const DwtStageArgs &a, int tx, int 
         const int gy = y0 + r, k = tx * kTileKX + kk;
         if (gy < 0 || gy >= a.ch || k >= nl) continue;
         const int16_t *row = sh.win[r];
-        const DwtPair p = dwt_pair([row, x0](int x) { return row[x - x0]; }, a.cw, k, a.f.am1, a.f.a0, a.f.a1, a.f.be);
+        const DwtPair p = dwt_pair([row, x0](int x) { return row[x - x0]; }, a.cw, k, a.f.am1, a.f.a0, a.f.a1, a.f.be, a.lim);
         sh.lo[r][kk] = p.low;
         sh.hi[r][kk] = p.has_high ? p.high : (int16_t)0;
         ovf |= p.overflow;
@@ -85,7 +86,7 @@ DWT_HD bool dwt_tile_cols(DwtTileShared &sh, const DwtStageArgs &a, int tx, int 
         const int kx = tx * kTileKX + kk, ky = ty * kTileKY + jj;
         if (ky >= nlh || kx >= (which ? nhw : nlw)) continue;
         const int16_t(*col)[kTileKX] = which ? sh.hi : sh.lo;
-        const DwtPair p = dwt_pair([col, kk, y0](int y) { return col[y - y0][kk]; }, a.ch, ky, a.f.am1, a.f.a0, a.f.a1, a.f.be);
+        const DwtPair p = dwt_pair([col, kk, y0](int y) { return col[y - y0][kk]; }, a.ch, ky, a.f.am1, a.f.a0, a.f.a1, a.f.be, a.lim);
         ovf |= p.overflow;
         if (!which) {                                           // low column: LL (top) and LH (below)
             a.ll[(size_t)ky * a.ll_stride + kx] = p.low;

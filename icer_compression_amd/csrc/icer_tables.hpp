@@ -11,11 +11,13 @@
 namespace icer {
 
 constexpr int kPlanes = 9;          // ICER_BITPLANES_TO_COMPRESS_16  (icer.h:44-46)
+constexpr int kPlanes8 = 7;         // ICER_BITPLANES_TO_COMPRESS_8   (icer.h:41-43)
 constexpr int kRingWords = 2048;    // ICER_CIRC_BUF_SIZE             (icer.h:27)
 constexpr int kHeaderBytes = 28;    // sizeof(icer_image_segment_typedef) (icer.h:293-305)
 constexpr int kMaxSegments = 32;    // ICER_MAX_SEGMENTS              (icer.h:29-31)
 constexpr int kMaxStages = 6;       // ICER_MAX_DECOMP_STAGES         (icer.h:32-34)
 constexpr int kMaxPackets = 800;    // ICER_MAX_PACKETS_16            (icer.h:38-40)
+constexpr int kMaxPackets8 = 300;   // ICER_MAX_PACKETS               (icer.h:35-37)
 constexpr int kNumBins = 17;
 constexpr int kNumContexts = 17;
 constexpr uint32_t kRescaleCap = 500;   // ICER_CONTEXT_RESCALING_CAP (icer.h:151)

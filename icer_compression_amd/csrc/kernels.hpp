@@ -39,38 +39,42 @@ dwt_tile_kernel(DwtStageArgs a, size_t src_plane, size_t coef_plane, size_t ll_p
 }
 
 // ------------------------------------------------------------------------------------------ LL mean
-// sum of the LL samples read as unsigned 16-bit (icer_compress.c:286-296).  grid = (blocks, planes)
+// sum of the LL samples read as unsigned 16-bit (icer_compress.c:286-296); uint8 twins: as unsigned 8-bit
+// (icer_compress.c:24-33; `mask` = 0xFF, the samples are sign-extended int8).  grid = (blocks, planes)
 __global__ void __launch_bounds__(256)
 ll_sum_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t stride, uint32_t llw, uint32_t llh,
-              unsigned long long *__restrict__ sums)
+              unsigned long long *__restrict__ sums, uint32_t mask)
 {
     const uint16_t *p = coef + blockIdx.y * plane;
     const uint32_t n = llw * llh;
     unsigned long long acc = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t r = i / llw, c = i - r * llw;
-        acc += p[(size_t)r * stride + c];
+        acc += p[(size_t)r * stride + c] & mask;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sums[blockIdx.y], acc);
 }
 
-// mean = sum / (llw*llh), must fit int16 (icer_compress.c:298-302).  One thread per plane.
+// mean = sum / (llw*llh) through a uint16_t, must fit int16 (icer_compress.c:298-302); uint8 twins: through a
+// uint8_t, must fit int8 (icer_compress.c:35-38).  One thread per plane.
 __global__ void ll_mean_kernel(const unsigned long long *__restrict__ sums, uint32_t n_planes, uint32_t ll_count,
-                               uint16_t *__restrict__ means, int *__restrict__ mean_ovf)
+                               uint16_t *__restrict__ means, int *__restrict__ mean_ovf, int sample_bits)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_planes) return;
-    const uint16_t m = (uint16_t)(sums[p] / ll_count);
+    const uint16_t m = sample_bits == 8 ? (uint16_t)(uint8_t)(sums[p] / ll_count) : (uint16_t)(sums[p] / ll_count);
     means[p] = m;
-    mean_ovf[p] = m > 32767 ? 1 : 0;
+    mean_ovf[p] = m > (sample_bits == 8 ? 127 : 32767) ? 1 : 0;
 }
 
 // LL -= mean (int16 wrap), then two's complement -> sign-magnitude over the whole plane
 // (icer_compress.c:304-313, icer_wavelet.c:871-877).  grid = (ceil(w/256), h, planes)
+// uint8 twins (icer_compress.c:40-51, icer_wavelet.c:852-858): the subtraction wraps at 8 bits and the int8
+// sign-magnitude word s|mmmmmmm (-128 -> sign, magnitude 0) is widened to the coder's s|0..0|mmmmmmm.
 __global__ void __launch_bounds__(256)
 finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t llw, uint32_t llh,
-                const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels)
+                const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels, int sample_bits)
 {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (c >= w) return;
@@ -78,6 +82,13 @@ finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t 
     uint16_t *q = coef + blockIdx.z * plane + (size_t)r * w + c;
     int16_t v = (int16_t)*q;
     if (r < llh && c < llw) v = (int16_t)(v - (int16_t)means[blockIdx.z]);
+    if (sample_bits == 8) {
+        const int8_t v8 = (int8_t)v;
+        const uint8_t m8 = (uint8_t)(v8 >> 7);
+        const uint8_t sm = (uint8_t)((((uint8_t)v8 + m8) ^ m8) | ((uint8_t)v8 & 0x80u));
+        *q = (uint16_t)(((sm & 0x80u) << 8) | (sm & 0x7Fu));
+        return;
+    }
     const uint16_t mask = (uint16_t)(v >> 15);
     *q = (uint16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
 }

@@ -98,25 +98,26 @@ inline void grid_rects(const SegmentGrid &g, std::vector<Rect> *out)
     }
 }
 
-inline void make_packets(std::vector<Packet> *pk, int stages, int channels)
+// `planes` = bit planes coded: 9 for the uint16 entry points, 7 for the uint8 twins (icer_compress.c:53-103, icer_color.c:73-131)
+inline void make_packets(std::vector<Packet> *pk, int stages, int channels, int planes = kPlanes)
 {
     pk->clear();
     if (channels == 1) {
         for (int st = 1; st <= stages; st++) {
             const uint64_t pr = uint64_t(1) << st;
-            for (int lsb = 0; lsb < kPlanes; lsb++) {
+            for (int lsb = 0; lsb < planes; lsb++) {
                 pk->push_back(Packet{(uint8_t)st, kHL, (uint8_t)lsb, 0, pr << lsb});
                 pk->push_back(Packet{(uint8_t)st, kLH, (uint8_t)lsb, 0, pr << lsb});
                 pk->push_back(Packet{(uint8_t)st, kHH, (uint8_t)lsb, 0, ((pr / 2) << lsb) + 1});
             }
         }
         const uint64_t pr = uint64_t(1) << stages;
-        for (int lsb = 0; lsb < kPlanes; lsb++) pk->push_back(Packet{(uint8_t)stages, kLL, (uint8_t)lsb, 0, (2 * pr) << lsb});
+        for (int lsb = 0; lsb < planes; lsb++) pk->push_back(Packet{(uint8_t)stages, kLL, (uint8_t)lsb, 0, (2 * pr) << lsb});
     } else {
         // QUIRK D4: a 32-bit priority doubled once per (plane, Y) and never reset per plane
         for (int st = 1; st <= stages; st++) {
             uint32_t pr = 1u << st;
-            for (int lsb = 0; lsb < kPlanes; lsb++)
+            for (int lsb = 0; lsb < planes; lsb++)
                 for (int ch = 0; ch < channels; ch++) {
                     if (ch == 0) pr *= 2;
                     pk->push_back(Packet{(uint8_t)st, kHL, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)(pr << lsb)});
@@ -125,7 +126,7 @@ inline void make_packets(std::vector<Packet> *pk, int stages, int channels)
                 }
         }
         uint32_t pr = 1u << stages;
-        for (int lsb = 0; lsb < kPlanes; lsb++)
+        for (int lsb = 0; lsb < planes; lsb++)
             for (int ch = 0; ch < channels; ch++) {
                 if (ch == 0) pr *= 2;
                 pk->push_back(Packet{(uint8_t)stages, kLL, (uint8_t)lsb, (uint8_t)ch, (uint64_t)(uint32_t)((2 * pr) << lsb)});
@@ -140,6 +141,7 @@ inline void make_packets(std::vector<Packet> *pk, int stages, int channels)
 struct Plan {
     size_t w = 0, h = 0;
     int channels = 0, stages = 0, segments = 0;
+    int sample_bits = 16;                  // 16: uint16 entry points; 8: the uint8 twins (int8 storage, 7 planes)
     int error = kOk;                       // non-zero: the reference would refuse this geometry
     std::vector<Packet> packets;           // priority order
     std::vector<UnitDesc> units;           // priority order: packet order, then segment number
@@ -160,9 +162,11 @@ inline int size_class(uint64_t pixels)
     return 4 * c + (int)frac;
 }
 
-inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int segments)
+inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int segments, int sample_bits = 16)
 {
-    p->w = w; p->h = h; p->channels = channels; p->stages = stages; p->segments = segments;
+    p->w = w; p->h = h; p->channels = channels; p->stages = stages; p->segments = segments; p->sample_bits = sample_bits;
+    // uint8 twins: ICER_BITPLANES_TO_COMPRESS_8 planes, the smaller packet table (ICER_MAX_PACKETS, icer.h:35-37)
+    const int planes = sample_bits == 8 ? kPlanes8 : kPlanes, max_packets = sample_bits == 8 ? kMaxPackets8 : kMaxPackets;
     p->units.clear(); p->final_order.clear(); p->work_order.clear();
     if (channels != 1 && channels != 3) return p->error = kInvalidInput;
     if (w == 0 || h == 0 || w > 65535 || h > 65535 || segments < 1) return p->error = kInvalidInput;
@@ -170,9 +174,9 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
     if (stages < 1 || stages > kMaxStages) return p->error = kTooManyStages;
     if (segments > kMaxSegments) return p->error = kTooManySegments;
     if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return p->error = kTooManyStages;   // icer_wavelet.c:63-68
-    if ((3 * stages + 1) * kPlanes * channels >= kMaxPackets) return p->error = kPacketCountExceeded;
+    if ((3 * stages + 1) * planes * channels >= max_packets) return p->error = kPacketCountExceeded;
 
-    make_packets(&p->packets, stages, channels);
+    make_packets(&p->packets, stages, channels, planes);
     SegmentGrid grid{};
     bool grid_valid = false;
     std::vector<Rect> rects;
@@ -202,12 +206,15 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
             p->units.push_back(u);
         }
     }
-    // D7: segment up, subband down, level down, plane down, channel up
+    // D7: segment up, subband down, level down, plane down, channel up (icer_compress.c:409-423 / :148-162,
+    // icer_color.c:508-527); the uint8 YUV variant walks subband, level and plane UP instead (icer_color.c:184-202)
+    const bool up = sample_bits == 8 && channels == 3;
     for (int sg = 0; sg <= kMaxSegments; sg++)
-        for (int sb = 3; sb >= 0; sb--)
-            for (int lv = kMaxStages; lv >= 0; lv--)
-                for (int lsb = kPlanes - 1; lsb >= 0; lsb--)
+        for (int isb = 0; isb < 4; isb++)
+            for (int ilv = 0; ilv <= kMaxStages; ilv++)
+                for (int il = 0; il < planes; il++)
                     for (int ch = 0; ch < channels; ch++) {
+                        const int sb = up ? isb : 3 - isb, lv = up ? ilv : kMaxStages - ilv, lsb = up ? il : planes - 1 - il;
                         const int64_t u = where[key(ch, lv, sb, lsb, sg)];
                         if (u >= 0) p->final_order.push_back((uint32_t)u);
                     }

@@ -75,3 +75,13 @@ def color_frame_yuv(w: int, h: int, seed: int = DEFAULT_SEED):
     cb = clip(((36962 * (bb - yy)) >> 16) + 128)
     cr = clip(((46727 * (rr - yy)) >> 16) + 128)
     return yy.astype(np.uint16), cb.astype(np.uint16), cr.astype(np.uint16)
+
+
+def gray_frame_u8(w: int, h: int, seed: int = 12345, mode: int = 1) -> np.ndarray:
+    """Input for the uint8 twins (int8 storage, 7 bit planes): the gray frame >> 2, i.e. 6-bit data."""
+    return (gray_frame(w, h, seed, mode) >> 2).astype(np.uint8)
+
+
+def color_frame_yuv_u8(w: int, h: int, seed: int = 12345):
+    """Y, U, V planes of color_frame_yuv >> 2 as uint8."""
+    return tuple((p >> 2).astype(np.uint8) for p in color_frame_yuv(w, h, seed))

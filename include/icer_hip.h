@@ -2,7 +2,7 @@
  * icer_hip.h -- C ABI of libicer_hip.so, the MI355X (gfx950) ICER encoder.
  *
  * Part 1 restates, with identical names, argument meaning, struct layout and return codes, the
- * entry points of lib_icer that an application needs for ENCODING through the uint16 path
+ * entry points of lib_icer that an application needs for ENCODING: the uint16 path and its uint8 twins
  * (TheRealOrange/icer_compression, lib_icer/inc/icer.h).  A program written against lib_icer links
  * against libicer_hip.so instead of libicer.a and produces byte-identical streams; the work runs
  * on the GPU (there is no CPU fallback: without a usable HIP device every compress call returns
@@ -79,6 +79,24 @@ int icer_compress_image_yuv_uint16(uint16_t *y_channel, uint16_t *u_channel, uin
                                    enum icer_filter_types filt, uint8_t segments,
                                    icer_output_data_buf_typedef *output_data);
 
+/* replaces icer_compress_image_uint8, icer.h:386-387 (lib_icer/src/icer_compress.c:17-166).  The uint8 twins treat
+ * the samples as int8 STORAGE (a pixel value above 127 is a negative number, lib_icer/src/icer_wavelet.c:231) and code
+ * 7 bit planes: only data of at most 7 bits survives the round trip, anything that leaves the int8 range during the
+ * transform makes the call return ICER_INTEGER_OVERFLOW exactly as the reference does.  `image` (host memory, w*h
+ * bytes) is overwritten with the int8 sign-magnitude wavelet coefficients; on ICER_INTEGER_OVERFLOW its contents are
+ * left untouched (the reference leaves partially transformed data there).  ICER_PACKET_COUNT_EXCEEDED is returned for
+ * (3*stages+1)*7*channels >= 300 packets as in the reference, without touching the image. */
+int icer_compress_image_uint8(uint8_t *image, size_t image_w, size_t image_h, uint8_t stages,
+                              enum icer_filter_types filt, uint8_t segments,
+                              icer_output_data_buf_typedef *output_data);
+
+/* replaces icer_compress_image_yuv_uint8, icer.h:388-390 (lib_icer/src/icer_color.c:18-206); note that its final
+ * re-ordering walks subbands, levels and bit planes upwards, unlike the other three entry points. */
+int icer_compress_image_yuv_uint8(uint8_t *y_channel, uint8_t *u_channel, uint8_t *v_channel,
+                                  size_t image_w, size_t image_h, uint8_t stages,
+                                  enum icer_filter_types filt, uint8_t segments,
+                                  icer_output_data_buf_typedef *output_data);
+
 /* ---- Part 2: batched / device-resident extension -------------------------------------------- */
 
 typedef struct icerx_encoder icerx_encoder;
@@ -89,6 +107,9 @@ typedef struct icerx_encoder icerx_encoder;
  * (ICER_TOO_MANY_STAGES, ...), or ICER_FATAL_ERROR when no usable device exists. */
 int icerx_encoder_create(icerx_encoder **enc, int device, size_t w, size_t h, int channels, int stages,
                          int filt, int segments, int max_frames);
+/* The same with the sample width: sample_bits = 16 (as icerx_encoder_create) or 8 for the uint8 twins. */
+int icerx_encoder_create_ex(icerx_encoder **enc, int device, size_t w, size_t h, int channels, int stages,
+                            int filt, int segments, int max_frames, int sample_bits);
 void icerx_encoder_destroy(icerx_encoder *enc);
 
 /* Encode n_frames frames that already live in device memory.
@@ -119,6 +140,11 @@ int icerx_encode_device_u8(icerx_encoder *enc, const uint8_t *d_frames, int n_fr
                            size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
 int icerx_encode_device_rgb8(icerx_encoder *enc, const uint8_t *d_rgb, int n_frames, size_t byte_quota, uint8_t *d_out,
                              size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
+
+/* uint8 twins on device-resident planes (encoder created with sample_bits = 8): n_frames * channels planes of w*h
+ * bytes (int8 storage), otherwise as icerx_encode_device. */
+int icerx_encode_device_s8(icerx_encoder *enc, const uint8_t *d_planes, int n_frames, size_t byte_quota, uint8_t *d_out,
+                           size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
 
 /* Host-buffer convenience wrapper: H2D, icerx_encode_device, D2H, synchronous. */
 int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, size_t byte_quota,

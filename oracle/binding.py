@@ -103,6 +103,18 @@ class Oracle:
         rc = self.lib.orc_compress_u16(ptrs, len(work), w, h, stages, filt, segments, quota, out, C.byref(used))
         return rc, bytes(out[: used.value]), work
 
+    def compress_u8(self, planes, stages, filt, segments, quota):
+        """uint8 twins: planes are (h, w) uint8 arrays (int8 storage).  Returns (rc, stream, mutated planes)."""
+        work = [np.ascontiguousarray(p, dtype=np.uint8).copy() for p in planes]
+        h, w = work[0].shape
+        ptrs = (C.c_void_p * len(work))(*[p.ctypes.data for p in work])
+        out = np.zeros(max(quota, 1), dtype=np.uint8)
+        used = C.c_size_t(0)
+        self.lib.orc_compress_u8.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_uint,
+                                             C.c_size_t, u8p, C.POINTER(C.c_size_t)]
+        rc = self.lib.orc_compress_u8(ptrs, len(work), w, h, stages, filt, segments, quota, out, C.byref(used))
+        return rc, bytes(out[: used.value]), work
+
 
 class Reference:
     """The reference library itself (symbols of lib_icer + ref_tap.c), loaded RTLD_LOCAL because it
@@ -169,6 +181,22 @@ class Reference:
             rc = self.lib.icer_compress_image_uint16(work[0], w, h, stages, filt, segments, C.byref(ob))
         else:
             rc = self.lib.icer_compress_image_yuv_uint16(work[0], work[1], work[2], w, h, stages, filt, segments, C.byref(ob))
+        return rc, bytes(buf[quota: quota + ob.size_used]), work
+
+    def compress_u8(self, planes, stages, filt, segments, quota):
+        work = [np.ascontiguousarray(p, dtype=np.uint8).copy() for p in planes]
+        h, w = work[0].shape
+        buf = np.zeros(2 * quota + 64, dtype=np.uint8)
+        ob = _OutBuf()
+        rc = self.lib.icer_init_output_struct(C.byref(ob), buf.ctypes.data, buf.size, quota)
+        assert rc == 0
+        sz, u8 = C.c_size_t, C.c_uint8
+        if len(work) == 1:
+            self.lib.icer_compress_image_uint8.argtypes = [u8p, sz, sz, u8, C.c_int, u8, C.POINTER(_OutBuf)]
+            rc = self.lib.icer_compress_image_uint8(work[0], w, h, stages, filt, segments, C.byref(ob))
+        else:
+            self.lib.icer_compress_image_yuv_uint8.argtypes = [u8p, u8p, u8p, sz, sz, u8, C.c_int, u8, C.POINTER(_OutBuf)]
+            rc = self.lib.icer_compress_image_yuv_uint8(work[0], work[1], work[2], w, h, stages, filt, segments, C.byref(ob))
         return rc, bytes(buf[quota: quota + ob.size_used]), work
 
     # table taps -------------------------------------------------------------------------

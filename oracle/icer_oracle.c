@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define PLANES 9            /* ICER_BITPLANES_TO_COMPRESS_16, icer.h:44-46 */
+#define MAX_PLANES 9        /* ICER_BITPLANES_TO_COMPRESS_16, icer.h:44-46 (ICER_BITPLANES_TO_COMPRESS_8 = 7, icer.h:41-43) */
 #define RING_WORDS 2048     /* ICER_CIRC_BUF_SIZE, icer.h:27 */
 #define HEADER_BYTES 28     /* sizeof(icer_image_segment_typedef), icer.h:293-305 */
 #define MAX_SEGMENTS 32     /* ICER_MAX_SEGMENTS, icer.h:29-31 */
@@ -48,9 +48,15 @@ static const int FILT[7][4] = {   /* alpha_-1, alpha_0, alpha_1, beta   (x16) */
     {0, 4, 4, 0}, {0, 4, 6, 4}, {-1, 4, 8, 6}, {0, 4, 5, 2}, {0, 3, 8, 6}, {0, 3, 9, 8}, {0, 4, 4, 4}};
 
 static int fits16(int32_t v) { return v >= -32768 && v <= 32767; }
+static int fits8(int32_t v) { return v >= -128 && v <= 127; }
 
-int orc_dwt_1d(int16_t *line, size_t n, size_t stride, int filt)
+/* `bits` = 16: icer_wavelet_transform_1d_uint16 (icer_wavelet.c:385-465); `bits` = 8: its int8 twin
+ * (icer_wavelet.c:215-296), whose samples live sign-extended in the int16 line: stores truncate to int8 and
+ * flag overflow at the int8 bounds, r[] is formed in int16 without wrapping (get_r_int8 :196-198). */
+static int dwt_1d_bits(int16_t *line, size_t n, size_t stride, int filt, int bits)
 {
+#define FITS(v) (bits == 8 ? fits8(v) : fits16(v))
+#define TRUNC(v) (bits == 8 ? (int16_t)(int8_t)(v) : (int16_t)(v))
     size_t nl = (n + 1) / 2, nh = n / 2;
     int odd = (int)(n & 1);
     int overflow = 0;
@@ -62,11 +68,11 @@ int orc_dwt_1d(int16_t *line, size_t n, size_t stride, int filt)
     for (size_t k = 0; k < nh; k++) {
         int32_t a = line[(2 * k) * stride], b = line[(2 * k + 1) * stride];
         int32_t l = floordiv(a + b, 2), h = a - b;
-        if (!fits16(l) || !fits16(h)) overflow = 1;
-        lo[k] = (int16_t)l;
-        hi[k] = (int16_t)h;
+        if (!FITS(l) || !FITS(h)) overflow = 1;
+        lo[k] = TRUNC(l);
+        hi[k] = TRUNC(h);
     }
-    if (odd) lo[nl - 1] = line[(n - 1) * stride];        /* lone last sample is a low */
+    if (odd) lo[nl - 1] = line[(n - 1) * stride];        /* lone last sample is a low (always in range) */
     hi[nh] = 0;                                          /* get_d_int16 :210-212: missing last high reads as 0 */
 
     /* step 2 (icer_wavelet.c:430-462).  r[k] = (int16)(lo[k-1]-lo[k]) -- QUIRK W1b: the
@@ -90,13 +96,31 @@ int orc_dwt_1d(int16_t *line, size_t n, size_t stride, int filt)
             sub = floordiv(am1 * rm + a0 * R(k) + a1 * R(k + 1) - be * dn + 8, 16);
         }
         int32_t h = (int32_t)hi[k] - sub;
-        if (!fits16(h)) overflow = 1;
-        out[k] = (int16_t)h;
+        if (!FITS(h)) overflow = 1;
+        out[k] = TRUNC(h);
     }
 #undef R
+#undef FITS
+#undef TRUNC
     for (size_t k = 0; k < nl; k++) line[k * stride] = lo[k];
     for (size_t k = 0; k < nh; k++) line[(nl + k) * stride] = out[k];
     free(lo); free(hi); free(out);
+    return overflow ? ORC_INTEGER_OVERFLOW : ORC_OK;
+}
+
+int orc_dwt_1d(int16_t *line, size_t n, size_t stride, int filt) { return dwt_1d_bits(line, n, stride, filt, 16); }
+
+static int dwt_stages_bits(int16_t *s, size_t w, size_t h, int stages, int filt, int bits)
+{
+    if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return ORC_TOO_MANY_STAGES;
+    int overflow = 0;
+    size_t cw = w, ch = h;
+    for (int st = 0; st < stages; st++) {
+        for (size_t r = 0; r < ch; r++) overflow |= (dwt_1d_bits(s + r * w, cw, 1, filt, bits) != ORC_OK);
+        for (size_t c = 0; c < cw; c++) overflow |= (dwt_1d_bits(s + c, ch, w, filt, bits) != ORC_OK);
+        cw = (cw + 1) / 2;
+        ch = (ch + 1) / 2;
+    }
     return overflow ? ORC_INTEGER_OVERFLOW : ORC_OK;
 }
 
@@ -189,7 +213,12 @@ int orc_partition_rects(const orc_partition *p, orc_rect *rects)
  * comparator icer_compress.c:8-15).  glibc's qsort is a stable merge sort, so ties keep
  * generation order: restated here as a stable insertion sort.
  * ---------------------------------------------------------------------------------------- */
-int orc_packet_list(orc_packet *out, int stages, int channels)
+static int packet_list_planes(orc_packet *out, int stages, int channels, int PLANES);
+int orc_packet_list(orc_packet *out, int stages, int channels) { return packet_list_planes(out, stages, channels, 9); }
+
+/* `PLANES` = ICER_BITPLANES_TO_COMPRESS_16 (9) or ICER_BITPLANES_TO_COMPRESS_8 (7); the uint8 variants
+ * (icer_compress.c:53-103, icer_color.c:73-131) are otherwise the same code */
+static int packet_list_planes(orc_packet *out, int stages, int channels, int PLANES)
 {
     int n = 0;
     if (channels == 1) {
@@ -561,6 +590,10 @@ typedef struct {
 static void put16(uint8_t *p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 static void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
+static int compress_core(uint16_t *const planes[], const uint16_t mean[3], int channels, size_t w, size_t h, int stages,
+                         unsigned segments, size_t quota, uint8_t *out, size_t *size_used,
+                         int PLANES, int max_packets, int yuv_order_up);
+
 int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
                      unsigned segments, size_t quota, uint8_t *out, size_t *size_used)
 {
@@ -590,13 +623,23 @@ int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h,
             for (size_t c = 0; c < llw; c++) s[r * w + c] = (int16_t)(s[r * w + c] - (int16_t)mean[ch]);
         orc_sign_magnitude(planes[ch], w * h);
     }
+    return compress_core(planes, mean, channels, w, h, stages, segments, quota, out, size_used, 9, MAX_PACKETS, 0);
+}
 
+/* packets in priority order -> coding units -> quota rule -> final order.  `planes` hold sign-magnitude words
+ * (bit 15 sign).  Shared by the uint16 (icer_compress.c:304-426, icer_color.c:388-530) and uint8
+ * (icer_compress.c:43-166, icer_color.c:62-206) entry points, which differ in the plane count, the packet-table
+ * size and -- YUV only -- the direction of the final re-ordering loops. */
+static int compress_core(uint16_t *const planes[], const uint16_t mean[3], int channels, size_t w, size_t h, int stages,
+                         unsigned segments, size_t quota, uint8_t *out, size_t *size_used,
+                         int PLANES, int max_packets, int yuv_order_up)
+{
     orc_packet pk[MAX_PACKETS];
-    if ((3 * stages + 1) * PLANES * channels >= MAX_PACKETS) return ORC_PACKET_COUNT_EXCEEDED;
-    int npk = orc_packet_list(pk, stages, channels);
+    if ((3 * stages + 1) * PLANES * channels >= max_packets) return ORC_PACKET_COUNT_EXCEEDED;
+    int npk = packet_list_planes(pk, stages, channels, PLANES);
 
     /* kept units, addressed [chan][level][subband][lsb][segment] for the final re-ordering */
-    static unit_blob kept[3][MAX_STAGES + 1][4][PLANES][MAX_SEGMENTS + 1];
+    static unit_blob kept[3][MAX_STAGES + 1][4][MAX_PLANES][MAX_SEGMENTS + 1];
     memset(kept, 0, sizeof kept);
 
     int rc = ORC_OK;
@@ -646,13 +689,16 @@ int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h,
     }
 
     /* D7: final order  segment up, subband down, level down, plane down, channel up
-     * (icer_compress.c:409-423, icer_color.c:508-527) */
+     * (icer_compress.c:409-423 and :148-162, icer_color.c:508-527); the uint8 YUV variant walks subband, level and
+     * plane UP instead (icer_color.c:184-202) */
     size_t off = 0;
     for (int sg = 0; sg <= MAX_SEGMENTS; sg++)
-        for (int sb = 3; sb >= 0; sb--)
-            for (int lv = MAX_STAGES; lv >= 0; lv--)
-                for (int lsb = PLANES - 1; lsb >= 0; lsb--)
+        for (int isb = 0; isb < 4; isb++)
+            for (int ilv = 0; ilv <= MAX_STAGES; ilv++)
+                for (int il = 0; il < PLANES; il++)
                     for (int ch = 0; ch < channels; ch++) {
+                        const int sb = yuv_order_up ? isb : 3 - isb, lv = yuv_order_up ? ilv : MAX_STAGES - ilv;
+                        const int lsb = yuv_order_up ? il : PLANES - 1 - il;
                         unit_blob *u = &kept[ch][lv][sb][lsb][sg];
                         if (!u->bytes) continue;
                         memcpy(out + off, u->bytes, u->len);
@@ -661,5 +707,53 @@ int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h,
                         u->bytes = NULL;
                     }
     *size_used = off;
+    return rc;
+}
+
+/* uint8 twins (icer_compress.c:17-166, icer_color.c:18-206): samples are int8 storage.  `planes8[c]` are mutated
+ * in place like the reference does (int8 DWT, LL-mean removal modulo 256, int8 sign-magnitude :852-858). */
+int orc_compress_u8(uint8_t *const planes8[], int channels, size_t w, size_t h, int stages, int filt,
+                    unsigned segments, size_t quota, uint8_t *out, size_t *size_used)
+{
+    *size_used = 0;
+    if (channels != 1 && channels != 3) return ORC_INVALID_INPUT;
+    if (stages < 1 || stages > MAX_STAGES) return ORC_TOO_MANY_STAGES;
+    uint16_t *wide[3] = {NULL, NULL, NULL};
+    int rc = ORC_OK;
+    for (int ch = 0; ch < channels; ch++) {
+        wide[ch] = (uint16_t *)malloc(sizeof(uint16_t) * w * h);
+        for (size_t i = 0; i < w * h; i++) wide[ch][i] = (uint16_t)(int16_t)(int8_t)planes8[ch][i];
+    }
+    for (int ch = 0; ch < channels && rc == ORC_OK; ch++)
+        rc = dwt_stages_bits((int16_t *)wide[ch], w, h, stages, filt, 8);
+    size_t llw = dim_low(w, stages), llh = dim_low(h, stages);
+    uint16_t mean[3] = {0, 0, 0};
+    if (rc == ORC_OK) {
+        /* icer_compress.c:24-38: the LL samples are summed as uint8, the mean must fit int8 */
+        for (int ch = 0; ch < channels; ch++) {
+            uint64_t sum = 0;
+            for (size_t r = 0; r < llh; r++)
+                for (size_t c = 0; c < llw; c++) sum += (uint8_t)wide[ch][r * w + c];
+            mean[ch] = (uint8_t)(sum / (llw * llh));
+        }
+        for (int ch = 0; ch < channels; ch++)
+            if (mean[ch] > 127) rc = ORC_INTEGER_OVERFLOW;
+    }
+    if (rc == ORC_OK) {
+        for (int ch = 0; ch < channels; ch++) {
+            int16_t *s16 = (int16_t *)wide[ch];
+            for (size_t r = 0; r < llh; r++)
+                for (size_t c = 0; c < llw; c++) s16[r * w + c] = (int16_t)(int8_t)(s16[r * w + c] - (int16_t)(int8_t)mean[ch]);
+            for (size_t i = 0; i < w * h; i++) {
+                /* icer_to_sign_magnitude_int8: -128 becomes 0x80 (sign set, magnitude 0) */
+                const int8_t v = (int8_t)s16[i];
+                const uint8_t m = v < 0 ? (uint8_t)(0x80u | ((uint8_t)(-(int)v) & 0x7Fu)) : (uint8_t)v;
+                planes8[ch][i] = m;
+                wide[ch][i] = (uint16_t)(((m & 0x80u) << 8) | (m & 0x7Fu));
+            }
+        }
+        rc = compress_core(wide, mean, channels, w, h, stages, segments, quota, out, size_used, 7, 300, channels == 3);
+    }
+    for (int ch = 0; ch < channels; ch++) free(wide[ch]);
     return rc;
 }

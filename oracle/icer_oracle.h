@@ -55,6 +55,10 @@ int      orc_pick_bin(uint32_t zero, uint32_t total);
 int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
                      unsigned segments, size_t quota, uint8_t *out, size_t *size_used);
 
+/* uint8 twins (icer_compress_image_uint8 / icer_compress_image_yuv_uint8): int8 storage, 7 bit planes */
+int orc_compress_u8(uint8_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
+                    unsigned segments, size_t quota, uint8_t *out, size_t *size_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,19 @@ def emu():
             return rc, bytes(out[: used.value]), work, bo.value
 
         @staticmethod
+        def compress_u8(planes, stages, filt, segs, quota, bpp=3):
+            """uint8 twins through the emulated pipeline; returns the planes as int8 sign-magnitude bytes"""
+            work = [np.ascontiguousarray(p, dtype=np.uint8).astype(np.int8).astype(np.int16).view(np.uint16).copy() for p in planes]
+            h, w = work[0].shape
+            ptrs = (C.c_void_p * len(work))(*[p.ctypes.data for p in work])
+            out = np.zeros(max(quota, 1) + 64, np.uint8)
+            used, bo = C.c_size_t(0), C.c_int(0)
+            L.emu_compress_bits.argtypes = L.emu_compress.argtypes + [C.c_int]
+            rc = L.emu_compress_bits(ptrs, len(work), w, h, stages, filt, segs, quota, bpp, out, C.byref(used), C.byref(bo), 8)
+            back = [(((p >> 8) & 0x80) | (p & 0x7F)).astype(np.uint8) for p in work]
+            return rc, bytes(out[: used.value]), back, bo.value
+
+        @staticmethod
         def code_unit(plane, x, y, w, h, sb, lsb, cap=None):
             cap = cap if cap is not None else ((w * h * 3 + 64) + 3) // 4 * 4
             out = np.zeros(cap + 8, np.uint8)

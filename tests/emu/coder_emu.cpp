@@ -38,13 +38,16 @@ extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t st
 
 // forward DWT with the structure of the product: one fused LDS-tile pass per stage (csrc/dwt_tile.hpp), the LL
 // band handed from stage to stage through a side buffer, the three detail bands written in place
-extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt)
+static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim);
+extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt) { return emu_dwt_lim(img, w, h, stages, filt, 32767); }
+static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim)
 {
     if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return kTooManyStages;
     std::vector<int16_t> src((int16_t *)img, (int16_t *)img + w * h), tmp(w * h);
     int16_t *coef = (int16_t *)img;
     static DwtTileShared sh;
     DwtStageArgs a;
+    a.lim = lim;
     a.f = filter_taps(filt);
     a.coef = coef; a.coef_stride = (uint32_t)w;
     a.src = src.data(); a.src_stride = (uint32_t)w;
@@ -70,32 +73,49 @@ extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt)
 }
 
 // whole-frame pipeline with the structure of api.hip::enqueue, on host memory
+extern "C" int emu_compress_bits(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
+                                 int segments, size_t quota, unsigned bits_per_pixel, uint8_t *out, size_t *size_used,
+                                 int *bound_overflow, int sample_bits);
 extern "C" int emu_compress(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
                             int segments, size_t quota, unsigned bits_per_pixel, uint8_t *out, size_t *size_used,
                             int *bound_overflow)
 {
+    return emu_compress_bits(planes, channels, w, h, stages, filt, segments, quota, bits_per_pixel, out, size_used, bound_overflow, 16);
+}
+// sample_bits = 8: the uint8 twins; `planes` then hold the int8 samples sign-extended (what widen_s8_kernel produces)
+extern "C" int emu_compress_bits(uint16_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
+                                 int segments, size_t quota, unsigned bits_per_pixel, uint8_t *out, size_t *size_used,
+                                 int *bound_overflow, int sample_bits)
+{
     *size_used = 0;
     *bound_overflow = 0;
     Plan plan;
-    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    int rc = build_plan(&plan, w, h, channels, stages, segments, sample_bits);
     if (rc) return rc;
     for (int c = 0; c < channels; c++)
-        if ((rc = emu_dwt(planes[c], w, h, stages, filt)) != kOk) return rc;
+        if ((rc = emu_dwt_lim(planes[c], w, h, stages, filt, sample_bits == 8 ? 127 : 32767)) != kOk) return rc;
     const size_t llw = dim_low(w, stages), llh = dim_low(h, stages);
     uint16_t means[3];
     for (int c = 0; c < channels; c++) {
         unsigned long long sum = 0;
         for (size_t r = 0; r < llh; r++)
-            for (size_t x = 0; x < llw; x++) sum += planes[c][r * w + x];
-        means[c] = (uint16_t)(sum / (llw * llh));
+            for (size_t x = 0; x < llw; x++) sum += planes[c][r * w + x] & (sample_bits == 8 ? 0xFFu : 0xFFFFu);   // ll_sum_kernel
+        means[c] = sample_bits == 8 ? (uint16_t)(uint8_t)(sum / (llw * llh)) : (uint16_t)(sum / (llw * llh));     // ll_mean_kernel
     }
     for (int c = 0; c < channels; c++)
-        if (means[c] > 32767) return kIntegerOverflow;
+        if (means[c] > (sample_bits == 8 ? 127 : 32767)) return kIntegerOverflow;
     for (int c = 0; c < channels; c++)
         for (size_t r = 0; r < h; r++)
             for (size_t x = 0; x < w; x++) {   // finalize_kernel
                 int16_t v = (int16_t)planes[c][r * w + x];
                 if (r < llh && x < llw) v = (int16_t)(v - (int16_t)means[c]);
+                if (sample_bits == 8) {
+                    const int8_t v8 = (int8_t)v;
+                    const uint8_t m8 = (uint8_t)(v8 >> 7);
+                    const uint8_t sm = (uint8_t)((((uint8_t)v8 + m8) ^ m8) | ((uint8_t)v8 & 0x80u));
+                    planes[c][r * w + x] = (uint16_t)(((sm & 0x80u) << 8) | (sm & 0x7Fu));
+                    continue;
+                }
                 const uint16_t mask = (uint16_t)(v >> 15);
                 planes[c][r * w + x] = (uint16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
             }

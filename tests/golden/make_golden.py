@@ -31,22 +31,48 @@ CASES = [
     ("C4_2048_frame0", "gray", 2048, 2048, 4, 0, 16, 2 * 2048 * 2048, 12345, 1),
     ("C4_2048_frame1", "gray", 2048, 2048, 4, 0, 16, 2 * 2048 * 2048, 12346, 1),
     ("C5_8192_frame0", "gray", 8192, 8192, 6, 0, 32, 2 * 8192 * 8192, 12345, 1),
+    # uint8 twins: the same synthetic frames >> 2, i.e. 6-bit data that stays inside int8
+    ("u8_512_gray", "gray8", 512, 512, 3, 0, 10, 2 * 512 * 512, 12345, 1),
+    ("u8_517x389_filtB_quota", "gray8", 517, 389, 4, 1, 7, 20000, 777, 1),
+    ("u8_2048_gray_4st_16seg", "gray8", 2048, 2048, 4, 0, 16, 2 * 2048 * 2048, 12345, 1),
+    ("u8_512_yuv_4st", "yuv8", 512, 512, 4, 0, 10, 2 * 512 * 512, 12345, 1),
+    ("u8_512_yuv_quota", "yuv8", 512, 512, 3, 0, 8, 60000, 12345, 1),
+    ("u8_256_yuv_5st_packet_table", "yuv8", 256, 256, 5, 0, 4, 1 << 20, 12345, 1),
+    ("u8_512_gray_full_range_overflow", "gray8full", 512, 512, 3, 0, 10, 2 * 512 * 512, 12345, 0),
 ]
+
+
+def planes_of(kind, w, h, seed, mode):
+    if kind == "gray":
+        return [synth.gray_frame(w, h, seed, mode)]
+    if kind == "yuv":
+        return list(synth.color_frame_yuv(w, h, seed))
+    if kind == "gray8":
+        return [synth.gray_frame_u8(w, h, seed, mode)]
+    if kind == "gray8full":
+        return [synth.gray_frame(w, h, seed, mode).astype("uint8")]
+    return list(synth.color_frame_yuv_u8(w, h, seed))
 
 
 def main():
     ref = Reference()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json")
     out = {}
+    if "--only-missing" in sys.argv and os.path.exists(path):      # (the 8192 x 8192 entry takes minutes)
+        with open(path) as fh:
+            out = json.load(fh)
     for name, kind, w, h, st, f, sg, q, seed, mode in CASES:
-        planes = [synth.gray_frame(w, h, seed, mode)] if kind == "gray" else list(synth.color_frame_yuv(w, h, seed))
+        if name in out:
+            continue
+        planes = planes_of(kind, w, h, seed, mode)
         t = time.time()
-        rc, stream, _ = ref.compress(planes, st, f, sg, q)
+        rc, stream, _ = (ref.compress_u8 if kind.endswith(("8", "8full")) else ref.compress)(planes, st, f, sg, q)
         dt = time.time() - t
         out[name] = dict(kind=kind, w=w, h=h, stages=st, filt=f, segments=sg, quota=q, seed=seed, mode=mode, rc=rc,
                          size=len(stream), crc32="%08x" % zlib.crc32(stream), sha256_16=hashlib.sha256(stream).hexdigest()[:16],
                          ref_seconds=round(dt, 3))
         print(name, out[name], flush=True)
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json"), "w") as fh:
+    with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
 
 

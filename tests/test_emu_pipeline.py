@@ -103,3 +103,31 @@ def _subband_area(w, h, lv, sb):
     sw = low(w, lv) if sb in (0, 2) else high(w, lv)
     sh = low(h, lv) if sb in (0, 1) else high(h, lv)
     return sw * sh
+
+
+def _u8_cases():
+    rng = np.random.default_rng(21)
+    for trial in range(40):
+        w, h = int(rng.integers(8, 150)), int(rng.integers(8, 150))
+        st = int(rng.integers(1, 6))
+        while ((w + (1 << st) - 1) >> st) < 3 or ((h + (1 << st) - 1) >> st) < 3:
+            st -= 1
+        sg = int(rng.integers(1, 17))
+        sg = min(sg, ((w + (1 << st) - 1) >> st) * ((h + (1 << st) - 1) >> st))
+        ch = 3 if trial % 3 == 0 else 1
+        amp, base = int(rng.choice([4, 8, 16, 30, 60, 127, 255])), int(rng.choice([0, 10, 40]))
+        planes = [np.clip(base + rng.integers(0, amp + 1, (h, w)), 0, 255).astype(np.uint8) for _ in range(ch)]
+        quota = int(rng.choice([w * h * 2 + 100, w * h * 2 + 100, 500, 3000]))
+        yield planes, st, int(rng.integers(0, 7)), sg, quota
+
+
+def test_uint8_twins_pipeline(emu, oracle):
+    """7 planes, int8 overflow rules, the 300-packet table and the upward final order of the uint8 YUV variant."""
+    seen = set()
+    for planes, st, filt, sg, quota in _u8_cases():
+        a, b = oracle.compress_u8(planes, st, filt, sg, quota), emu.compress_u8(planes, st, filt, sg, quota)
+        seen.add(a[0])
+        assert a[0] == b[0] and a[1] == b[1], (len(planes), planes[0].shape, st, filt, sg, quota, a[0], b[0])
+        if a[0] in (0, -5):
+            assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+    assert {0, -1, -5} <= seen, seen

@@ -187,3 +187,66 @@ def test_golden_vectors_full_size(golden, name):
     assert rc == g["rc"] and len(stream) == g["size"]
     assert "%08x" % zlib.crc32(stream) == g["crc32"]
     assert hashlib.sha256(stream).hexdigest()[:16] == g["sha256_16"]
+
+
+# ---- uint8 twins ------------------------------------------------------------------------------------
+def _u8_planes(g):
+    if g["kind"] == "gray8":
+        return [synth.gray_frame_u8(g["w"], g["h"], g["seed"], g["mode"])]
+    if g["kind"] == "gray8full":
+        return [synth.gray_frame(g["w"], g["h"], g["seed"], g["mode"]).astype(np.uint8)]
+    return list(synth.color_frame_yuv_u8(g["w"], g["h"], g["seed"]))
+
+
+U8_GOLDEN = ["u8_512_gray", "u8_517x389_filtB_quota", "u8_2048_gray_4st_16seg", "u8_512_yuv_4st", "u8_512_yuv_quota",
+             "u8_256_yuv_5st_packet_table", "u8_512_gray_full_range_overflow"]
+
+
+@pytest.mark.parametrize("name", U8_GOLDEN)
+def test_uint8_twins_golden_vectors(golden, oracle, name):
+    """icer_compress_image_uint8 / icer_compress_image_yuv_uint8 of libicer_hip.so against the reference's digests and,
+    for the in-place side effect on the image, against the oracle."""
+    g = golden[name]
+    planes = _u8_planes(g)
+    rc, stream, left = api.compress_u8(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+    assert rc == g["rc"] and len(stream) == g["size"]
+    assert "%08x" % zlib.crc32(stream) == g["crc32"] and hashlib.sha256(stream).hexdigest()[:16] == g["sha256_16"]
+    if rc in (0, -5):
+        want = oracle.compress_u8(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+        assert all(np.array_equal(a, b) for a, b in zip(left, want[2]))
+
+
+def test_uint8_twins_random_cases(oracle):
+    rng = np.random.default_rng(31)
+    seen = set()
+    for trial in range(60):
+        w, h = int(rng.integers(8, 300)), int(rng.integers(8, 300))
+        st = int(rng.integers(1, 7))
+        while ((w + (1 << st) - 1) >> st) < 3 or ((h + (1 << st) - 1) >> st) < 3:
+            st -= 1
+        sg = min(int(rng.integers(1, 33)), ((w + (1 << st) - 1) >> st) * ((h + (1 << st) - 1) >> st))
+        ch = 3 if trial % 3 == 0 else 1
+        amp, base = int(rng.choice([4, 8, 16, 30, 60, 127, 255])), int(rng.choice([0, 10, 40]))
+        planes = [np.clip(base + rng.integers(0, amp + 1, (h, w)), 0, 255).astype(np.uint8) for _ in range(ch)]
+        quota = int(rng.choice([w * h * 2 + 100, w * h * 2 + 100, 500, 3000]))
+        filt = int(rng.integers(0, 7))
+        a, b = api.compress_u8(planes, st, filt, sg, quota), oracle.compress_u8(planes, st, filt, sg, quota)
+        seen.add(b[0])
+        assert a[0] == b[0] and a[1] == b[1], (trial, w, h, st, filt, sg, ch, amp, base, quota, a[0], b[0])
+        if b[0] in (0, -5):
+            assert all(np.array_equal(p, q) for p, q in zip(a[2], b[2]))
+    assert {0, -1, -5} <= seen
+
+
+def test_uint8_twins_device_resident_batch(oracle):
+    """icerx_encoder_create_ex(sample_bits = 8) + icerx_encode_device_s8 on a batch of frames"""
+    import torch
+    w, h, st, sg, n = 256, 192, 3, 6, 5
+    frames = np.stack([synth.gray_frame_u8(w, h, 100 + k, 1) for k in range(n)])
+    quota = 2 * w * h
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=n, sample_bits=8)
+    res = enc.encode_torch_s8(torch.from_numpy(frames).cuda(), quota)
+    enc.close()
+    for k in range(n):
+        rc, stream, _ = oracle.compress_u8([frames[k]], st, 0, sg, quota)
+        assert res[k] == (rc, stream)

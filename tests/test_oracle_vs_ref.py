@@ -78,15 +78,48 @@ def test_yuv_streams_and_16bit(oracle, reference):
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2][0], b[2][0])
 
 
-SMALL_GOLDEN = ["kat_512_m1", "kat_512_m0", "kat_512_quota30000", "kat_odd_517x389_filtC", "kat_color_512_quota"]
+def test_uint8_twins(oracle, reference):
+    """icer_compress_image_uint8 / _yuv_uint8: int8 storage, 7 planes, 300-packet table, and the
+    upward final order of the YUV variant.  (A first packet whose subband has fewer pixels than segments is undefined
+    behaviour in the reference and excluded.)"""
+    rng = np.random.default_rng(11)
+    seen = {}
+    for trial in range(150):
+        w, h = int(rng.integers(5, 200)), int(rng.integers(5, 200))
+        st = int(rng.integers(1, 7))
+        while ((w + (1 << st) - 1) >> st) < 3 or ((h + (1 << st) - 1) >> st) < 3:
+            st -= 1
+        sg = min(int(rng.integers(1, 33)), ((w + (1 << st) - 1) >> st) * ((h + (1 << st) - 1) >> st))
+        ch = 3 if trial % 3 == 0 else 1
+        amp, base = int(rng.choice([4, 8, 16, 30, 60, 127, 255])), int(rng.choice([0, 10, 40]))
+        planes = [np.clip(base + rng.integers(0, amp + 1, (h, w)), 0, 255).astype(np.uint8) for _ in range(ch)]
+        quota = int(rng.choice([w * h * 2 + 100, w * h * 2 + 100, 500, 3000, 200]))
+        filt = int(rng.integers(0, 7))
+        a, b = reference.compress_u8(planes, st, filt, sg, quota), oracle.compress_u8(planes, st, filt, sg, quota)
+        seen[a[0]] = seen.get(a[0], 0) + 1
+        assert a[0] == b[0] and a[1] == b[1], (trial, w, h, st, filt, sg, ch, amp, base, quota, a[0], b[0])
+        if a[0] in (0, -5):
+            assert all(np.array_equal(p, r) for p, r in zip(a[2], b[2]))
+    assert seen.get(0, 0) >= 5 and seen.get(-5, 0) >= 5 and seen.get(-1, 0) >= 5 and seen.get(-9, 0) >= 1, seen
+
+
+SMALL_GOLDEN = ["kat_512_m1", "kat_512_m0", "kat_512_quota30000", "kat_odd_517x389_filtC", "kat_color_512_quota",
+                "u8_512_gray", "u8_517x389_filtB_quota", "u8_512_yuv_4st", "u8_512_yuv_quota", "u8_256_yuv_5st_packet_table",
+                "u8_512_gray_full_range_overflow"]
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDEN)
 def test_oracle_reproduces_golden_vectors(oracle, golden, name):
     """Runs everywhere (no reference needed): the committed digests came from the reference build."""
     g = golden[name]
-    planes = [synth.gray_frame(g["w"], g["h"], g["seed"], g["mode"])] if g["kind"] == "gray" else \
-        list(synth.color_frame_yuv(g["w"], g["h"], g["seed"]))
-    rc, stream, _ = oracle.compress(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+    if g["kind"] in ("gray8", "gray8full", "yuv8"):
+        planes = [synth.gray_frame_u8(g["w"], g["h"], g["seed"], g["mode"])] if g["kind"] == "gray8" else \
+            [synth.gray_frame(g["w"], g["h"], g["seed"], g["mode"]).astype(np.uint8)] if g["kind"] == "gray8full" else \
+            list(synth.color_frame_yuv_u8(g["w"], g["h"], g["seed"]))
+        rc, stream, _ = oracle.compress_u8(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+    else:
+        planes = [synth.gray_frame(g["w"], g["h"], g["seed"], g["mode"])] if g["kind"] == "gray" else \
+            list(synth.color_frame_yuv(g["w"], g["h"], g["seed"]))
+        rc, stream, _ = oracle.compress(planes, g["stages"], g["filt"], g["segments"], g["quota"])
     assert rc == g["rc"] and len(stream) == g["size"] and "%08x" % zlib.crc32(stream) == g["crc32"]
     assert hashlib.sha256(stream).hexdigest()[:16] == g["sha256_16"]
