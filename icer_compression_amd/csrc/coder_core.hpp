@@ -764,7 +764,7 @@ ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
     {
         LV(ww.node) = 1;
         LV(ww.cb) = (lane >= 1 && lane <= 7) ? (uint32_t)lane : (uint32_t)s.tab.cand_bin[lane];
-        LV(ww.ce) = s.tab.cand_node[lane];
+        LV(ww.ce) = LV(ww.cb) ? (uint32_t)s.tab.node_c[LV(ww.cb) & 7u][s.tab.cand_node[lane]] & 7u : 0u;
     }
     ww.next = 0;
     ww.gen = 0;
@@ -828,9 +828,10 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
             const uint32_t b = LV(ww.cb);
             const bool first = lane >= 1 && lane <= 7;
             const uint32_t n = b ? (uint32_t)q.binn[b] : 0u;
-            const uint32_t h = n >= 16u ? (((n >> 1) + 3u) & ~3u) : n;          // (short walks are not worth splitting)
+            const uint32_t h = n >= 18u ? (n + 1u) >> 1 : n;                     // (short walks are not worth splitting)
             const uint32_t r0 = first ? 0u : h, len = first ? h : n - h;
-            uint32_t node = first ? LV(ww.node) : LV(ww.ce);
+            // compact node number (0 = root); the candidates' ones were looked up once (walk_wave_init)
+            uint32_t node = first ? (uint32_t)s.tab.node_c[b & 7u][LV(ww.node)] : LV(ww.ce);
             uint64_t st_lo = 0;
             if (b && len) {
                 uint64_t lo = ((uint64_t)q.binbits[b][0] | ((uint64_t)q.binbits[b][1] << 32)) >> 8;      // ranks 0..55
@@ -841,23 +842,21 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
                 if (r0 == 64u) { lo = hi; hi = 0; }
                 else if (r0) { lo = (lo >> r0) | (hi << (64u - r0)); hi >>= r0; }                            // the segment starts at bit 0
                 uint32_t r = 0;
-                for (; r + 4u <= len; r += 4) {
-                    const uint32_t e = s.tab.v2v_step[b][node][(uint32_t)(lo >> r) & 15u];
-                    st_lo |= (uint64_t)((e >> 5) & 15u) << r;
-                    node = e & 31u;
+                for (; r + 6u <= len; r += 6) {
+                    const uint32_t e = s.tab.v2v_step6[b][node][(uint32_t)(lo >> r) & 63u];
+                    st_lo |= (uint64_t)(e >> 4) << r;
+                    node = e & 7u;
                 }
-                for (; r < len; r++) {                          // last 1..3 bits one at a time (only where the segment ends at n)
-                    const uint32_t bit = (uint32_t)((lo >> r) & 1ull);
-                    if (node == 1u) st_lo |= 1ull << r;
-                    // one step: append the bit, back to the root when the input is a code word
-                    uint32_t nin = 31u - (uint32_t)clz32(node);
-                    uint32_t acc = (node ^ (1u << nin)) | (bit << nin);
-                    nin++;
-                    node = (nin == 5u || ((s.tab.v2v_term[b][nin] >> acc) & 1u)) ? 1u : (acc | (1u << nin));
+                if (r < len) {                                  // last 1..5 bits: flags from the zero-padded step, node from the tail table
+                    const uint32_t k = len - r, bits = (uint32_t)(lo >> r) & ((1u << k) - 1u);
+                    const uint32_t e = s.tab.v2v_step6[b][node][bits];
+                    st_lo |= (uint64_t)((e >> 4) & ((1u << k) - 1u)) << r;
+                    node = s.tab.v2v_tail[b][node][(1u << k) | bits];
                 }
             }
             LV(stl0) = (uint32_t)st_lo; LV(stl1) = (uint32_t)(st_lo >> 32);
-            LV(wnode) = node; LV(wh) = h; LV(wn) = n;
+            LV(wnode) = b ? (uint32_t)s.tab.node_full[b & 7u][node & 7u] : 1u;   // back to the tree's own numbering
+            LV(wh) = h; LV(wn) = n;
         }
         ICER_TICK(7)
         // lane b fetches the second half from the lane that started at the node the first half ended in

@@ -47,10 +47,15 @@ struct CoderTables {
     uint16_t v2v[8][32];
     // bins 1..7: [bin][n] = set of input values that are complete code words of n input bits (bit v set)
     uint32_t v2v_term[8][8];
-    // bins 1..7: four input bits at a time.  A node of the code tree is numbered (partial input | 1 << bits so
-    // far), the root is 1.  [bin][node][nibble] -> node after the 4 bits | (bit k set: a code word starts at the
-    // k-th of the 4 bits) << 5
-    uint16_t v2v_step[8][32][16];
+    // bins 1..7: SIX input bits at a time.  A node of the code tree is numbered (partial input | 1 << bits so far),
+    // the root is 1; the trees have at most 8 nodes, numbered compactly 0..7 (root = 0) by node_c / node_full.
+    // v2v_step6[bin][compact node][6 bits] -> compact node after the 6 bits | (bit k set: a code word starts at the
+    // k-th of the 6 bits) << 4.  The last 1..5 bits of a walk use the same entry for the start flags (padded with
+    // zeros: a flag depends on earlier bits only) and v2v_tail[bin][compact node][1 << k | bits] for the node after k bits.
+    uint16_t v2v_step6[8][8][64];
+    uint8_t v2v_tail[8][8][64];
+    uint8_t node_c[8][32];      // node -> compact number (0xFF: not a node of this bin's tree)
+    uint8_t node_full[8][8];    // compact number -> node
     // the walker wave splits a bin's walk in two: lanes 1..7 walk the first half from the known node, lane L >= 8
     // walks the second half of bin cand_bin[L] assuming it is entered at node cand_node[L] (one lane per node of
     // the bin's code tree, 46 in all; cand_bin = 0: lane unused); cand_lane[bin][node] = that lane
@@ -95,20 +100,44 @@ inline void build_coder_tables(CoderTables *t)
         t->v2v[c.bin][c.val] = (uint16_t)(c.nin | (c.nout << 4) | (c.code << 8));
         t->v2v_term[c.bin][c.nin] |= 1u << c.val;
     }
-    for (int b = 1; b <= 7; b++)
-        for (uint32_t node = 1; node < 32; node++)
-            for (uint32_t nib = 0; nib < 16; nib++) {
-                uint32_t nin = 0;
-                while ((2u << nin) <= node) nin++;                 // node = acc | 1 << nin
-                uint32_t acc = node ^ (1u << nin), starts = 0;
-                for (int k = 0; k < 4; k++) {
-                    if (nin == 0) starts |= 1u << k;
-                    acc |= ((nib >> k) & 1u) << nin;
-                    nin++;
-                    if (nin == 5 || ((t->v2v_term[b][nin] >> acc) & 1u)) { acc = 0; nin = 0; }
+    memset(t->node_c, 0xFF, sizeof t->node_c);
+    for (uint32_t b = 1; b <= 7; b++) {
+        // the tree's nodes: the root and every proper prefix of a code word's input
+        uint32_t count = 0;
+        for (uint32_t node = 1; node < 32; node++) {
+            uint32_t nin = 0;
+            while ((2u << nin) <= node) nin++;                     // node = acc | 1 << nin
+            const uint32_t acc = node ^ (1u << nin);
+            bool is_node = node == 1;
+            for (const V &c : codes)
+                if (c.bin == b && nin && nin < c.nin && (c.val & ((1u << nin) - 1u)) == acc) is_node = true;
+            if (is_node && count < 8) { t->node_c[b][node] = (uint8_t)count; t->node_full[b][count] = (uint8_t)node; count++; }
+        }
+        // one input bit from a node (icer_encoding.c:87-98): back to the root when the input is a code word
+        auto step1 = [&](uint32_t node, uint32_t bit) {
+            uint32_t nin = 0;
+            while ((2u << nin) <= node) nin++;
+            uint32_t acc = (node ^ (1u << nin)) | (bit << nin);
+            nin++;
+            return (nin == 5 || ((t->v2v_term[b][nin] >> acc) & 1u)) ? 1u : (acc | (1u << nin));
+        };
+        for (uint32_t cn = 0; cn < count; cn++) {
+            for (uint32_t bits = 0; bits < 64; bits++) {
+                uint32_t node = t->node_full[b][cn], starts = 0;
+                for (int k = 0; k < 6; k++) {
+                    if (node == 1) starts |= 1u << k;
+                    node = step1(node, (bits >> k) & 1u);
                 }
-                t->v2v_step[b][node][nib] = (uint16_t)((acc | (1u << nin)) | (starts << 5));
+                t->v2v_step6[b][cn][bits] = (uint16_t)(t->node_c[b][node] | (starts << 4));
             }
+            for (uint32_t k = 1; k <= 5; k++)
+                for (uint32_t bits = 0; bits < (1u << k); bits++) {
+                    uint32_t node = t->node_full[b][cn];
+                    for (uint32_t i = 0; i < k; i++) node = step1(node, (bits >> i) & 1u);
+                    t->v2v_tail[b][cn][(1u << k) | bits] = t->node_c[b][node];
+                }
+        }
+    }
     {
         uint32_t lane = 8;
         for (uint32_t b = 1; b <= 7; b++)

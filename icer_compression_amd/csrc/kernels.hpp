@@ -138,7 +138,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     // Role of each wavefront.  Waves w and w + 4 of a workgroup share a SIMD (observed placement, used for speed
     // only): the count wave, which issues the most vector instructions per chunk, gets a SIMD to itself and the
     // other issue-heavy roles are paired with latency-bound ones.
-    constexpr uint32_t kPixel = 0, kGolomb = 1, kWalker = 2, kCount = 3, kMerge = 4, kDrain = 5, kRecords = 6, kCompact = 7;
+    constexpr uint32_t kWalker = 0, kPixel = 1, kGolomb = 2, kMerge = 3, kCompact = 4, kCount = 5, kRecords = 6, kDrain = 7;
     if (wave == 0) unit_state_init(s);
     if (threadIdx.x == 64) s.nchunks = (u.w * u.h + 63u) / 64u;
     if (wave == kMerge) build_crc_table(s);

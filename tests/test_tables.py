@@ -5,7 +5,8 @@ import numpy as np
 
 
 class CoderTables(C.Structure):     # mirrors icer::CoderTables
-    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_step", ((C.c_uint16 * 16) * 32) * 8),
+    _fields_ = [("v2v", (C.c_uint16 * 32) * 8), ("v2v_term", (C.c_uint32 * 8) * 8), ("v2v_step6", ((C.c_uint16 * 64) * 8) * 8), ("v2v_tail", ((C.c_uint8 * 64) * 8) * 8),
+                ("node_c", (C.c_uint8 * 32) * 8), ("node_full", (C.c_uint8 * 8) * 8),
                 ("cand_bin", C.c_uint8 * 64), ("cand_node", C.c_uint8 * 64), ("cand_lane", (C.c_uint8 * 32) * 8), ("v2v_flush", ((C.c_uint8 * 6) * 9) * 8),
                 ("gm", C.c_uint16 * 17), ("gl", C.c_uint16 * 17), ("gi", C.c_uint16 * 17),
                 ("ginv", C.c_uint32 * 17), ("cut", C.c_uint32 * 16), ("binlut", C.c_uint32 * 257),
@@ -40,46 +41,59 @@ def test_tables_equal_reference(emu, reference):
         assert t.cut[i] == reference.lib.ref_tap_cutoff(i)
 
 
-def test_nibble_step_table_equals_four_single_steps(emu, reference):
-    """v2v_step[bin][node][nibble] must equal four applications of the reference's per-bit rule
-    (icer_encoding.c:87-98: a prefix is complete when the table entry's input length equals the bits consumed)."""
-    t = _tables(emu)
-    for b in range(1, 8):
-        partial = {1}                                   # reachable nodes: root + every proper prefix of a code
-        for pre in range(32):
-            nin, _, _ = reference.custom_code(b, pre)
-            for k in range(1, nin):
-                partial.add((pre & ((1 << k) - 1)) | (1 << k))
-        for node in partial:
-            for nib in range(16):
-                nin = node.bit_length() - 1
-                acc, starts = node ^ (1 << nin), 0
-                for k in range(4):
-                    if nin == 0:
-                        starts |= 1 << k
-                    acc |= ((nib >> k) & 1) << nin
-                    nin += 1
-                    if reference.custom_code(b, acc)[0] == nin:
-                        acc, nin = 0, 0
-                    assert nin < 5
-                e = t.v2v_step[b][node][nib]
-                assert (e & 31, (e >> 5) & 15) == (acc | (1 << nin), starts), (b, node, nib)
+def _tree_nodes(reference, b):
+    partial = {1}                                       # root + every proper prefix of a code word's input
+    for pre in range(32):
+        nin, _, _ = reference.custom_code(b, pre)
+        for k in range(1, nin):
+            partial.add((pre & ((1 << k) - 1)) | (1 << k))
+    return partial
 
 
-def test_walker_candidate_lanes_cover_every_tree_node(emu):
-    """Every node the nibble-step table can land on has exactly one candidate lane (the split walk relies on it)."""
+def _walk(reference, b, node, bits, nbits):
+    """nbits applications of the reference's per-bit rule (icer_encoding.c:87-98: a prefix is complete when the table
+    entry's input length equals the bits consumed); returns (node after, start flags)"""
+    nin = node.bit_length() - 1
+    acc, starts = node ^ (1 << nin), 0
+    for k in range(nbits):
+        if nin == 0:
+            starts |= 1 << k
+        acc |= ((bits >> k) & 1) << nin
+        nin += 1
+        if reference.custom_code(b, acc)[0] == nin:
+            acc, nin = 0, 0
+        assert nin < 5
+    return acc | (1 << nin), starts
+
+
+def test_six_bit_step_tables_equal_single_steps(emu, reference):
+    """v2v_step6 / v2v_tail (compact node numbers) against repeated single-bit steps of the reference's rule."""
     t = _tables(emu)
     for b in range(1, 8):
-        reach, todo = {1}, [1]
-        while todo:
-            node = todo.pop()
-            for nib in range(16):
-                nxt = t.v2v_step[b][node][nib] & 31
-                if nxt not in reach:
-                    reach.add(nxt)
-                    todo.append(nxt)
-        lanes = {node: t.cand_lane[b][node] for node in reach}
-        assert all(8 <= ln < 64 for ln in lanes.values()) and len(set(lanes.values())) == len(reach), (b, lanes)
+        nodes = _tree_nodes(reference, b)
+        assert len(nodes) <= 8
+        assert sorted(n for n in range(32) if t.node_c[b][n] != 0xFF) == sorted(nodes) and t.node_c[b][1] == 0
+        for node in nodes:
+            cn = t.node_c[b][node]
+            assert t.node_full[b][cn] == node
+            for bits in range(64):
+                after, starts = _walk(reference, b, node, bits, 6)
+                e = t.v2v_step6[b][cn][bits]
+                assert (t.node_full[b][e & 7], e >> 4) == (after, starts), (b, node, bits)
+            for k in range(1, 6):
+                for bits in range(1 << k):
+                    after, starts = _walk(reference, b, node, bits, k)
+                    assert t.node_full[b][t.v2v_tail[b][cn][(1 << k) | bits]] == after
+                    assert (t.v2v_step6[b][cn][bits] >> 4) & ((1 << k) - 1) == starts
+
+
+def test_walker_candidate_lanes_cover_every_tree_node(emu, reference):
+    """Every node of a bin's code tree has exactly one candidate lane (the split walk relies on it)."""
+    t = _tables(emu)
+    for b in range(1, 8):
+        nodes = _tree_nodes(reference, b)
+        lanes = {node: t.cand_lane[b][node] for node in nodes}
+        assert all(8 <= ln < 64 for ln in lanes.values()) and len(set(lanes.values())) == len(nodes), (b, lanes)
         assert all(t.cand_bin[ln] == b and t.cand_node[ln] == node for node, ln in lanes.items())
     assert sum(1 for ln in range(64) if t.cand_bin[ln]) == 46
 
