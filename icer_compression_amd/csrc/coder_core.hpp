@@ -159,6 +159,7 @@ struct CoderShared {
     RecSlot rq[kQueueDepth];
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
+    uint32_t gk[kNumBins];          // golomb wave: zero-run length of each Golomb bin's open word as of its last chunk (0 = none)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
     uint32_t alloc;             // words allocated so far          (merge wave)
     uint32_t popped;            // words popped so far             (drain wave, or the merge wave while it holds the drain)
@@ -915,15 +916,12 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
 // ==========================================================================================
 // golomb wave (bins 0 and 8..16)
 // ==========================================================================================
-struct GolombWave {
-    LANEVAR(uint32_t, k);       // lane b (8..16): zero-run length of bin b's open word (0 = no open word)
+struct GolombWave {             // (the bins' zero-run lengths live in CoderShared::gk)
     uint32_t next, gen;         // as WalkWave
 };
 
 ICER_DEV void golomb_wave_init(GolombWave &gw)
 {
-    DECL_LANE;
-    FOR_LANES { LV(gw.k) = 0; }
     gw.next = 0;
     gw.gen = 0;
 }
@@ -945,7 +943,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             gw.next = s.last_exact + 1u;
             FOR_LANES
             {
-                if (lane >= 8 && lane <= 16) LV(gw.k) = st_acc(s.bin_state[lane]);
+                if (lane >= 8 && lane <= 16) s.gk[lane] = st_acc(s.bin_state[lane]);
             }
         }
         const uint32_t j = gw.next;
@@ -959,7 +957,6 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         ICER_TICK(10)
         const EventSlot &q = s.eq[j % kQueueDepth];
         RecSlot &o = s.rq[j % kQueueDepth];
-        LANEVAR(uint32_t, opv);                             // lane b: open_pos of bin b
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
         LANEVAR(uint32_t, fl1); LANEVAR(uint32_t, fl2);     // bit0: a word starts at this event, bit1: a word ends here
         LANEVAR(uint32_t, wd1); LANEVAR(uint32_t, wd2);     // finished ring word of an end event
@@ -969,14 +966,17 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             LV(ev1) = q.ev1[lane];
             LV(ev2) = q.ev2[lane];
             LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
-            LV(opv) = 255;
+            // a bin without events in this chunk keeps its run length and its open word (open_pos 255)
+            if (lane == 0 || (lane >= 8 && lane <= 16)) o.binst[lane] = st_pack(255u, s.gk[lane], 0u);
             // bin 0 (uncoded): every event is a complete one-bit word (E3)
             if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
             if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
         }
+        WAVE_SYNC();
         // Golomb bins 8..16, no loop over bins: the lanes of one bin are found from per-bit ballots of (bin - 8); an
         // event's run length = zeros of its bin since the bin's previous one-event (or since the chunk start, plus the
         // run carried in), modulo m; a word starts where that is 0 and ends at a one or when the run reaches m - 1.
+        // The lane holding a bin's last event of the chunk also leaves the bin's state (run length, open word).
 #define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
         ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
         {
@@ -985,14 +985,10 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                 const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u);
                 const uint64_t J0 = BALLOT(LV(ev2) & 1u), J1 = BALLOT(LV(ev2) & 2u), J2 = BALLOT(LV(ev2) & 4u), J3 = BALLOT((LV(ev2) & 31u) == 16u);
                 const uint64_t O1 = G1 & BALLOT(LV(ev1) & 0x20u), O2 = G2 & BALLOT(LV(ev2) & 0x20u);       // one-events
-                LANEVAR(uint32_t, kin1); LANEVAR(uint32_t, kin2); LANEVAR(uint32_t, idx);
-                FOR_LANES { LV(idx) = LV(ev1) & 31u; }
-                WAVE_GATHER(kin1, gw.k, idx)
-                FOR_LANES { LV(idx) = LV(ev2) & 31u; }
-                WAVE_GATHER(kin2, gw.k, idx)
+                LANEVAR(uint32_t, ka1); LANEVAR(uint32_t, ka2);     // run length after the event if it is the bin's last one, else ~0
                 // key of a bin: bin - 8 = 0..8, i.e. the low three bits of the bin number and "bin == 16"
                 LANEVAR(uint64_t, ma1); LANEVAR(uint64_t, mb1); LANEVAR(uint64_t, ma2); LANEVAR(uint64_t, mb2);   // events of this lane's bins
-#define ICER_GOLOMB_LANE(EV, SLOT, KIN, FL, WD, MA, MB)                                                       \
+#define ICER_GOLOMB_LANE(EV, SLOT, KA, FL, WD, MA, MB)                                                        \
                 if (((EV) & 0x98u) >= 0x88u) {                                                                \
                     const uint32_t b_ = (EV) & 31u, key_ = (b_ & 7u) | (b_ == 16u ? 8u : 0u);                  \
                     const uint64_t m1_ = ICER_MATCH(key_, G1, K0, K1, K2, K3), m2_ = ICER_MATCH(key_, G2, J0, J1, J2, J3); \
@@ -1001,46 +997,44 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                     const uint32_t pos_ = 2u * (uint32_t)lane + (SLOT);                                         \
                     const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                      \
                     const int lo_ = last_lt(m1_ & O1, m2_ & O2, pos_);                                          \
-                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : (KIN) + zb_;           \
+                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : s.gk[b_] + zb_;         \
                     const uint32_t m = s.tab.gm[b_], inv = s.tab.ginv[b_];                                      \
                     const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
                     const uint32_t bit_ = ((EV) >> 5) & 1u;                                                     \
                     FL = (kb_ == 0u ? 1u : 0u) | ((bit_ || kb_ + 1u == m) ? 2u : 0u);                           \
                     WD = bit_ ? golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);               \
+                    const uint32_t before_ = cnt_lt_own(m1_, m2_, lane, (SLOT));                                \
+                    if (before_ + 1u == (uint32_t)(popc64(m1_) + popc64(m2_))) KA = (FL & 2u) ? 0u : kb_ + 1u;  \
                 }
                 FOR_LANES
                 {
-                    LV(ma1) = 0; LV(mb1) = 0; LV(ma2) = 0; LV(mb2) = 0;
-                    ICER_GOLOMB_LANE(LV(ev1), 0u, LV(kin1), LV(fl1), LV(wd1), LV(ma1), LV(mb1))
-                    ICER_GOLOMB_LANE(LV(ev2), 1u, LV(kin2), LV(fl2), LV(wd2), LV(ma2), LV(mb2))
+                    LV(ma1) = 0; LV(mb1) = 0; LV(ma2) = 0; LV(mb2) = 0; LV(ka1) = ~0u; LV(ka2) = ~0u;
+                    ICER_GOLOMB_LANE(LV(ev1), 0u, LV(ka1), LV(fl1), LV(wd1), LV(ma1), LV(mb1))
+                    ICER_GOLOMB_LANE(LV(ev2), 1u, LV(ka2), LV(fl2), LV(wd2), LV(ma2), LV(mb2))
                 }
 #undef ICER_GOLOMB_LANE
-                // word starts of the Golomb bins; an end event's word began at its bin's latest start
+                // word starts of the Golomb bins; an end event's word began at its bin's latest start, and so did the
+                // word a bin's last event leaves open
+                WAVE_SYNC();
                 const uint64_t SB1 = G1 & BALLOT(LV(fl1) & 1u), SB2 = G2 & BALLOT(LV(fl2) & 1u);
                 FOR_LANES
                 {
-                    if ((LV(ev1) & 0x98u) >= 0x88u && (LV(fl1) & 2u)) {
+                    if ((LV(ev1) & 0x98u) >= 0x88u && ((LV(fl1) & 2u) || LV(ka1) != ~0u)) {
                         const int sp = last_le(SB1 & LV(ma1), SB2 & LV(mb1), 2u * (uint32_t)lane);
-                        LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+                        if (LV(fl1) & 2u) LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
+                        if (LV(ka1) != ~0u) {
+                            const uint32_t b = LV(ev1) & 31u;
+                            s.gk[b] = LV(ka1);
+                            o.binst[b] = st_pack(LV(ka1) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka1), 0u);
+                        }
                     }
-                    if ((LV(ev2) & 0x98u) >= 0x88u && (LV(fl2) & 2u)) {
+                    if ((LV(ev2) & 0x98u) >= 0x88u && ((LV(fl2) & 2u) || LV(ka2) != ~0u)) {
                         const int sp = last_le(SB1 & LV(ma2), SB2 & LV(mb2), 2u * (uint32_t)lane + 1u);
-                        LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
-                    }
-                    // lane b = 8..16: bin b's state after the chunk
-                    if (lane >= 8 && lane <= 16) {
-                        const uint32_t key = (uint32_t)lane - 8u;
-                        const uint64_t M1 = ICER_MATCH(key, G1, K0, K1, K2, K3), M2 = ICER_MATCH(key, G2, J0, J1, J2, J3);
-                        if (M1 | M2) {
-                            const uint64_t Z1 = M1 & ~O1, Z2 = M2 & ~O2;
-                            const int lastone = last_le(M1 & O1, M2 & O2, 127u);
-                            const uint32_t ztot = (uint32_t)(popc64(Z1) + popc64(Z2));
-                            const uint32_t zafter = lastone >= 0 ? ztot - cnt_lt(Z1, Z2, (uint32_t)lastone) : LV(gw.k) + ztot;
-                            const uint32_t m = s.tab.gm[lane], inv = s.tab.ginv[lane];
-                            const uint32_t k_out = zafter - ((zafter * inv) >> 20) * m;
-                            const int laststart = last_le(SB1 & M1, SB2 & M2, 127u);
-                            LV(gw.k) = k_out;
-                            LV(opv) = k_out ? (laststart >= 0 ? (uint32_t)laststart : 255u) : 254u;
+                        if (LV(fl2) & 2u) LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
+                        if (LV(ka2) != ~0u) {
+                            const uint32_t b = LV(ev2) & 31u;
+                            s.gk[b] = LV(ka2);
+                            o.binst[b] = st_pack(LV(ka2) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka2), 0u);
                         }
                     }
                 }
@@ -1058,7 +1052,6 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             if (!(b2 >= 0x81u && b2 <= 0x87u)) {
                 o.rec[2 * lane + 1] = (b2 & 0x80u) ? (LV(fl2) | ((b2 & 31u) << 2) | (LV(sp2) << 8) | (LV(wd2) << 16)) : 0u;
             }
-            if (lane == 0 || (lane >= 8 && lane <= 16)) o.binst[lane] = st_pack(LV(opv), LV(gw.k), 0u);
         }
         ICER_PUBLISH(o.gtag, chunk_tag(j, gw.gen))
         gw.next = j + 1u;
@@ -1526,7 +1519,7 @@ ICER_DEV void unit_state_init(CoderShared &s)
     FOR_LANES
     {
         for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
-        if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; }
+        if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.gk[lane] = 0; }
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
             s.p_done = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
