@@ -1,40 +1,48 @@
-// coder_core.hpp -- one workgroup of six wavefronts codes one ICER coding unit
+// coder_core.hpp -- one workgroup of eight wavefronts codes one ICER coding unit
 // (channel, level, subband, plane, segment).
 //
-// Replaces, for the uint16 path, the reference's per-segment chain
+// Replaces the reference's per-segment chain (the uint8 twins are the same code on 7 planes)
 //   icer_compress_bitplane_uint16   lib_icer/src/icer_context_modeller.c:312-457
 //   icer_encode_bit / icer_compute_bin   icer_encoding.c:37-112, icer_util.c:48-56
 //   icer_popbuf_while_avail / icer_flush_encode   icer_encoding.c:114-189
 // and must emit the identical payload bits.
 //
 // The segment is coded in chunks of 64 pixels (raster order inside the segment).  The reference is a
-// sequential state machine; its state splits into parts that only depend on their own history, so six
+// sequential state machine; its state splits into parts that only depend on their own history, so eight
 // wavefronts work on consecutive chunks at the same time (a software pipeline), handing chunks over
-// through small LDS queues (depth kQueueDepth):
+// through small LDS queues (depth kQueueDepth).  A lone wavefront issues one instruction every four cycles
+// whatever its kind, so a wave's time per chunk is its instruction count x 4 plus LDS round trips: the roles
+// are cut so that no wave has more than ~550 instructions per chunk.
 //
 //   pixel wave     per chunk: pixel category, magnitude bit, 8-neighbour context, sign context (64 lanes,
-//     (stateless)    pure function of the 3x3 window; the next chunk's window is prefetched).
-//   count wave     the adaptive counts every event sees = counts at chunk start + rank among the chunk's
-//     (17 context    events of the same context (ballot + v_mbcnt; the at-most-one rescale per context and
-//      counters)     chunk in closed form); probability fold + bin selection.  Output: 128 event bytes.
-//   walker wave    bins 1..7 (variable-to-variable codes): events of a bin are compacted into a dense
-//     (partial       sequence, lane b walks bin b's sequence through the code tree (termination mask in a
-//      inputs)       register) and marks where code words start/end.
-//   golomb wave    bin 0 and the Golomb bins 8..16 in closed form on ballot masks: run length since the bin's
-//     (run lengths)  previous one-event, mod m, gives word starts/ends and the finished words.
+//     (stateless)    pure function of the 3x3 window; the next chunk's window is prefetched); rank of every event
+//                    among the chunk's events of the same context (ballot match + v_mbcnt), per-context totals.
+//   count wave     the adaptive counts every event sees = counts at chunk start + the prepared rank (the
+//     (17 context    at-most-one rescale per context and chunk in closed form); probability fold + bin selection
+//      counters)     (exact division + look-up).  Output: 128 event bytes.
+//   compaction     bins 1..7: rank of every event inside its bin, the bin's input bits as a dense bit string, the
+//     wave           rank -> position list.
+//   walker wave    bins 1..7 (variable-to-variable codes): lane b walks the first half of bin b's bit string
+//     (partial       through the code tree six bits per table look-up, one lane per tree node walks the second half
+//      inputs)       speculatively; marks where code words start.
+//   records wave   bins 1..7: from the start flags, per event: does a word start / end here, the finished word,
+//     (stateless)    the position of its first event.
+//   golomb wave    bin 0 and the Golomb bins 8..16 in closed form on ballot masks, no loop over bins: run length
+//     (run lengths)  since the bin's previous one-event, mod m, gives word starts/ends and the finished words.
 //   merge wave     ring slots = prefix count of word-start flags (allocation order = order of first events,
-//     (ring tail,    E2); end events write the finished word into the slot of the word's first event; the exact
-//      open slots)   path.
+//     (ring tail,    E2); end events write the finished word into the slot of the word's first event; chunks in
+//      open slots)   which the ring overflows (hybrid_chunk).
 //   drain wave     finished words popped from the head of the ring 64 at a time (ballot of done flags, prefix
 //     (ring head,    sum of lengths, ds_or into the LDS bit stage); whole 32-bit words stored to HBM.  Parks on
-//      bit stage)    request when the merge wave needs the exact ring occupancy (exact path, end of unit).
-// The walker and golomb waves run one chunk ahead of the merge wave's verdict (speculation, see below).
+//      bit stage)    request when the merge wave needs the exact ring occupancy (overflow chunks, end of unit).
+// The walker, records and golomb waves run ahead of the merge wave's verdict (speculation, see below).
 //
 // Exactness: word boundaries depend on each bin alone only while the 2048-word ring cannot fill up inside
-// the chunk (used + events <= 2048): then no forced flush of the oldest open word (E5) can fire.  Otherwise
-// (~0.3-2.5 % of chunks) the merge wave replays the reference state machine event by event on one lane,
-// with draining deferred to the 64-lane drain (it is only observable through `used` when a word is allocated),
-// and the walker and golomb waves discard their speculative results and reload their state.
+// the chunk (used + words opened <= 2048): then no forced flush of the oldest open word (E5) can fire.  Otherwise
+// (~1-2 % of the chunks of dense planes) the speculative results are right up to the first word start that finds
+// the ring full; the merge wave commits up to there, force-completes the oldest word like icer_flush_encode,
+// replays the remaining events of that one bin, and the speculating waves discard what they produced for later
+// chunks and reload their state (generation counter).
 //
 // Written with the SPMD macros of wave.hpp (see there for the tests-only CPU build).
 #pragma once
@@ -159,6 +167,7 @@ struct CoderShared {
     RecSlot rq[kQueueDepth];
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
+    uint8_t ctx_tab[48];            // pixel wave: context table of the unit's subband (see pixel_wave_run)
     uint32_t gk[kNumBins];          // golomb wave: zero-run length of each Golomb bin's open word as of its last chunk (0 = none)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
     uint32_t alloc;             // words allocated so far          (merge wave)
@@ -431,17 +440,23 @@ struct PixelWave {                // next chunk's 3x3 coefficient window, one pi
     {                                                                                                  \
         const bool in_ = (BASE) + (uint32_t)lane < npix;                                               \
         const uint32_t r_ = in_ ? LV(cw.row) : 0u, c_ = in_ ? LV(cw.col) : 0u;                          \
-        const uint16_t *q_ = a.seg + (size_t)r_ * a.stride + c_;                                       \
         const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < a.w, hasN_ = r_ > 0, hasS_ = r_ + 1 < a.h;          \
-        LV(cw.nC) = q_[0];                                                                             \
-        LV(cw.nW) = hasW_ ? q_[-1] : 0u;                                                               \
-        LV(cw.nE) = hasE_ ? q_[1] : 0u;                                                                \
-        LV(cw.nN) = hasN_ ? *(q_ - a.stride) : 0u;                                                     \
-        LV(cw.nS) = hasS_ ? *(q_ + a.stride) : 0u;                                                     \
-        LV(cw.nNW) = (hasN_ && hasW_) ? *(q_ - a.stride - 1) : 0u;                                     \
-        LV(cw.nNE) = (hasN_ && hasE_) ? *(q_ - a.stride + 1) : 0u;                                     \
-        LV(cw.nSW) = (hasS_ && hasW_) ? *(q_ + a.stride - 1) : 0u;                                     \
-        LV(cw.nSE) = (hasS_ && hasE_) ? *(q_ + a.stride + 1) : 0u;                                     \
+        /* nine unconditional loads from clamped (always valid) positions, then selects: no divergent branches */ \
+        const uint32_t cW_ = hasW_ ? c_ - 1u : c_, cE_ = hasE_ ? c_ + 1u : c_;                          \
+        const uint16_t *pC_ = a.seg + (size_t)r_ * a.stride;                                           \
+        const uint16_t *pN_ = hasN_ ? pC_ - a.stride : pC_, *pS_ = hasS_ ? pC_ + a.stride : pC_;        \
+        const uint32_t vC_ = pC_[c_], vW_ = pC_[cW_], vE_ = pC_[cE_];                                   \
+        const uint32_t vN_ = pN_[c_], vNW_ = pN_[cW_], vNE_ = pN_[cE_];                                 \
+        const uint32_t vS_ = pS_[c_], vSW_ = pS_[cW_], vSE_ = pS_[cE_];                                 \
+        LV(cw.nC) = vC_;                                                                               \
+        LV(cw.nW) = hasW_ ? vW_ : 0u;                                                                  \
+        LV(cw.nE) = hasE_ ? vE_ : 0u;                                                                  \
+        LV(cw.nN) = hasN_ ? vN_ : 0u;                                                                  \
+        LV(cw.nS) = hasS_ ? vS_ : 0u;                                                                  \
+        LV(cw.nNW) = (hasN_ && hasW_) ? vNW_ : 0u;                                                     \
+        LV(cw.nNE) = (hasN_ && hasE_) ? vNE_ : 0u;                                                     \
+        LV(cw.nSW) = (hasS_ && hasW_) ? vSW_ : 0u;                                                     \
+        LV(cw.nSE) = (hasS_ && hasE_) ? vSE_ : 0u;                                                     \
         /* advance to the same lane of the next chunk */                                               \
         if (a.w >= 64u) {                                                                              \
             uint32_t nc_ = LV(cw.col) + 64u;                                                           \
@@ -463,7 +478,15 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
     const uint32_t lsb = (uint32_t)a.lsb;
     const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
     if (j0 == 0 && npix) {
-        FOR_LANES { LV(cw.row) = (uint32_t)lane / a.w; LV(cw.col) = (uint32_t)lane - LV(cw.row) * a.w; }
+        FOR_LANES
+        {
+            LV(cw.row) = (uint32_t)lane / a.w; LV(cw.col) = (uint32_t)lane - LV(cw.row) * a.w;
+            // context of a not-yet-significant pixel by neighbour counts (icer_config.c:26-67): HH indexed
+            // (h + v) * 5 + d, the other subbands (h * 3 + v) * 5 + d with h, v <= 2, d <= 4
+            if (lane < 45) s.ctx_tab[lane] = (uint8_t)(is_hh ? ctx_hh((uint32_t)lane / 5u, (uint32_t)lane % 5u)
+                                                            : ctx_plain((uint32_t)lane / 15u, ((uint32_t)lane / 5u) % 3u, (uint32_t)lane % 5u));
+        }
+        WAVE_SYNC();
         ICER_FETCH_WINDOW(0u)
     }
 
@@ -500,14 +523,11 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             uint32_t hh = sW + sE, vv = sN + sS;
             const uint32_t dd = ICER_SIG(xNW, lsb) + ICER_SIG(xNE, lsb) + ICER_SIG(xSW, lsb + 1) + ICER_SIG(xSE, lsb + 1);
 #undef ICER_SIG
-            uint32_t ctx;
-            if (cat == 3) ctx = 31;                               // uncoded: no model context
-            else if (cat == 2) ctx = 11;
-            else if (cat == 1) ctx = (hh + vv == 0) ? 9u : 10u;
-            else {
-                if (is_hl) { const uint32_t t = hh; hh = vv; vv = t; }
-                ctx = is_hh ? ctx_hh(hh + vv, dd) : ctx_plain(hh, vv, dd);
-            }
+            // category 0: the subband's context table (built once per unit, ctx_tab); 1: 9 / 10; 2: 11; 3: uncoded
+            if (is_hl) { const uint32_t t = hh; hh = vv; vv = t; }
+            const uint32_t c0 = s.ctx_tab[is_hh ? (hh + vv) * 5u + dd : (hh * 3u + vv) * 5u + dd];
+            const uint32_t c1 = (hh + vv == 0) ? 9u : 10u;
+            const uint32_t ctx = cat == 0 ? c0 : cat == 1 ? c1 : cat == 2 ? 11u : 31u;
             LV(valid1) = valid ? 1u : 0u;
             LV(ctx1) = ctx;
             LV(bit1) = bit;
