@@ -57,6 +57,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_LOAD_CNT(x) (x)
 #define ICER_WAIT_UNTIL(cond) { assert(cond); }
 #define ICER_WAIT_RELAXED(cond) { assert(cond); }
+#define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB = s.abort; { const uint32_t V = (X); (void)V; assert((PRED) || AB); }
 #define ICER_PUBLISH(x, v) { (x) = (v); }
 #define ICER_PUBLISH2(x1, v1, x2, v2) { (x1) = (v1); (x2) = (v2); }
 #define ICER_ACQUIRE()
@@ -76,6 +77,14 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_WAIT_UNTIL(cond) ICER_SPIN(cond, 1)
 // for waits of a wave that runs AHEAD of the pipeline (its queue is full): poll rarely, leave the issue slots to others
 #define ICER_WAIT_RELAXED(cond) ICER_SPIN(cond, 6)
+// wait until PRED holds for V = the counter X, or the unit is abandoned; the counter and the abort word are read
+// together (one LDS round trip per poll) and AB receives the abort word
+#define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB; { uint32_t spins_ = 0; for (;;) {                          \
+        const uint32_t V = ICER_LOAD_CNT(X); AB = ICER_LOAD_CNT(s.abort);                                             \
+        if ((PRED) || AB) break;                                                                                      \
+        __builtin_amdgcn_s_sleep(SLEEP);                                                                              \
+        if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); AB = 2u; break; } } \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 #define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), pv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) { __hip_atomic_store(&(x1), pv1_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&(x2), pv2_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } }
 #define ICER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -176,7 +185,7 @@ struct CoderShared {
     uint32_t flushed_words;     // payload words already written to HBM
     // merge -> drain wave: odd = "park, I need the drain state", even = released; the drain wave answers in hold_ack
     uint32_t hold_seq, hold_ack, drain_exit;
-    uint32_t helper_next, helper_gen, nchunks;   // records wave's cursor / generation; chunks of the unit
+    uint32_t nchunks;           // chunks of the unit
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
     uint32_t p_done, a_done, c_done, b_done, abort;
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
@@ -586,8 +595,8 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
 #undef ICER_MATCH
         ICER_TICK(0)
         // queue slot j % D is free once the count wave has consumed chunk j - D
-        ICER_WAIT_RELAXED(j < ICER_LOAD_CNT(s.a_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
-        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_WAIT_CNT(s.a_done, ad_, j < ad_ + kQueueDepth, ab_, 6)
+        if (ab_) break;
         ICER_TICK(1)
         PixelSlot &o = s.pq[j % kQueueDepth];
         FOR_LANES
@@ -620,8 +629,8 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         LV(ctot) = j0 == 0 ? 4u : LV(cs.ctot);
     }
     for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.p_done) > j || ICER_LOAD_CNT(s.abort))
-        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_WAIT_CNT(s.p_done, pd_, pd_ > j, ab_, 1)
+        if (ab_) break;
         ICER_TICK(2)
         const PixelSlot &in = s.pq[j % kQueueDepth];
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
@@ -695,8 +704,8 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         const uint32_t nev = (uint32_t)(popc64(BALLOT(LV(ev1) != 0u)) + popc64(BALLOT(LV(ev2) != 0u)));
         ICER_TICK(4)
         // queue slot j % D is free once the assembly wave has retired chunk j - D
-        ICER_WAIT_RELAXED(j < ICER_LOAD_CNT(s.b_done) + kQueueDepth || ICER_LOAD_CNT(s.abort))
-        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_WAIT_CNT(s.b_done, bd_, j < bd_ + kQueueDepth, ab2_, 6)
+        if (ab2_) break;
         ICER_TICK(5)
         EventSlot &q = s.eq[j % kQueueDepth];
         FOR_LANES
@@ -719,8 +728,8 @@ ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, u
     DECL_LANE;
     ICER_TIMERS_DECL
     for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.a_done) > j || ICER_LOAD_CNT(s.abort))
-        if (ICER_LOAD_CNT(s.abort)) break;
+        ICER_WAIT_CNT(s.a_done, ad_, ad_ > j, ab_, 1)
+        if (ab_) break;
         ICER_ACQUIRE()
         ICER_TICK(25)
         EventSlot &q = s.eq[j % kQueueDepth];
@@ -814,8 +823,9 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
     (void)a;
     uint32_t done = 0;
     for (;;) {
-        if (ICER_LOAD_CNT(s.abort)) break;
-        const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
+        // (control words read together: one LDS round trip)
+        const uint32_t ab_ = ICER_LOAD_CNT(s.abort), seq = ICER_LOAD_CNT(s.exact_seq), cd_ = ICER_LOAD_CNT(s.c_done);
+        if (ab_) break;
         if (seq != ww.gen) {
             // everything walked after chunk last_exact is void; the replay left the bins' partial inputs in LDS
             ICER_ACQUIRE()
@@ -827,7 +837,7 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
             }
         }
         const uint32_t j = ww.next;
-        if (j >= nchunks || ICER_LOAD_CNT(s.c_done) <= j) {
+        if (j >= nchunks || cd_ <= j) {
             if (ICER_LOAD_CNT(s.b_done) >= nchunks || done >= max_chunks) break;
             ICER_IDLE()
             continue;
@@ -955,8 +965,8 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
     (void)a;
     uint32_t done = 0;
     for (;;) {
-        if (ICER_LOAD_CNT(s.abort)) break;
-        const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
+        const uint32_t ab_ = ICER_LOAD_CNT(s.abort), seq = ICER_LOAD_CNT(s.exact_seq), ad_ = ICER_LOAD_CNT(s.a_done);
+        if (ab_) break;
         if (seq != gw.gen) {
             ICER_ACQUIRE()
             gw.gen = seq;
@@ -967,7 +977,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             }
         }
         const uint32_t j = gw.next;
-        if (j >= nchunks || ICER_LOAD_CNT(s.a_done) <= j) {
+        if (j >= nchunks || ad_ <= j) {
             if (ICER_LOAD_CNT(s.b_done) >= nchunks || done >= max_chunks) break;
             ICER_IDLE()
             continue;
@@ -1098,12 +1108,31 @@ struct MergeChunk {             // one chunk's events with their code-word roles
 // wait for the (speculative) results of the golomb, walker and records waves for chunk j and unpack them.
 // (Every wait of the merge wave also ends when the unit is abandoned: the drain wave may have found the payload
 // slot too small and left.)
-ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_PARAMS)
+// Returns false when the unit was abandoned; *popped = the drain wave's pop count as of the same moment.
+ICER_DEV bool merge_gather(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t gen, uint32_t *popped ICER_TIMER_PARAMS)
 {
     DECL_LANE;
     const RecSlot &rq = s.rq[j % kQueueDepth];
-    const uint32_t tag = chunk_tag(j, s.exact_seq);
-    ICER_WAIT_UNTIL((ICER_LOAD_CNT(rq.gtag) == tag && ICER_LOAD_CNT(rq.rtag) == tag) || ICER_LOAD_CNT(s.abort))
+    const uint32_t tag = chunk_tag(j, gen);
+    uint32_t ab_ = 0;
+#ifdef ICER_WAVE_EMU
+    assert((rq.gtag == tag && rq.rtag == tag) || s.abort);
+    ab_ = s.abort;
+    *popped = s.popped;
+#else
+    {   // both tags, the abort word and the pop count per poll in one LDS round trip
+        uint32_t spins_ = 0;
+        for (;;) {
+            const uint32_t g_ = ICER_LOAD_CNT(rq.gtag), r_ = ICER_LOAD_CNT(rq.rtag);
+            ab_ = ICER_LOAD_CNT(s.abort);
+            *popped = ICER_LOAD_CNT(s.popped);
+            if (((g_ == tag) & (r_ == tag)) | (ab_ != 0u)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); ab_ = 2u; break; }
+        }
+    }
+#endif
+    if (ab_) return false;
     ICER_ACQUIRE()
     ICER_TICK(18)
     FOR_LANES
@@ -1116,6 +1145,7 @@ ICER_DEV void merge_gather(CoderShared &s, MergeChunk &c, uint32_t j ICER_TIMER_
     c.S1 = BALLOT(LV(c.fl1) & 1u);
     c.S2 = BALLOT(LV(c.fl2) & 1u);
     ICER_TICK(19)
+    return true;
 }
 
 // the bins' open words and coder state after the chunk
@@ -1317,25 +1347,28 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t t
 // Records wave: once the walker wave has walked chunk r, every event lane of bins 1..7 derives from the bin's
 // start flags whether a code word starts / ends at its event and, for an end, the finished ring word and the
 // position of the word's first event.  `max_steps` bounds one call in the emulation (the GPU passes ~0u).
-ICER_DEV void records_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_steps)
+struct RecordsWave { uint32_t next = 0, gen = 0; };     // next chunk / generation, as WalkWave
+
+ICER_DEV void records_wave_run(CoderShared &s, const UnitArgs &a, RecordsWave &rw, uint32_t max_steps)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     ICER_IDLE_DECL
     const uint32_t nchunks = s.nchunks;
     for (uint32_t step = 0;;) {
-        if (ICER_LOAD_CNT(s.abort)) break;
-        const uint32_t seq = ICER_LOAD_CNT(s.exact_seq);
-        if (seq != s.helper_gen) {                      // records for chunks after last_exact are void
+        // (control words read together: one LDS round trip; the tag is the walker's for the chunk we expect next --
+        // after a roll-back it is simply re-read on the next pass)
+        const uint32_t ab_ = ICER_LOAD_CNT(s.abort), seq = ICER_LOAD_CNT(s.exact_seq);
+        const uint32_t tg_ = ICER_LOAD_CNT(s.wq[rw.next % kQueueDepth].tag);
+        if (ab_) break;
+        if (seq != rw.gen) {                            // records for chunks after last_exact are void
             ICER_ACQUIRE()
-            FOR_LANES
-            {
-                if (lane == 0) { s.helper_gen = seq; s.helper_next = s.last_exact + 1u; }
-            }
-            WAVE_SYNC();
+            rw.gen = seq;
+            rw.next = s.last_exact + 1u;
+            continue;
         }
-        const uint32_t r = s.helper_next, gen = s.helper_gen;
-        if (r >= nchunks || ICER_LOAD_CNT(s.wq[r % kQueueDepth].tag) != chunk_tag(r, gen)) {
+        const uint32_t r = rw.next, gen = rw.gen;
+        if (r >= nchunks || tg_ != chunk_tag(r, gen)) {
             if (ICER_LOAD_CNT(s.b_done) >= nchunks || step >= max_steps) break;
             ICER_IDLE()
             continue;
@@ -1379,11 +1412,7 @@ ICER_DEV void records_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_s
             }
 #undef ICER_V2V_RECORD
         ICER_PUBLISH(ro.rtag, chunk_tag(r, gen))
-        FOR_LANES
-        {
-            if (lane == 0) s.helper_next = r + 1u;
-        }
-        WAVE_SYNC();
+        rw.next = r + 1u;
         ICER_TICK(21)
         step++;
         ICER_IDLE_RESET
@@ -1447,10 +1476,11 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
     DECL_LANE;
     ICER_TIMERS_DECL
     uint32_t tail = s.alloc;                                // allocation count (this wave owns it)
+    uint32_t gen = s.exact_seq;                             // generation (this wave bumps it)
     for (uint32_t j = j0; j < j1; j++) {
         MergeChunk c;
-        merge_gather(s, c, j ICER_TIMER_PASS);
-        if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+        uint32_t popped_seen;
+        if (!merge_gather(s, c, j, gen, &popped_seen ICER_TIMER_PASS)) { ICER_TIMERS_STORE(a.timers) return false; }
         // If the ring cannot fill up inside this chunk no forced flush (E5) is possible and word boundaries depend
         // on each bin alone: the speculative results say how many words the chunk opens *if* no flush happens, and
         // if they all fit none happens.  The drain wave's pop count may lag, which only over-estimates the
@@ -1459,7 +1489,7 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         const uint32_t nstarts = (uint32_t)(popc64(c.S1) + popc64(c.S2));
         bool held = false, fast = true;
         ICER_COUNT(31)
-        if (tail - ICER_LOAD_CNT(s.popped) + nstarts > (uint32_t)kRingWords) {
+        if (tail - popped_seen + nstarts > (uint32_t)kRingWords) {
             ICER_DRAIN_HOLD(s, a)
             if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             held = true;
@@ -1486,7 +1516,8 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
                 {
                     if (lane == 0) s.last_exact = j;
                 }
-                ICER_PUBLISH(s.exact_seq, s.exact_seq + 1u)
+                gen++;
+                ICER_PUBLISH(s.exact_seq, gen)
             } else {
                 ICER_EMU_COUNT(0);
             }
@@ -1544,7 +1575,6 @@ ICER_DEV void unit_state_init(CoderShared &s)
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
             s.p_done = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
             for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; }
-            s.helper_next = 0; s.helper_gen = 0;
         }
     }
     WAVE_SYNC();
@@ -1561,6 +1591,7 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
     CountWave cs;
     WalkWave ww;
     GolombWave gw;
+    RecordsWave rw;
     walk_wave_init(s, ww);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
     golomb_wave_init(gw);
@@ -1572,7 +1603,7 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
         // both speculating waves run as far ahead as events allow (and roll back when told to)
         walk_wave_run(s, a, ww, nchunks, kQueueDepth);
         golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
-        records_wave_run(s, a, kQueueDepth);
+        records_wave_run(s, a, rw, kQueueDepth);
         if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
         drain_wave_run(s, a, jb & 1u);              // the drain lags behind the merge wave on purpose

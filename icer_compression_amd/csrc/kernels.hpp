@@ -171,7 +171,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         golomb_wave_init(gw);
         golomb_wave_run(s, a, gw, nchunks, ~0u);
     } else if (wave == kRecords) {
-        records_wave_run(s, a, ~0u);
+        RecordsWave rw;
+        records_wave_run(s, a, rw, ~0u);
     } else if (wave == kDrain) {
         drain_wave_run(s, a, ~0u);
     } else if (wave == kCompact) {
