@@ -250,3 +250,49 @@ def test_uint8_twins_device_resident_batch(oracle):
     for k in range(n):
         rc, stream, _ = oracle.compress_u8([frames[k]], st, 0, sg, quota)
         assert res[k] == (rc, stream)
+
+
+def test_cli_matches_reference_cli_semantics(oracle, tmp_path):
+    """tools/icer_util_hip.c: same options as the reference's `icer_util compress`, same .bin for the
+    same pixels (gray widening, RGB -> Y/Cb/Cr, stb_image's channel conversions, quota rule)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "icer_util_hip")
+    libdir = os.path.join(root, "icer_compression_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "icer_util_hip.c"),
+                           "-L", libdir, "-licer_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    rng = np.random.default_rng(9)
+    w, h = 200, 144
+    gray = synth.gray_frame(w, h, 3, 1).astype(np.uint8)
+    rgb = np.stack([synth.gray_frame(w, h, 10 + c, 1).astype(np.uint8) for c in range(3)], axis=-1)
+    rgb[::7, ::5] = rng.integers(0, 256, rgb[::7, ::5].shape)
+    (tmp_path / "g.pgm").write_bytes(b"P5\n# comment\n%d %d\n255\n" % (w, h) + gray.tobytes())
+    (tmp_path / "c.ppm").write_bytes(b"P6 %d %d 255\n" % (w, h) + rgb.tobytes())
+    stride = (3 * w + 3) // 4 * 4
+    rows = np.zeros((h, stride), np.uint8)
+    rows[:, : 3 * w] = rgb[::-1, :, ::-1].reshape(h, 3 * w)                   # bottom-up, BGR
+    hdr = b"BM" + (54 + stride * h).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") + \
+        w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(24)
+    (tmp_path / "c.bmp").write_bytes(hdr + rows.tobytes())
+
+    def ycbcr(img):
+        r, g, b = (img[:, :, c].astype(np.int64) for c in range(3))
+        clip = lambda v: np.clip(v, 0, 255)
+        y = clip((19595 * r + 38470 * g + 7471 * b) >> 16)
+        return [p.astype(np.uint16) for p in (y, clip(((36962 * (b - y)) >> 16) + 128), clip(((46727 * (r - y)) >> 16) + 128))]
+
+    luma = lambda img: ((77 * img[:, :, 0].astype(np.uint32) + 150 * img[:, :, 1].astype(np.uint32) + 29 * img[:, :, 2].astype(np.uint32)) >> 8).astype(np.uint16)
+    cases = [("g.pgm", [], [gray.astype(np.uint16)], 4, 0, 6, w * h),                                 # defaults of the reference CLI
+             ("g.pgm", ["-s", "3", "-f", "C", "-g", "9", "-t", "4000"], [gray.astype(np.uint16)], 3, 2, 9, 4000),
+             ("g.pgm", ["--color", "-s", "2"], ycbcr(np.repeat(gray[:, :, None], 3, axis=2)), 2, 0, 6, 3 * w * h),
+             ("c.ppm", ["--stages", "3", "--segments", "4"], ycbcr(rgb), 3, 0, 4, 3 * w * h),
+             ("c.ppm", ["-G", "-f", "q"], [luma(rgb)], 4, 6, 6, w * h),
+             ("c.bmp", ["-t", "9000", "-g", "3"], ycbcr(rgb), 4, 0, 3, 9000)]
+    for name, opts, planes, st, f, sg, q in cases:
+        r = subprocess.run([exe, "compress", str(tmp_path / name), str(tmp_path / "o.bin")] + opts, capture_output=True, text=True)
+        rc, stream, _ = oracle.compress(planes, st, f, sg, q)
+        assert r.returncode == 0 and rc in (0, -5), r.stdout + r.stderr
+        assert (tmp_path / "o.bin").read_bytes() == stream, (name, opts)
+    assert subprocess.run([exe, "decompress", "a", "b", "-G"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "compress", str(tmp_path / "g.pgm"), str(tmp_path / "o.bin"), "-c", "-G"], capture_output=True).returncode == 1
