@@ -12,7 +12,6 @@
 #pragma once
 #include <algorithm>
 #include <stdint.h>
-#include <stdlib.h>
 #include <vector>
 
 #include "icer_tables.hpp"
@@ -229,10 +228,8 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
         for (size_t i = 0; i < n; i++) by_size[i] = (uint32_t)i;
         // (equal sizes: low bit planes first -- they are the dense, slow ones, and when a launch has more large units
         // than the chip has CUs the ones that double up should be the cheap high planes)
-        const bool lsb_first = !getenv("ICER_HIP_OLD_ORDER");
         std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) {
             const uint64_t pa = (uint64_t)p->units[a].w * p->units[a].h, pb = (uint64_t)p->units[b].w * p->units[b].h;
-            if (!lsb_first) return pa > pb;
             const int ca = size_class(pa), cb = size_class(pb);        // "equal" = within about 20 %
             if (ca != cb) return ca > cb;
             if (p->units[a].lsb != p->units[b].lsb) return p->units[a].lsb < p->units[b].lsb;
