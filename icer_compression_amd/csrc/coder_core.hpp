@@ -561,7 +561,17 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         LANEVAR(uint32_t, w1); LANEVAR(uint32_t, w2); LANEVAR(uint32_t, cnw);
 #define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
         ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
-        {
+        // A blank chunk -- 64 pixels that are and stay insignificant with no significant neighbour, i.e. 64 zero events
+        // of context 0 and no sign event; more than half of all chunks, the high planes mostly -- needs no matching:
+        // the rank of an event is its lane number and so is the number of zeros before it.
+        if (BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull) {
+            FOR_LANES
+            {
+                LV(w1) = 0x80u | ((uint32_t)lane << 8) | ((uint32_t)lane << 16);
+                LV(w2) = 0;
+                LV(cnw) = lane == 0 ? (64u | (64u << 8)) : 0u;
+            }
+        } else {
             // magnitude-bit events: contexts 0..11; sign events: contexts 12..16, keyed by context - 12
             const uint64_t V = BALLOT(LV(valid1) && LV(ctx1) != 31u);
             const uint64_t B0 = BALLOT(LV(ctx1) & 1u), B1 = BALLOT(LV(ctx1) & 2u), B2 = BALLOT(LV(ctx1) & 4u), B3 = BALLOT(LV(ctx1) & 8u);
@@ -738,6 +748,20 @@ ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, u
         {
             LV(ev1) = q.ev1[lane];
             LV(ev2) = q.ev2[lane];
+        }
+        const uint64_t V1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), V2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u));
+        if ((V1 | V2) == 0ull) {
+            // no event of bins 1..7 in this chunk (the rule in the sparse high planes): only the counts are read downstream
+            FOR_LANES
+            {
+                if (lane < 8) q.binn[lane] = 0;
+            }
+            ICER_PUBLISH(s.c_done, j + 1u)
+            ICER_TICK(26)
+            continue;
+        }
+        FOR_LANES
+        {
             if (lane < 48) (&q.binbits[0][0])[lane] = 0;
         }
         WAVE_SYNC();
@@ -746,7 +770,6 @@ ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, u
         // are found from per-bit ballots of the bin number (no loop over bins).
         {
 #define ICER_MATCH3(KEY, V, B0, B1, B2) ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)))
-            const uint64_t V1 = BALLOT((LV(ev1) & 0x98u) == 0x80u && (LV(ev1) & 7u)), V2 = BALLOT((LV(ev2) & 0x98u) == 0x80u && (LV(ev2) & 7u));
             const uint64_t P0 = BALLOT(LV(ev1) & 1u), P1 = BALLOT(LV(ev1) & 2u), P2 = BALLOT(LV(ev1) & 4u);
             const uint64_t Q0 = BALLOT(LV(ev2) & 1u), Q1 = BALLOT(LV(ev2) & 2u), Q2 = BALLOT(LV(ev2) & 4u);
             FOR_LANES
@@ -848,7 +871,25 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
         const EventSlot &q = s.eq[j % kQueueDepth];
         WalkSlot &o = s.wq[j % kQueueDepth];
         RecSlot &ro = s.rq[j % kQueueDepth];
-        // A bin's walk is a chain of dependent table look-ups, four input bits each.  To halve the chain the bin's
+        if (BALLOT(lane >= 1 && lane <= 7 && q.binn[lane & 7] != 0) == 0ull) {
+            // no event of bins 1..7 in this chunk: nothing to walk, the bins keep their state
+            FOR_LANES
+            {
+                if (lane >= 1 && lane <= 7) {
+                    const uint32_t node = LV(ww.node), nin = 31u - (uint32_t)clz32(node);
+                    o.bincarry[lane] = (uint8_t)node;
+                    o.post_nin[lane] = (uint8_t)nin;
+                    ro.binst[lane] = st_pack(255u, node ^ (1u << nin), nin);
+                }
+            }
+            ICER_TICK(8)
+            ICER_PUBLISH(o.tag, chunk_tag(j, ww.gen))
+            ww.next = j + 1u;
+            done++;
+            ICER_IDLE_RESET
+            continue;
+        }
+        // A bin's walk is a chain of dependent table look-ups, six input bits each.  To halve the chain the bin's
         // n ranks are cut at h (a multiple of 4): lane b (1..7) walks [0, h) from the node carried in, and one lane
         // per node of the bin's code tree (CoderTables::cand_*) walks [h, n) as if entered at that node; when the
         // first half is done its end node says which of them was right.
@@ -1009,7 +1050,27 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         // The lane holding a bin's last event of the chunk also leaves the bin's state (run length, open word).
 #define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
         ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
-        {
+        const uint32_t e0 = READLANE(ev1, 0);
+        if ((e0 & 0xB8u) >= 0x88u && (e0 & 0x20u) == 0u && BALLOT(LV(ev1) != e0 || LV(ev2) != 0u) == 0ull) {
+            // 64 zero events of one Golomb bin and nothing else (what a blank chunk turns into once its context's
+            // estimate has settled): the run simply continues, lane L sees run length (k + L) mod m
+            const uint32_t b = e0 & 31u, m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = s.gk[b];
+            WAVE_SYNC();
+            FOR_LANES
+            {
+                const uint32_t z = k_in + (uint32_t)lane;
+                const uint32_t kb = z - ((z * inv) >> 20) * m;
+                const uint32_t ends = kb + 1u == m ? 1u : 0u;
+                LV(fl1) = (kb == 0u ? 1u : 0u) | (ends << 1);
+                LV(wd1) = kWordDone | (1u << 11) | 1u;
+                if (ends) LV(sp1) = kb <= (uint32_t)lane ? 2u * ((uint32_t)lane - kb) : 255u;
+                if (lane == 63) {
+                    const uint32_t k_after = ends ? 0u : kb + 1u;
+                    s.gk[b] = k_after;
+                    o.binst[b] = st_pack(k_after ? (kb <= 63u ? 2u * (63u - kb) : 255u) : 254u, k_after, 0u);
+                }
+            }
+        } else {
             const uint64_t G1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), G2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u);
             if (G1 | G2) {
                 const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u);
