@@ -1050,24 +1050,37 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         // The lane holding a bin's last event of the chunk also leaves the bin's state (run length, open word).
 #define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
         ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+        LANEVAR(uint32_t, ka1); LANEVAR(uint32_t, ka2);     // run length after the event if it is the bin's last one, else ~0
+        // 64 zero events of Golomb bins in at most two runs of lanes (first bin b0, then bin b1) and nothing else -- what
+        // a blank chunk turns into once its context's estimate has settled; the bin changes where the estimate crosses
+        // a cut-off or is rescaled.  The runs simply continue: the r-th event of a run sees run length (k + r) mod m.
         const uint32_t e0 = READLANE(ev1, 0);
-        if ((e0 & 0xB8u) >= 0x88u && (e0 & 0x20u) == 0u && BALLOT(LV(ev1) != e0 || LV(ev2) != 0u) == 0ull) {
-            // 64 zero events of one Golomb bin and nothing else (what a blank chunk turns into once its context's
-            // estimate has settled): the run simply continues, lane L sees run length (k + L) mod m
-            const uint32_t b = e0 & 31u, m = s.tab.gm[b], inv = s.tab.ginv[b], k_in = s.gk[b];
+        const uint64_t D = BALLOT(LV(ev1) != e0);
+        const uint32_t c = D ? (uint32_t)ffs64(D) : 64u;                    // first lane of the second run
+        const uint32_t e1 = READLANE(ev1, c & 63u);
+        if (BALLOT((LV(ev1) & 0xB8u) < 0x88u || (LV(ev1) & 0x20u) != 0u || LV(ev2) != 0u || ((uint32_t)lane >= c && LV(ev1) != e1)) == 0ull) {
             WAVE_SYNC();
             FOR_LANES
             {
-                const uint32_t z = k_in + (uint32_t)lane;
+                const uint32_t b = LV(ev1) & 31u, m = s.tab.gm[b], inv = s.tab.ginv[b];
+                const uint32_t r = (uint32_t)lane >= c ? (uint32_t)lane - c : (uint32_t)lane;      // rank inside the run
+                const uint32_t z = s.gk[b] + r;
                 const uint32_t kb = z - ((z * inv) >> 20) * m;
                 const uint32_t ends = kb + 1u == m ? 1u : 0u;
+                const uint32_t first = kb <= r ? 2u * ((uint32_t)lane - kb) : 255u;               // first event of the word this event is in
                 LV(fl1) = (kb == 0u ? 1u : 0u) | (ends << 1);
                 LV(wd1) = kWordDone | (1u << 11) | 1u;
-                if (ends) LV(sp1) = kb <= (uint32_t)lane ? 2u * ((uint32_t)lane - kb) : 255u;
-                if (lane == 63) {
-                    const uint32_t k_after = ends ? 0u : kb + 1u;
-                    s.gk[b] = k_after;
-                    o.binst[b] = st_pack(k_after ? (kb <= 63u ? 2u * (63u - kb) : 255u) : 254u, k_after, 0u);
+                if (ends) LV(sp1) = first;
+                LV(ka1) = ((uint32_t)lane == 63u || (uint32_t)lane + 1u == c) ? (ends ? 0u : kb + 1u) : ~0u;   // last event of its bin
+                LV(ka2) = first;
+            }
+            WAVE_SYNC();
+            FOR_LANES
+            {
+                if (LV(ka1) != ~0u) {
+                    const uint32_t b = LV(ev1) & 31u;
+                    s.gk[b] = LV(ka1);
+                    o.binst[b] = st_pack(LV(ka1) ? LV(ka2) : 254u, LV(ka1), 0u);
                 }
             }
         } else {
@@ -1076,7 +1089,6 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                 const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u);
                 const uint64_t J0 = BALLOT(LV(ev2) & 1u), J1 = BALLOT(LV(ev2) & 2u), J2 = BALLOT(LV(ev2) & 4u), J3 = BALLOT((LV(ev2) & 31u) == 16u);
                 const uint64_t O1 = G1 & BALLOT(LV(ev1) & 0x20u), O2 = G2 & BALLOT(LV(ev2) & 0x20u);       // one-events
-                LANEVAR(uint32_t, ka1); LANEVAR(uint32_t, ka2);     // run length after the event if it is the bin's last one, else ~0
                 // key of a bin: bin - 8 = 0..8, i.e. the low three bits of the bin number and "bin == 16"
                 LANEVAR(uint64_t, ma1); LANEVAR(uint64_t, mb1); LANEVAR(uint64_t, ma2); LANEVAR(uint64_t, mb2);   // events of this lane's bins
 #define ICER_GOLOMB_LANE(EV, SLOT, KA, FL, WD, MA, MB)                                                        \

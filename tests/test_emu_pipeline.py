@@ -131,3 +131,16 @@ def test_uint8_twins_pipeline(emu, oracle):
         if a[0] in (0, -5):
             assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
     assert {0, -1, -5} <= seen, seen
+
+
+def test_blank_chunk_shortcuts(emu, oracle):
+    """Long runs of blank chunks (all-zero events of context 0 wandering through the Golomb bins and the count rescales),
+    interrupted by isolated significant pixels: the pixel / compaction / walker / golomb shortcuts against the oracle."""
+    rng = np.random.default_rng(17)
+    for (w, h, spikes) in [(300, 257, 0), (300, 257, 3), (640, 200, 40), (64, 1000, 7), (1000, 70, 200)]:
+        plane = np.zeros((h, w), np.uint16)
+        for _ in range(spikes):
+            plane[int(rng.integers(0, h)), int(rng.integers(0, w))] = int(rng.integers(1, 300)) | (int(rng.integers(0, 2)) << 15)
+        for sb in (0, 1, 2, 3):
+            for lsb in (0, 3, 8):
+                assert emu.code_unit(plane, 0, 0, w, h, sb, lsb) == oracle.code_unit(plane, 0, 0, w, h, sb, lsb), (w, h, spikes, sb, lsb)
