@@ -467,7 +467,10 @@ int icerx_encode_device_rgb8(icerx_encoder *e, const uint8_t *d_rgb, int n_frame
 int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, size_t byte_quota, uint8_t *out,
                       size_t out_stride, uint64_t *sizes, int32_t *rcs)
 {
-    if (!e || n_frames < 1 || n_frames > e->max_frames) return ICER_INVALID_INPUT;
+    if (!e || !frames || !out || !sizes || !rcs || n_frames < 1 || n_frames > e->max_frames || e->sample_bits != 16) {
+        set_error("icerx_encode_host: invalid arguments (needs a 16-bit encoder, 1 <= n_frames <= max_frames)");
+        return ICER_INVALID_INPUT;
+    }
     HIP_TRY(hipSetDevice(e->device));
     const size_t plane = e->w * e->h, P = (size_t)n_frames * e->channels;
     if (upload_units(e, byte_quota, nullptr)) return ICER_FATAL_ERROR;
