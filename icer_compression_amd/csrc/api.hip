@@ -78,9 +78,9 @@ struct icerx_encoder {
     DevBuf<int16_t> coef, tmp;
     DevBuf<unsigned long long> sums;
     DevBuf<uint16_t> means;
-    DevBuf<int> flags;                  // [0,P) dwt overflow  [P,2P) mean overflow  [2P,2P+F) frame skip  [2P+F] bound overflow  [2P+F+1, +F) quota hit
+    DevBuf<int> flags;                  // [0,P) dwt overflow  [P,2P) mean overflow  [2P,2P+F) frame skip  [2P+F] bound overflow
     DevBuf<UnitDesc> units;
-    DevBuf<uint32_t> work_order, split_order, final_order, unit_bits;
+    DevBuf<uint32_t> work_order, final_order, unit_bits, done_bytes;
     DevBuf<uint64_t> final_off;
     DevBuf<uint8_t> slots;
     DevBuf<CoderTables> tables;
@@ -150,10 +150,9 @@ int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
     if (e->units_uploaded && e->slot_quota == quota) return 0;
     assign_slots(&e->plan, quota, e->bits_per_pixel);
     const size_t n = e->plan.units.size();
-    if (e->units.ensure(n) || e->work_order.ensure(n) || e->split_order.ensure(n) || e->final_order.ensure(n)) return ICER_FATAL_ERROR;
+    if (e->units.ensure(n) || e->work_order.ensure(n) || e->final_order.ensure(n)) return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpyAsync(e->units.p, e->plan.units.data(), n * sizeof(UnitDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(e->work_order.p, e->plan.work_order.data(), n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(e->split_order.p, e->plan.split_order.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(e->final_order.p, e->plan.final_order.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));       // the host vectors may change on the next re-plan
     e->slot_quota = quota;
@@ -230,30 +229,16 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
 
     // ---- coding units
-    int *quota_hit = bound_ovf + 1;
-    // Progressive mode: with a byte quota far below the lossless size only the first part of the priority
-    // order can end up in the stream.  The units are then coded range by range in priority order, and a probe
-    // after each range stops the remaining launches of a frame (they exit at once) when its quota is exhausted.
-    // Not used for large quotas: every range would wait for its own largest unit.
+    // Progressive mode: with a byte quota far below the lossless size only the first part of the priority order can end
+    // up in the stream.  The units are then launched in priority order with the quota: a unit whose finished
+    // higher-priority predecessors alone already exceed it stops (at its start, or at its next check) -- see
+    // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
-    if (!progressive) {
-        hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64 * kUnitWaves), 0, st,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                           e->work_order.p, n_units, e->tables.p, e->means.p, skip, quota_hit, e->slots.p,
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p);
-    } else {
-        HIP_TRY(hipMemsetAsync(e->unit_bits.p, 0, (size_t)n_frames * n_units * 4, st));
-        const std::vector<uint32_t> &rb = e->plan.split_begin;
-        for (size_t r = 0; r + 1 < rb.size(); r++) {
-            hipLaunchKernelGGL(code_units_kernel, dim3(rb[r + 1] - rb[r], n_frames), dim3(64 * kUnitWaves), 0, st,
-                               reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                               e->split_order.p + rb[r], n_units, e->tables.p, e->means.p, skip, quota_hit, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p);
-            if (r + 2 < rb.size())
-                hipLaunchKernelGGL(quota_probe_kernel, dim3(n_frames), dim3(64), 0, st, e->unit_bits.p, n_units, rb[r + 1],
-                                   (uint64_t)quota, quota_hit);
-        }
-    }
+    if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
+    hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64 * kUnitWaves), 0, st,
+                       reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                       progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
+                       e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
@@ -330,6 +315,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -352,7 +338,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
-    e->units.release(); e->work_order.release(); e->split_order.release(); e->final_order.release(); e->unit_bits.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);

@@ -201,7 +201,33 @@ struct UnitArgs {
     uint32_t *out_words;        // payload slot (4-byte aligned)
     uint32_t cap_words;         // slot capacity in 32-bit words
     uint64_t *timers;           // profiling build only (may be null)
+    // progressive mode (small byte quota): the frame's per-unit results so far in priority order, this unit's place in
+    // that order and the quota; null / 0 otherwise.  See quota_already_spent.
+    const uint32_t *done_bytes;
+    uint32_t prio_index;
+    uint64_t early_quota;
 };
+
+// Progressive mode.  The stream keeps units in priority order until the first one that does not fit the byte quota
+// (icer_partition.c:321-336, `break` in the packet loop); everything after it is dropped.  done_bytes[j] is 0 while
+// unit j is unfinished, its size (header + payload bytes) once it is coded, ~0 if it can not fit whatever comes
+// before it.  If the finished units of higher priority ALONE already exceed the quota, the cut lies before this unit
+// and it can stop: its result can not be part of the stream.  (A lower bound of the prefix sum, so never a false
+// positive; units before the cut always run to completion.)  One wavefront; wave-uniform result.
+#ifndef ICER_WAVE_EMU
+ICER_DEV bool quota_already_spent(const UnitArgs &a)
+{
+    if (!a.early_quota) return false;
+    DECL_LANE;
+    unsigned long long sum = 0;
+    for (uint32_t j = (uint32_t)lane; j < a.prio_index; j += 64) {
+        const uint32_t d = __hip_atomic_load(&a.done_bytes[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum += d == ~0u ? a.early_quota + 1ull : (unsigned long long)d;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    return sum > a.early_quota;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // exact coder steps (restatement of E1-E6; draining is left to wave_drain)
@@ -500,6 +526,10 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
     }
 
     for (uint32_t j = j0; j < j1; j++) {
+#ifndef ICER_WAVE_EMU
+        // progressive mode: has the byte quota been used up by units of higher priority in the meantime?
+        if ((j & 127u) == 127u && quota_already_spent(a)) { ICER_PUBLISH(s.abort, 3u) break; }
+#endif
         const uint32_t base = j * 64u;
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);

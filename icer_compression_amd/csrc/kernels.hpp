@@ -100,8 +100,9 @@ __global__ void __launch_bounds__(64 * kUnitWaves)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
-                  const int *__restrict__ frame_skip, const int *__restrict__ quota_hit, uint8_t *__restrict__ slots,
-                  size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers)
+                  const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
+                  size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
+                  uint32_t *__restrict__ done_bytes, uint64_t early_quota)
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
@@ -110,20 +111,35 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     if (trace && threadIdx.x == 0) {
         trace[0] = wall_clock64();
         trace[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-        trace[3] = work_order[blockIdx.x];
+        trace[3] = work_order ? work_order[blockIdx.x] : blockIdx.x;
     }
     if (timers && frame == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
         timers[9 * 32 + 4 * kTraceUnits + (threadIdx.x >> 6)] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
-    const uint32_t ui = work_order[blockIdx.x];
+    const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
     const uint32_t wave = threadIdx.x >> 6;
-    // DWT / mean overflow: the reference emits nothing.  Progressive mode: an earlier priority range already
-    // exhausted this frame's byte quota, so this unit can not be part of the stream.
-    if (frame_skip[frame] || quota_hit[frame]) {
+    // DWT / mean overflow: the reference emits nothing.
+    if (frame_skip[frame]) {
         if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
         return;
     }
     const UnitDesc u = units[ui];
+    if (early_quota) {
+        // progressive mode: units are launched in priority order; one whose higher-priority predecessors have already
+        // used up the quota can not be in the stream (quota_already_spent)
+        UnitArgs pa;
+        pa.done_bytes = done_bytes + (size_t)frame * n_units; pa.prio_index = ui; pa.early_quota = early_quota;
+        __shared__ int skip_unit;                   // (one wave decides for the workgroup: the inputs keep changing)
+        if (wave == 0) {
+            const bool spent = quota_already_spent(pa);
+            if (threadIdx.x == 0) skip_unit = spent ? 1 : 0;
+        }
+        __syncthreads();
+        if (skip_unit) {
+            if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
+            return;
+        }
+    }
     switch (u.prio) {                             // s_setprio takes an immediate
     case 3: __builtin_amdgcn_s_setprio(3); break;
     case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -152,6 +168,9 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.subband = (int)u.subband; a.lsb = (int)u.lsb;
     a.out_words = slot_words + kHeaderBytes / 4;
     a.cap_words = u.cap_words;
+    a.done_bytes = early_quota ? done_bytes + (size_t)frame * n_units : nullptr;
+    a.prio_index = ui;
+    a.early_quota = early_quota;
     // profiling build: per-wave cycle counters of the level-1 (largest) units, one row per bit plane
     a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
@@ -180,6 +199,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     } else {
         uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (s.abort == 2u) bits = kUnitFailed;        // a bounded spin expired: internal error, never a silent hang
+        if (s.abort == 3u) bits = 0;                  // progressive mode: stopped, the quota cut lies before this unit
         if (bits != kUnitTooBig && bits != kUnitFailed) {
             // make this wave's payload stores visible to its own loads before the CRC pass reads them
             __threadfence();
@@ -191,7 +211,15 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
             f.image_w = img_w; f.image_h = img_h;
             finish_unit_wave(s, f);
         }
-        if ((threadIdx.x & 63) == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
+        if ((threadIdx.x & 63) == 0) {
+            unit_bits[(size_t)frame * n_units + ui] = bits;
+            if (early_quota && s.abort != 3u) {
+                // a unit that outgrew a slot sized by the quota can not fit; one that outgrew the bits-per-pixel bound is
+                // unknown (the batch is redone with larger slots if it matters)
+                const uint32_t d = bits == kUnitTooBig ? (u.cap_is_bound ? 0u : ~0u) : bits == kUnitFailed ? 0u : kHeaderBytes + ((bits + 7u) >> 3);
+                __hip_atomic_store(&done_bytes[(size_t)frame * n_units + ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
 #ifdef ICER_PHASE_TIMERS
         if (trace && (threadIdx.x & 63) == 0) trace[1] = wall_clock64();
 #endif
@@ -231,17 +259,6 @@ scan_kernel(const uint32_t *__restrict__ unit_bits, const uint32_t *__restrict__
     if (kept < n_units && threadIdx.x == 0 && bits[kept] == kUnitTooBig && units[kept].cap_is_bound)
         atomicOr(bound_overflow, 1);
     if (threadIdx.x == 0) { sizes[frame] = used; rcs[frame] = rc; }
-}
-
-// progressive mode, between two priority ranges: has the quota walk over the units coded so far (priority
-// order, the first n_coded of them) already hit the cut?  grid = frames, block = 64.
-__global__ void __launch_bounds__(64)
-quota_probe_kernel(const uint32_t *__restrict__ unit_bits, uint32_t n_units, uint32_t n_coded, uint64_t quota,
-                   int *__restrict__ quota_hit)
-{
-    const uint32_t frame = blockIdx.x;
-    if (quota_hit[frame]) return;
-    if (quota_cut_wave(unit_bits + (size_t)frame * n_units, n_coded, quota) < n_coded && threadIdx.x == 0) quota_hit[frame] = 1;
 }
 
 // copy every kept unit (header + payload) to its place in the final stream.  grid = (units, frames)

@@ -19,7 +19,6 @@
 namespace icer {
 
 constexpr int kXcds = 8;             // MI355X: 8 XCDs, workgroup b of a launch is placed on XCD b % 8
-constexpr int kQuotaRanges = 12;     // progressive mode: launches per frame batch (each followed by a quota probe)
 
 struct Packet {
     uint8_t level, subband, lsb, chan;
@@ -146,9 +145,6 @@ struct Plan {
     std::vector<UnitDesc> units;           // priority order: packet order, then segment number
     std::vector<uint32_t> final_order;     // D7 order -> index into units
     std::vector<uint32_t> work_order;      // launch order (largest units first) -> index into units
-    // progressive mode (small byte quota): the same units grouped into kQuotaRanges consecutive priority ranges,
-    // largest first inside a range; range r = split_order[split_begin[r] .. split_begin[r+1])
-    std::vector<uint32_t> split_order, split_begin;
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
 };
 
@@ -249,21 +245,6 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
             for (int x = 0; x < kXcds; x++)
                 if (k < lists[x].size()) p->work_order.push_back(lists[x][k]);
                 // (a shorter list simply stops contributing; the tail then drifts off the b % 8 pattern, harmless)
-    }
-    // progressive mode: priority ranges of about n/kQuotaRanges units each, aligned to whole packets
-    {
-        const size_t n = p->units.size(), per = (size_t)segments;
-        p->split_order.resize(n);
-        p->split_begin.assign(1, 0);
-        for (int r = 1; r < kQuotaRanges; r++) {
-            size_t cut = n * r / kQuotaRanges / per * per;
-            if (cut > p->split_begin.back()) p->split_begin.push_back((uint32_t)cut);
-        }
-        p->split_begin.push_back((uint32_t)n);
-        for (size_t i = 0; i < n; i++) p->split_order[i] = (uint32_t)i;
-        for (size_t r = 0; r + 1 < p->split_begin.size(); r++)
-            std::stable_sort(p->split_order.begin() + p->split_begin[r], p->split_order.begin() + p->split_begin[r + 1],
-                             [&](uint32_t a, uint32_t b) { return (uint64_t)p->units[a].w * p->units[a].h > (uint64_t)p->units[b].w * p->units[b].h; });
     }
     // the launch is latency-bound by its largest units: give their waves issue priority over the small ones
     const uint64_t biggest = p->units.empty() ? 1 : (uint64_t)p->units[p->work_order[0]].w * p->units[p->work_order[0]].h;
