@@ -296,3 +296,25 @@ def test_cli_matches_reference_cli_semantics(oracle, tmp_path):
         assert (tmp_path / "o.bin").read_bytes() == stream, (name, opts)
     assert subprocess.run([exe, "decompress", "a", "b", "-G"], capture_output=True).returncode == 2
     assert subprocess.run([exe, "compress", str(tmp_path / "g.pgm"), str(tmp_path / "o.bin"), "-c", "-G"], capture_output=True).returncode == 1
+
+
+def test_progressive_mode_batch_with_different_cut_points(oracle):
+    """Small byte quotas (units launched in priority order, stopping once the quota is spent): frames of one batch
+    whose cuts fall at very different places, one of them an all-zero frame, plus a YUV batch."""
+    w, h, st, sg = 384, 320, 4, 9
+    frames = np.stack([synth.gray_frame(w, h, 50, 0), synth.gray_frame(w, h, 51, 1), np.zeros((h, w), np.uint16),
+                       (synth.gray_frame(w, h, 52, 1) // 16).astype(np.uint16), synth.gray_frame(w, h, 53, 0)])
+    for quota in (300, 2500, 20000, w * h // 2 - 1):
+        enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=len(frames))
+        res = enc.encode_host(frames[:, None], quota)
+        enc.close()
+        for k in range(len(frames)):
+            rc, stream, _ = oracle.compress([frames[k]], st, 0, sg, quota)
+            assert res[k] == (rc, stream), (quota, k, res[k][0], rc, len(res[k][1]), len(stream))
+    planes = [np.stack(synth.color_frame_yuv(256, 192, 60 + k)) for k in range(3)]
+    enc = api.Encoder(256, 192, 3, 3, 1, 5, max_frames=3)
+    res = enc.encode_host(np.stack(planes), 9000)
+    enc.close()
+    for k in range(3):
+        rc, stream, _ = oracle.compress(list(planes[k]), 3, 1, 5, 9000)
+        assert res[k] == (rc, stream)
