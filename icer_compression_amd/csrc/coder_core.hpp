@@ -703,8 +703,10 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
                 if (LV(valid1) && LV(ctx1) != 31u) { LV(t1) = LV(t0) + LV(rk1); LV(z1) = LV(zz0) + LV(zb1); }
                 LV(idx) = LV(ctx2);
             }
-            WAVE_GATHER(t0, ctot, idx)
-            WAVE_GATHER(zz0, czer, idx)
+            if (BALLOT(LV(valid2) != 0u)) {                       // (no sign events in most chunks of the high planes)
+                WAVE_GATHER(t0, ctot, idx)
+                WAVE_GATHER(zz0, czer, idx)
+            }
             LANEVAR(uint32_t, cross);
             FOR_LANES
             {
