@@ -50,6 +50,37 @@ def cpu_baseline(frame: np.ndarray, expect_crc: str):
             "sample": f"1 full {W}x{H} frame (same input as the GPU run), {dt:.2f} s, stream matches golden: {ok}"}
 
 
+def cpu_all_cores():
+    """the CPU encoder on ALL host cores of this box -- P worker processes (oracle/cpu_worker.py: the
+    library is not re-entrant), one frame each (frame k uses seed 12345 + k), started together; value = P frames over the
+    time of the slowest encode.  Bounded: every worker is killed after 120 s."""
+    import subprocess
+    from oracle import binding
+    binding.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(cores, 32))
+    cmd = [sys.executable, "-m", "oracle.cpu_worker"]
+    ps = [subprocess.Popen(cmd + [str(12345 + k), str(W), str(H), str(STAGES), str(FILT), str(SEGMENTS)], cwd=ROOT,
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(procs)]
+    times, ok = [], True
+    deadline = time.time() + 120
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            rc, _, sec = out.split()
+            ok = ok and rc == "0"
+            times.append(float(sec))
+        except Exception:
+            p.kill()
+            ok = False
+    if not times:
+        return {"error": "no CPU worker finished"}
+    slowest = max(times)
+    return {"value": round(len(times) * W * H / slowest / 1e6, 3), "unit": "Mpixels/s", "cores": procs,
+            "kind": "reference" if binding.have_reference() else "port",
+            "sample": f"{len(times)} of {procs} processes x 1 full {W}x{H} frame in parallel, slowest encode {slowest:.2f} s, all rc 0: {ok}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +227,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_frames[0], gold["crc32"])
             line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
+            try:
+                line["cpu_all_cores"] = cpu_all_cores()
+            except Exception as exc:                                   # reported, never fatal for the GPU numbers
+                line["cpu_all_cores"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     enc.close()
     if world > 1:
