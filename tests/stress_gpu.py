@@ -20,7 +20,8 @@ def main():
     orc = Oracle()
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
-        w, h = int(rng.integers(5, 700)), int(rng.integers(5, 700))
+        big = rng.random() < 0.03                       # now and then a large frame (long coding units, deep queues)
+        w, h = (int(rng.integers(700, 2200)), int(rng.integers(700, 2200))) if big else (int(rng.integers(5, 700)), int(rng.integers(5, 700)))
         st = int(rng.integers(1, 7))
         while ((w + (1 << st) - 1) >> st) < 3 or ((h + (1 << st) - 1) >> st) < 3:
             st -= 1
@@ -39,18 +40,21 @@ def main():
         quota = int(rng.choice([2 * w * h + 64, max(64, w * h // 3), max(40, w * h // 20), 100 + int(rng.integers(0, 3000))]))
         color = rng.random() < 0.2
         planes = [img] if not color else [img, np.roll(img, 3, 0), np.roll(img, 5, 1)]
+        u8 = rng.random() < 0.2                          # the uint8 twins on 6-bit versions of the same planes
+        if u8:
+            planes = [(p >> int(rng.choice([0, 2, 4]))).astype(np.uint8) for p in planes]
         try:
-            a = api.compress(planes, st, filt, sg, quota)
+            a = (api.compress_u8 if u8 else api.compress)(planes, st, filt, sg, quota)
         except Exception as exc:                                   # noqa: BLE001
             print("EXCEPTION", w, h, st, filt, sg, quota, exc)
             bad += 1
             continue
-        b = orc.compress(planes, st, filt, sg, quota)
+        b = (orc.compress_u8 if u8 else orc.compress)(planes, st, filt, sg, quota)
         same = a[0] == b[0] and a[1] == b[1] and (a[0] not in (0, -5) or all(np.array_equal(p, q) for p, q in zip(a[2], b[2])))
         n += 1
         if not same:
             bad += 1
-            print("MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color)),
+            print("MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color), u8=bool(u8)),
                   "rc", a[0], b[0], "len", len(a[1]), len(b[1]), flush=True)
     print(f"stress: {n} cases, {bad} mismatches, {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
