@@ -555,24 +555,24 @@ static int compress_planes(void *const planes[], int channels, size_t w, size_t 
         if (e) { icerx_encoder_destroy(e); g_cached = nullptr; }
         const char *dev = getenv("ICER_HIP_DEVICE");
         const int rc = icerx_encoder_create_ex(&e, dev ? atoi(dev) : 0, w, h, channels, stages, filt, segments, 1, sample_bits);
-        if (rc == ICER_PACKET_COUNT_EXCEEDED && sample_bits == 8) {
-            // The reference finds its packet table too small only after the transform and the LL-mean check
-            // (icer_color.c:31-131): an integer overflow there is what it reports.  Run those on the three planes as
-            // three gray frames (112 packets) and look at their return codes.
+        if (rc == ICER_PACKET_COUNT_EXCEEDED || rc == ICER_TOO_MANY_SEGMENTS) {
+            // The reference finds its packet table too small, or the segment grid impossible, only after the transform
+            // and the LL-mean check (icer_color.c:31-131, icer_compress.c:279-400): an integer overflow there is what it
+            // reports.  Run those on the planes as gray frames with one segment and look at their return codes.
             icerx_encoder *t = nullptr;
-            if (icerx_encoder_create_ex(&t, dev ? atoi(dev) : 0, w, h, 1, stages, filt, 1, channels, 8) == 0) {
-                const size_t plane = w * h;
-                std::vector<uint8_t> host((size_t)channels * plane), out((size_t)channels * 128);
-                std::vector<uint64_t> sizes(channels);
+            if (icerx_encoder_create_ex(&t, dev ? atoi(dev) : 0, w, h, 1, stages, filt, 1, channels, sample_bits) == 0) {
+                const size_t plane = w * h, n = (size_t)channels * plane;
                 std::vector<int32_t> rcs(channels, 0);
-                for (int c = 0; c < channels; c++) memcpy(host.data() + (size_t)c * plane, planes[c], plane);
                 int r = 0;
-                if (t->in8.ensure(host.size()) || t->in.ensure(host.size())) r = ICER_FATAL_ERROR;
-                if (!r && hipMemcpy(t->in8.p, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) r = ICER_FATAL_ERROR;
+                if (t->in.ensure(n) || (sample_bits == 8 && t->in8.ensure(n))) r = ICER_FATAL_ERROR;
+                for (int c = 0; c < channels && !r; c++) {
+                    const hipError_t he = sample_bits == 8 ? hipMemcpy(t->in8.p + (size_t)c * plane, planes[c], plane, hipMemcpyHostToDevice)
+                                                           : hipMemcpy(t->in.p + (size_t)c * plane, planes[c], plane * 2, hipMemcpyHostToDevice);
+                    if (he != hipSuccess) r = ICER_FATAL_ERROR;
+                }
                 if (!r) {
-                    hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((host.size() + 255) / 256, 4096)), dim3(256), 0, nullptr,
-                                       t->in8.p, t->in.p, host.size());
-                    // (icerx_encode_host takes uint16 frames: the widened planes are already on the device, so go below it)
+                    if (sample_bits == 8)
+                        hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, nullptr, t->in8.p, t->in.p, n);
                     for (;;) {
                         if (upload_units(t, 64, nullptr) || t->out.ensure((size_t)channels * 128)) { r = ICER_FATAL_ERROR; break; }
                         bool regrow = false;
