@@ -138,7 +138,7 @@ struct PixelSlot {              // pixel wave -> count wave
 struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint8_t ev1[64];            // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | bin, 0 = none
     uint8_t ev2[64];            // sign event of pixel `lane`
-    uint32_t nev;               // number of events in the chunk
+    uint32_t blank;             // 1: the chunk is 64 zero events of context 0 and nothing else (PixelSlot::cn[17])
     // bins 1..7, compacted per bin in coding order (rank = number of earlier events of the same bin):
     uint8_t rk1[64], rk2[64];   // rank of this lane's events inside their bin
     uint8_t binseq[8][128];     // rank -> position of the event
@@ -594,7 +594,8 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         // A blank chunk -- 64 pixels that are and stay insignificant with no significant neighbour, i.e. 64 zero events
         // of context 0 and no sign event; more than half of all chunks, the high planes mostly -- needs no matching:
         // the rank of an event is its lane number and so is the number of zeros before it.
-        if (BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull) {
+        const bool blank = BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull;
+        if (blank) {
             FOR_LANES
             {
                 LV(w1) = 0x80u | ((uint32_t)lane << 8) | ((uint32_t)lane << 16);
@@ -644,6 +645,7 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             o.e[lane][0] = LV(w1);
             o.e[lane][1] = LV(w2);
             if (lane < 17) o.cn[lane] = (uint16_t)LV(cnw);
+            if (lane == 17) o.cn[17] = blank ? 1u : 0u;            // handed on to the golomb wave (EventSlot::blank)
         }
         ICER_PUBLISH(s.p_done, j + 1u)
     }
@@ -743,7 +745,6 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             LV(ev1) = e1;
             LV(ev2) = e2;
         }
-        const uint32_t nev = (uint32_t)(popc64(BALLOT(LV(ev1) != 0u)) + popc64(BALLOT(LV(ev2) != 0u)));
         ICER_TICK(4)
         // queue slot j % D is free once the assembly wave has retired chunk j - D
         ICER_WAIT_CNT(s.b_done, bd_, j < bd_ + kQueueDepth, ab2_, 6)
@@ -754,7 +755,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         {
             q.ev1[lane] = (uint8_t)LV(ev1);
             q.ev2[lane] = (uint8_t)LV(ev2);
-            if (lane == 0) q.nev = nev;
+            if (lane == 0) q.blank = in.cn[17];
         }
         ICER_PUBLISH(s.a_done, j + 1u)
     }
@@ -1086,11 +1087,18 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         // 64 zero events of Golomb bins in at most two runs of lanes (first bin b0, then bin b1) and nothing else -- what
         // a blank chunk turns into once its context's estimate has settled; the bin changes where the estimate crosses
         // a cut-off or is rescaled.  The runs simply continue: the r-th event of a run sees run length (k + r) mod m.
-        const uint32_t e0 = READLANE(ev1, 0);
-        const uint64_t D = BALLOT(LV(ev1) != e0);
-        const uint32_t c = D ? (uint32_t)ffs64(D) : 64u;                    // first lane of the second run
-        const uint32_t e1 = READLANE(ev1, c & 63u);
-        if (BALLOT((LV(ev1) & 0xB8u) < 0x88u || (LV(ev1) & 0x20u) != 0u || LV(ev2) != 0u || ((uint32_t)lane >= c && LV(ev1) != e1)) == 0ull) {
+        // (only a blank chunk can qualify -- the count wave hands the pixel wave's flag on -- so the test costs the
+        // other chunks one LDS read)
+        uint32_t c = 64, e1 = 0;                                            // first lane and event of the second run
+        bool runs = q.blank != 0u;
+        if (runs) {
+            const uint32_t e0 = READLANE(ev1, 0);
+            const uint64_t D = BALLOT(LV(ev1) != e0);
+            c = D ? (uint32_t)ffs64(D) : 64u;
+            e1 = READLANE(ev1, c & 63u);
+            runs = BALLOT((LV(ev1) & 0xB8u) < 0x88u || (LV(ev1) & 0x20u) != 0u || LV(ev2) != 0u || ((uint32_t)lane >= c && LV(ev1) != e1)) == 0ull;
+        }
+        if (runs) {
             WAVE_SYNC();
             FOR_LANES
             {
