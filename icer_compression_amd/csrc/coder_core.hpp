@@ -465,6 +465,7 @@ ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit, uint32_t max_rounds
 struct PixelWave {                // next chunk's 3x3 coefficient window, one pixel per lane
     LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
     LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
+    LANEVAR(uint32_t, has);                             // which neighbours exist: bit 0 W, 1 E, 2 N, 3 S
     LANEVAR(uint32_t, row); LANEVAR(uint32_t, col);     // raster coordinates of this lane's pixel in the next chunk
 };
 
@@ -483,15 +484,11 @@ struct PixelWave {                // next chunk's 3x3 coefficient window, one pi
         const uint32_t vC_ = pC_[c_], vW_ = pC_[cW_], vE_ = pC_[cE_];                                   \
         const uint32_t vN_ = pN_[c_], vNW_ = pN_[cW_], vNE_ = pN_[cE_];                                 \
         const uint32_t vS_ = pS_[c_], vSW_ = pS_[cW_], vSE_ = pS_[cE_];                                 \
-        LV(cw.nC) = vC_;                                                                               \
-        LV(cw.nW) = hasW_ ? vW_ : 0u;                                                                  \
-        LV(cw.nE) = hasE_ ? vE_ : 0u;                                                                  \
-        LV(cw.nN) = hasN_ ? vN_ : 0u;                                                                  \
-        LV(cw.nS) = hasS_ ? vS_ : 0u;                                                                  \
-        LV(cw.nNW) = (hasN_ && hasW_) ? vNW_ : 0u;                                                     \
-        LV(cw.nNE) = (hasN_ && hasE_) ? vNE_ : 0u;                                                     \
-        LV(cw.nSW) = (hasS_ && hasW_) ? vSW_ : 0u;                                                     \
-        LV(cw.nSE) = (hasS_ && hasE_) ? vSE_ : 0u;                                                     \
+        /* the loaded values are not touched before the next chunk needs them (the loads stay in flight meanwhile):  \
+         * which neighbours exist is kept as a mask and applied then */                                \
+        LV(cw.nC) = vC_; LV(cw.nW) = vW_; LV(cw.nE) = vE_; LV(cw.nN) = vN_; LV(cw.nS) = vS_;             \
+        LV(cw.nNW) = vNW_; LV(cw.nNE) = vNE_; LV(cw.nSW) = vSW_; LV(cw.nSE) = vSE_;                     \
+        LV(cw.has) = (hasW_ ? 1u : 0u) | (hasE_ ? 2u : 0u) | (hasN_ ? 4u : 0u) | (hasS_ ? 8u : 0u);     \
         /* advance to the same lane of the next chunk */                                               \
         if (a.w >= 64u) {                                                                              \
             uint32_t nc_ = LV(cw.col) + 64u;                                                           \
@@ -526,10 +523,6 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
     }
 
     for (uint32_t j = j0; j < j1; j++) {
-#ifndef ICER_WAVE_EMU
-        // progressive mode: has the byte quota been used up by units of higher priority in the meantime?
-        if ((j & 127u) == 127u && quota_already_spent(a)) { ICER_PUBLISH(s.abort, 3u) break; }
-#endif
         const uint32_t base = j * 64u;
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
@@ -537,8 +530,12 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         LANEVAR(uint32_t, cNW); LANEVAR(uint32_t, cNE); LANEVAR(uint32_t, cSW); LANEVAR(uint32_t, cSE);
         FOR_LANES
         {
-            LV(cC) = LV(cw.nC); LV(cW) = LV(cw.nW); LV(cE) = LV(cw.nE); LV(cN) = LV(cw.nN); LV(cS) = LV(cw.nS);
-            LV(cNW) = LV(cw.nNW); LV(cNE) = LV(cw.nNE); LV(cSW) = LV(cw.nSW); LV(cSE) = LV(cw.nSE);
+            const uint32_t hm = LV(cw.has);
+            const bool hW = hm & 1u, hE = hm & 2u, hN = hm & 4u, hS = hm & 8u;
+            LV(cC) = LV(cw.nC); LV(cW) = hW ? LV(cw.nW) : 0u; LV(cE) = hE ? LV(cw.nE) : 0u;
+            LV(cN) = hN ? LV(cw.nN) : 0u; LV(cS) = hS ? LV(cw.nS) : 0u;
+            LV(cNW) = (hN && hW) ? LV(cw.nNW) : 0u; LV(cNE) = (hN && hE) ? LV(cw.nNE) : 0u;
+            LV(cSW) = (hS && hW) ? LV(cw.nSW) : 0u; LV(cSE) = (hS && hE) ? LV(cw.nSE) : 0u;
         }
         // the next chunk's window is fetched while this one is processed (the LDS-only fences never drain vmcnt)
         if (base + 64u < npix) ICER_FETCH_WINDOW(base + 64u)
@@ -771,6 +768,12 @@ ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, u
     DECL_LANE;
     ICER_TIMERS_DECL
     for (uint32_t j = j0; j < j1; j++) {
+#ifndef ICER_WAVE_EMU
+        // progressive mode: has the byte quota been used up by units of higher priority in the meantime?  (Checked by
+        // this wave because it has the slack and no other global memory traffic: in the pixel wave the check's loads
+        // made the compiler wait for the window prefetch at once.)
+        if ((j & 127u) == 127u && quota_already_spent(a)) { ICER_PUBLISH(s.abort, 3u) break; }
+#endif
         ICER_WAIT_CNT(s.a_done, ad_, ad_ > j, ab_, 1)
         if (ab_) break;
         ICER_ACQUIRE()
