@@ -247,7 +247,7 @@ scan_kernel(const uint32_t *__restrict__ unit_bits, const uint32_t *__restrict__
         for (uint32_t i = threadIdx.x; i < n_units; i += 64) failed |= bits[i] == kUnitFailed;
         if (__ballot(failed)) {
             for (uint32_t i = threadIdx.x; i < n_units; i += 64) foff[i] = ~0ull;
-            if (threadIdx.x == 0) { sizes[frame] = 0; rcs[frame] = kFatalError; }
+            if (threadIdx.x == 0) { sizes[frame] = 0; rcs[frame] = kFatalError; atomicOr(bound_overflow, 2); }
             return;
         }
     }

@@ -55,7 +55,7 @@ def main():
         if not same:
             bad += 1
             print("MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color), u8=bool(u8)),
-                  "rc", a[0], b[0], "len", len(a[1]), len(b[1]), flush=True)
+                  "rc", a[0], b[0], "len", len(a[1]), len(b[1]), api.load_library().icerx_last_error() if a[0] == -10 else "", flush=True)
     print(f"stress: {n} cases, {bad} mismatches, {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
 
