@@ -1727,6 +1727,52 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
     }
     return merge_wave_finish(s, a);
 }
+
+// tests only: the same eight waves under a RANDOM scheduler -- at every step one wave is picked at random and runs one
+// chunk if its inputs are there (exactly the conditions the GPU waits for), so waves lag and lead each other in ways
+// the deterministic order above never produces.  A state in which no wave can move is a protocol deadlock: reported as
+// kUnitFailed.
+static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, uint32_t seed)
+{
+    unit_state_init(s);
+    PixelWave pw;
+    CountWave cs;
+    WalkWave ww;
+    GolombWave gw;
+    RecordsWave rw;
+    walk_wave_init(s, ww);
+    golomb_wave_init(gw);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    uint32_t jp = 0, ja = 0, jc = 0, jb = 0, idle = 0;
+    uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+    while (jb < nchunks) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        const uint32_t pick = (uint32_t)(rng >> 33) % 8u;
+        bool moved = false;
+        switch (pick) {
+        case 0: if (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; moved = true; } break;
+        case 1: if (ja < s.p_done && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; moved = true; } break;
+        case 2: if (jc < s.a_done) { compact_wave_run(s, a, jc, jc + 1); jc++; moved = true; } break;
+        case 3: moved = walk_wave_run(s, a, ww, nchunks, 1u) != 0; break;
+        case 4: moved = golomb_wave_run(s, a, gw, nchunks, 1u) != 0; break;
+        case 5: { const uint32_t before = rw.next, g = rw.gen; records_wave_run(s, a, rw, 1u); moved = rw.next != before || rw.gen != g; } break;
+        case 6: {
+            const RecSlot &rq = s.rq[jb % kQueueDepth];
+            const uint32_t tag = chunk_tag(jb, s.exact_seq);
+            if (rq.gtag == tag && rq.rtag == tag) {
+                if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+                jb++;
+                moved = true;
+            }
+        } break;
+        default: { const uint32_t before = s.popped; drain_wave_run(s, a, 1u); moved = s.popped != before; } break;
+        }
+        if (s.abort) return kUnitTooBig;
+        idle = moved ? 0u : idle + 1u;
+        if (idle > 100000u) return kUnitFailed;
+    }
+    return merge_wave_finish(s, a);
+}
 #endif
 
 }  // namespace icer

@@ -90,6 +90,16 @@ def emu():
             return bits, bytes(out[: (max(bits, 0) + 7) // 8])
 
         @staticmethod
+        def code_unit_random(plane, x, y, w, h, sb, lsb, seed):
+            """the same unit under the random wave scheduler (code_unit_emu_random); bits = -10: the waves dead-locked"""
+            cap = ((w * h * 3 + 64) + 3) // 4 * 4
+            out = np.zeros(cap + 8, np.uint8)
+            L.emu_code_unit_random.restype = C.c_long
+            L.emu_code_unit_random.argtypes = L.emu_code_unit.argtypes + [C.c_uint32]
+            bits = L.emu_code_unit_random(plane.ctypes.data + 2 * (y * plane.shape[1] + x), w, h, plane.shape[1], sb, lsb, out, cap, seed)
+            return bits, bytes(out[: (max(bits, 0) + 7) // 8])
+
+        @staticmethod
         def dwt(img, stages, filt):
             b = np.ascontiguousarray(img, dtype=np.uint16).copy()
             rc = L.emu_dwt(b, b.shape[1], b.shape[0], stages, filt)

@@ -36,6 +36,25 @@ extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t st
     return res;
 }
 
+// the same under the random wave scheduler (code_unit_emu_random); -10 = the waves dead-locked
+extern "C" long emu_code_unit_random(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
+                                     uint8_t *out, size_t cap_bytes, uint32_t seed)
+{
+    memset(&g_sh, 0xA5, sizeof g_sh);
+    build_coder_tables(&g_sh.tab);
+    UnitArgs a;
+    a.seg = seg; a.stride = (uint32_t)stride; a.w = (uint32_t)w; a.h = (uint32_t)h;
+    a.subband = subband; a.lsb = lsb;
+    a.cap_words = (uint32_t)(cap_bytes / 4);
+    std::vector<uint32_t> words(a.cap_words + 1, 0);
+    a.out_words = words.data();
+    a.timers = nullptr;
+    const uint32_t bits = code_unit_emu_random(g_sh, a, seed);
+    const long res = bits == kUnitTooBig ? -5 : bits == kUnitFailed ? -10 : (long)bits;
+    if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
+    return res;
+}
+
 // forward DWT with the structure of the product: one fused LDS-tile pass per stage (csrc/dwt_tile.hpp), the LL
 // band handed from stage to stage through a side buffer, the three detail bands written in place
 static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim);

@@ -144,3 +144,25 @@ def test_blank_chunk_shortcuts(emu, oracle):
         for sb in (0, 1, 2, 3):
             for lsb in (0, 3, 8):
                 assert emu.code_unit(plane, 0, 0, w, h, sb, lsb) == oracle.code_unit(plane, 0, 0, w, h, sb, lsb), (w, h, spikes, sb, lsb)
+
+
+def test_random_wave_schedules(emu, oracle):
+    """The eight waves of a coding unit under a random scheduler (one wave at a time, picked at random, runs one chunk if
+    its inputs are there): every interleaving must give the oracle's bits, and none may dead-lock (bits = -10)."""
+    rng = np.random.default_rng(23)
+    for trial in range(12):
+        w, h = int(rng.integers(64, 400)), int(rng.integers(64, 300))
+        if trial % 3 == 0:
+            v = rng.normal(0, float(rng.choice([2, 6, 20])), (h, w)).astype(np.int32)
+        elif trial % 3 == 1:
+            v = (rng.integers(-300, 300, (h, w)) * (rng.random((h, w)) < 0.05)).astype(np.int32)
+        else:
+            v = rng.normal(0, 3, (h, w))
+            v[:, : w // 3] *= 0.1
+            v[h // 2:, :] *= 20
+            v = v.astype(np.int32)
+        plane = np.ascontiguousarray(np.minimum(np.abs(v), 32767).astype(np.uint16) | ((v < 0).astype(np.uint16) << 15))
+        for sb, lsb in ((0, 0), (3, 1), (1, 4)):
+            want = oracle.code_unit(plane, 0, 0, w, h, sb, lsb)
+            for k in range(4):
+                assert emu.code_unit_random(plane, 0, 0, w, h, sb, lsb, 1000 * trial + k) == want, (trial, sb, lsb, k)
