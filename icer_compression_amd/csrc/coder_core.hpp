@@ -56,7 +56,6 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // cross-wave hand-off: the emulation runs the waves in an order in which every wait is already satisfied
 #define ICER_LOAD_CNT(x) (x)
 #define ICER_WAIT_UNTIL(cond) { assert(cond); }
-#define ICER_WAIT_RELAXED(cond) { assert(cond); }
 #define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB = s.abort; { const uint32_t V = (X); (void)V; assert((PRED) || AB); }
 #define ICER_PUBLISH(x, v) { (x) = (v); }
 #define ICER_PUBLISH2(x1, v1, x2, v2) { (x1) = (v1); (x2) = (v2); }
@@ -75,8 +74,6 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
         if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } } \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 #define ICER_WAIT_UNTIL(cond) ICER_SPIN(cond, 1)
-// for waits of a wave that runs AHEAD of the pipeline (its queue is full): poll rarely, leave the issue slots to others
-#define ICER_WAIT_RELAXED(cond) ICER_SPIN(cond, 6)
 // wait until PRED holds for V = the counter X, or the unit is abandoned; the counter and the abort word are read
 // together (one LDS round trip per poll) and AB receives the abort word
 #define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB; { uint32_t spins_ = 0; for (;;) {                          \
@@ -926,7 +923,7 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
             continue;
         }
         // A bin's walk is a chain of dependent table look-ups, six input bits each.  To halve the chain the bin's
-        // n ranks are cut at h (a multiple of 4): lane b (1..7) walks [0, h) from the node carried in, and one lane
+        // n ranks are cut at h = ceil(n / 2): lane b (1..7) walks [0, h) from the node carried in, and one lane
         // per node of the bin's code tree (CoderTables::cand_*) walks [h, n) as if entered at that node; when the
         // first half is done its end node says which of them was right.
         LANEVAR(uint32_t, stl0); LANEVAR(uint32_t, stl1);       // start flags by rank, relative to the segment (a segment has <= 64 ranks)

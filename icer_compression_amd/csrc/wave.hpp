@@ -36,7 +36,6 @@ static inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }     
 static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline int clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
 static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
-#define LANEARG(T, name) T (&name)[64]
 #define LDS_OR(REF, VAL) ((REF) |= (VAL))
 #define READLANE(X, L) (X[L])
 // DST[lane] = SRC[IDX[lane]] (statement; not inside FOR_LANES)
@@ -68,7 +67,6 @@ static __device__ __forceinline__ int ffs64(uint64_t m) { return m ? (int)__buil
 static __device__ __forceinline__ int clz32(uint32_t v) { return v ? (int)__builtin_clz(v) : 32; }
 static __device__ __forceinline__ int clz64(uint64_t v) { return v ? (int)__builtin_clzll(v) : 64; }
 static __device__ __forceinline__ uint32_t brev32(uint32_t v) { return __brev(v); }
-#define LANEARG(T, name) T name
 #define LDS_OR(REF, VAL) atomicOr(&(REF), (VAL))
 #define READLANE(X, L) ((uint32_t)__builtin_amdgcn_readlane((int)(X), (int)(L)))
 #define WAVE_GATHER(DST, SRC, IDX) { DST = (uint32_t)__shfl((int)(SRC), (int)(IDX)); }
