@@ -49,7 +49,24 @@
 #include "icer_tables.hpp"
 #include "wave.hpp"
 
-#ifdef ICER_WAVE_EMU
+#if defined(ICER_WAVE_EMU) && defined(ICER_WAVE_THREADS)
+// tests only (tests/emu/threads_main.cpp): the lane-loop build with every wave on its own CPU thread and REAL waits --
+// the hand-off protocol under true concurrency, optionally under ThreadSanitizer (fence + relaxed atomic = the LDS
+// release / acquire pairs of the GPU build, so a data race it reports is a hole in the protocol).
+#include <assert.h>
+#include <atomic>
+#include <thread>
+#define ICER_EMU_COUNT(i)
+// (acquire / release on the counters themselves: ThreadSanitizer does not model stand-alone fences)
+#define ICER_LOAD_CNT(x) __atomic_load_n(&(x), __ATOMIC_ACQUIRE)
+#define ICER_POLL_PAUSE(n) std::this_thread::yield()
+#define ICER_SET_ABORT2() __atomic_store_n(&s.abort, 2u, __ATOMIC_RELAXED)
+#define ICER_FENCE_ACQ() std::atomic_thread_fence(std::memory_order_acquire)
+#define ICER_FENCE_REL() std::atomic_thread_fence(std::memory_order_release)
+#define ICER_STORE_CNT(x, v) __atomic_store_n(&(x), (v), __ATOMIC_RELEASE)
+#define ICER_LANE0
+constexpr uint32_t kPollLimit = 50u * 1000u * 1000u;
+#elif defined(ICER_WAVE_EMU)
 #include <assert.h>
 extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path chunks, [1] exact-path chunks
 #define ICER_EMU_COUNT(i) (g_emu_chunks[i]++)
@@ -68,26 +85,47 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-// Every spin is bounded (kSpinLimit polls, seconds of wall time): a wave that would wait longer declares the unit
+#define ICER_POLL_PAUSE(n) __builtin_amdgcn_s_sleep(n)
+#define ICER_SET_ABORT2() __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define ICER_FENCE_ACQ() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+#define ICER_FENCE_REL() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define ICER_STORE_CNT(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define ICER_LANE0 if (lane == 0)
+#define kPollLimit kSpinLimit
+#endif
+
+#if !defined(ICER_WAVE_EMU) || defined(ICER_WAVE_THREADS)
+// Every spin is bounded (kPollLimit polls, seconds of wall time): a wave that would wait longer declares the unit
 // failed (abort = 2), which every other wait observes; the host then reports ICER_FATAL_ERROR instead of hanging.
-#define ICER_SPIN(cond, SLEEP) { uint32_t spins_ = 0; while (!(cond)) { __builtin_amdgcn_s_sleep(SLEEP); \
-        if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } } \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+#define ICER_SPIN(cond, SLEEP) { uint32_t spins_ = 0; while (!(cond)) { ICER_POLL_PAUSE(SLEEP); \
+        if (++spins_ > kPollLimit) { ICER_SET_ABORT2(); break; } } \
+    ICER_FENCE_ACQ(); }
 #define ICER_WAIT_UNTIL(cond) ICER_SPIN(cond, 1)
 // wait until PRED holds for V = the counter X, or the unit is abandoned; the counter and the abort word are read
 // together (one LDS round trip per poll) and AB receives the abort word
 #define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB; { uint32_t spins_ = 0; for (;;) {                          \
         const uint32_t V = ICER_LOAD_CNT(X); AB = ICER_LOAD_CNT(s.abort);                                             \
         if ((PRED) || AB) break;                                                                                      \
-        __builtin_amdgcn_s_sleep(SLEEP);                                                                              \
-        if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); AB = 2u; break; } } \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
-#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&(x), pv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) { __hip_atomic_store(&(x1), pv1_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(&(x2), pv2_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } }
-#define ICER_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#define ICER_IDLE() { __builtin_amdgcn_s_sleep(1); if (++idle_spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } }
+        ICER_POLL_PAUSE(SLEEP);                                                                                       \
+        if (++spins_ > kPollLimit) { ICER_SET_ABORT2(); AB = 2u; break; } }                                           \
+    ICER_FENCE_ACQ(); }
+#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); ICER_FENCE_REL(); ICER_LANE0 ICER_STORE_CNT(x, pv_); }
+#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); ICER_FENCE_REL(); ICER_LANE0 { ICER_STORE_CNT(x1, pv1_); ICER_STORE_CNT(x2, pv2_); } }
+#define ICER_ACQUIRE() ICER_FENCE_ACQ();
+#define ICER_IDLE() { ICER_POLL_PAUSE(1); if (++idle_spins_ > kPollLimit) { ICER_SET_ABORT2(); break; } }
 #define ICER_IDLE_DECL uint32_t idle_spins_ = 0;
 #define ICER_IDLE_RESET idle_spins_ = 0;
+#endif
+
+// ring words are read by the drain wave while the merge wave may be finishing a later word of the same 64-word window
+// (it then sees the open marker or the finished word, both fine): plain 16-bit LDS accesses on the GPU, relaxed atomics
+// in the threaded test build so that ThreadSanitizer does not report this intended overlap
+#ifdef ICER_WAVE_THREADS
+#define RING_LD(i) ((uint32_t)__atomic_load_n(&s.ring[i], __ATOMIC_RELAXED))
+#define RING_ST(i, v) __atomic_store_n(&s.ring[i], (uint16_t)(v), __ATOMIC_RELAXED)
+#else
+#define RING_LD(i) ((uint32_t)s.ring[i])
+#define RING_ST(i, v) (s.ring[i] = (uint16_t)(v))
 #endif
 
 // Optional per-wave cycle counters (s_memtime) for tools/phase_profile.py; compiled in only with
@@ -248,13 +286,12 @@ ICER_DEV uint32_t st_pack(uint32_t op, uint32_t acc, uint32_t nin) { return op |
 ICER_DEV void seq_complete_head(CoderShared &s)
 {
     const uint32_t head = s.popped & (kRingWords - 1);
-    const uint32_t w = s.ring[head];
+    const uint32_t w = RING_LD(head);
     if (!(w & kWordDone)) {
         const int bin = (int)(w & 31u);
         if (bin >= 8) {
             const uint32_t k = st_acc(s.bin_state[bin]);
-            s.ring[head] = (uint16_t)((k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u)
-                                                                            : golomb_word(s.tab, bin, k));
+            RING_ST(head, (k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u) : golomb_word(s.tab, bin, k));
             s.bin_state[bin] = 0;
             s.bin_slot[bin] = -1;
         } else if (bin >= 1) {
@@ -264,7 +301,7 @@ ICER_DEV void seq_complete_head(CoderShared &s)
             const uint32_t pre = (acc | ((f & 15u) << nin)) & 31u;
             const uint32_t e = s.tab.v2v[bin][pre];
             // QUIRK (kept): the completed input is not checked to be a real code word
-            s.ring[head] = (uint16_t)(kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8));
+            RING_ST(head, (kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8)));
             s.bin_state[bin] = 0;
             s.bin_slot[bin] = -1;
         }
@@ -414,7 +451,7 @@ ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit, uint32_t max_rounds
         LANEVAR(uint32_t, w); LANEVAR(uint32_t, len); LANEVAR(uint32_t, off);
         FOR_LANES
         {
-            LV(w) = (uint32_t)lane < used ? s.ring[(head + (uint32_t)lane) & (kRingWords - 1)] : 0u;
+            LV(w) = (uint32_t)lane < used ? RING_LD((head + (uint32_t)lane) & (kRingWords - 1)) : 0u;
         }
         const uint64_t done = BALLOT((LV(w) & kWordDone) != 0u);
         const uint32_t n = (uint32_t)ffs64(~done);               // leading finished words
@@ -1228,7 +1265,7 @@ ICER_DEV bool merge_gather(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t g
     const RecSlot &rq = s.rq[j % kQueueDepth];
     const uint32_t tag = chunk_tag(j, gen);
     uint32_t ab_ = 0;
-#ifdef ICER_WAVE_EMU
+#if defined(ICER_WAVE_EMU) && !defined(ICER_WAVE_THREADS)
     assert((rq.gtag == tag && rq.rtag == tag) || s.abort);
     ab_ = s.abort;
     *popped = s.popped;
@@ -1240,8 +1277,8 @@ ICER_DEV bool merge_gather(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t g
             ab_ = ICER_LOAD_CNT(s.abort);
             *popped = ICER_LOAD_CNT(s.popped);
             if (((g_ == tag) & (r_ == tag)) | (ab_ != 0u)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins_ > kSpinLimit) { __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); ab_ = 2u; break; }
+            ICER_POLL_PAUSE(1);
+            if (++spins_ > kPollLimit) { ICER_SET_ABORT2(); ab_ = 2u; break; }
         }
     }
 #endif
@@ -1285,18 +1322,18 @@ ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t tail)
     const uint64_t S1 = c.S1, S2 = c.S2;
     FOR_LANES
     {
-        if (LV(c.fl1) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1)] = (uint16_t)LV(c.ev1);
-        if (LV(c.fl2) & 1u) s.ring[(tail + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1)] = (uint16_t)LV(c.ev2);
+        if (LV(c.fl1) & 1u) RING_ST((tail + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1), LV(c.ev1));
+        if (LV(c.fl2) & 1u) RING_ST((tail + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1), LV(c.ev2));
     }
     FOR_LANES
     {
         if (LV(c.fl1) & 2u) {
             const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1)] : (tail + cnt_lt(S1, S2, LV(c.sp1)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd1);
+            RING_ST(slot & (kRingWords - 1), LV(c.wd1));
         }
         if (LV(c.fl2) & 2u) {
             const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2)] : (tail + cnt_lt(S1, S2, LV(c.sp2)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd2);
+            RING_ST(slot & (kRingWords - 1), LV(c.wd2));
         }
     }
     WAVE_SYNC();
@@ -1312,19 +1349,19 @@ ICER_DEV void commit_range(CoderShared &s, MergeChunk &c, uint32_t tail0, uint32
     FOR_LANES
     {
         const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
-        if ((LV(c.fl1) & 1u) && p1 >= lo && p1 < hi) s.ring[(tail0 + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev1) & 31u);
-        if ((LV(c.fl2) & 1u) && p2 >= lo && p2 < hi) s.ring[(tail0 + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1)] = (uint16_t)(LV(c.ev2) & 31u);
+        if ((LV(c.fl1) & 1u) && p1 >= lo && p1 < hi) RING_ST((tail0 + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1), (LV(c.ev1) & 31u));
+        if ((LV(c.fl2) & 1u) && p2 >= lo && p2 < hi) RING_ST((tail0 + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1), (LV(c.ev2) & 31u));
     }
     FOR_LANES
     {
         const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
         if ((LV(c.fl1) & 2u) && p1 >= lo && p1 < hi) {
             const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp1)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd1);
+            RING_ST(slot & (kRingWords - 1), LV(c.wd1));
         }
         if ((LV(c.fl2) & 2u) && p2 >= lo && p2 < hi) {
             const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp2)));
-            s.ring[slot & (kRingWords - 1)] = (uint16_t)LV(c.wd2);
+            RING_ST(slot & (kRingWords - 1), LV(c.wd2));
         }
     }
     WAVE_SYNC();
@@ -1373,7 +1410,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t t
         if (alloc - s.popped == (uint32_t)kRingWords) {
             // still full: the head word is open.  Its bin, and that bin's state just before P:
             const uint32_t head = s.popped & (kRingWords - 1);
-            const uint32_t hb = s.ring[head] & 31u;
+            const uint32_t hb = RING_LD(head) & 31u;
             const uint64_t E1 = BALLOT((LV(c.ev1) & 0x9Fu) == (0x80u | hb)), E2 = BALLOT((LV(c.ev2) & 0x9Fu) == (0x80u | hb));
             const int x = last_lt(S1 & E1, S2 & E2, P);                           // first event of the open word, -1: carried in
             const uint32_t lo = x < 0 ? 0u : (uint32_t)x;
@@ -1398,7 +1435,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t t
             }
             FOR_LANES
             {
-                if (lane == 0) s.ring[head] = (uint16_t)word;
+                if (lane == 0) RING_ST(head, word);
             }
             WAVE_SYNC();
             // bin hb starts afresh at P: replay its remaining events of the chunk
@@ -1576,7 +1613,7 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
 }
 
 // merge wave: take over / give back the drain state
-#ifdef ICER_WAVE_EMU
+#if defined(ICER_WAVE_EMU) && !defined(ICER_WAVE_THREADS)
 #define ICER_DRAIN_HOLD(S, A) { (S).hold_seq |= 1u; drain_wave_run((S), (A), 0u); assert((S).hold_ack == (S).hold_seq); }
 #else
 #define ICER_DRAIN_HOLD(S, A) { const uint32_t hs_ = (S).hold_seq | 1u; ICER_PUBLISH((S).hold_seq, hs_) ICER_WAIT_UNTIL(ICER_LOAD_CNT((S).hold_ack) == hs_ || ICER_LOAD_CNT((S).abort)) }
@@ -1693,7 +1730,29 @@ ICER_DEV void unit_state_init(CoderShared &s)
     WAVE_SYNC();
 }
 
-#ifdef ICER_WAVE_EMU
+#if defined(ICER_WAVE_EMU) && defined(ICER_WAVE_THREADS)
+// tests only: one CPU thread per wave, the roles started exactly like code_units_kernel starts them
+static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
+{
+    unit_state_init(s);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    s.nchunks = nchunks;
+    uint32_t bits = kUnitTooBig;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    std::thread t[8];
+    t[0] = std::thread([&] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks); });
+    t[1] = std::thread([&] { CountWave cs; count_wave_run(s, a, cs, 0, nchunks); });
+    t[2] = std::thread([&] { compact_wave_run(s, a, 0, nchunks); });
+    t[3] = std::thread([&] { WalkWave ww; walk_wave_init(s, ww); walk_wave_run(s, a, ww, nchunks, ~0u); });
+    t[4] = std::thread([&] { GolombWave gw; golomb_wave_init(gw); golomb_wave_run(s, a, gw, nchunks, ~0u); });
+    t[5] = std::thread([&] { RecordsWave rw; records_wave_run(s, a, rw, ~0u); });
+    t[6] = std::thread([&] { drain_wave_run(s, a, ~0u); });
+    t[7] = std::thread([&] { bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig; });
+    for (auto &th : t) th.join();
+    if (__atomic_load_n(&s.abort, __ATOMIC_RELAXED) == 2u) bits = kUnitFailed;
+    return bits;
+}
+#elif defined(ICER_WAVE_EMU)
 // tests only: the seven waves interleaved on one CPU thread.  Each wave runs as far ahead as the queues and
 // the speculation rule allow, so slot reuse and the discard/reload protocol are exercised, not just the
 // lock-step order.

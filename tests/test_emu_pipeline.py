@@ -166,3 +166,35 @@ def test_random_wave_schedules(emu, oracle):
             want = oracle.code_unit(plane, 0, 0, w, h, sb, lsb)
             for k in range(4):
                 assert emu.code_unit_random(plane, 0, 0, w, h, sb, lsb, 1000 * trial + k) == want, (trial, sb, lsb, k)
+
+
+def test_waves_as_real_threads(oracle, tmp_path):
+    """The lane-loop build with every wave on its own CPU thread and real waits (tests/emu/threads_main.cpp): the hand-off
+    protocol under true concurrency must neither dead-lock (bits = -10) nor change a bit.  (The same program built with
+    -fsanitize=thread and tests/emu/tsan.supp is how the protocol was checked for data races.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "threads_main")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-unknown-pragmas", "-o", exe,
+                           os.path.join(root, "tests", "emu", "threads_main.cpp")])
+
+    def fnv(data):
+        hsh = 1469598103934665603
+        for x in data:
+            hsh = ((hsh ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % hsh
+
+    rng = np.random.default_rng(29)
+    for trial in range(6):
+        w, h = int(rng.integers(64, 300)), int(rng.integers(32, 200))
+        v = rng.normal(0, float(rng.choice([2, 6, 20])), (h, w)) if trial % 2 == 0 else \
+            rng.integers(-300, 300, (h, w)) * (rng.random((h, w)) < 0.1)
+        v = v.astype(np.int32)
+        plane = np.ascontiguousarray(np.minimum(np.abs(v), 32767).astype(np.uint16) | ((v < 0).astype(np.uint16) << 15))
+        plane.tofile(tmp_path / "plane.raw")
+        for sb, lsb in ((0, 0), (3, 2)):
+            bits, payload = oracle.code_unit(plane, 0, 0, w, h, sb, lsb)
+            r = subprocess.run([exe, str(tmp_path / "plane.raw"), str(w), str(h), str(sb), str(lsb), "3"], capture_output=True,
+                               text=True, timeout=300)
+            assert r.returncode == 0 and r.stdout.split("\n")[:3] == [f"{bits} {fnv(payload)}"] * 3, (trial, sb, lsb, r.stdout, r.stderr[:500])
