@@ -722,6 +722,9 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             LV(z2) = 0; LV(t2) = 0;
         }
 
+#ifdef ICER_WAVE_THREADS
+        assert(ICER_LOAD_CNT(s.p_done) <= j + kQueueDepth);      // (test build) the pixel wave has not recycled this slot
+#endif
         // ---- adaptive counts per event (C5) --------------------------------------------------------------
         // counts an event sees = its context's counts at chunk start + the ranks the pixel wave prepared; lane c
         // owns context c and advances its counters by the chunk's totals.  A context that reaches the rescale
@@ -1561,6 +1564,10 @@ ICER_DEV void records_wave_run(CoderShared &s, const UnitArgs &a, RecordsWave &r
                 ICER_V2V_RECORD(e2, (uint32_t)q.rk2[lane], 2 * lane + 1)
             }
 #undef ICER_V2V_RECORD
+#ifdef ICER_WAVE_THREADS
+        // (test build) the walker's slot was not recycled under our feet: same chunk, or a roll-back made it void
+        assert(ICER_LOAD_CNT(o.tag) == chunk_tag(r, gen) || ICER_LOAD_CNT(s.exact_seq) != gen);
+#endif
         ICER_PUBLISH(ro.rtag, chunk_tag(r, gen))
         rw.next = r + 1u;
         ICER_TICK(21)
@@ -1684,6 +1691,13 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             ICER_DRAIN_RELEASE(s)
             ICER_PUBLISH(s.b_done, j + 1u)
         } else {
+#ifdef ICER_WAVE_THREADS
+            {   // (test build) nobody recycled the chunk's slots before it was retired
+                const RecSlot &rq_ = s.rq[j % kQueueDepth];
+                assert(ICER_LOAD_CNT(rq_.gtag) == chunk_tag(j, gen) && ICER_LOAD_CNT(rq_.rtag) == chunk_tag(j, gen));
+                assert(ICER_LOAD_CNT(s.a_done) <= j + kQueueDepth);
+            }
+#endif
             // the new words (and the finished ones) become visible to the drain wave; the chunk's queue slots are free
             ICER_PUBLISH2(s.alloc, tail, s.b_done, j + 1u)
         }
