@@ -199,6 +199,28 @@ class Reference:
             rc = self.lib.icer_compress_image_yuv_uint8(work[0], work[1], work[2], w, h, stages, filt, segments, C.byref(ob))
         return rc, bytes(buf[quota: quota + ob.size_used]), work
 
+    def decompress(self, stream: bytes, channels, stages, filt, segments):
+        """The reference DECODER (icer_decompress_image_[yuv_]uint16, icer.h:461-466) on a stream: returns
+        (rc, [planes]).  Used for encode -> decode round trips of the HIP encoder's output."""
+        sz = C.c_size_t
+        buf = np.frombuffer(stream, dtype=np.uint8).copy()
+        w, h = sz(0), sz(0)
+        self.lib.icer_get_image_dimensions.argtypes = [u8p, sz, C.POINTER(sz), C.POINTER(sz)]
+        rc = self.lib.icer_get_image_dimensions(buf, buf.size, C.byref(w), C.byref(h))
+        if rc != 0:
+            return rc, []
+        planes = [np.zeros((h.value, w.value), np.uint16) for _ in range(channels)]
+        n = w.value * h.value
+        if channels == 1:
+            self.lib.icer_decompress_image_uint16.argtypes = [u16p, C.POINTER(sz), C.POINTER(sz), sz, u8p, sz, C.c_uint8, C.c_int, C.c_uint8]
+            rc = self.lib.icer_decompress_image_uint16(planes[0], C.byref(w), C.byref(h), n, buf, buf.size, stages, filt, segments)
+        else:
+            self.lib.icer_decompress_image_yuv_uint16.argtypes = [u16p, u16p, u16p, C.POINTER(sz), C.POINTER(sz), sz, u8p, sz, C.c_uint8,
+                                                                  C.c_int, C.c_uint8]
+            rc = self.lib.icer_decompress_image_yuv_uint16(planes[0], planes[1], planes[2], C.byref(w), C.byref(h), n, buf, buf.size,
+                                                           stages, filt, segments)
+        return rc, planes
+
     # table taps -------------------------------------------------------------------------
     def custom_code(self, b, prefix):
         a, o, c = C.c_int(), C.c_int(), C.c_int()

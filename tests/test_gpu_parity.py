@@ -318,3 +318,16 @@ def test_progressive_mode_batch_with_different_cut_points(oracle):
     for k in range(3):
         rc, stream, _ = oracle.compress(list(planes[k]), 3, 1, 5, 9000)
         assert res[k] == (rc, stream)
+
+
+def test_round_trip_through_the_reference_decoder(reference):
+    """Encode on the GPU, decode with the reference's own decoder (oracle/_ref), compare with the input: the
+    size-independent property at BASELINE configs[1] size (4096 x 4096, lossless) and on a YUV frame."""
+    for planes, st, f, sg in [([synth.gray_frame(4096, 4096, 12345, 1)], 5, 0, 10), ([synth.gray_frame(517, 389, 9, 1)], 4, 4, 7),
+                              (list(synth.color_frame_yuv(512, 384, 4)), 4, 0, 10)]:
+        h, w = planes[0].shape
+        enc = api.Encoder(w, h, len(planes), st, f, sg, max_frames=1)
+        (rc, stream), = enc.encode_host(np.stack(planes)[None], 2 * w * h * len(planes))
+        enc.close()
+        drc, back = reference.decompress(stream, len(planes), st, f, sg)
+        assert rc == 0 and drc == 0 and all(np.array_equal(a, b) for a, b in zip(back, planes))
