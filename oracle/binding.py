@@ -116,6 +116,29 @@ class Oracle:
         return rc, bytes(out[: used.value]), work
 
 
+    def decompress(self, stream: bytes, channels, stages, filt, segments, bufsize=None, bits=16):
+        """Decoder restatement (orc_decompress_u16 / _u8).  Returns (rc, w, h, [planes])."""
+        sz = C.c_size_t
+        buf = np.frombuffer(stream, dtype=np.uint8).copy() if len(stream) else np.zeros(1, np.uint8)
+        w, h = sz(0), sz(0)
+        if bufsize is None:
+            bufsize = _stream_dims(stream)
+        dt = np.uint16 if bits == 16 else np.uint8
+        planes = [np.zeros(max(bufsize, 1), dt) for _ in range(channels)]
+        ptrs = (C.c_void_p * channels)(*[p.ctypes.data for p in planes])
+        fn = self.lib.orc_decompress_u16 if bits == 16 else self.lib.orc_decompress_u8
+        fn.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(sz), C.POINTER(sz), sz, u8p, sz, C.c_int, C.c_int, C.c_uint]
+        rc = fn(ptrs, channels, C.byref(w), C.byref(h), bufsize, buf, len(stream), stages, filt, segments)
+        return rc, w.value, h.value, planes
+
+
+def _stream_dims(stream: bytes) -> int:
+    """w * h from the first packet header of a stream written by an encoder (test helper)."""
+    if len(stream) < 28:
+        return 0
+    return int.from_bytes(stream[8:12], "little") * int.from_bytes(stream[12:16], "little")
+
+
 class Reference:
     """The reference library itself (symbols of lib_icer + ref_tap.c), loaded RTLD_LOCAL because it
     exports the same icer_* names as the product library."""
@@ -220,6 +243,36 @@ class Reference:
             rc = self.lib.icer_decompress_image_yuv_uint16(planes[0], planes[1], planes[2], C.byref(w), C.byref(h), n, buf, buf.size,
                                                            stages, filt, segments)
         return rc, planes
+
+    def decompress_raw(self, stream: bytes, channels, stages, filt, segments, bufsize=None, bits=16):
+        """Same surface as Oracle.decompress: (rc, w, h, [flat planes of bufsize samples])."""
+        sz = C.c_size_t
+        if bufsize is None:
+            bufsize = _stream_dims(stream)
+        # The reference decoder has no end-of-packet check: a unit whose contexts it cannot reproduce (any coefficient
+        # above the coded planes) makes it read on, past the packet and past the end of the stream.  Zeros behind the
+        # stream make that read defined here -- and equal to the restatement's rule (bits past the end read as 0).
+        buf = np.zeros(len(stream) + 4 * bufsize + 4096, np.uint8)
+        buf[: len(stream)] = np.frombuffer(stream, dtype=np.uint8)
+        w, h = sz(0), sz(0)
+        dt, p_t = (np.uint16, u16p) if bits == 16 else (np.uint8, u8p)
+        planes = [np.zeros(max(bufsize, 1), dt) for _ in range(channels)]
+        tail = [C.POINTER(sz), C.POINTER(sz), sz, u8p, sz, C.c_uint8, C.c_int, C.c_uint8]
+        if channels == 1:
+            fn = self.lib.icer_decompress_image_uint16 if bits == 16 else self.lib.icer_decompress_image_uint8
+            fn.argtypes = [p_t] + tail
+            rc = fn(planes[0], C.byref(w), C.byref(h), bufsize, buf, len(stream), stages, filt, segments)
+        else:
+            fn = self.lib.icer_decompress_image_yuv_uint16 if bits == 16 else self.lib.icer_decompress_image_yuv_uint8
+            fn.argtypes = [p_t, p_t, p_t] + tail
+            rc = fn(planes[0], planes[1], planes[2], C.byref(w), C.byref(h), bufsize, buf, len(stream), stages, filt, segments)
+        return rc, w.value, h.value, planes
+
+    def decode_entry(self, b, code):
+        """icer_custom_decode_scheme[b][code] -> (code bits, reversed pattern, pattern bits)"""
+        arr = (C.c_uint8 * (17 * 32 * 3)).in_dll(self.lib, "icer_custom_decode_scheme")
+        k = (b * 32 + code) * 3
+        return arr[k], arr[k + 2], arr[k + 1]
 
     # table taps -------------------------------------------------------------------------
     def custom_code(self, b, prefix):

@@ -757,3 +757,492 @@ int orc_compress_u8(uint8_t *const planes8[], int channels, size_t w, size_t h, 
     for (int ch = 0; ch < channels; ch++) free(wide[ch]);
     return rc;
 }
+
+/* ==========================================================================================
+ * DECODER  (SURVEY.md section 8f, row "next-1": the consumer of the streams the hot path writes)
+ *
+ * Restates   icer_find_packet_in_bytestream          icer_compress.c:569-588
+ *            icer_decode_bit and its bit readers      icer_decoding.c:12-194
+ *            icer_decompress_bitplane_uint16/_uint8   icer_context_modeller.c:461-602 / :167-310
+ *            icer_decompress_partition_uint16/_uint8  icer_partition.c:393-494 / :171-275
+ *            icer_decompress_image_[yuv_]uint16/8     icer_compress.c:430-536 / :168-277, icer_color.c:534-663 / :208-340
+ *            the inverse lifting DWT                  icer_wavelet.c:81-103, 175-191, 467-550 (int8 twin :298-383)
+ * for streams made of CRC-valid packets written by an ICER encoder.  Where the reference would read or write out
+ * of bounds on hostile input (packet fields used as array indices unchecked, header reads past the end of the
+ * buffer, bit reads past the end of the stream) this restatement ignores the packet / reads zeros instead; those
+ * cases are not part of the parity claim.
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_DECODER_OUT_OF_DATA (-7)       /* ICER_DECODER_OUT_OF_DATA, icer.h:100 */
+#define ORC_DECODED_INVALID_DATA (-8)      /* ICER_DECODED_INVALID_DATA, icer.h:101 */
+
+/* one packet = 28-byte header + payload; NULL payload = absent */
+typedef struct { const uint8_t *hdr; } packet_ref;
+
+/* icer_find_packet_in_bytestream, icer_compress.c:569-588: first offset at which a header with the preamble, a
+ * matching header CRC, a payload that fits and a matching payload CRC starts.  Returns 1 and the offset just
+ * behind the packet, or 0 with *next = len. */
+static int find_packet(const uint8_t *data, size_t len, const uint8_t **pkt, size_t *next)
+{
+    for (size_t off = 0; off < len; off++) {
+        if (len - off < HEADER_BYTES) continue;                 /* (the reference reads the header regardless) */
+        const uint8_t *p = data + off;
+        if (p[0] != 0x5B || p[1] != 0x60) continue;
+        const uint32_t hcrc = (uint32_t)p[24] | ((uint32_t)p[25] << 8) | ((uint32_t)p[26] << 16) | ((uint32_t)p[27] << 24);
+        if (hcrc != orc_crc32(p, 24)) continue;
+        const uint32_t bits = (uint32_t)p[16] | ((uint32_t)p[17] << 8) | ((uint32_t)p[18] << 16) | ((uint32_t)p[19] << 24);
+        const size_t nbytes = (size_t)(bits / 8u) + ((bits % 8u) ? 1u : 0u);
+        if (nbytes > len - off - HEADER_BYTES) continue;
+        const uint32_t dcrc = (uint32_t)p[20] | ((uint32_t)p[21] << 8) | ((uint32_t)p[22] << 16) | ((uint32_t)p[23] << 24);
+        if (dcrc != orc_crc32(p + HEADER_BYTES, nbytes)) continue;
+        *pkt = p;
+        *next = off + HEADER_BYTES + nbytes;
+        return 1;
+    }
+    *pkt = NULL;
+    *next = len;
+    return 0;
+}
+
+/* entropy decoder state of one packet (icer_decoder_context_typedef, icer.h:330-340) */
+#define PEND_MAX 1100
+typedef struct {
+    const uint8_t *bytes;       /* payload */
+    size_t avail;               /* bytes readable from `bytes` up to the end of the whole stream */
+    uint32_t total_bits;        /* data_length of the packet */
+    size_t ind;                 /* read cursor: byte, bit */
+    unsigned off;
+    size_t words;               /* code words decoded so far */
+    int n[17];                  /* bits pending per bin */
+    size_t index[17];           /* `words` when the bin's last code word was read */
+    uint8_t pend[17][PEND_MAX]; /* pending bits, served from the TOP (icer_decoding.c:186-190) */
+} dcoder;
+
+static void dcoder_init(dcoder *d, const uint8_t *payload, size_t avail, uint32_t total_bits)   /* :12-26 */
+{
+    memset(d, 0, sizeof *d);
+    d->bytes = payload; d->avail = avail; d->total_bits = total_bits;
+}
+static unsigned dbyte(const dcoder *d, size_t i) { return i < d->avail ? d->bytes[i] : 0u; }
+
+/* icer_get_bit_from_codeword :46-57: the k-th bit (1-based) ahead of the cursor, cursor unchanged */
+static int peek_bit(const dcoder *d, unsigned k)
+{
+    const unsigned o = d->off + (k - 1);
+    return (int)((dbyte(d, d->ind + o / 8) >> (o % 8)) & 1u);
+}
+/* icer_get_bits_from_codeword :59-82 / icer_pop_bits_from_codeword :84-105: `nb` bits LSB first, byte-sized pieces.
+ * QUIRK: decoded_bits_total is never advanced in the reference, so the out-of-data test only ever compares the
+ * piece size with the packet's total length. */
+static int read_bits(dcoder *d, unsigned nb, int consume)
+{
+    int num = 0;
+    unsigned got = 0, off = d->off;
+    size_t ind = d->ind;
+    while (nb) {
+        const unsigned take = (8 - off) < nb ? (8 - off) : nb;
+        if (take > d->total_bits) return ORC_DECODER_OUT_OF_DATA;
+        num |= (int)(((dbyte(d, ind) >> off) & ((1u << take) - 1u)) << got);
+        nb -= take; got += take; off += take;
+        if (off / 8) ind++;
+        off %= 8;
+        if (consume) { d->off = off; d->ind = ind; }
+    }
+    return num;
+}
+static void push_bits(dcoder *d, int bin, unsigned value, unsigned nb)       /* icer_push_bin_bits :28-44 */
+{
+    for (unsigned k = 0; k < nb; k++) {
+        if (d->n[bin] < PEND_MAX) d->pend[bin][d->n[bin]] = (uint8_t)((k < 16 ? (value >> k) : 0u) & 1u);
+        d->n[bin]++;
+    }
+}
+
+/* decode table of bins 1..7: code word value -> {code length, source pattern reversed, pattern length}
+ * (icer_init.c:38-120: the inverse of the coding scheme, pattern stored reversed so that it pops in input order) */
+static struct { uint8_t code_bits, pattern_rev, pattern_bits; } decode_lut[17][32];
+static int decode_ready = 0;
+static void decode_tables_init(void)
+{
+    if (decode_ready) return;
+    coder_tables_init();
+    memset(decode_lut, 0, sizeof decode_lut);
+    for (int b = 1; b <= 7; b++)
+        for (int k = 0; k < 9; k++) {
+            const v2v e = V2V[b][k];
+            if (e.in_bits == 0) continue;
+            decode_lut[b][e.out_code].code_bits = e.out_bits;
+            decode_lut[b][e.out_code].pattern_rev = (uint8_t)reverse_bits(e.in_val, e.in_bits);
+            decode_lut[b][e.out_code].pattern_bits = e.in_bits;
+        }
+    decode_ready = 1;
+}
+/* test tap: decode table entry */
+void orc_decode_entry(int bin, int code, int *code_bits, int *pattern_rev, int *pattern_bits)
+{
+    decode_tables_init();
+    *code_bits = decode_lut[bin][code].code_bits;
+    *pattern_rev = decode_lut[bin][code].pattern_rev;
+    *pattern_bits = decode_lut[bin][code].pattern_bits;
+}
+
+/* icer_decode_bit, icer_decoding.c:108-194 */
+static int decode_bit(dcoder *d, int *bit, uint32_t zero, uint32_t total)
+{
+    int inv = 0;
+    if (zero < (total >> 1)) { zero = total - zero; inv = 1; }
+    const int bin = orc_pick_bin(zero, total);
+    /* a new code word is due when the bin has nothing pending, or when RING_WORDS code words have been read since
+     * the bin's last one: the encoder's ring was full then and it force-completed that word (:128) */
+    if (d->n[bin] <= 0 || d->words - d->index[bin] >= RING_WORDS) {
+        d->n[bin] = 0;
+        if (bin >= 8) {
+            if (peek_bit(d, 1)) {                                    /* "1": a full run of m zeros */
+                read_bits(d, 1, 1);
+                push_bits(d, bin, 0, golomb[bin].m);
+            } else {
+                /* QUIRK: an out-of-data result of these reads is used as a number (only possible when the
+                 * packet is shorter than one code word, which an encoder never writes) */
+                uint16_t k = (uint16_t)read_bits(d, golomb[bin].l, 0);
+                k = (uint16_t)reverse_bits(k, golomb[bin].l);
+                if (k < golomb[bin].i) {
+                    read_bits(d, golomb[bin].l, 1);
+                    push_bits(d, bin, 1, 1);
+                    push_bits(d, bin, 0, k);
+                } else {
+                    k = (uint16_t)read_bits(d, golomb[bin].l + 1u, 1);
+                    k = (uint16_t)reverse_bits(k, golomb[bin].l + 1);
+                    push_bits(d, bin, 1, 1);
+                    push_bits(d, bin, 0, (unsigned)(uint16_t)(k - golomb[bin].i));
+                }
+            }
+        } else if (bin >= 1) {
+            unsigned code = 0, nb = 0;
+            do {
+                /* QUIRK: refuses a code word that ends on the packet's last bit but one or later when ... the
+                 * running count is never advanced, so this only bites packets no longer than one code word */
+                if (nb + 1 >= d->total_bits) return ORC_DECODER_OUT_OF_DATA;
+                code |= (unsigned)peek_bit(d, nb + 1) << nb;
+                nb++;
+                if (code >= 32) return ORC_DECODED_INVALID_DATA;
+                if (decode_lut[bin][code].code_bits == nb) {
+                    push_bits(d, bin, decode_lut[bin][code].pattern_rev, decode_lut[bin][code].pattern_bits);
+                    if ((int)code != read_bits(d, nb, 1)) return ORC_DECODED_INVALID_DATA;
+                    break;
+                }
+            } while (nb < 10);
+        } else {
+            const int b = read_bits(d, 1, 1);
+            if (b == ORC_DECODER_OUT_OF_DATA) return ORC_DECODER_OUT_OF_DATA;
+            push_bits(d, bin, b != 0, 1);
+        }
+        d->words++;
+        d->index[bin] = d->words;
+    }
+    /* serve the top pending bit.  QUIRK: with a multiple of 32 bits pending (or none, after a code word that matched
+     * nothing) the reference shifts by -1; as compiled for x86-64 that reads a zero bit and leaves the real one in
+     * place -- which is a zero of a Golomb run whenever an encoder wrote the packet */
+    int b = 0;
+    if ((d->n[bin] & 31) != 0 && d->n[bin] > 0 && d->n[bin] <= PEND_MAX) b = d->pend[bin][d->n[bin] - 1];
+    d->n[bin]--;
+    *bit = inv ? !b : b;
+    return ORC_OK;
+}
+
+/* icer_decompress_bitplane_uint16 / _uint8 (icer_context_modeller.c:461-602 / :167-310): adds bit plane `lsb` of one
+ * segment to the sign-magnitude words in `seg` (sign at bit `sign_bit`), which hold the planes above it. */
+static int decode_unit(uint16_t *seg, size_t w, size_t h, size_t rowstride, int subband, int lsb, int sign_bit, dcoder *d)
+{
+    if (lsb + 1 >= sign_bit + 1) return ORC_BITPLANE_OUT_OF_RANGE;
+    const unsigned mask = (1u << sign_bit) - 1u;
+    uint32_t zero[17], total[17];
+    for (int k = 0; k < 17; k++) { zero[k] = 2; total[k] = 4; }
+#define MAG(r, cc) (seg[(r) * rowstride + (cc)] & mask)
+#define NEG(r, cc) ((seg[(r) * rowstride + (cc)] >> sign_bit) & 1u)
+#define SIG(r, cc, l) (((r) < 0 || (cc) < 0 || (r) >= (long)h || (cc) >= (long)w) ? 0 : ((MAG(r, cc) >> (l)) != 0))
+#define SGN(r, cc, l) ((SIG(r, cc, l) && NEG(r, cc)) ? -1 : 0)
+    for (long r = 0; r < (long)h; r++) {
+        for (long cc = 0; cc < (long)w; cc++) {
+            uint16_t *pos = &seg[r * rowstride + cc];
+            const unsigned m = MAG(r, cc);
+            int msb = 0;
+            for (unsigned t = m | 1; t > 1; t >>= 1) msb++;
+            int cat = msb < lsb ? 0 : msb - lsb;
+            if (cat > 3) cat = 3;
+            int bit, res;
+            if (cat == 3) {
+                if ((res = decode_bit(d, &bit, 1, 2)) != ORC_OK) return res;
+                *pos |= (uint16_t)(bit << lsb);
+                continue;
+            }
+            int ctx;
+            if (cat == 2) ctx = 11;
+            else {
+                int hh = SIG(r, cc - 1, lsb) + SIG(r, cc + 1, lsb + 1);
+                int vv = SIG(r - 1, cc, lsb) + SIG(r + 1, cc, lsb + 1);
+                int dd = SIG(r - 1, cc - 1, lsb) + SIG(r - 1, cc + 1, lsb) + SIG(r + 1, cc - 1, lsb + 1) + SIG(r + 1, cc + 1, lsb + 1);
+                if (cat == 1) ctx = (hh + vv == 0) ? 9 : 10;
+                else {
+                    if (subband == SB_HL) { int t = hh; hh = vv; vv = t; }
+                    ctx = (subband == SB_HH) ? ctx_hh(hh + vv, dd) : ctx_plain(hh, vv, dd);
+                }
+            }
+            if ((res = decode_bit(d, &bit, zero[ctx], total[ctx])) != ORC_OK) return res;
+            *pos |= (uint16_t)(bit << lsb);
+            model_update(&zero[ctx], &total[ctx], !bit);
+            if (cat == 0 && bit) {
+                int sh = SGN(r, cc - 1, lsb) + SGN(r, cc + 1, lsb + 1) + 2;
+                int sv = SGN(r - 1, cc, lsb) + SGN(r + 1, cc, lsb + 1) + 2;
+                if (subband == SB_HL) { int t = sh; sh = sv; sv = t; }
+                const int sctx = SIGN_CTX[sh][sv];
+                int agree;
+                if ((res = decode_bit(d, &agree, zero[sctx], total[sctx])) != ORC_OK) return res;
+                *pos |= (uint16_t)(((agree ^ SIGN_PRED[sh][sv]) & 1) << sign_bit);
+                model_update(&zero[sctx], &total[sctx], agree == 0);
+            }
+        }
+    }
+#undef MAG
+#undef NEG
+#undef SIG
+#undef SGN
+    return ORC_OK;
+}
+
+/* icer_find_k (icer_wavelet.c:823-848): the reference's search for a k with 3^k + 1 <= len; it does not always
+ * return the largest one, which is harmless, but the slices it picks decide the order below */
+static unsigned shuffle_k(size_t len)
+{
+    unsigned lo_k = 0, hi_k = 11, res = 0;                  /* MAX_K - 1, icer.h:28; uint8_t arithmetic in the reference */
+    while (lo_k < hi_k) {
+        const unsigned mid = (hi_k + lo_k) / 2;
+        size_t slice = 1;
+        for (unsigned e = 0; e < mid; e++) slice *= 3;
+        slice += 1;
+        if (len > slice) { lo_k = mid + 1; res = mid; }
+        else if (len < slice) hi_k = (mid - 1) & 0xFFu;
+        else break;
+    }
+    return res;
+}
+static void idx_reverse(size_t *a, size_t from, size_t to)
+{
+    while (from < to) { const size_t t = a[from]; a[from] = a[to]; a[to] = t; from++; to--; }
+}
+/* icer_interleave_uint16 / _uint8 (icer_wavelet.c:705-763 / :570-628) as a permutation: src[i] = position in the
+ * [lows | highs] layout of the value that ends up at position i.  The reference shuffles in place (rotations by
+ * reversal, then cycle leaders over slices of 3^k + 1); for the uint16 routine, and for even lengths, the result is
+ * the plain interleave.  QUIRK: the uint8 routine uses a different rotation bound for ODD lengths (:614 vs :749),
+ * which scrambles the line -- the reference's uint8 decoder is only usable when every level has even sides. */
+static void interleave_order(size_t len, int bits, size_t *src)
+{
+    const int odd = (int)(len & 1);
+    const size_t n = len - (size_t)odd;
+    for (size_t i = 0; i < len; i++) src[i] = i;
+    if (odd) {                                              /* the lone last low goes to the end */
+        const size_t t = src[n / 2];
+        for (size_t i = n / 2; i < n; i++) src[i] = src[i + 1];
+        src[len - 1] = t;
+    }
+    size_t done = 0;
+    while (done < n) {
+        const unsigned k = shuffle_k(n - done);
+        size_t slice = 1;
+        for (unsigned e = 0; e < k; e++) slice *= 3;
+        slice += 1;
+        const size_t half = slice / 2, left = n - done;
+        const size_t halfleft = left / 2 - ((bits == 8 && odd) ? 0u : 1u);
+        idx_reverse(src, done + half, done + halfleft + half);
+        idx_reverse(src, done + half, done + slice - 1);
+        idx_reverse(src, done + slice, done + halfleft + half);
+        for (size_t i = 1; i < slice; i *= 3) {
+            size_t j = i, carry = src[done + j];
+            do {
+                j = j < half ? 2 * j : (j - half) * 2 + 1;
+                const size_t t = src[done + j]; src[done + j] = carry; carry = t;
+            } while (j != i);
+        }
+        done += slice;
+    }
+}
+
+/* inverse of dwt_1d_bits (icer_wavelet.c:467-550, int8 twin :298-383): [lows | highs] -> samples.  `order` =
+ * interleave_order(n, bits). */
+static void idwt_1d_bits(int16_t *line, size_t n, size_t stride, int filt, int bits, const size_t *order)
+{
+#define TRUNC(v) (bits == 8 ? (int16_t)(int8_t)(v) : (int16_t)(v))
+    const size_t nl = (n + 1) / 2, nh = n / 2;
+    const int odd = (int)(n & 1);
+    int16_t *lo = (int16_t *)malloc(sizeof(int16_t) * (nl + 1));
+    int16_t *hi = (int16_t *)malloc(sizeof(int16_t) * (nh + 2));
+    int16_t *v = (int16_t *)malloc(sizeof(int16_t) * (n + 1));
+    for (size_t k = 0; k < nl; k++) lo[k] = line[k * stride];
+    for (size_t k = 0; k < nh; k++) hi[k] = line[(nl + k) * stride];
+    /* step 1 (:484-515): undo the prediction from the last high to the first, so hi[k + 1] is already restored
+     * when hi[k] needs it -- as the forward step read it unmodified */
+#define R(k) ((int32_t)(int16_t)(lo[(k) - 1] - lo[(k)]))
+    const int am1 = FILT[filt][0], a0 = FILT[filt][1], a1 = FILT[filt][2], be = FILT[filt][3];
+    for (size_t it = 0; it < nh; it++) {
+        const size_t k = nh - 1 - it;
+        int32_t add;
+        if (k == 0) {
+            add = floordiv(R(1), 4);
+        } else if (k == 1 && am1 != 0) {
+            /* QUIRK (filter C, mirror of W3): reads hi[1] itself, which still holds the transformed value here
+             * while the forward step subtracted a term of the original one -- the reference's own round trip is
+             * therefore not exact for filter C */
+            const int32_t x = (odd && nl == 3) ? 0 : hi[1];
+            add = floordiv(2 * R(1) + 3 * R(2) - 2 * x + 4, 8);
+        } else if (!odd && k == nh - 1) {
+            add = floordiv(R(nh - 1), 4);
+        } else {
+            const int32_t rm = (k >= 2) ? R(k - 1) : 1;
+            const int32_t dn = (odd && k + 1 == nl - 1) ? 0 : hi[k + 1];
+            add = floordiv(am1 * rm + a0 * R(k) + a1 * R(k + 1) - be * dn + 8, 16);
+        }
+        hi[k] = TRUNC((int32_t)hi[k] + add);
+    }
+#undef R
+    /* step 2 (:517-545): pair (mean, difference) -> samples, still in the [lows | highs] layout; then the interleave (:547) */
+    for (size_t k = 0; k < nh; k++) {
+        const int32_t low = lo[k], high = hi[k];
+        const int32_t a = low + floordiv(high + 1, 2);
+        v[k] = TRUNC(a);
+        v[nl + k] = TRUNC(a - high);
+    }
+    if (odd) v[nl - 1] = lo[nl - 1];
+    for (size_t i = 0; i < n; i++) line[i * stride] = v[order[i]];
+#undef TRUNC
+    free(lo); free(hi); free(v);
+}
+
+/* icer_inverse_wavelet_transform_stages_uint16 (:81-103) over icer_inverse_wavelet_transform_2d_uint16 (:175-191):
+ * deepest level first, every column of the level's region, then every row.  (Overflow is only reported through a
+ * return value that the decoders ignore.) */
+static void idwt_stages_bits(int16_t *s, size_t w, size_t h, int stages, int filt, int bits)
+{
+    if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return;      /* ICER_TOO_MANY_STAGES, ignored by the callers */
+    size_t *order = (size_t *)malloc(sizeof(size_t) * ((w > h ? w : h) + 1));
+    for (int it = 1; it <= stages; it++) {
+        const size_t cw = dim_low(w, stages - it), ch = dim_low(h, stages - it);
+        interleave_order(ch, bits, order);
+        for (size_t c = 0; c < cw; c++) idwt_1d_bits(s + c, ch, w, filt, bits, order);
+        interleave_order(cw, bits, order);
+        for (size_t r = 0; r < ch; r++) idwt_1d_bits(s + r * w, cw, 1, filt, bits, order);
+    }
+    free(order);
+}
+
+/* icer_decompress_partition_uint16 / _uint8 (icer_partition.c:393-494 / :171-275): every segment of one subband,
+ * planes from the top down until one is missing or fails */
+typedef const uint8_t *packet_table[MAX_STAGES + 1][4][MAX_SEGMENTS + 1][MAX_PLANES];
+
+static void decode_subband(uint16_t *base, const orc_partition *part, size_t rowstride, const uint8_t *pk[][MAX_PLANES],
+                           int planes, int sign_bit, const uint8_t *stream_end, dcoder *d)
+{
+    orc_rect rects[MAX_SEGMENTS + 64];
+    const int nseg = orc_partition_rects(part, rects);
+    for (int sg = 0; sg < nseg && sg <= MAX_SEGMENTS; sg++) {
+        for (int lsb = planes - 1; lsb >= 0 && pk[sg][lsb] != NULL; lsb--) {
+            const uint8_t *top = pk[sg][planes - 1], *p = pk[sg][lsb];
+            const uint32_t bits = (uint32_t)p[16] | ((uint32_t)p[17] << 8) | ((uint32_t)p[18] << 16) | ((uint32_t)p[19] << 24);
+            dcoder_init(d, p + HEADER_BYTES, (size_t)(stream_end - (p + HEADER_BYTES)), bits);
+            /* (subband type from the top plane's header, :432-434) */
+            if (decode_unit(base + (size_t)rects[sg].y * rowstride + rects[sg].x, rects[sg].w, rects[sg].h, rowstride,
+                            top[5], lsb, sign_bit, d) != ORC_OK) break;
+        }
+    }
+}
+
+/* icer_decompress_image_uint16 / _yuv_uint16 (icer_compress.c:430-536, icer_color.c:534-663) and the uint8 twins
+ * (icer_compress.c:168-277, icer_color.c:208-340) on widened samples: `planes[c]` (w*h words each) receive
+ * the decoded image; *w / *h are taken from the last valid packet (left as passed in when there is none). */
+static int decompress_core(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
+                           const uint8_t *data, size_t len, int stages, int filt, unsigned segments, int bits)
+{
+    decode_tables_init();
+    if (channels != 1 && channels != 3) return ORC_INVALID_INPUT;
+    if (stages < 1 || stages > MAX_STAGES) return ORC_TOO_MANY_STAGES;       /* (reference: out-of-bounds table) */
+    const int nplanes = bits == 8 ? 7 : 9, sign_bit = bits == 8 ? 7 : 15;
+    static packet_table table[3];
+    memset(table, 0, sizeof table);
+    uint16_t mean[3] = {0, 0, 0};                   /* (YUV: a channel without packets reads an uninitialised mean) */
+    for (size_t off = 0; off < len;) {
+        const uint8_t *p;
+        size_t next;
+        if (find_packet(data + off, len - off, &p, &next)) {
+            const int lv = p[4], sb = p[5], sg = p[6], lsb = p[7] & 15, ch = channels == 3 ? (p[7] >> 4) : 0;
+            if (lv <= MAX_STAGES && sb < 4 && sg <= MAX_SEGMENTS && lsb < MAX_PLANES && ch < 3) table[ch][lv][sb][sg][lsb] = p;
+            *w = (size_t)p[8] | ((size_t)p[9] << 8) | ((size_t)p[10] << 16) | ((size_t)p[11] << 24);
+            *h = (size_t)p[12] | ((size_t)p[13] << 8) | ((size_t)p[14] << 16) | ((size_t)p[15] << 24);
+            if (ch < 3) mean[ch] = (uint16_t)(p[2] | (p[3] << 8));
+        }
+        off += next;
+    }
+    if (bufsize < (*w) * (*h)) return ORC_BYTE_QUOTA_EXCEEDED;
+    const size_t iw = *w, ih = *h;
+    for (int c = 0; c < channels; c++) memset(planes[c], 0, sizeof(uint16_t) * iw * ih);
+    dcoder *d = (dcoder *)malloc(sizeof(dcoder));
+    int rc = ORC_OK;
+    for (int lv = 1; lv <= stages && rc == ORC_OK; lv++) {
+        for (int c = 0; c < channels && rc == ORC_OK; c++) {
+            for (int pass = (lv == stages ? 0 : 1); pass < 4 && rc == ORC_OK; pass++) {
+                const int sb = pass;                                     /* LL (deepest level only), HL, LH, HH */
+                size_t sw, sh, ox, oy;
+                switch (sb) {
+                case SB_LL: sw = dim_low(iw, lv);  sh = dim_low(ih, lv);  ox = 0; oy = 0; break;
+                case SB_HL: sw = dim_high(iw, lv); sh = dim_low(ih, lv);  ox = dim_low(iw, lv); oy = 0; break;
+                case SB_LH: sw = dim_low(iw, lv);  sh = dim_high(ih, lv); ox = 0; oy = dim_low(ih, lv); break;
+                default:    sw = dim_high(iw, lv); sh = dim_high(ih, lv); ox = dim_low(iw, lv); oy = dim_low(ih, lv); break;
+                }
+                orc_partition part;
+                /* (unlike the encoder, P1, the decoder does stop on a grid error) */
+                if ((rc = orc_partition_make(&part, sw, sh, segments)) != ORC_OK) break;
+                decode_subband(planes[c] + oy * iw + ox, &part, iw, table[c][lv][sb], nplanes, sign_bit, data + len, d);
+            }
+        }
+    }
+    free(d);
+    if (rc != ORC_OK) return rc;
+    const size_t llw = dim_low(iw, stages), llh = dim_low(ih, stages);
+    for (int c = 0; c < channels; c++) {
+        int16_t *s = (int16_t *)planes[c];
+        /* icer_from_sign_magnitude_int16 / _int8 (icer_wavelet.c:880-886 / :860-866); sign with zero magnitude -> 0 */
+        for (size_t i = 0; i < iw * ih; i++) {
+            const unsigned v = planes[c][i];
+            const int neg = (v >> sign_bit) & 1u, mag = (int)(v & ((1u << sign_bit) - 1u));
+            s[i] = (int16_t)(neg ? -mag : mag);
+        }
+        /* LL mean back in, modulo the sample width (icer_compress.c:522-531) */
+        for (size_t r = 0; r < llh; r++)
+            for (size_t cc = 0; cc < llw; cc++) {
+                if (bits == 8) s[r * iw + cc] = (int16_t)(int8_t)(s[r * iw + cc] + (int8_t)mean[c]);
+                else s[r * iw + cc] = (int16_t)(s[r * iw + cc] + (int16_t)mean[c]);
+            }
+        idwt_stages_bits(s, iw, ih, stages, filt, bits);
+        for (size_t i = 0; i < iw * ih; i++)                                 /* icer_remove_negative_*, icer_util.c:70-91 */
+            if (s[i] < 0) s[i] = 0;
+    }
+    return ORC_OK;
+}
+
+int orc_decompress_u16(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
+                       const uint8_t *data, size_t len, int stages, int filt, unsigned segments)
+{
+    return decompress_core(planes, channels, w, h, bufsize, data, len, stages, filt, segments, 16);
+}
+
+int orc_decompress_u8(uint8_t *const planes8[], int channels, size_t *w, size_t *h, size_t bufsize,
+                      const uint8_t *data, size_t len, int stages, int filt, unsigned segments)
+{
+    if (channels != 1 && channels != 3) return ORC_INVALID_INPUT;
+    /* the image size is only known after the packet scan: widen into scratch planes of the buffer's size */
+    uint16_t *wide[3] = {NULL, NULL, NULL};
+    size_t cap = bufsize;
+    for (int c = 0; c < channels; c++) wide[c] = (uint16_t *)calloc(cap ? cap : 1, sizeof(uint16_t));
+    const int rc = decompress_core(wide, channels, w, h, bufsize, data, len, stages, filt, segments, 8);
+    if (rc != ORC_BYTE_QUOTA_EXCEEDED && rc != ORC_INVALID_INPUT && rc != ORC_TOO_MANY_STAGES)
+        for (int c = 0; c < channels; c++)
+            for (size_t i = 0; i < (*w) * (*h) && i < cap; i++) planes8[c][i] = (uint8_t)wide[c][i];
+    for (int c = 0; c < channels; c++) free(wide[c]);
+    return rc;
+}

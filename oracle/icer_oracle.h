@@ -2,7 +2,7 @@
  * icer_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
  * Plain-C CPU restatement of the ICER *encoder* hot path of TheRealOrange/icer_compression
- * (lib_icer).  It exists to check the MI355X/HIP product path; nothing in the product may
+ * (lib_icer), and of its decoder (the consumer of those streams).  It exists to check the MI355X/HIP product path; nothing in the product may
  * include, link or call it (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg).
  *
  * Parity status: PINNED.  tests/test_oracle_vs_ref.py compares every function here with the
@@ -58,6 +58,15 @@ int orc_compress_u16(uint16_t *const planes[], int channels, size_t w, size_t h,
 /* uint8 twins (icer_compress_image_uint8 / icer_compress_image_yuv_uint8): int8 storage, 7 bit planes */
 int orc_compress_u8(uint8_t *const planes[], int channels, size_t w, size_t h, int stages, int filt,
                     unsigned segments, size_t quota, uint8_t *out, size_t *size_used);
+
+/* Whole-frame DECODERS (icer_decompress_image_[yuv_]uint16 / _uint8, icer.h:447-466): the stream's packets ->
+ * `planes[c]` (each >= bufsize samples).  *w / *h are set from the stream (and are inputs when it holds no valid
+ * packet, as in the reference).  Return value = reference return code. */
+int orc_decompress_u16(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
+                       const uint8_t *data, size_t len, int stages, int filt, unsigned segments);
+int orc_decompress_u8(uint8_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
+                      const uint8_t *data, size_t len, int stages, int filt, unsigned segments);
+void orc_decode_entry(int bin, int code, int *code_bits, int *pattern_rev, int *pattern_bits);
 
 #ifdef __cplusplus
 }
