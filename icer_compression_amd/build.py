@@ -44,5 +44,24 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+DEC_LIB = os.path.join(PKG, "libicer_hip_dec.so")
+DEC_DEPS = ["decoder.hip", "decoder_core.hpp", "decoder_plan.hpp", "plan.hpp", "icer_tables.hpp"]
+
+
+def build_decoder_library(force: bool = False, verbose: bool = False) -> str:
+    """libicer_hip_dec.so: the decoder, a separate library -- see include/icer_hip_dec.h."""
+    deps = [os.path.join(CSRC, f) for f in DEC_DEPS] + [os.path.join(PKG, "..", "include", "icer_hip_dec.h")]
+    if not force and os.path.exists(DEC_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(DEC_LIB) for d in deps):
+        return DEC_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wall", "-o", DEC_LIB,
+           os.path.join(CSRC, "decoder.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DEC_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_decoder_library(force=True, verbose=True))

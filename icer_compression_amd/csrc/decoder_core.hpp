@@ -1,0 +1,437 @@
+// decoder_core.hpp -- device side of the ICER *decoder* (SURVEY.md 8f, row next-1): the consumer of the streams the
+// encoder hot path writes.  Plain per-thread code, shared between the gfx950 build (decoder.hip) and a g++ build
+// for tests/emu (the authoring container has no GPU); no wave-level cooperation yet.
+//
+// STATUS: first correct version.  Checked bit-for-bit against the decoder oracle on the CPU build; cross-compiled for
+// gfx950; NOT yet run or measured on a GPU.  It is not part of libicer_hip.so.
+//
+// Restates, per segment ("chain": the bit planes of one segment of one subband of one channel, top plane first):
+//   entropy decoder        icer_decode_bit + bit readers            lib_icer/src/icer_decoding.c:12-194
+//   bit-plane decoder      icer_decompress_bitplane_uint16/_uint8   icer_context_modeller.c:461-602 / :167-310
+//   plane loop             icer_decompress_partition_uint16/_uint8  icer_partition.c:427-443
+// and per line of a level:
+//   inverse lifting step   icer_inverse_wavelet_transform_1d_uint16/_uint8   icer_wavelet.c:467-550 / :298-383
+// The quirks listed in DESIGN.md 6b (no end-of-packet check, one-code-word packets refused, "2048 code words ago"
+// flush rule, filter C, the uint8 interleave of odd lines) are reproduced.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "icer_tables.hpp"
+
+#ifndef ICER_HD
+#if defined(__HIPCC__)
+#define ICER_HD __host__ __device__ __forceinline__
+#else
+#define ICER_HD inline
+#endif
+#endif
+
+namespace icer {
+
+constexpr int kDecoderOutOfData = -7;      // ICER_DECODER_OUT_OF_DATA, icer.h:100
+constexpr int kDecodedInvalidData = -8;    // ICER_DECODED_INVALID_DATA, icer.h:101
+constexpr uint32_t kNoPacket = 0xFFFFFFFFu;
+
+// tables of the entropy decoder (built on the host from the coder's tables, ~0.7 KiB)
+struct DecoderTables {
+    // bins 1..7: [bin][code word value] -> code bits | pattern bits << 4 | reversed source pattern << 8 (0 = no entry):
+    // the inverse of CoderTables::v2v (icer_init.c:38-120; reversed so that the pattern pops in input order)
+    uint16_t dec[8][32];
+    uint16_t gm[17], gl[17], gi[17];       // Golomb parameters of bins 8..16
+    uint32_t cut[16];                      // probability cut-offs x65536 between the bins (icer_config.c:69-87)
+};
+
+inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
+{
+    memset(d, 0, sizeof *d);
+    for (int b = 1; b <= 7; b++)
+        for (uint32_t v = 0; v < 32; v++) {
+            const uint32_t e = t.v2v[b][v];
+            if (!e) continue;
+            const uint32_t nin = e & 15u, nout = (e >> 4) & 15u, code = e >> 8;
+            uint32_t rev = 0;
+            for (uint32_t k = 0; k < nin; k++) rev |= ((v >> k) & 1u) << (nin - 1u - k);
+            d->dec[b][code] = (uint16_t)(nout | (nin << 4) | (rev << 8));
+        }
+    for (int b = 0; b < 17; b++) { d->gm[b] = t.gm[b]; d->gl[b] = t.gl[b]; d->gi[b] = t.gi[b]; }
+    for (int k = 0; k < 16; k++) d->cut[k] = t.cut[k];
+}
+
+// one chain = one segment of one subband of one channel
+struct ChainDesc {
+    uint32_t chan;              // channel plane the segment lives in
+    uint32_t first;             // index of the segment's first sample in that plane
+    uint16_t w, h;              // segment size
+    uint32_t pkt[kPlanes];      // per bit plane: byte offset of the packet (its header) in the stream, kNoPacket = absent
+};
+
+// ------------------------------------------------------------------------------------------ entropy decoder
+struct EntropyDecoder {
+    const uint8_t *stream;      // the whole stream
+    uint32_t stream_len;        // bytes behind it read as zero (the reference reads whatever lies there)
+    uint32_t base;              // first payload byte of the packet
+    uint32_t total_bits;        // data_length of the packet
+    uint32_t pos;               // bit cursor relative to base
+    uint32_t words;             // code words read so far
+    int16_t n[kNumBins];        // bits pending per bin, served from the top
+    uint8_t bits[kNumBins];     // bins 0..7: the pending pattern (bit k = k-th from the bottom); bins 8..16: bottom bit
+    uint32_t index[kNumBins];   // `words` when the bin's last code word was read
+};
+
+ICER_HD void entropy_init(EntropyDecoder &d, const uint8_t *stream, uint32_t stream_len, uint32_t base, uint32_t total_bits)
+{
+    d.stream = stream; d.stream_len = stream_len; d.base = base; d.total_bits = total_bits; d.pos = 0; d.words = 0;
+    for (int b = 0; b < kNumBins; b++) { d.n[b] = 0; d.bits[b] = 0; d.index[b] = 0; }
+}
+ICER_HD uint32_t entropy_byte(const EntropyDecoder &d, uint32_t i)
+{
+    const uint32_t at = d.base + i;
+    return at < d.stream_len ? d.stream[at] : 0u;
+}
+// the k-th bit (1-based) ahead of the cursor (icer_get_bit_from_codeword :46-57)
+ICER_HD uint32_t entropy_peek(const EntropyDecoder &d, uint32_t k)
+{
+    const uint32_t p = d.pos + (k - 1u);
+    return (entropy_byte(d, p >> 3) >> (p & 7u)) & 1u;
+}
+// `nb` bits LSB first, in pieces that end at byte boundaries (icer_get_bits_from_codeword :59-82 /
+// icer_pop_bits_from_codeword :84-105).  QUIRK: the reference never advances its count of decoded bits, so the
+// out-of-data test compares each piece with the packet's whole length.
+ICER_HD int entropy_read(EntropyDecoder &d, uint32_t nb, bool consume)
+{
+    int num = 0;
+    uint32_t got = 0, p = d.pos;
+    while (nb) {
+        const uint32_t room = 8u - (p & 7u), take = room < nb ? room : nb;
+        if (take > d.total_bits) return kDecoderOutOfData;
+        num |= (int)(((entropy_byte(d, p >> 3) >> (p & 7u)) & ((1u << take) - 1u)) << got);
+        nb -= take; got += take; p += take;
+        if (consume) d.pos = p;
+    }
+    return num;
+}
+ICER_HD uint32_t reverse_low_bits(uint32_t v, uint32_t n)            // icer_reverse_bits, icer.h:601-610 (16-bit)
+{
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < n; k++) { r = (r << 1) | (v & 1u); v >>= 1; }
+    return r & 0xFFFFu;
+}
+ICER_HD int pick_bin_plain(const DecoderTables &t, uint32_t zero, uint32_t total)     // icer_compute_bin, icer_util.c:48-56
+{
+    const uint32_t lhs = zero * 65536u;
+    for (int b = 16; b >= 1; b--)
+        if (lhs >= total * t.cut[b - 1]) return b;
+    return 0;
+}
+
+// icer_decode_bit, icer_decoding.c:108-194
+ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *bit, uint32_t zero, uint32_t total)
+{
+    bool inv = false;
+    if (zero < (total >> 1)) { zero = total - zero; inv = true; }
+    const int bin = pick_bin_plain(t, zero, total);
+    // a new code word is due when nothing is pending, or when kRingWords code words have been read since this bin's
+    // last one: the encoder's ring was full then and it force-completed the bin's word (:128)
+    if (d.n[bin] <= 0 || d.words - d.index[bin] >= (uint32_t)kRingWords) {
+        d.n[bin] = 0;
+        d.bits[bin] = 0;
+        if (bin >= 8) {
+            const uint32_t m = t.gm[bin], l = t.gl[bin], gi = t.gi[bin];
+            if (entropy_peek(d, 1)) {                              // "1": a full run of m zeros
+                entropy_read(d, 1, true);
+                d.n[bin] = (int16_t)m;
+            } else {
+                // (QUIRK: an out-of-data result is used as a number; only reachable with a packet shorter than one
+                // code word, which no encoder writes)
+                uint32_t k = reverse_low_bits((uint32_t)entropy_read(d, l, false) & 0xFFFFu, l);
+                if (k < gi) {
+                    entropy_read(d, l, true);
+                } else {
+                    k = reverse_low_bits((uint32_t)entropy_read(d, l + 1u, true) & 0xFFFFu, l + 1u);
+                    k = (k - gi) & 0xFFFFu;
+                }
+                d.bits[bin] = 1;                                   // a one at the bottom, k zeros on top of it
+                const uint32_t cnt = 1u + k;
+                d.n[bin] = (int16_t)(cnt > 32767u ? 32767u : cnt);
+            }
+        } else if (bin >= 1) {
+            uint32_t code = 0, nb = 0;
+            do {
+                // QUIRK (:159): with the count never advanced this refuses exactly the packets that are no longer than
+                // the code word being read
+                if (nb + 1u >= d.total_bits) return kDecoderOutOfData;
+                code |= entropy_peek(d, nb + 1u) << nb;
+                nb++;
+                if (code >= 32u) return kDecodedInvalidData;
+                const uint32_t e = t.dec[bin][code];
+                if ((e & 15u) == nb) {
+                    d.bits[bin] = (uint8_t)(e >> 8);
+                    d.n[bin] = (int16_t)((e >> 4) & 15u);
+                    if ((int)code != entropy_read(d, nb, true)) return kDecodedInvalidData;
+                    break;
+                }
+            } while (nb < 10u);
+        } else {
+            const int b = entropy_read(d, 1, true);
+            if (b == kDecoderOutOfData) return kDecoderOutOfData;
+            d.bits[bin] = (uint8_t)(b != 0);
+            d.n[bin] = 1;
+        }
+        d.words++;
+        d.index[bin] = d.words;
+    }
+    // serve the top pending bit (:186-190).  Golomb bins hold zeros above one bottom bit; the reference's shift by -1 at
+    // multiples of 32 pending bits reads a zero, which is what lies there; after a code word that matched nothing the
+    // count goes to -1 and a zero is served.
+    uint32_t b = 0;
+    const int n = d.n[bin];
+    if (n > 0) {
+        if (bin >= 8) b = (n == 1) ? d.bits[bin] : 0u;
+        else b = (d.bits[bin] >> (n - 1)) & 1u;
+    }
+    d.n[bin] = (int16_t)(n - 1);
+    *bit = inv ? (b ^ 1u) : b;
+    return kOk;
+}
+
+// ------------------------------------------------------------------------------------------ bit-plane decoder
+// context tables (icer_config.c:26-67)
+ICER_HD int dec_ctx_plain(int h, int v, int d)
+{
+    if (h == 2) return 8;
+    if (h == 1) return v == 0 ? (d == 0 ? 5 : d == 1 ? 6 : 7) : 7;
+    if (v == 0) return d > 2 ? 2 : d;
+    return v == 1 ? 3 : 4;
+}
+ICER_HD int dec_ctx_hh(int hv, int d)
+{
+    if (d >= 3) return 8;
+    const int k = hv > 2 ? 2 : hv;
+    if (d == 0) return k;
+    if (d == 1) return 3 + k;
+    return hv == 0 ? 6 : 7;
+}
+ICER_HD int dec_sign_ctx(int sh, int sv)      // icer_sign_context_table
+{
+    if (sh == 2) return sv == 2 ? 12 : 13;
+    if (sv == 2) return 15;
+    return ((sh < 2) == (sv < 2)) ? 14 : 16;
+}
+ICER_HD int dec_sign_pred(int sh, int sv)     // icer_sign_prediction_table
+{
+    if (sh < 2) return 1;
+    if (sh == 2) return sv > 2 ? 1 : 0;
+    return 0;
+}
+ICER_HD void dec_model_update(uint16_t &zero, uint16_t &total, bool was_zero)
+{
+    // icer_context_modeller.c:546-552 (QUIRK C5: a halved zero count is computed and dropped when zero <= total)
+    total++;
+    zero = (uint16_t)(zero + (was_zero ? 1 : 0));
+    if (total >= kRescaleCap) {
+        total >>= 1;
+        if (zero > total) zero >>= 1;
+    }
+}
+
+// adds bit plane `lsb` to the sign-magnitude words of one segment (sign at bit `sign_bit`)
+ICER_HD int decode_plane(uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int subband, int lsb, int sign_bit,
+                         EntropyDecoder &d, const DecoderTables &t)
+{
+    if (lsb + 1 >= sign_bit + 1) return kBitplaneOutOfRange;
+    const uint32_t mask = (1u << sign_bit) - 1u;
+    uint16_t zero[kNumContexts], total[kNumContexts];
+    for (int k = 0; k < kNumContexts; k++) { zero[k] = 2; total[k] = 4; }
+    for (uint32_t r = 0; r < h; r++) {
+        uint16_t *row = seg + (size_t)r * stride;
+        const uint16_t *up = r > 0 ? row - stride : nullptr, *dn = r + 1 < h ? row + stride : nullptr;
+        uint32_t left = 0;                       // the sample to the left, this plane already decoded
+        for (uint32_t c = 0; c < w; c++) {
+            const uint32_t cur = row[c];
+            const uint32_t m = cur & mask;
+            int msb = 0;
+            for (uint32_t v = m | 1u; v > 1u; v >>= 1) msb++;
+            int cat = msb < lsb ? 0 : msb - lsb;
+            if (cat > 3) cat = 3;
+            uint32_t bit;
+            int res;
+            if (cat == 3) {
+                if ((res = entropy_decode(d, t, &bit, 1, 2)) != kOk) return res;
+                left = cur | (bit << lsb);
+                row[c] = (uint16_t)left;
+                continue;
+            }
+            const bool has_r = c + 1 < w;
+            const uint32_t right = has_r ? row[c + 1] : 0u;
+            const uint32_t u0 = up ? up[c] : 0u, d0 = dn ? dn[c] : 0u;
+            int ctx;
+            if (cat == 2) ctx = 11;
+            else {
+                // neighbours already visited count at this plane, the others at the plane above (:509-521)
+                const uint32_t ul = (up && c > 0) ? up[c - 1] : 0u, ur = (up && has_r) ? up[c + 1] : 0u;
+                const uint32_t dl = (dn && c > 0) ? dn[c - 1] : 0u, dr = (dn && has_r) ? dn[c + 1] : 0u;
+                int hh = (c > 0 && ((left & mask) >> lsb)) + (((right & mask) >> (lsb + 1)) != 0);
+                int vv = (((u0 & mask) >> lsb) != 0) + (((d0 & mask) >> (lsb + 1)) != 0);
+                const int dd = (((ul & mask) >> lsb) != 0) + (((ur & mask) >> lsb) != 0) +
+                               (((dl & mask) >> (lsb + 1)) != 0) + (((dr & mask) >> (lsb + 1)) != 0);
+                if (cat == 1) ctx = (hh + vv == 0) ? 9 : 10;
+                else {
+                    if (subband == kHL) { const int x = hh; hh = vv; vv = x; }
+                    ctx = subband == kHH ? dec_ctx_hh(hh + vv, dd) : dec_ctx_plain(hh, vv, dd);
+                }
+            }
+            if ((res = entropy_decode(d, t, &bit, zero[ctx], total[ctx])) != kOk) return res;
+            uint32_t val = cur | (bit << lsb);
+            dec_model_update(zero[ctx], total[ctx], bit == 0);
+            if (cat == 0 && bit) {
+                // sign: only negative significant neighbours count (QUIRK C6)
+                auto sgn = [&](uint32_t v, int plane) { return (((v & mask) >> plane) != 0 && ((v >> sign_bit) & 1u)) ? -1 : 0; };
+                int sh = (c > 0 ? sgn(left, lsb) : 0) + sgn(right, lsb + 1) + 2;
+                int sv = sgn(u0, lsb) + sgn(d0, lsb + 1) + 2;
+                if (subband == kHL) { const int x = sh; sh = sv; sv = x; }
+                const int sctx = dec_sign_ctx(sh, sv);
+                uint32_t agree;
+                if ((res = entropy_decode(d, t, &agree, zero[sctx], total[sctx])) != kOk) { row[c] = (uint16_t)val; return res; }
+                val |= ((agree ^ (uint32_t)dec_sign_pred(sh, sv)) & 1u) << sign_bit;
+                dec_model_update(zero[sctx], total[sctx], agree == 0);
+            }
+            row[c] = (uint16_t)val;
+            left = val;
+        }
+    }
+    return kOk;
+}
+
+// all planes of one chain, top plane first, until one is missing or fails (icer_partition.c:427-443)
+ICER_HD void decode_chain(uint16_t *plane, size_t stride, const ChainDesc &c, int subband, const uint8_t *stream,
+                          uint32_t stream_len, const DecoderTables &t, int planes, int sign_bit)
+{
+    EntropyDecoder d;
+    for (int lsb = planes - 1; lsb >= 0; lsb--) {
+        const uint32_t at = c.pkt[lsb];
+        if (at == kNoPacket) break;
+        const uint8_t *p = stream + at;
+        const uint32_t bits = (uint32_t)p[16] | ((uint32_t)p[17] << 8) | ((uint32_t)p[18] << 16) | ((uint32_t)p[19] << 24);
+        entropy_init(d, stream, stream_len, at + (uint32_t)kHeaderBytes, bits);
+        if (decode_plane(plane + c.first, c.w, c.h, stride, subband, lsb, sign_bit, d, t) != kOk) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sample post-processing
+// icer_from_sign_magnitude_int16 / _int8 (icer_wavelet.c:880-886 / :860-866); a set sign with zero magnitude gives 0
+ICER_HD int16_t from_sign_magnitude(uint32_t v, int sign_bit)
+{
+    const int32_t mag = (int32_t)(v & ((1u << sign_bit) - 1u));
+    return (int16_t)(((v >> sign_bit) & 1u) ? -mag : mag);
+}
+// the LL mean comes back in modulo the sample width (icer_compress.c:522-531 / :260-269)
+ICER_HD int16_t add_ll_mean(int16_t s, uint16_t mean, int bits)
+{
+    return bits == 8 ? (int16_t)(int8_t)(s + (int8_t)mean) : (int16_t)(s + (int16_t)mean);
+}
+
+// ------------------------------------------------------------------------------------------ inverse DWT, one line
+ICER_HD int32_t dec_floordiv(int32_t a, int32_t b)            // icer_floor_div_int32, icer.h:562-566 (b > 0)
+{
+    int32_t q = a / b;
+    if ((a % b) != 0 && a < 0) q--;
+    return q;
+}
+// src: [lows | highs] of a line of n samples (stride in samples); dst: the samples, value v of the [lows | highs]
+// layout going to position pos_of[v] (the plain interleave, except for the uint8 routine's odd lines -- see
+// interleave_positions).  `bits` = 8: int8 storage (truncating stores), icer_wavelet.c:298-383.
+ICER_HD void idwt_line(const int16_t *src, int16_t *dst, uint32_t n, size_t stride, const FilterTaps f, int bits,
+                       const uint32_t *pos_of)
+{
+    const uint32_t nl = (n + 1u) / 2u, nh = n / 2u;
+    const bool odd = (n & 1u) != 0;
+#define LO(k) ((int32_t)src[(size_t)(k) * stride])
+#define HI(k) ((int32_t)src[(size_t)(nl + (k)) * stride])
+#define RR(k) ((int32_t)(int16_t)(LO((k) - 1) - LO(k)))             /* get_r_int16 :206-208 (QUIRK W1b: wraps) */
+#define TR(v) (bits == 8 ? (int16_t)(int8_t)(v) : (int16_t)(v))
+    int32_t next_hi = 0;                                             // restored high k + 1
+    for (uint32_t it = 0; it < nh; it++) {
+        const uint32_t k = nh - 1u - it;
+        int32_t add;
+        if (k == 0) add = dec_floordiv(RR(1), 4);
+        else if (k == 1 && f.am1 != 0) {
+            // QUIRK (filter C, mirror of W3): the reference reads high 1 itself, still unrestored
+            const int32_t x = (odd && nl == 3u) ? 0 : HI(1);
+            add = dec_floordiv(2 * RR(1) + 3 * RR(2) - 2 * x + 4, 8);
+        } else if (!odd && k == nh - 1u) add = dec_floordiv(RR(nh - 1u), 4);
+        else {
+            const int32_t rm = k >= 2u ? RR(k - 1u) : 1;
+            const int32_t dn = (odd && k + 1u == nl - 1u) ? 0 : next_hi;
+            add = dec_floordiv(f.am1 * rm + f.a0 * RR(k) + f.a1 * RR(k + 1u) - f.be * dn + 8, 16);
+        }
+        const int32_t hi = TR(HI(k) + add);
+        next_hi = hi;
+        const int32_t a = LO(k) + dec_floordiv(hi + 1, 2);
+        dst[(size_t)pos_of[k] * stride] = TR(a);
+        dst[(size_t)pos_of[nl + k] * stride] = TR(a - hi);
+    }
+    if (odd) dst[(size_t)pos_of[nl - 1u] * stride] = (int16_t)LO(nl - 1u);
+#undef LO
+#undef HI
+#undef RR
+#undef TR
+}
+
+// ------------------------------------------------------------------------------------------ host-side helpers
+// icer_find_k (icer_wavelet.c:823-848): the reference's search for a slice 3^k + 1 <= len (not always the largest)
+inline unsigned shuffle_slice_k(size_t len)
+{
+    unsigned lo_k = 0, hi_k = 11, res = 0;
+    while (lo_k < hi_k) {
+        const unsigned mid = (hi_k + lo_k) / 2;
+        size_t slice = 1;
+        for (unsigned e = 0; e < mid; e++) slice *= 3;
+        slice += 1;
+        if (len > slice) { lo_k = mid + 1; res = mid; }
+        else if (len < slice) hi_k = (mid - 1) & 0xFFu;
+        else break;
+    }
+    return res;
+}
+// Where each value of the [lows | highs] layout ends up after icer_interleave_uint16 / _uint8
+// (icer_wavelet.c:705-763 / :570-628).  The in-place shuffle is followed on an index array; for the uint16 routine and
+// for even lengths the result is the plain interleave.  QUIRK: the uint8 routine rotates with a different bound on odd
+// lengths (:614 vs :749) and scrambles such lines.  pos_of has `len` entries.
+inline void interleave_positions(size_t len, int bits, uint32_t *pos_of)
+{
+    if (len == 0) return;
+    uint32_t *src = new uint32_t[len + 1];
+    const bool odd = (len & 1) != 0;
+    const size_t n = len - (odd ? 1 : 0);
+    for (size_t i = 0; i < len; i++) src[i] = (uint32_t)i;
+    auto rev = [&](size_t a, size_t b) { while (a < b) { const uint32_t x = src[a]; src[a] = src[b]; src[b] = x; a++; b--; } };
+    if (odd) {
+        const uint32_t x = src[n / 2];
+        for (size_t i = n / 2; i < n; i++) src[i] = src[i + 1];
+        src[len - 1] = x;
+    }
+    for (size_t done = 0; done < n;) {
+        const unsigned k = shuffle_slice_k(n - done);
+        size_t slice = 1;
+        for (unsigned e = 0; e < k; e++) slice *= 3;
+        slice += 1;
+        const size_t half = slice / 2, left = n - done, halfleft = left / 2 - ((bits == 8 && odd) ? 0 : 1);
+        rev(done + half, done + halfleft + half);
+        rev(done + half, done + slice - 1);
+        rev(done + slice, done + halfleft + half);
+        for (size_t i = 1; i < slice; i *= 3) {
+            size_t j = i;
+            uint32_t carry = src[done + j];
+            do {
+                j = j < half ? 2 * j : (j - half) * 2 + 1;
+                const uint32_t x = src[done + j]; src[done + j] = carry; carry = x;
+            } while (j != i);
+        }
+        done += slice;
+    }
+    for (size_t i = 0; i < len; i++) pos_of[src[i]] = (uint32_t)i;
+    delete[] src;
+}
+
+}  // namespace icer

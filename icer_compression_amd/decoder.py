@@ -1,0 +1,70 @@
+"""Host-side mirror of the reference's DECODING interface over the C ABI of libicer_hip_dec.so
+(include/icer_hip_dec.h).
+
+STATUS: the device code behind it is checked against the decoder oracle in its CPU build (tests/test_emu_decoder.py) and
+cross-compiles for gfx950, but has not yet been run on a GPU; its GPU tests (tests/test_gpu_decoder.py) are opt-in.
+
+The reference's callers do (example/src/example_decode.c, example/src/icer_util.c `decompress`)
+    icer_get_image_dimensions(stream, len, &w, &h);  buf = malloc(w * h * 2);
+    rc = icer_decompress_image_uint16(buf, &w, &h, w * h, stream, len, stages, filt, segments);
+The functions below keep those names, argument order and return codes, numpy arrays standing in for the pointers.
+There is no CPU fallback: every decompress call needs libicer_hip_dec.so and a HIP device and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libicer_hip_dec.so")
+ICER_DECODER_OUT_OF_DATA = -7
+ICER_DECODED_INVALID_DATA = -8
+
+_lib = None
+_sz = C.c_size_t
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def load_library() -> C.CDLL:
+    """dlopen libicer_hip_dec.so (RTLD_LOCAL: it exports the same icer_* names as the reference)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -m icer_compression_amd.build` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH, mode=os.RTLD_LOCAL)
+    lib.icer_get_image_dimensions.argtypes = [_u8p, _sz, C.POINTER(_sz), C.POINTER(_sz)]
+    tail = [C.POINTER(_sz), C.POINTER(_sz), _sz, _u8p, _sz, C.c_uint8, C.c_int, C.c_uint8]
+    for name, n in (("icer_decompress_image_uint16", 1), ("icer_decompress_image_yuv_uint16", 3),
+                    ("icer_decompress_image_uint8", 1), ("icer_decompress_image_yuv_uint8", 3)):
+        getattr(lib, name).argtypes = [C.c_void_p] * n + tail
+    lib.icerx_decoder_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def icer_get_image_dimensions(stream: bytes):
+    """-> (rc, w, h)"""
+    lib = load_library()
+    buf = np.frombuffer(stream, dtype=np.uint8).copy() if len(stream) else np.zeros(1, np.uint8)
+    w, h = _sz(0), _sz(0)
+    rc = lib.icer_get_image_dimensions(buf, len(stream), C.byref(w), C.byref(h))
+    return rc, w.value, h.value
+
+
+def decompress(stream: bytes, channels: int, stages: int, filt: int, segments: int, bufsize: int | None = None, bits: int = 16):
+    """icer_decompress_image_[yuv_]uint16 / _uint8 on a host stream -> (rc, w, h, [flat planes of bufsize samples])."""
+    lib = load_library()
+    if channels not in (1, 3):
+        raise ValueError("channels must be 1 or 3")
+    if bufsize is None:
+        rc, w, h = icer_get_image_dimensions(stream)
+        bufsize = w * h if rc == 0 else 0
+    buf = np.frombuffer(stream, dtype=np.uint8).copy() if len(stream) else np.zeros(1, np.uint8)
+    planes = [np.zeros(max(bufsize, 1), np.uint16 if bits == 16 else np.uint8) for _ in range(channels)]
+    fn = getattr(lib, "icer_decompress_image_" + ("yuv_" if channels == 3 else "") + ("uint16" if bits == 16 else "uint8"))
+    w, h = _sz(0), _sz(0)
+    rc = fn(*[p.ctypes.data for p in planes], C.byref(w), C.byref(h), bufsize, buf, len(stream), stages, filt, segments)
+    return rc, w.value, h.value, planes

@@ -1,0 +1,57 @@
+/*
+ * icer_hip_dec.h -- C ABI of libicer_hip_dec.so, the MI355X (gfx950) ICER *decoder* (SURVEY.md 8f, row next-1).
+ *
+ * STATUS: first version.  The device code is checked bit-for-bit against the decoder oracle in its CPU build
+ * (tests/test_emu_decoder.py) and cross-compiles for gfx950, but it has NOT yet been run or measured on a GPU; it is a
+ * separate library so that libicer_hip.so (the measured encoder) is unaffected.  See DESIGN.md 6b.
+ *
+ * Same names, argument meaning and return codes as the decoding entry points of lib_icer
+ * (TheRealOrange/icer_compression, lib_icer/inc/icer.h); the work runs on the GPU and there is no CPU fallback
+ * (without a usable HIP device the image functions return ICER_FATAL_ERROR and print the reason to stderr).
+ * Results equal the reference's for streams made of CRC-valid packets; where the reference reads memory it does not
+ * own (bits behind the end of the stream, packet fields used as indices unchecked, the mean of a YUV channel without
+ * packets) this library reads zeros / ignores the packet / uses 0.
+ */
+#ifndef ICER_HIP_DEC_H
+#define ICER_HIP_DEC_H
+
+#include "icer_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces icer_get_image_dimensions, icer.h:374 (lib_icer/src/icer_compress.c:541-566): size fields of the first
+ * CRC-valid packet.  Host only.  ICER_INVALID_INPUT for null arguments, ICER_DECODER_OUT_OF_DATA when no packet is found. */
+int icer_get_image_dimensions(const uint8_t *datastream, size_t data_length, size_t *image_w, size_t *image_h);
+
+/* replaces icer_decompress_image_uint16, icer.h:461-462 (lib_icer/src/icer_compress.c:430-536).  `image` (host memory,
+ * image_bufsize samples) receives the decoded image; *image_w / *image_h are set from the stream.  `stages`, `filt`
+ * and `segments` must be the ones the stream was made with.  ICER_BYTE_QUOTA_EXCEEDED when the buffer is too small,
+ * ICER_TOO_MANY_SEGMENTS when a subband is too small for the segment grid (the image then holds the sign-magnitude
+ * words decoded up to that point, as in the reference). */
+int icer_decompress_image_uint16(uint16_t *image, size_t *image_w, size_t *image_h, size_t image_bufsize,
+                                 const uint8_t *datastream, size_t data_length, uint8_t stages,
+                                 enum icer_filter_types filt, uint8_t segments);
+
+/* replaces icer_decompress_image_yuv_uint16, icer.h:463-465 (lib_icer/src/icer_color.c:534-663) */
+int icer_decompress_image_yuv_uint16(uint16_t *y_channel, uint16_t *u_channel, uint16_t *v_channel, size_t *image_w,
+                                     size_t *image_h, size_t image_bufsize, const uint8_t *datastream,
+                                     size_t data_length, uint8_t stages, enum icer_filter_types filt, uint8_t segments);
+
+/* replace icer_decompress_image_uint8 / icer_decompress_image_yuv_uint8, icer.h:407-411
+ * (lib_icer/src/icer_compress.c:168-277, icer_color.c:208-340): int8 storage, 7 bit planes */
+int icer_decompress_image_uint8(uint8_t *image, size_t *image_w, size_t *image_h, size_t image_bufsize,
+                                const uint8_t *datastream, size_t data_length, uint8_t stages,
+                                enum icer_filter_types filt, uint8_t segments);
+int icer_decompress_image_yuv_uint8(uint8_t *y_channel, uint8_t *u_channel, uint8_t *v_channel, size_t *image_w,
+                                    size_t *image_h, size_t image_bufsize, const uint8_t *datastream,
+                                    size_t data_length, uint8_t stages, enum icer_filter_types filt, uint8_t segments);
+
+/* last error message of this thread's most recent failing call ("" if none) */
+const char *icerx_decoder_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+// decoder_emu.cpp -- TEST ONLY.  The decoder's device functions (decoder_core.hpp) and host planner (decoder_plan.hpp)
+// compiled by g++ and driven the way decoder.hip drives them on the GPU: one "thread" per candidate, per chain, per
+// line.  Lets tests/test_emu_decoder.py check the device code against the decoder oracle without a GPU.
+#include "../../icer_compression_amd/csrc/decoder_core.hpp"
+#include "../../icer_compression_amd/csrc/decoder_plan.hpp"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace icer;
+
+// planes[c]: >= bufsize uint16 words; for sample_bits = 8 the low byte of each word is the uint8 result.
+extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
+                              const uint8_t *data, size_t len, int stages, int filt, unsigned segments, int sample_bits)
+{
+    uint32_t crc_tab[256];
+    build_crc32_table(crc_tab);
+    // candidate kernel: one thread per byte offset; payload kernel: one thread per candidate
+    std::vector<PacketCandidate> cands;
+    for (uint32_t off = 0; off < (uint32_t)len; off++) {
+        PacketCandidate c;
+        if (header_candidate(crc_tab, data, (uint32_t)len, off, &c)) cands.push_back(c);
+    }
+    for (PacketCandidate &c : cands) check_payload(crc_tab, data, &c);
+    DecodePlan pl;
+    plan_decode(&pl, data, cands, channels, stages, segments, sample_bits, *w, *h, bufsize);
+    *w = pl.w; *h = pl.h;
+    if (pl.rc == kInvalidInput || pl.rc == kTooManyStages || pl.rc == kByteQuotaExceeded) return pl.rc;
+    const size_t W = pl.w, H = pl.h;
+    for (int c = 0; c < channels; c++) memset(planes[c], 0, sizeof(uint16_t) * W * H);
+    CoderTables ct;
+    build_coder_tables(&ct);
+    DecoderTables dt;
+    build_decoder_tables(&dt, ct);
+    const int nplanes = sample_bits == 8 ? kPlanes8 : kPlanes, sign_bit = sample_bits == 8 ? 7 : 15;
+    // chain kernel: one thread per chain
+    for (size_t i = 0; i < pl.chains.size(); i++)
+        decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit);
+    if (!pl.transform) return pl.rc;
+    const FilterTaps taps = filter_taps(filt);
+    std::vector<int16_t> tmp(W * H);
+    std::vector<uint32_t> pos_col, pos_row;
+    for (int c = 0; c < channels; c++) {
+        int16_t *s = (int16_t *)planes[c];
+        for (size_t i = 0; i < W * H; i++) s[i] = from_sign_magnitude(planes[c][i], sign_bit);
+        const size_t llw = dim_low(W, stages), llh = dim_low(H, stages);
+        for (size_t r = 0; r < llh; r++)
+            for (size_t x = 0; x < llw; x++) s[r * W + x] = add_ll_mean(s[r * W + x], pl.mean[c], sample_bits);
+        for (const DecodeLevel &lv : pl.levels) {
+            pos_col.resize(lv.ch); pos_row.resize(lv.cw);
+            interleave_positions(lv.ch, sample_bits, pos_col.data());
+            interleave_positions(lv.cw, sample_bits, pos_row.data());
+            for (uint32_t x = 0; x < lv.cw; x++) idwt_line(s + x, tmp.data() + x, lv.ch, W, taps, sample_bits, pos_col.data());
+            for (uint32_t r = 0; r < lv.ch; r++) idwt_line(tmp.data() + (size_t)r * W, s + (size_t)r * W, lv.cw, 1, taps, sample_bits, pos_row.data());
+        }
+        for (size_t i = 0; i < W * H; i++) {                    // icer_remove_negative_*, icer_util.c:70-91
+            if (s[i] < 0) s[i] = 0;
+            if (sample_bits == 8) planes[c][i] &= 0xFFu;
+        }
+    }
+    return pl.rc;
+}

@@ -12,8 +12,8 @@ from icer_compression_amd import api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "icer_hip.h")).read()
+def _declared_functions(header="icer_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(icerx?_[a-z0-9_]+)\s*\(", src)))
 
@@ -25,6 +25,31 @@ def test_library_exports_every_declared_symbol():
             "icerx_encoder_create", "icerx_encode_device"} <= set(names)
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_decoder_library_exports_every_declared_symbol_and_has_no_cpu_fallback():
+    """include/icer_hip_dec.h <-> libicer_hip_dec.so (the decoder)"""
+    from icer_compression_amd import decoder
+    lib = decoder.load_library()
+    names = _declared_functions("icer_hip_dec.h")
+    assert {"icer_get_image_dimensions", "icer_decompress_image_uint16", "icer_decompress_image_yuv_uint16",
+            "icer_decompress_image_uint8", "icer_decompress_image_yuv_uint8"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+    # host-only entry point: size fields of the first CRC-valid packet (icer_compress.c:541-566)
+    from oracle.binding import Oracle
+    rc, stream, _ = Oracle().compress([np.arange(40 * 24, dtype=np.uint16).reshape(24, 40) % 200], 2, 0, 3, 1 << 16)
+    assert decoder.icer_get_image_dimensions(stream) == (0, 40, 24)
+    assert decoder.icer_get_image_dimensions(b"\x00" * 9 + stream) == (0, 40, 24)
+    assert decoder.icer_get_image_dimensions(stream[:27])[0] == decoder.ICER_DECODER_OUT_OF_DATA
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        rc, w, h, _ = decoder.decompress(stream, 1, 2, 0, 3)
+        assert rc == api.ICER_FATAL_ERROR and b"no usable HIP device" in lib.icerx_decoder_last_error()
 
 
 def test_output_struct_layout_and_init():

@@ -1,0 +1,102 @@
+"""The decoder's DEVICE code (icer_compression_amd/csrc/decoder_core.hpp + decoder_plan.hpp), compiled by g++ and driven
+like decoder.hip drives it on the GPU (tests/emu/decoder_emu.cpp), against the decoder oracle -- which
+tests/test_oracle_decoder.py pins to the reference decoder.  CPU only: this is how the device decoder is checked in a
+container without a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.binding import Oracle
+from tests.test_oracle_decoder import packets, random_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emu", "decoder_emu.cpp")
+LIB = os.path.join(HERE, "emu", "libdecoder_emu.so")
+CSRC = os.path.join(HERE, "..", "icer_compression_amd", "csrc")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("decoder_core.hpp", "decoder_plan.hpp", "plan.hpp", "icer_tables.hpp")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB, SRC])
+    lib = C.CDLL(LIB)
+    sz = C.c_size_t
+    lib.emu_decompress.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(sz), C.POINTER(sz), sz, u8p, sz, C.c_int, C.c_int,
+                                   C.c_uint, C.c_int]
+
+    def decompress(stream, channels, stages, filt, segments, bufsize=None, bits=16, w0=0, h0=0):
+        if bufsize is None:
+            bufsize = int.from_bytes(stream[8:12], "little") * int.from_bytes(stream[12:16], "little") if len(stream) >= 28 else 0
+        buf = np.frombuffer(stream, dtype=np.uint8).copy() if len(stream) else np.zeros(1, np.uint8)
+        planes = [np.zeros(max(bufsize, 1), np.uint16) for _ in range(channels)]
+        ptrs = (C.c_void_p * channels)(*[p.ctypes.data for p in planes])
+        w, h = sz(w0), sz(h0)
+        rc = lib.emu_decompress(ptrs, channels, C.byref(w), C.byref(h), bufsize, buf, len(stream), stages, filt, segments, bits)
+        if bits == 8:
+            planes = [p.astype(np.uint8) for p in planes]
+        return rc, w.value, h.value, planes
+    return decompress
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def same(a, b):
+    return a[0] == b[0] and a[1:3] == b[1:3] and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+
+
+def test_device_decoder_matches_the_oracle_on_random_streams(emu, orc):
+    rng = np.random.default_rng(424242)
+    done, rcs = 0, set()
+    for _ in range(220):
+        planes, st, filt, sg, ch, bits, quota = random_case(rng)
+        rc, stream, _ = (orc.compress if bits == 16 else orc.compress_u8)(planes, st, filt, sg, quota)
+        if not stream:
+            continue
+        dsg = sg if rng.random() < 0.9 else int(rng.integers(1, 33))
+        dst = st if rng.random() < 0.9 else int(rng.integers(1, 7))
+        a = emu(stream, ch, dst, filt, dsg, bits=bits)
+        b = orc.decompress(stream, ch, dst, filt, dsg, bits=bits)
+        if b[0] == -3 and bits == 8:
+            # (a grid error leaves sign-magnitude words behind; the oracle's uint8 wrapper narrows them the same way)
+            pass
+        assert same(a, b), (planes[0].shape, st, dst, filt, sg, dsg, ch, bits, quota, a[0], b[0])
+        rcs.add(a[0])
+        done += 1
+    assert done > 150 and {0, -3} <= rcs
+
+
+def test_device_decoder_on_damaged_streams(emu, orc):
+    from icer_compression_amd import synth
+    rng = np.random.default_rng(8)
+    img = synth.gray_frame(160, 120, 3, 1)
+    rc, stream, _ = orc.compress([img], 3, 1, 5, 2 * 160 * 120)
+    pk = packets(stream)
+    variants = [b"", b"\x5b\x60" * 40, stream[: len(stream) // 2], stream[: len(stream) - 1], stream[5:],
+                b"".join(reversed(pk)), b"".join(pk + pk[:7]), b"\x00" * 9 + stream + b"\x5b\x60\x00"]
+    for _ in range(10):
+        s = bytearray(stream)
+        for _ in range(int(rng.integers(1, 6))):
+            s[int(rng.integers(0, len(s)))] ^= 1 << int(rng.integers(0, 8))
+        variants.append(bytes(s))
+    for s in variants:
+        assert same(emu(s, 1, 3, 1, 5, bufsize=160 * 120), orc.decompress(s, 1, 3, 1, 5, bufsize=160 * 120)), len(s)
+    assert emu(stream, 1, 3, 1, 5, bufsize=160 * 120 - 1)[0] == -5
+    assert emu(stream, 2, 3, 1, 5)[0] == -11 and emu(stream, 1, 7, 1, 5)[0] == -4
+
+
+def test_device_decoder_headline_frame(emu, orc):
+    """1024 x 1024 (the largest frame the CPU build of the device code decodes in a few seconds): lossless round trip"""
+    from icer_compression_amd import synth
+    img = synth.gray_frame(1024, 1024, 12345, 1)
+    rc, stream, _ = orc.compress([img], 4, 0, 16, 2 * 1024 * 1024)
+    rc2, w, h, planes = emu(stream, 1, 4, 0, 16)
+    assert (rc, rc2, w, h) == (0, 0, 1024, 1024) and np.array_equal(planes[0].reshape(1024, 1024), img)

@@ -1,0 +1,90 @@
+"""GPU parity tests of the decoder (libicer_hip_dec.so through its C ABI) against the decoder oracle.
+
+OPT-IN (set ICER_GPU_DECODER_TESTS=1): the decoder's device code has so far only been run in its CPU build
+(tests/test_emu_decoder.py); these tests are what its first GPU run executes, and they join the default `-m gpu` set
+once they have passed on hardware.  See DESIGN.md 6b.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from icer_compression_amd import synth
+from oracle.binding import Oracle
+from tests.test_oracle_decoder import random_case
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("ICER_GPU_DECODER_TESTS") != "1",
+                                 reason="decoder not yet validated on hardware: opt in with ICER_GPU_DECODER_TESTS=1")]
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from icer_compression_amd import decoder
+    decoder.load_library()
+    return decoder
+
+
+def same(a, b):
+    return a[0] == b[0] and a[1:3] == b[1:3] and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+
+
+@pytest.mark.timeout(600)
+def test_random_streams(dec, orc):
+    rng = np.random.default_rng(99)
+    done = 0
+    for _ in range(120):
+        planes, st, filt, sg, ch, bits, quota = random_case(rng)
+        rc, stream, _ = (orc.compress if bits == 16 else orc.compress_u8)(planes, st, filt, sg, quota)
+        if not stream:
+            continue
+        dsg = sg if rng.random() < 0.9 else int(rng.integers(1, 33))
+        h, w = planes[0].shape
+        a = dec.decompress(stream, ch, st, filt, dsg, bufsize=w * h, bits=bits)
+        b = orc.decompress(stream, ch, st, filt, dsg, bufsize=w * h, bits=bits)
+        assert same(a, b), (planes[0].shape, st, filt, sg, dsg, ch, bits, quota, a[0], b[0])
+        done += 1
+    assert done > 80
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", ["kat_512_m1", "kat_512_quota30000", "kat_odd_517x389_filtC", "kat_color_512_quota",
+                                  "u8_512_gray", "u8_517x389_filtB_quota", "u8_512_yuv_4st", "C2_4096_gray_5st_10seg"])
+def test_golden_decodes(dec, orc, name):
+    """digests of the reference DECODER's output (tests/golden/make_golden.py)"""
+    g = GOLDEN[name]
+    kind, w, h = g["kind"], g["w"], g["h"]
+    if kind == "gray":
+        planes = [synth.gray_frame(w, h, g["seed"], g["mode"])]
+    elif kind == "yuv":
+        planes = list(synth.color_frame_yuv(w, h, g["seed"]))
+    elif kind == "gray8":
+        planes = [synth.gray_frame_u8(w, h, g["seed"], g["mode"])]
+    else:
+        planes = list(synth.color_frame_yuv_u8(w, h, g["seed"]))
+    u8 = kind.endswith("8")
+    rc, stream, _ = (orc.compress_u8 if u8 else orc.compress)(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+    assert hashlib.sha256(stream).hexdigest()[:16] == g["sha256_16"]
+    drc, dw, dh, out = dec.decompress(stream, len(planes), g["stages"], g["filt"], g["segments"], bits=8 if u8 else 16)
+    hsh = hashlib.sha256()
+    for p in out:
+        hsh.update(p.tobytes())
+    assert (drc, dw, dh, hsh.hexdigest()[:16]) == (g["decoded_rc"], g["decoded_w"], g["decoded_h"], g["decoded_sha256_16"])
+
+
+@pytest.mark.timeout(300)
+def test_error_paths(dec, orc):
+    img = synth.gray_frame(160, 120, 3, 1)
+    rc, stream, _ = orc.compress([img], 3, 1, 5, 2 * 160 * 120)
+    assert dec.decompress(stream, 1, 3, 1, 5, bufsize=160 * 120 - 1)[0] == -5
+    for s in (b"", stream[: len(stream) // 2], stream[5:], b"\x00" * 9 + stream + b"\x5b\x60\x00"):
+        assert same(dec.decompress(s, 1, 3, 1, 5, bufsize=160 * 120), orc.decompress(s, 1, 3, 1, 5, bufsize=160 * 120)), len(s)
