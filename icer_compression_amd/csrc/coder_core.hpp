@@ -65,6 +65,7 @@
 #define ICER_FENCE_REL() std::atomic_thread_fence(std::memory_order_release)
 #define ICER_STORE_CNT(x, v) __atomic_store_n(&(x), (v), __ATOMIC_RELEASE)
 #define ICER_LANE0
+#define ICER_GLOBAL_RELEASE() std::atomic_thread_fence(std::memory_order_release)
 constexpr uint32_t kPollLimit = 50u * 1000u * 1000u;
 #elif defined(ICER_WAVE_EMU)
 #include <assert.h>
@@ -77,6 +78,7 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_PUBLISH(x, v) { (x) = (v); }
 #define ICER_PUBLISH2(x1, v1, x2, v2) { (x1) = (v1); (x2) = (v2); }
 #define ICER_ACQUIRE()
+#define ICER_GLOBAL_RELEASE()
 #define ICER_IDLE() break;     /* the emulation never waits: hand control back to the scheduler */
 #define ICER_IDLE_DECL
 #define ICER_IDLE_RESET
@@ -91,6 +93,8 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_FENCE_REL() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define ICER_STORE_CNT(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ICER_LANE0 if (lane == 0)
+// all address spaces: also waits for this wave's global stores (vmcnt) -- used once per unit, see drain_wave_run
+#define ICER_GLOBAL_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 #define kPollLimit kSpinLimit
 #endif
 
@@ -1590,8 +1594,12 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
         const uint32_t hs = ICER_LOAD_CNT(s.hold_seq);
         if (hs & 1u) {
             // parked: the merge wave owns popped / bitpos / the bit stage until it releases the hold
+            const uint32_t ex_ = ICER_LOAD_CNT(s.drain_exit);
+            // (end of unit: the payload words this wave stored are read back by the merge wave for the CRC; the hand-off
+            // fences are LDS-only, so the stores are completed explicitly before the acknowledgement)
+            if (ex_) ICER_GLOBAL_RELEASE();
             ICER_PUBLISH(s.hold_ack, hs)
-            if (ICER_LOAD_CNT(s.drain_exit) || step >= max_steps) break;
+            if (ex_ || step >= max_steps) break;
             ICER_IDLE()
             continue;
         }
