@@ -235,87 +235,138 @@ ICER_HD void dec_model_update(uint16_t &zero, uint16_t &total, bool was_zero)
     }
 }
 
-// adds bit plane `lsb` to the sign-magnitude words of one segment (sign at bit `sign_bit`)
-ICER_HD int decode_plane(uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int subband, int lsb, int sign_bit,
-                         EntropyDecoder &d, const DecoderTables &t)
+// One bit plane of one segment as a resumable job: plane_step decodes the next sample (row-major) and adds its bit of
+// plane `lsb` -- and its sign, when the sample becomes significant -- to the sign-magnitude word (sign at `sign_bit`).
+struct PlaneDecoder {
+    EntropyDecoder d;
+    uint16_t zero[kNumContexts], total[kNumContexts];      // context model (icer_init_context_model_vals :607-613)
+    uint32_t r, c;              // next sample
+    uint32_t left;              // the sample to the left, this plane already decoded
+    uint32_t done;              // samples finished (= r * w + c)
+    int lsb;
+    int status;                 // 1 = running, 0 = finished (kOk), < 0 = failed with that code, 2 = not started
+};
+
+ICER_HD void plane_begin(PlaneDecoder &p, int lsb, int sign_bit, uint32_t w, uint32_t h)
 {
-    if (lsb + 1 >= sign_bit + 1) return kBitplaneOutOfRange;
+    for (int k = 0; k < kNumContexts; k++) { p.zero[k] = 2; p.total[k] = 4; }
+    p.r = 0; p.c = 0; p.left = 0; p.done = 0; p.lsb = lsb;
+    p.status = (lsb + 1 >= sign_bit + 1) ? kBitplaneOutOfRange : ((w == 0 || h == 0) ? kOk : 1);
+}
+
+// one sample (icer_context_modeller.c:495-598); sets p.status when the plane ends or fails
+ICER_HD void plane_step(PlaneDecoder &p, uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int subband, int sign_bit,
+                        const DecoderTables &t)
+{
+    const int lsb = p.lsb;
     const uint32_t mask = (1u << sign_bit) - 1u;
-    uint16_t zero[kNumContexts], total[kNumContexts];
-    for (int k = 0; k < kNumContexts; k++) { zero[k] = 2; total[k] = 4; }
-    for (uint32_t r = 0; r < h; r++) {
-        uint16_t *row = seg + (size_t)r * stride;
-        const uint16_t *up = r > 0 ? row - stride : nullptr, *dn = r + 1 < h ? row + stride : nullptr;
-        uint32_t left = 0;                       // the sample to the left, this plane already decoded
-        for (uint32_t c = 0; c < w; c++) {
-            const uint32_t cur = row[c];
-            const uint32_t m = cur & mask;
-            int msb = 0;
-            for (uint32_t v = m | 1u; v > 1u; v >>= 1) msb++;
-            int cat = msb < lsb ? 0 : msb - lsb;
-            if (cat > 3) cat = 3;
-            uint32_t bit;
-            int res;
-            if (cat == 3) {
-                if ((res = entropy_decode(d, t, &bit, 1, 2)) != kOk) return res;
-                left = cur | (bit << lsb);
-                row[c] = (uint16_t)left;
-                continue;
-            }
-            const bool has_r = c + 1 < w;
-            const uint32_t right = has_r ? row[c + 1] : 0u;
-            const uint32_t u0 = up ? up[c] : 0u, d0 = dn ? dn[c] : 0u;
-            int ctx;
-            if (cat == 2) ctx = 11;
+    const uint32_t r = p.r, c = p.c;
+    uint16_t *row = seg + (size_t)r * stride;
+    const uint16_t *up = r > 0 ? row - stride : nullptr, *dn = r + 1 < h ? row + stride : nullptr;
+    const uint32_t left = p.left;
+    const uint32_t cur = row[c];
+    const uint32_t m = cur & mask;
+    int msb = 0;
+    for (uint32_t v = m | 1u; v > 1u; v >>= 1) msb++;
+    int cat = msb < lsb ? 0 : msb - lsb;
+    if (cat > 3) cat = 3;
+    uint32_t bit, val;
+    int res;
+    if (cat == 3) {
+        if ((res = entropy_decode(p.d, t, &bit, 1, 2)) != kOk) { p.status = res; return; }
+        val = cur | (bit << lsb);
+    } else {
+        const bool has_r = c + 1 < w;
+        const uint32_t right = has_r ? row[c + 1] : 0u;
+        const uint32_t u0 = up ? up[c] : 0u, d0 = dn ? dn[c] : 0u;
+        int ctx;
+        if (cat == 2) ctx = 11;
+        else {
+            // neighbours already visited count at this plane, the others at the plane above (:509-521)
+            const uint32_t ul = (up && c > 0) ? up[c - 1] : 0u, ur = (up && has_r) ? up[c + 1] : 0u;
+            const uint32_t dl = (dn && c > 0) ? dn[c - 1] : 0u, dr = (dn && has_r) ? dn[c + 1] : 0u;
+            int hh = (c > 0 && ((left & mask) >> lsb)) + (((right & mask) >> (lsb + 1)) != 0);
+            int vv = (((u0 & mask) >> lsb) != 0) + (((d0 & mask) >> (lsb + 1)) != 0);
+            const int dd = (((ul & mask) >> lsb) != 0) + (((ur & mask) >> lsb) != 0) +
+                           (((dl & mask) >> (lsb + 1)) != 0) + (((dr & mask) >> (lsb + 1)) != 0);
+            if (cat == 1) ctx = (hh + vv == 0) ? 9 : 10;
             else {
-                // neighbours already visited count at this plane, the others at the plane above (:509-521)
-                const uint32_t ul = (up && c > 0) ? up[c - 1] : 0u, ur = (up && has_r) ? up[c + 1] : 0u;
-                const uint32_t dl = (dn && c > 0) ? dn[c - 1] : 0u, dr = (dn && has_r) ? dn[c + 1] : 0u;
-                int hh = (c > 0 && ((left & mask) >> lsb)) + (((right & mask) >> (lsb + 1)) != 0);
-                int vv = (((u0 & mask) >> lsb) != 0) + (((d0 & mask) >> (lsb + 1)) != 0);
-                const int dd = (((ul & mask) >> lsb) != 0) + (((ur & mask) >> lsb) != 0) +
-                               (((dl & mask) >> (lsb + 1)) != 0) + (((dr & mask) >> (lsb + 1)) != 0);
-                if (cat == 1) ctx = (hh + vv == 0) ? 9 : 10;
-                else {
-                    if (subband == kHL) { const int x = hh; hh = vv; vv = x; }
-                    ctx = subband == kHH ? dec_ctx_hh(hh + vv, dd) : dec_ctx_plain(hh, vv, dd);
-                }
+                if (subband == kHL) { const int x = hh; hh = vv; vv = x; }
+                ctx = subband == kHH ? dec_ctx_hh(hh + vv, dd) : dec_ctx_plain(hh, vv, dd);
             }
-            if ((res = entropy_decode(d, t, &bit, zero[ctx], total[ctx])) != kOk) return res;
-            uint32_t val = cur | (bit << lsb);
-            dec_model_update(zero[ctx], total[ctx], bit == 0);
-            if (cat == 0 && bit) {
-                // sign: only negative significant neighbours count (QUIRK C6)
-                auto sgn = [&](uint32_t v, int plane) { return (((v & mask) >> plane) != 0 && ((v >> sign_bit) & 1u)) ? -1 : 0; };
-                int sh = (c > 0 ? sgn(left, lsb) : 0) + sgn(right, lsb + 1) + 2;
-                int sv = sgn(u0, lsb) + sgn(d0, lsb + 1) + 2;
-                if (subband == kHL) { const int x = sh; sh = sv; sv = x; }
-                const int sctx = dec_sign_ctx(sh, sv);
-                uint32_t agree;
-                if ((res = entropy_decode(d, t, &agree, zero[sctx], total[sctx])) != kOk) { row[c] = (uint16_t)val; return res; }
-                val |= ((agree ^ (uint32_t)dec_sign_pred(sh, sv)) & 1u) << sign_bit;
-                dec_model_update(zero[sctx], total[sctx], agree == 0);
-            }
-            row[c] = (uint16_t)val;
-            left = val;
+        }
+        if ((res = entropy_decode(p.d, t, &bit, p.zero[ctx], p.total[ctx])) != kOk) { p.status = res; return; }
+        val = cur | (bit << lsb);
+        dec_model_update(p.zero[ctx], p.total[ctx], bit == 0);
+        if (cat == 0 && bit) {
+            // sign: only negative significant neighbours count (QUIRK C6)
+            auto sgn = [&](uint32_t v, int plane) { return (((v & mask) >> plane) != 0 && ((v >> sign_bit) & 1u)) ? -1 : 0; };
+            int sh = (c > 0 ? sgn(left, lsb) : 0) + sgn(right, lsb + 1) + 2;
+            int sv = sgn(u0, lsb) + sgn(d0, lsb + 1) + 2;
+            if (subband == kHL) { const int x = sh; sh = sv; sv = x; }
+            const int sctx = dec_sign_ctx(sh, sv);
+            uint32_t agree;
+            if ((res = entropy_decode(p.d, t, &agree, p.zero[sctx], p.total[sctx])) != kOk) { row[c] = (uint16_t)val; p.status = res; return; }
+            val |= ((agree ^ (uint32_t)dec_sign_pred(sh, sv)) & 1u) << sign_bit;
+            dec_model_update(p.zero[sctx], p.total[sctx], agree == 0);
         }
     }
-    return kOk;
+    row[c] = (uint16_t)val;
+    p.done++;
+    if (c + 1 < w) { p.c = c + 1; p.left = val; }
+    else { p.c = 0; p.left = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
+}
+
+ICER_HD uint32_t packet_bits(const uint8_t *stream, uint32_t at)
+{
+    const uint8_t *p = stream + at;
+    return (uint32_t)p[16] | ((uint32_t)p[17] << 8) | ((uint32_t)p[18] << 16) | ((uint32_t)p[19] << 24);
 }
 
 // all planes of one chain, top plane first, until one is missing or fails (icer_partition.c:427-443)
 ICER_HD void decode_chain(uint16_t *plane, size_t stride, const ChainDesc &c, int subband, const uint8_t *stream,
                           uint32_t stream_len, const DecoderTables &t, int planes, int sign_bit)
 {
-    EntropyDecoder d;
+    PlaneDecoder p;
     for (int lsb = planes - 1; lsb >= 0; lsb--) {
         const uint32_t at = c.pkt[lsb];
         if (at == kNoPacket) break;
-        const uint8_t *p = stream + at;
-        const uint32_t bits = (uint32_t)p[16] | ((uint32_t)p[17] << 8) | ((uint32_t)p[18] << 16) | ((uint32_t)p[19] << 24);
-        entropy_init(d, stream, stream_len, at + (uint32_t)kHeaderBytes, bits);
-        if (decode_plane(plane + c.first, c.w, c.h, stride, subband, lsb, sign_bit, d, t) != kOk) break;
+        entropy_init(p.d, stream, stream_len, at + (uint32_t)kHeaderBytes, packet_bits(stream, at));
+        plane_begin(p, lsb, sign_bit, c.w, c.h);
+        while (p.status == 1) plane_step(p, plane + c.first, c.w, c.h, stride, subband, sign_bit, t);
+        if (p.status != kOk) break;
     }
+}
+
+// ---- the planes of a chain side by side.  Plane lsb reads, of the plane above, the samples to the right and in the
+// row below (significance and sign at lsb + 1), so it can run while the plane above is still at work as long as that one
+// has finished sample (r + 1, c + 1) -- one row and one sample of lag per plane; nothing a plane writes is visible to the
+// planes above it (they shift those bits out and have passed the sample).  Every packet becomes a job of its own.
+// samples of the plane above that must be finished before this plane decodes sample (r, c)
+ICER_HD uint32_t plane_needs(uint32_t r, uint32_t c, uint32_t w, uint32_t h)
+{
+    if (r + 1 >= h) return w * h;
+    return (r + 1) * w + (c + 1 < w ? c + 1 : w - 1) + 1;
+}
+// may the plane below `above` decode its next sample?  (false for good once `above` has failed or was never started)
+ICER_HD bool plane_ready(const PlaneDecoder &me, int above_status, uint32_t above_done, uint32_t w, uint32_t h)
+{
+    if (me.status != 1) return false;
+    if (above_status == kOk) return true;
+    if (above_status != 1) return false;
+    return above_done >= plane_needs(me.r, me.c, w, h);
+}
+// When plane q fails, the reference has not started the planes below it: what they wrote is taken back -- their
+// magnitude bits, and the sign of a sample whose remaining magnitude is zero (a sign is only ever set by the plane that
+// makes the sample significant).
+ICER_HD void chain_rollback(uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int failed_lsb, int sign_bit)
+{
+    const uint32_t keep = ((1u << sign_bit) - 1u) & ~((1u << failed_lsb) - 1u);
+    for (uint32_t r = 0; r < h; r++)
+        for (uint32_t c = 0; c < w; c++) {
+            const uint32_t v = seg[(size_t)r * stride + c], m = v & keep;
+            seg[(size_t)r * stride + c] = (uint16_t)(m ? (m | (v & (1u << sign_bit))) : 0u);
+        }
 }
 
 // ------------------------------------------------------------------------------------------ sample post-processing

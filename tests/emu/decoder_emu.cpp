@@ -9,6 +9,53 @@
 
 using namespace icer;
 
+// The planes of a chain side by side, in lock step (what a group of lanes -- one per packet -- would do): every
+// iteration each plane whose upper neighbour is far enough ahead (plane_ready) decodes one sample.  Checks the
+// dependency rule and the roll-back after a failing plane (decoder_core.hpp) against the serial order.
+static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDesc &c, int subband, const uint8_t *stream,
+                                  uint32_t stream_len, const DecoderTables &t, int planes, int sign_bit, unsigned long long *stats)
+{
+    PlaneDecoder pd[kPlanes];
+    bool chain_open = true;
+    for (int j = 0; j < planes; j++) {
+        const int lsb = planes - 1 - j;
+        const uint32_t at = c.pkt[lsb];
+        pd[j].status = 2; pd[j].done = 0; pd[j].lsb = lsb;
+        if (at == kNoPacket) chain_open = false;
+        if (!chain_open) continue;
+        entropy_init(pd[j].d, stream, stream_len, at + (uint32_t)kHeaderBytes, packet_bits(stream, at));
+        plane_begin(pd[j], lsb, sign_bit, c.w, c.h);
+    }
+    uint16_t *seg = plane + c.first;
+    for (;;) {
+        int st[kPlanes]; uint32_t dn[kPlanes];
+        for (int j = 0; j < planes; j++) { st[j] = pd[j].status; dn[j] = pd[j].done; }     // as of the iteration's start
+        bool any = false;
+        int active = 0;
+        for (int j = 0; j < planes; j++) {
+            const bool go = j == 0 ? pd[0].status == 1 : plane_ready(pd[j], st[j - 1], dn[j - 1], c.w, c.h);
+            if (!go) continue;
+            plane_step(pd[j], seg, c.w, c.h, stride, subband, sign_bit, t);
+            any = true; active++;
+        }
+        if (!any) break;
+        if (stats) { stats[0]++; stats[1] += (unsigned long long)active; }
+    }
+    for (int j = 0; j < planes; j++)
+        if (pd[j].status < 0) {                                  // the highest failing plane
+            bool below = false;
+            for (int k = j + 1; k < planes; k++) below |= pd[k].status != 2 && pd[k].done > 0;
+            if (below) { chain_rollback(seg, c.w, c.h, stride, pd[j].lsb, sign_bit); if (stats) stats[2]++; }
+            break;
+        }
+}
+
+static int g_lockstep = 0;
+static unsigned long long g_stats[3];
+// mode 1: decode chains with the lock-step schedule; stats: iterations, samples decoded, roll-backs
+extern "C" void emu_decoder_mode(int lockstep) { g_lockstep = lockstep; g_stats[0] = g_stats[1] = g_stats[2] = 0; }
+extern "C" void emu_decoder_stats(unsigned long long *out) { out[0] = g_stats[0]; out[1] = g_stats[1]; out[2] = g_stats[2]; }
+
 // planes[c]: >= bufsize uint16 words; for sample_bits = 8 the low byte of each word is the uint8 result.
 extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
                               const uint8_t *data, size_t len, int stages, int filt, unsigned segments, int sample_bits)
@@ -34,8 +81,10 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     build_decoder_tables(&dt, ct);
     const int nplanes = sample_bits == 8 ? kPlanes8 : kPlanes, sign_bit = sample_bits == 8 ? 7 : 15;
     // chain kernel: one thread per chain
-    for (size_t i = 0; i < pl.chains.size(); i++)
-        decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit);
+    for (size_t i = 0; i < pl.chains.size(); i++) {
+        if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        else decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit);
+    }
     if (!pl.transform) return pl.rc;
     const FilterTaps taps = filter_taps(filt);
     std::vector<int16_t> tmp(W * H);

@@ -41,6 +41,7 @@ def emu():
         if bits == 8:
             planes = [p.astype(np.uint8) for p in planes]
         return rc, w.value, h.value, planes
+    decompress.lib = lib
     return decompress
 
 
@@ -100,3 +101,29 @@ def test_device_decoder_headline_frame(emu, orc):
     rc, stream, _ = orc.compress([img], 4, 0, 16, 2 * 1024 * 1024)
     rc2, w, h, planes = emu(stream, 1, 4, 0, 16)
     assert (rc, rc2, w, h) == (0, 0, 1024, 1024) and np.array_equal(planes[0].reshape(1024, 1024), img)
+
+
+def test_planes_side_by_side_schedule(emu, orc):
+    """every packet as a job of its own: a plane may decode sample (r, c) once the plane above has finished
+    (r + 1, c + 1); a failing plane takes back what the planes below it wrote.  Same images as the serial order --
+    including quota-cut streams, one-code-word packets (refused by the reference decoder) and data above the coded planes,
+    where the decoder derails and planes fail at arbitrary points."""
+    emu.lib.emu_decoder_mode(1)
+    try:
+        rng = np.random.default_rng(77)
+        done = 0
+        for _ in range(200):
+            planes, st, filt, sg, ch, bits, quota = random_case(rng)
+            rc, stream, _ = (orc.compress if bits == 16 else orc.compress_u8)(planes, st, filt, sg, quota)
+            if not stream:
+                continue
+            assert same(emu(stream, ch, st, filt, sg, bits=bits), orc.decompress(stream, ch, st, filt, sg, bits=bits)), \
+                (planes[0].shape, st, filt, sg, ch, bits, quota)
+            done += 1
+        stats = (C.c_ulonglong * 3)()
+        emu.lib.emu_decoder_stats(stats)
+        assert done > 150
+        assert stats[2] > 0                       # roll-backs happened
+        assert stats[1] / stats[0] > 3.0          # samples per lock-step iteration: the planes really overlap
+    finally:
+        emu.lib.emu_decoder_mode(0)
