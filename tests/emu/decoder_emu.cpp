@@ -9,6 +9,9 @@
 
 using namespace icer;
 
+static int g_lockstep = 0;
+static unsigned long long g_stats[3];
+
 // The planes of a chain side by side, in lock step (what a group of lanes -- one per packet -- would do): every
 // iteration each plane whose upper neighbour is far enough ahead (plane_ready) decodes one sample.  Checks the
 // dependency rule and the roll-back after a failing plane (decoder_core.hpp) against the serial order.
@@ -32,7 +35,10 @@ static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDes
         for (int j = 0; j < planes; j++) { st[j] = pd[j].status; dn[j] = pd[j].done; }     // as of the iteration's start
         bool any = false;
         int active = 0;
-        for (int j = 0; j < planes; j++) {
+        for (int jj = 0; jj < planes; jj++) {
+            // (mode 2 walks the planes bottom-up inside an iteration: lanes of a wave have no order among themselves,
+            // so the result must not depend on it)
+            const int j = g_lockstep == 2 ? planes - 1 - jj : jj;
             const bool go = j == 0 ? pd[0].status == 1 : plane_ready(pd[j], st[j - 1], dn[j - 1], c.w, c.h);
             if (!go) continue;
             plane_step(pd[j], seg, c.w, c.h, stride, subband, sign_bit, t);
@@ -50,8 +56,6 @@ static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDes
         }
 }
 
-static int g_lockstep = 0;
-static unsigned long long g_stats[3];
 // mode 1: decode chains with the lock-step schedule; stats: iterations, samples decoded, roll-backs
 extern "C" void emu_decoder_mode(int lockstep) { g_lockstep = lockstep; g_stats[0] = g_stats[1] = g_stats[2] = 0; }
 extern "C" void emu_decoder_stats(unsigned long long *out) { out[0] = g_stats[0]; out[1] = g_stats[1]; out[2] = g_stats[2]; }
