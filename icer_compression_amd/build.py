@@ -45,7 +45,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 DEC_LIB = os.path.join(PKG, "libicer_hip_dec.so")
-DEC_DEPS = ["decoder.hip", "decoder_core.hpp", "decoder_plan.hpp", "plan.hpp", "icer_tables.hpp"]
+DEC_DEPS = ["decoder.hip", "decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp", "wave.hpp", "plan.hpp", "icer_tables.hpp"]
 
 
 def build_decoder_library(force: bool = False, verbose: bool = False) -> str:

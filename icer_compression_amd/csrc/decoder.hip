@@ -10,11 +10,13 @@
 #include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
 
 #include "../../include/icer_hip_dec.h"
+#include "decoder_wave.hpp"
 #include "decoder_core.hpp"
 #include "decoder_plan.hpp"
 
@@ -73,6 +75,19 @@ decode_chains_kernel(uint16_t *__restrict__ planes, size_t plane_samples, uint32
     if (i >= n) return;
     const ChainDesc c = chains[i];
     decode_chain(planes + (size_t)c.chan * plane_samples, image_w, c, subbands[i], stream, len, *tables, nplanes, sign_bit);
+}
+
+// the same with one wavefront per chain and one lane per packet (decoder_wave.hpp); dynamic LDS = the row ring
+__global__ void __launch_bounds__(64)
+decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t plane_samples, uint32_t image_w,
+                          const ChainDesc *__restrict__ chains, const uint8_t *__restrict__ subbands,
+                          const uint8_t *__restrict__ stream, uint32_t len, const DecoderTables *__restrict__ tables,
+                          int nplanes, int sign_bit, uint32_t pitch)
+{
+    extern __shared__ uint16_t ring[];
+    const ChainDesc c = chains[blockIdx.x];
+    decode_chain_wave(ring, pitch, planes + (size_t)c.chan * plane_samples, image_w, c, subbands[blockIdx.x], stream, len,
+                      *tables, nplanes, sign_bit, nullptr);
 }
 
 // sign-magnitude words -> int16, LL mean back in (grid.y = channel)
@@ -202,8 +217,18 @@ int decompress_planes(void *const planes[], int channels, size_t *image_w, size_
             HIP_TRY(hipMemcpy(d_chains, pl.chains.data(), sizeof(ChainDesc) * n, hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc(&d_sub, n));
             HIP_TRY(hipMemcpy(d_sub, pl.chain_subband.data(), n, hipMemcpyHostToDevice));
-            decode_chains_kernel<<<(n + 63u) / 64u, 64>>>(d_planes, samples, (uint32_t)W, d_chains, d_sub, n, d_stream, len,
-                                                         d_tables, nplanes, sign_bit);
+            // ICER_DEC_WAVE=1: the planes of a segment side by side (one wavefront per chain), if its rows fit the LDS ring
+            uint32_t pitch = 2;
+            for (const ChainDesc &c : pl.chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
+            const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t);
+            const char *mode = getenv("ICER_DEC_WAVE");
+            if (mode && mode[0] == '1' && ring_bytes <= 65536u) {
+                decode_chains_wave_kernel<<<n, 64, ring_bytes>>>(d_planes, samples, (uint32_t)W, d_chains, d_sub, d_stream, len,
+                                                                 d_tables, nplanes, sign_bit, pitch);
+            } else {
+                decode_chains_kernel<<<(n + 63u) / 64u, 64>>>(d_planes, samples, (uint32_t)W, d_chains, d_sub, n, d_stream, len,
+                                                             d_tables, nplanes, sign_bit);
+            }
             HIP_TRY(hipGetLastError());
         }
 

@@ -255,16 +255,16 @@ ICER_HD void plane_begin(PlaneDecoder &p, int lsb, int sign_bit, uint32_t w, uin
 }
 
 // one sample (icer_context_modeller.c:495-598); sets p.status when the plane ends or fails
-ICER_HD void plane_step(PlaneDecoder &p, uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int subband, int sign_bit,
-                        const DecoderTables &t)
+// `img`: the segment's samples, at(r, c) / put(r, c, v) (global memory, or a ring of rows in LDS)
+template <class Img>
+ICER_HD void plane_step_img(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, int subband, int sign_bit, const DecoderTables &t)
 {
     const int lsb = p.lsb;
     const uint32_t mask = (1u << sign_bit) - 1u;
     const uint32_t r = p.r, c = p.c;
-    uint16_t *row = seg + (size_t)r * stride;
-    const uint16_t *up = r > 0 ? row - stride : nullptr, *dn = r + 1 < h ? row + stride : nullptr;
+    const bool up = r > 0, dn = r + 1 < h;
     const uint32_t left = p.left;
-    const uint32_t cur = row[c];
+    const uint32_t cur = img.at(r, c);
     const uint32_t m = cur & mask;
     int msb = 0;
     for (uint32_t v = m | 1u; v > 1u; v >>= 1) msb++;
@@ -277,14 +277,14 @@ ICER_HD void plane_step(PlaneDecoder &p, uint16_t *seg, uint32_t w, uint32_t h, 
         val = cur | (bit << lsb);
     } else {
         const bool has_r = c + 1 < w;
-        const uint32_t right = has_r ? row[c + 1] : 0u;
-        const uint32_t u0 = up ? up[c] : 0u, d0 = dn ? dn[c] : 0u;
+        const uint32_t right = has_r ? img.at(r, c + 1) : 0u;
+        const uint32_t u0 = up ? img.at(r - 1, c) : 0u, d0 = dn ? img.at(r + 1, c) : 0u;
         int ctx;
         if (cat == 2) ctx = 11;
         else {
             // neighbours already visited count at this plane, the others at the plane above (:509-521)
-            const uint32_t ul = (up && c > 0) ? up[c - 1] : 0u, ur = (up && has_r) ? up[c + 1] : 0u;
-            const uint32_t dl = (dn && c > 0) ? dn[c - 1] : 0u, dr = (dn && has_r) ? dn[c + 1] : 0u;
+            const uint32_t ul = (up && c > 0) ? img.at(r - 1, c - 1) : 0u, ur = (up && has_r) ? img.at(r - 1, c + 1) : 0u;
+            const uint32_t dl = (dn && c > 0) ? img.at(r + 1, c - 1) : 0u, dr = (dn && has_r) ? img.at(r + 1, c + 1) : 0u;
             int hh = (c > 0 && ((left & mask) >> lsb)) + (((right & mask) >> (lsb + 1)) != 0);
             int vv = (((u0 & mask) >> lsb) != 0) + (((d0 & mask) >> (lsb + 1)) != 0);
             const int dd = (((ul & mask) >> lsb) != 0) + (((ur & mask) >> lsb) != 0) +
@@ -306,15 +306,28 @@ ICER_HD void plane_step(PlaneDecoder &p, uint16_t *seg, uint32_t w, uint32_t h, 
             if (subband == kHL) { const int x = sh; sh = sv; sv = x; }
             const int sctx = dec_sign_ctx(sh, sv);
             uint32_t agree;
-            if ((res = entropy_decode(p.d, t, &agree, p.zero[sctx], p.total[sctx])) != kOk) { row[c] = (uint16_t)val; p.status = res; return; }
+            if ((res = entropy_decode(p.d, t, &agree, p.zero[sctx], p.total[sctx])) != kOk) { img.put(r, c, val); p.status = res; return; }
             val |= ((agree ^ (uint32_t)dec_sign_pred(sh, sv)) & 1u) << sign_bit;
             dec_model_update(p.zero[sctx], p.total[sctx], agree == 0);
         }
     }
-    row[c] = (uint16_t)val;
+    img.put(r, c, val);
     p.done++;
     if (c + 1 < w) { p.c = c + 1; p.left = val; }
     else { p.c = 0; p.left = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
+}
+
+// the segment in place, in the channel plane
+struct GlobalImage {
+    uint16_t *seg; size_t stride;
+    ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return seg[(size_t)r * stride + c]; }
+    ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { seg[(size_t)r * stride + c] = (uint16_t)v; }
+};
+ICER_HD void plane_step(PlaneDecoder &p, uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int subband, int sign_bit,
+                        const DecoderTables &t)
+{
+    GlobalImage img{seg, stride};
+    plane_step_img(p, img, w, h, subband, sign_bit, t);
 }
 
 ICER_HD uint32_t packet_bits(const uint8_t *stream, uint32_t at)

@@ -1,0 +1,151 @@
+// decoder_wave.hpp -- one wavefront per chain, one LANE per packet: the bit planes of a segment decoded side by side
+// (decoder_core.hpp, plane_ready) over a ring of rows in LDS.  Written with the SPMD macros of wave.hpp, so the same
+// source runs in the CPU lane-loop build (tests/emu/decoder_emu.cpp) where its ring / retire / roll-back logic is
+// checked against the decoder oracle.
+//
+// STATUS: second decode kernel, checked on the CPU build only; cross-compiled for gfx950, not yet run on a GPU
+// (DESIGN.md 6b).  decoder.hip uses it when ICER_DEC_WAVE=1 and the segment rows fit the LDS ring.
+//
+// Lane j < planes decodes plane planes-1-j.  All lanes are in one wavefront, so there are no waits: every iteration a
+// lane either decodes its next sample or sits out (its upper neighbour is not far enough ahead, or the ring has no room).
+// The samples live in a ring of kRingRows rows: the most advanced plane reads row r + 1, the least advanced row r - 1,
+// and consecutive planes are about one row apart, so the live rows (planes + 2 of them) fit the ring; a row that no
+// running plane can still touch is written back to the channel plane by the whole wave and its slot is zeroed for the row
+// kRingRows further down.
+#pragma once
+#include "wave.hpp"
+
+#include "decoder_core.hpp"
+
+// global-memory fence of the (rare) roll-back pass, which reads back samples other lanes of this wave have stored
+#ifdef ICER_WAVE_EMU
+#define ICER_DEC_GLOBAL_FENCE()
+#else
+#define ICER_DEC_GLOBAL_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent")
+#endif
+
+namespace icer {
+
+constexpr uint32_t kRingRows = 16;          // >= kPlanes + 3; power of two
+
+struct RingImage {
+    uint16_t *ring; uint32_t pitch;
+    ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return ring[(r & (kRingRows - 1u)) * pitch + c]; }
+    ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { ring[(r & (kRingRows - 1u)) * pitch + c] = (uint16_t)v; }
+};
+
+// `ring`: kRingRows * pitch words of LDS (pitch >= c.w); `plane`: the channel plane (zero where not yet decoded).
+// stats (tests): [0] iterations, [1] samples decoded, [2] roll-backs, [3] chains that ended with rows not retired.
+ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane, size_t stride, const ChainDesc &c,
+                                int subband, const uint8_t *stream, uint32_t stream_len, const DecoderTables &t,
+                                int planes, int sign_bit, unsigned long long *stats)
+{
+    DECL_LANE;
+    const uint32_t w = c.w, h = c.h;
+    uint16_t *seg = plane + c.first;
+    // planes that can run: from the top down to the first missing packet (icer_partition.c:431)
+    int nrun = 0;
+    while (nrun < planes && c.pkt[planes - 1 - nrun] != kNoPacket) nrun++;
+    LANEVAR(PlaneDecoder, pd);
+    FOR_LANES
+    {
+        for (uint32_t i = (uint32_t)lane; i < kRingRows * pitch; i += 64) ring[i] = 0;
+        LV(pd).status = 2; LV(pd).done = 0; LV(pd).r = 0; LV(pd).c = 0; LV(pd).lsb = 0;
+        if (lane < nrun) {
+            const int lsb = planes - 1 - lane;
+            const uint32_t at = c.pkt[lsb];
+            entropy_init(LV(pd).d, stream, stream_len, at + (uint32_t)kHeaderBytes, packet_bits(stream, at));
+            plane_begin(LV(pd), lsb, sign_bit, w, h);
+        }
+    }
+    uint32_t retired = 0;                                    // rows written back so far (wave-uniform)
+    for (;;) {
+        WAVE_SYNC();
+        // where every plane stands at the start of the iteration
+        LANEVAR(uint32_t, st); LANEVAR(uint32_t, dn); LANEVAR(uint32_t, row);
+        FOR_LANES
+        {
+            LV(st) = (uint32_t)LV(pd).status; LV(dn) = LV(pd).done; LV(row) = LV(pd).r;
+        }
+        uint32_t st_u[kPlanes], dn_u[kPlanes], row_u[kPlanes];
+        for (int j = 0; j < nrun; j++) { st_u[j] = READLANE(st, j); dn_u[j] = READLANE(dn, j); row_u[j] = READLANE(row, j); }
+        // a plane under a failed or cancelled one never runs (again): cancel it, top-down
+        for (int j = 1; j < nrun; j++) {
+            const int above = (int)st_u[j - 1];
+            if (st_u[j] == 1u && (above < 0 || above == 2)) st_u[j] = 2u;
+        }
+        LANEVAR(uint32_t, go);
+        FOR_LANES
+        {
+            bool g = false;
+            if (lane < nrun) {
+                uint32_t mine = 0;
+                int above_status = kOk;
+                uint32_t above_done = 0;
+                for (int j = 0; j < nrun; j++)              // (uniform arrays are not indexed by the lane number)
+                    if (lane == j) {
+                        mine = st_u[j];
+                        if (j > 0) { above_status = (int)st_u[j - 1]; above_done = dn_u[j - 1]; }
+                    }
+                if (LV(pd).status == 1 && mine == 2u) LV(pd).status = 2;
+                g = lane == 0 ? LV(pd).status == 1 : plane_ready(LV(pd), above_status, above_done, w, h);
+                g = g && LV(pd).r + 1u < retired + kRingRows;            // row r + 1 has its slot
+            }
+            LV(go) = g ? 1u : 0u;
+        }
+        const uint64_t G = BALLOT(LV(go) != 0u);
+        // rows below `limit` are dead: a running plane in row r still reads row r - 1
+        uint32_t limit = h;
+        for (int j = 0; j < nrun; j++)
+            if (st_u[j] == 1u) { const uint32_t l = row_u[j] > 0u ? row_u[j] - 1u : 0u; if (l < limit) limit = l; }
+        const bool retire = retired < limit;
+        if (G == 0ull && !retire) break;
+        FOR_LANES
+        {
+            if (LV(go)) {
+                RingImage img{ring, pitch};
+                plane_step_img(LV(pd), img, w, h, subband, sign_bit, t);
+            }
+        }
+        WAVE_SYNC();
+        if (retire) {
+            uint16_t *slot = ring + (retired & (kRingRows - 1u)) * pitch;
+            FOR_LANES
+            {
+                for (uint32_t x = (uint32_t)lane; x < w; x += 64) { seg[(size_t)retired * stride + x] = slot[x]; slot[x] = 0; }
+            }
+            retired++;
+        }
+        if (stats) { stats[0]++; stats[1] += (unsigned long long)popc64(G); }
+    }
+    if (stats && retired != h) stats[3]++;
+    // a failed plane: the planes below it are taken back (chain_rollback), on the written-back samples
+    LANEVAR(uint32_t, st2); LANEVAR(uint32_t, dn2);
+    FOR_LANES
+    {
+        LV(st2) = (uint32_t)LV(pd).status; LV(dn2) = LV(pd).done;
+    }
+    int failed = -1;
+    bool below = false;
+    for (int j = 0; j < nrun; j++) {
+        const int sj = (int)READLANE(st2, j);
+        if (failed < 0) { if (sj < 0) failed = j; }
+        else below = below || READLANE(dn2, j) > 0u;
+    }
+    if (failed >= 0 && below) {
+        const int failed_lsb = planes - 1 - failed;
+        const uint32_t keep = ((1u << sign_bit) - 1u) & ~((1u << failed_lsb) - 1u);
+        ICER_DEC_GLOBAL_FENCE();
+        FOR_LANES
+        {
+            for (uint32_t i = (uint32_t)lane; i < w * h; i += 64) {
+                uint16_t *p = seg + (size_t)(i / w) * stride + (i % w);
+                const uint32_t v = *p, m = v & keep;
+                *p = (uint16_t)(m ? (m | (v & (1u << sign_bit))) : 0u);
+            }
+        }
+        if (stats) stats[2]++;
+    }
+}
+
+}  // namespace icer

@@ -1,6 +1,7 @@
 // decoder_emu.cpp -- TEST ONLY.  The decoder's device functions (decoder_core.hpp) and host planner (decoder_plan.hpp)
 // compiled by g++ and driven the way decoder.hip drives them on the GPU: one "thread" per candidate, per chain, per
 // line.  Lets tests/test_emu_decoder.py check the device code against the decoder oracle without a GPU.
+#include "../../icer_compression_amd/csrc/decoder_wave.hpp"      // (lane-loop build of the SPMD macros: -DICER_WAVE_EMU)
 #include "../../icer_compression_amd/csrc/decoder_core.hpp"
 #include "../../icer_compression_amd/csrc/decoder_plan.hpp"
 #include <stdlib.h>
@@ -10,7 +11,7 @@
 using namespace icer;
 
 static int g_lockstep = 0;
-static unsigned long long g_stats[3];
+static unsigned long long g_stats[4];
 
 // The planes of a chain side by side, in lock step (what a group of lanes -- one per packet -- would do): every
 // iteration each plane whose upper neighbour is far enough ahead (plane_ready) decodes one sample.  Checks the
@@ -56,9 +57,10 @@ static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDes
         }
 }
 
-// mode 1: decode chains with the lock-step schedule; stats: iterations, samples decoded, roll-backs
-extern "C" void emu_decoder_mode(int lockstep) { g_lockstep = lockstep; g_stats[0] = g_stats[1] = g_stats[2] = 0; }
-extern "C" void emu_decoder_stats(unsigned long long *out) { out[0] = g_stats[0]; out[1] = g_stats[1]; out[2] = g_stats[2]; }
+// mode 1 / 2: decode chains with the lock-step schedule (planes top-down / bottom-up inside an iteration); mode 3: the
+// wave kernel of decoder_wave.hpp (LDS row ring).  stats: iterations, samples decoded, roll-backs, chains with rows left
+extern "C" void emu_decoder_mode(int lockstep) { g_lockstep = lockstep; g_stats[0] = g_stats[1] = g_stats[2] = g_stats[3] = 0; }
+extern "C" void emu_decoder_stats(unsigned long long *out) { for (int i = 0; i < 4; i++) out[i] = g_stats[i]; }
 
 // planes[c]: >= bufsize uint16 words; for sample_bits = 8 the low byte of each word is the uint8 result.
 extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,
@@ -85,8 +87,12 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     build_decoder_tables(&dt, ct);
     const int nplanes = sample_bits == 8 ? kPlanes8 : kPlanes, sign_bit = sample_bits == 8 ? 7 : 15;
     // chain kernel: one thread per chain
+    uint32_t pitch = 2;
+    for (const ChainDesc &c : pl.chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
+    std::vector<uint16_t> ring((size_t)kRingRows * pitch);
     for (size_t i = 0; i < pl.chains.size(); i++) {
-        if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        if (g_lockstep == 3) decode_chain_wave(ring.data(), pitch, planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
         else decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit);
     }
     if (!pl.transform) return pl.rc;

@@ -22,9 +22,10 @@ u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 @pytest.fixture(scope="module")
 def emu():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("decoder_core.hpp", "decoder_plan.hpp", "plan.hpp", "icer_tables.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp", "wave.hpp", "plan.hpp",
+                                                    "icer_tables.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-DICER_WAVE_EMU", "-o", LIB, SRC])
     lib = C.CDLL(LIB)
     sz = C.c_size_t
     lib.emu_decompress.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(sz), C.POINTER(sz), sz, u8p, sz, C.c_int, C.c_int,
@@ -103,13 +104,14 @@ def test_device_decoder_headline_frame(emu, orc):
     assert (rc, rc2, w, h) == (0, 0, 1024, 1024) and np.array_equal(planes[0].reshape(1024, 1024), img)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_planes_side_by_side_schedule(emu, orc, mode):
     """every packet as a job of its own: a plane may decode sample (r, c) once the plane above has finished
     (r + 1, c + 1); a failing plane takes back what the planes below it wrote.  Same images as the serial order --
     including quota-cut streams, one-code-word packets (refused by the reference decoder) and data above the coded planes,
     where the decoder derails and planes fail at arbitrary points."""
-    emu.lib.emu_decoder_mode(mode)        # 1: planes top-down inside a lock-step iteration, 2: bottom-up
+    # 1: planes top-down inside a lock-step iteration, 2: bottom-up, 3: the wave kernel (decoder_wave.hpp, LDS row ring)
+    emu.lib.emu_decoder_mode(mode)
     try:
         rng = np.random.default_rng(77 + mode)
         done = 0
@@ -121,7 +123,7 @@ def test_planes_side_by_side_schedule(emu, orc, mode):
             assert same(emu(stream, ch, st, filt, sg, bits=bits), orc.decompress(stream, ch, st, filt, sg, bits=bits)), \
                 (planes[0].shape, st, filt, sg, ch, bits, quota)
             done += 1
-        stats = (C.c_ulonglong * 3)()
+        stats = (C.c_ulonglong * 4)()
         emu.lib.emu_decoder_stats(stats)
         assert done > 120
         assert stats[1] / stats[0] > 3.0          # samples per lock-step iteration: the planes really overlap
@@ -150,5 +152,6 @@ def test_planes_side_by_side_schedule(emu, orc, mode):
             hit += not np.array_equal(a[3][0].reshape(160, 192), img)
         emu.lib.emu_decoder_stats(stats)
         assert hit > 0 and stats[2] > 0           # roll-backs happened
+        assert stats[3] == 0                      # (wave kernel) every chain wrote all its rows back
     finally:
         emu.lib.emu_decoder_mode(0)

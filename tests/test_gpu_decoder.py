@@ -38,8 +38,20 @@ def same(a, b):
     return a[0] == b[0] and a[1:3] == b[1:3] and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
 
 
+@pytest.fixture(params=["0", "1"], ids=["thread-per-chain", "wave-per-chain"])
+def kernel(request):
+    """ICER_DEC_WAVE: which decode kernel decoder.hip launches (read per call)"""
+    old = os.environ.get("ICER_DEC_WAVE")
+    os.environ["ICER_DEC_WAVE"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("ICER_DEC_WAVE", None)
+    else:
+        os.environ["ICER_DEC_WAVE"] = old
+
+
 @pytest.mark.timeout(600)
-def test_random_streams(dec, orc):
+def test_random_streams(dec, orc, kernel):
     rng = np.random.default_rng(99)
     done = 0
     for _ in range(120):
@@ -59,7 +71,7 @@ def test_random_streams(dec, orc):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("name", ["kat_512_m1", "kat_512_quota30000", "kat_odd_517x389_filtC", "kat_color_512_quota",
                                   "u8_512_gray", "u8_517x389_filtB_quota", "u8_512_yuv_4st", "C2_4096_gray_5st_10seg"])
-def test_golden_decodes(dec, orc, name):
+def test_golden_decodes(dec, orc, name, kernel):
     """digests of the reference DECODER's output (tests/golden/make_golden.py)"""
     g = GOLDEN[name]
     kind, w, h = g["kind"], g["w"], g["h"]
@@ -82,7 +94,7 @@ def test_golden_decodes(dec, orc, name):
 
 
 @pytest.mark.timeout(300)
-def test_error_paths(dec, orc):
+def test_error_paths(dec, orc, kernel):
     img = synth.gray_frame(160, 120, 3, 1)
     rc, stream, _ = orc.compress([img], 3, 1, 5, 2 * 160 * 120)
     assert dec.decompress(stream, 1, 3, 1, 5, bufsize=160 * 120 - 1)[0] == -5
