@@ -266,6 +266,12 @@ ICER_DEV bool quota_already_spent(const UnitArgs &a)
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     return sum > a.early_quota;
 }
+#elif defined(ICER_WAVE_THREADS)
+// tests only (threaded build): the stop is a flag that another thread raises at an arbitrary moment
+ICER_DEV bool quota_already_spent(const UnitArgs &a)
+{
+    return a.early_quota && __atomic_load_n(a.done_bytes, __ATOMIC_RELAXED) != 0u;
+}
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -809,7 +815,7 @@ ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, u
     DECL_LANE;
     ICER_TIMERS_DECL
     for (uint32_t j = j0; j < j1; j++) {
-#ifndef ICER_WAVE_EMU
+#if !defined(ICER_WAVE_EMU) || defined(ICER_WAVE_THREADS)
         // progressive mode: has the byte quota been used up by units of higher priority in the meantime?  (Checked by
         // this wave because it has the slack and no other global memory traffic: in the pixel wave the check's loads
         // made the compiler wait for the window prefetch at once.)

@@ -198,3 +198,42 @@ def test_waves_as_real_threads(oracle, tmp_path):
             r = subprocess.run([exe, str(tmp_path / "plane.raw"), str(w), str(h), str(sb), str(lsb), "3"], capture_output=True,
                                text=True, timeout=300)
             assert r.returncode == 0 and r.stdout.split("\n")[:3] == [f"{bits} {fnv(payload)}"] * 3, (trial, sb, lsb, r.stdout, r.stderr[:500])
+
+
+def test_waves_as_real_threads_wind_down(oracle, tmp_path):
+    """Abandoning a unit under true concurrency (same threaded build): the progressive-mode stop raised by another thread at
+    an arbitrary moment, and a payload slot that is too small.  Every wave must leave -- no dead-lock (-10), no hang (the
+    subprocess time-out) -- and a unit that does finish must still be bit-exact."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "threads_main")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-unknown-pragmas", "-o", exe,
+                           os.path.join(root, "tests", "emu", "threads_main.cpp")])
+
+    def fnv(data):
+        hsh = 1469598103934665603
+        for x in data:
+            hsh = ((hsh ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % hsh
+
+    rng = np.random.default_rng(31)
+    seen = set()
+    for trial in range(3):
+        w, h = int(rng.integers(200, 400)), int(rng.integers(150, 300))
+        v = rng.normal(0, float(rng.choice([6, 20])), (h, w)).astype(np.int32)
+        plane = np.ascontiguousarray(np.minimum(np.abs(v), 32767).astype(np.uint16) | ((v < 0).astype(np.uint16) << 15))
+        plane.tofile(tmp_path / "plane.raw")
+        bits, payload = oracle.code_unit(plane, 0, 0, w, h, 0, 0)
+        good = f"{bits} {fnv(payload)}"
+        # the stop arrives somewhere inside (or just after) the unit's run time
+        for stop_us, cap_div in ((3000000, 1), (20000, 1), (0, 40), (20000, 40)):
+            r = subprocess.run([exe, str(tmp_path / "plane.raw"), str(w), str(h), "0", "0", "8", str(stop_us), str(cap_div)],
+                               capture_output=True, text=True, timeout=600)
+            lines = [x for x in r.stdout.split("\n") if x]
+            assert r.returncode == 0 and len(lines) == 8, (r.stdout, r.stderr[:500])
+            for x in lines:
+                assert x in (good, "-3 0", "-5 0"), (trial, stop_us, cap_div, x)
+                assert not (x == "-3 0" and stop_us == 0) and not (x == "-5 0" and cap_div == 1), (trial, stop_us, cap_div, x)
+                seen.add(x if x != good else "ok")
+    assert seen == {"ok", "-3 0", "-5 0"}, seen
