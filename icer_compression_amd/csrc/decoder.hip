@@ -5,7 +5,13 @@
 //   | clamp, narrow, copy back.
 // First version: correctness before speed; every loop is bounded by the stream / image size and no
 // kernel waits on another thread.
+#ifndef ICER_HOST_MOCK
 #include <hip/hip_runtime.h>
+// kernel launches go through these two macros so that tests/emu/hip_mock.h (CPU, tests only) can stand in for them
+#define ICER_LAUNCH(kernel, grid, block, shmem, ...) kernel<<<(grid), (block), (shmem)>>>(__VA_ARGS__)
+#define ICER_LAUNCH_WAVE(kernel, grid, shmem, ...) kernel<<<(grid), 64, (shmem)>>>(__VA_ARGS__)
+#define ICER_DYNAMIC_LDS(T, name) extern __shared__ T name[]
+#endif
 
 #include <algorithm>
 #include <stdarg.h>
@@ -84,7 +90,7 @@ decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t plane_samples, u
                           const uint8_t *__restrict__ stream, uint32_t len, const DecoderTables *__restrict__ tables,
                           int nplanes, int sign_bit, uint32_t pitch)
 {
-    extern __shared__ uint16_t ring[];
+    ICER_DYNAMIC_LDS(uint16_t, ring);
     const ChainDesc c = chains[blockIdx.x];
     decode_chain_wave(ring, pitch, planes + (size_t)c.chan * plane_samples, image_w, c, subbands[blockIdx.x], stream, len,
                       *tables, nplanes, sign_bit, nullptr);
@@ -175,14 +181,14 @@ int decompress_planes(void *const planes[], int channels, size_t *image_w, size_
             if (d_cands) { HIP_TRY(hipFree(d_cands)); d_cands = nullptr; }
             HIP_TRY(hipMalloc(&d_cands, sizeof(PacketCandidate) * cap));
             HIP_TRY(hipMemset(d_count, 0, sizeof(uint32_t)));
-            count_headers_kernel<<<(len + 255u) / 256u, 256>>>(d_stream, len, d_crc, d_cands, cap, d_count);
+            ICER_LAUNCH(count_headers_kernel, (len + 255u) / 256u, 256, 0, d_stream, len, d_crc, d_cands, cap, d_count);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpy(&count, d_count, sizeof count, hipMemcpyDeviceToHost));
             if (count <= cap) break;
             cap = count;                                    // (more header look-alikes than expected: once more, all of them)
         }
         if (count) {
-            check_payloads_kernel<<<(count + 63u) / 64u, 64>>>(d_stream, d_crc, d_cands, count);
+            ICER_LAUNCH(check_payloads_kernel, (count + 63u) / 64u, 64, 0, d_stream, d_crc, d_cands, count);
             HIP_TRY(hipGetLastError());
             cands.resize(count);
             HIP_TRY(hipMemcpy(cands.data(), d_cands, sizeof(PacketCandidate) * count, hipMemcpyDeviceToHost));
@@ -223,11 +229,11 @@ int decompress_planes(void *const planes[], int channels, size_t *image_w, size_
             const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t);
             const char *mode = getenv("ICER_DEC_WAVE");
             if (mode && mode[0] == '1' && ring_bytes <= 65536u) {
-                decode_chains_wave_kernel<<<n, 64, ring_bytes>>>(d_planes, samples, (uint32_t)W, d_chains, d_sub, d_stream, len,
-                                                                 d_tables, nplanes, sign_bit, pitch);
+                ICER_LAUNCH_WAVE(decode_chains_wave_kernel, n, ring_bytes, d_planes, samples, (uint32_t)W, d_chains, d_sub, d_stream, len,
+                                 d_tables, nplanes, sign_bit, pitch);
             } else {
-                decode_chains_kernel<<<(n + 63u) / 64u, 64>>>(d_planes, samples, (uint32_t)W, d_chains, d_sub, n, d_stream, len,
-                                                             d_tables, nplanes, sign_bit);
+                ICER_LAUNCH(decode_chains_kernel, (n + 63u) / 64u, 64, 0, d_planes, samples, (uint32_t)W, d_chains, d_sub, n, d_stream, len,
+                            d_tables, nplanes, sign_bit);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -235,8 +241,8 @@ int decompress_planes(void *const planes[], int channels, size_t *image_w, size_
         // 4. samples
         if (pl.transform) {
             const dim3 grid_all((unsigned)((samples + 255u) / 256u), (unsigned)channels);
-            unsign_kernel<<<grid_all, 256>>>(d_planes, samples, (uint32_t)W, (uint32_t)dim_low(W, stages), (uint32_t)dim_low(H, stages),
-                                            pl.mean[0], pl.mean[1], pl.mean[2], sign_bit, bits);
+            ICER_LAUNCH(unsign_kernel, grid_all, 256, 0, d_planes, samples, (uint32_t)W, (uint32_t)dim_low(W, stages),
+                        (uint32_t)dim_low(H, stages), pl.mean[0], pl.mean[1], pl.mean[2], sign_bit, bits);
             HIP_TRY(hipGetLastError());
             if (!pl.levels.empty()) {
                 const FilterTaps taps = filter_taps(filt);
@@ -248,15 +254,15 @@ int decompress_planes(void *const planes[], int channels, size_t *image_w, size_
                     pos.resize(lv.ch);
                     interleave_positions(lv.ch, bits, pos.data());
                     HIP_TRY(hipMemcpy(d_pos, pos.data(), sizeof(uint32_t) * lv.ch, hipMemcpyHostToDevice));
-                    idwt_lines_kernel<<<dim3((lv.cw + 63u) / 64u, (unsigned)channels), 64>>>(
-                        (const int16_t *)d_planes, (int16_t *)d_tmp, samples, (uint32_t)W, lv.cw, lv.ch, taps, bits, d_pos, false);
+                    ICER_LAUNCH(idwt_lines_kernel, dim3((lv.cw + 63u) / 64u, (unsigned)channels), 64, 0,
+                                (const int16_t *)d_planes, (int16_t *)d_tmp, samples, (uint32_t)W, lv.cw, lv.ch, taps, bits, d_pos, false);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipDeviceSynchronize());            // (d_pos is reused for the rows)
                     pos.resize(lv.cw);
                     interleave_positions(lv.cw, bits, pos.data());
                     HIP_TRY(hipMemcpy(d_pos, pos.data(), sizeof(uint32_t) * lv.cw, hipMemcpyHostToDevice));
-                    idwt_lines_kernel<<<dim3((lv.ch + 63u) / 64u, (unsigned)channels), 64>>>(
-                        (const int16_t *)d_tmp, (int16_t *)d_planes, samples, (uint32_t)W, lv.cw, lv.ch, taps, bits, d_pos, true);
+                    ICER_LAUNCH(idwt_lines_kernel, dim3((lv.ch + 63u) / 64u, (unsigned)channels), 64, 0,
+                                (const int16_t *)d_tmp, (int16_t *)d_planes, samples, (uint32_t)W, lv.cw, lv.ch, taps, bits, d_pos, true);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipDeviceSynchronize());
                 }
@@ -266,10 +272,10 @@ int decompress_planes(void *const planes[], int channels, size_t *image_w, size_
         // 5. results
         if (bits == 8) HIP_TRY(hipMalloc(&d_out8, total));
         if (pl.transform) {
-            clamp_kernel<<<(unsigned)((total + 255u) / 256u), 256>>>(d_planes, total, d_out8);
+            ICER_LAUNCH(clamp_kernel, (unsigned)((total + 255u) / 256u), 256, 0, d_planes, total, d_out8);
             HIP_TRY(hipGetLastError());
         } else if (bits == 8) {
-            narrow_kernel<<<(unsigned)((total + 255u) / 256u), 256>>>(d_planes, total, d_out8);
+            ICER_LAUNCH(narrow_kernel, (unsigned)((total + 255u) / 256u), 256, 0, d_planes, total, d_out8);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipDeviceSynchronize());

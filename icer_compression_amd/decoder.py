@@ -27,40 +27,46 @@ _sz = C.c_size_t
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
-def load_library() -> C.CDLL:
-    """dlopen libicer_hip_dec.so (RTLD_LOCAL: it exports the same icer_* names as the reference)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -m icer_compression_amd.build` (there is no CPU fallback)")
-    lib = C.CDLL(LIB_PATH, mode=os.RTLD_LOCAL)
+def bind(path: str) -> C.CDLL:
+    """dlopen a build of the decoder library (RTLD_LOCAL: it exports the same icer_* names as the reference) and declare
+    its entry points.  (tests/test_emu_decoder.py binds a CPU mock build of decoder.hip's host pipeline this way.)"""
+    lib = C.CDLL(path, mode=os.RTLD_LOCAL)
     lib.icer_get_image_dimensions.argtypes = [_u8p, _sz, C.POINTER(_sz), C.POINTER(_sz)]
     tail = [C.POINTER(_sz), C.POINTER(_sz), _sz, _u8p, _sz, C.c_uint8, C.c_int, C.c_uint8]
     for name, n in (("icer_decompress_image_uint16", 1), ("icer_decompress_image_yuv_uint16", 3),
                     ("icer_decompress_image_uint8", 1), ("icer_decompress_image_yuv_uint8", 3)):
         getattr(lib, name).argtypes = [C.c_void_p] * n + tail
     lib.icerx_decoder_last_error.restype = C.c_char_p
-    _lib = lib
     return lib
 
 
-def icer_get_image_dimensions(stream: bytes):
+def load_library() -> C.CDLL:
+    """libicer_hip_dec.so of this package"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -m icer_compression_amd.build` (there is no CPU fallback)")
+        _lib = bind(LIB_PATH)
+    return _lib
+
+
+def icer_get_image_dimensions(stream: bytes, lib=None):
     """-> (rc, w, h)"""
-    lib = load_library()
+    lib = lib or load_library()
     buf = np.frombuffer(stream, dtype=np.uint8).copy() if len(stream) else np.zeros(1, np.uint8)
     w, h = _sz(0), _sz(0)
     rc = lib.icer_get_image_dimensions(buf, len(stream), C.byref(w), C.byref(h))
     return rc, w.value, h.value
 
 
-def decompress(stream: bytes, channels: int, stages: int, filt: int, segments: int, bufsize: int | None = None, bits: int = 16):
+def decompress(stream: bytes, channels: int, stages: int, filt: int, segments: int, bufsize: int | None = None, bits: int = 16,
+               lib=None):
     """icer_decompress_image_[yuv_]uint16 / _uint8 on a host stream -> (rc, w, h, [flat planes of bufsize samples])."""
-    lib = load_library()
+    lib = lib or load_library()
     if channels not in (1, 3):
         raise ValueError("channels must be 1 or 3")
     if bufsize is None:
-        rc, w, h = icer_get_image_dimensions(stream)
+        rc, w, h = icer_get_image_dimensions(stream, lib)
         bufsize = w * h if rc == 0 else 0
     buf = np.frombuffer(stream, dtype=np.uint8).copy() if len(stream) else np.zeros(1, np.uint8)
     planes = [np.zeros(max(bufsize, 1), np.uint16 if bits == 16 else np.uint8) for _ in range(channels)]

@@ -155,3 +155,53 @@ def test_planes_side_by_side_schedule(emu, orc, mode):
         assert stats[3] == 0                      # (wave kernel) every chain wrote all its rows back
     finally:
         emu.lib.emu_decoder_mode(0)
+
+
+def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
+    """decoder.hip itself -- its C ABI, allocations, copies, launch geometries and clean-up -- compiled by g++ against
+    tests/emu/hip_mock.h (device memory = poisoned host memory, a launch = a loop over the grid) and called through
+    icer_compression_amd/decoder.py like the GPU library will be: both decode kernels, error paths, odd streams.
+    (The same build under -fsanitize=address,undefined is how the host code was checked for wrong sizes.)"""
+    from icer_compression_amd import decoder, synth
+    root = os.path.dirname(HERE)
+    lib_path = str(tmp_path / "libdecoder_mock.so")
+    subprocess.check_call(["g++", "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas",
+                           "-DICER_HOST_MOCK", "-DICER_WAVE_EMU", "-include", os.path.join(HERE, "emu", "hip_mock.h"),
+                           "-o", lib_path, os.path.join(root, "icer_compression_amd", "csrc", "decoder.hip")])
+    lib = decoder.bind(lib_path)
+    old = os.environ.get("ICER_DEC_WAVE")
+    try:
+        rng = np.random.default_rng(2024)
+        done = 0
+        for _ in range(45):
+            planes, st, filt, sg, ch, bits, quota = random_case(rng)
+            rc, stream, _ = (orc.compress if bits == 16 else orc.compress_u8)(planes, st, filt, sg, quota)
+            if not stream:
+                continue
+            dsg = sg if rng.random() < 0.9 else int(rng.integers(1, 33))
+            h, w = planes[0].shape
+            want = orc.decompress(stream, ch, st, filt, dsg, bufsize=w * h, bits=bits)
+            for mode in ("0", "1"):
+                os.environ["ICER_DEC_WAVE"] = mode
+                assert same(decoder.decompress(stream, ch, st, filt, dsg, bufsize=w * h, bits=bits, lib=lib), want), \
+                    (mode, planes[0].shape, st, filt, sg, dsg, ch, bits, quota)
+            done += 1
+        assert done > 30
+        img = synth.gray_frame(160, 120, 3, 1)
+        rc, stream, _ = orc.compress([img], 3, 1, 5, 2 * 160 * 120)
+        for s in (b"", b"\x5b\x60" * 40, stream[: len(stream) // 2], stream[5:], b"\x00" * 9 + stream + b"\x5b\x60\x00",
+                  b"".join(reversed(packets(stream)))):
+            for mode in ("0", "1"):
+                os.environ["ICER_DEC_WAVE"] = mode
+                assert same(decoder.decompress(s, 1, 3, 1, 5, bufsize=160 * 120, lib=lib),
+                            orc.decompress(s, 1, 3, 1, 5, bufsize=160 * 120)), len(s)
+        assert decoder.decompress(stream, 1, 3, 1, 5, bufsize=160 * 120 - 1, lib=lib)[0] == -5
+        assert decoder.decompress(stream, 1, 3, 1, 5, lib=lib)[1:3] == (160, 120)
+        os.environ["ICER_MOCK_NO_DEVICE"] = "1"
+        assert decoder.decompress(stream, 1, 3, 1, 5, lib=lib)[0] == -10
+    finally:
+        os.environ.pop("ICER_MOCK_NO_DEVICE", None)
+        if old is None:
+            os.environ.pop("ICER_DEC_WAVE", None)
+        else:
+            os.environ["ICER_DEC_WAVE"] = old
