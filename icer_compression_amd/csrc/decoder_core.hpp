@@ -74,6 +74,9 @@ struct EntropyDecoder {
     uint32_t total_bits;        // data_length of the packet
     uint32_t pos;               // bit cursor relative to base
     uint32_t words;             // code words read so far
+    uint64_t win;               // (packets of >= 8 bits) the next win_bits bits of the payload, from `pos` on
+    uint32_t win_bits;
+    uint32_t win_next;          // next payload byte to load into the window
     int16_t n[kNumBins];        // bits pending per bin, served from the top
     uint8_t bits[kNumBins];     // bins 0..7: the pending pattern (bit k = k-th from the bottom); bins 8..16: bottom bit
     uint32_t index[kNumBins];   // `words` when the bin's last code word was read
@@ -82,6 +85,7 @@ struct EntropyDecoder {
 ICER_HD void entropy_init(EntropyDecoder &d, const uint8_t *stream, uint32_t stream_len, uint32_t base, uint32_t total_bits)
 {
     d.stream = stream; d.stream_len = stream_len; d.base = base; d.total_bits = total_bits; d.pos = 0; d.words = 0;
+    d.win = 0; d.win_bits = 0; d.win_next = 0;
     for (int b = 0; b < kNumBins; b++) { d.n[b] = 0; d.bits[b] = 0; d.index[b] = 0; }
 }
 ICER_HD uint32_t entropy_byte(const EntropyDecoder &d, uint32_t i)
@@ -89,26 +93,49 @@ ICER_HD uint32_t entropy_byte(const EntropyDecoder &d, uint32_t i)
     const uint32_t at = d.base + i;
     return at < d.stream_len ? d.stream[at] : 0u;
 }
-// the k-th bit (1-based) ahead of the cursor (icer_get_bit_from_codeword :46-57)
-ICER_HD uint32_t entropy_peek(const EntropyDecoder &d, uint32_t k)
+// The bit readers below keep the reference's semantics (icer_get_bit_from_codeword :46-57, icer_get_bits_from_codeword
+// :59-82, icer_pop_bits_from_codeword :84-105) but serve the bits from a 64-bit window that is refilled four bytes at a
+// time.  QUIRK kept: the reference never advances its count of decoded bits, so its out-of-data test compares each
+// byte-bounded piece of a read (at most 8 bits) with the packet's whole length -- it can only fire in packets shorter
+// than 8 bits, and those take the literal path.
+ICER_HD void entropy_fill(EntropyDecoder &d)               // afterwards the window holds at least 32 bits
 {
-    const uint32_t p = d.pos + (k - 1u);
-    return (entropy_byte(d, p >> 3) >> (p & 7u)) & 1u;
+    while (d.win_bits < 32u) {
+        uint32_t v = 0;
+        for (uint32_t i = 0; i < 4u; i++) v |= entropy_byte(d, d.win_next + i) << (8u * i);
+        d.win_next += 4u;
+        d.win |= (uint64_t)v << d.win_bits;
+        d.win_bits += 32u;
+    }
 }
-// `nb` bits LSB first, in pieces that end at byte boundaries (icer_get_bits_from_codeword :59-82 /
-// icer_pop_bits_from_codeword :84-105).  QUIRK: the reference never advances its count of decoded bits, so the
-// out-of-data test compares each piece with the packet's whole length.
+// the k-th bit (1-based, k <= 11) ahead of the cursor
+ICER_HD uint32_t entropy_peek(EntropyDecoder &d, uint32_t k)
+{
+    if (d.total_bits < 8u) {
+        const uint32_t p = d.pos + (k - 1u);
+        return (entropy_byte(d, p >> 3) >> (p & 7u)) & 1u;
+    }
+    entropy_fill(d);
+    return (uint32_t)(d.win >> (k - 1u)) & 1u;
+}
+// `nb` (<= 11) bits LSB first
 ICER_HD int entropy_read(EntropyDecoder &d, uint32_t nb, bool consume)
 {
-    int num = 0;
-    uint32_t got = 0, p = d.pos;
-    while (nb) {
-        const uint32_t room = 8u - (p & 7u), take = room < nb ? room : nb;
-        if (take > d.total_bits) return kDecoderOutOfData;
-        num |= (int)(((entropy_byte(d, p >> 3) >> (p & 7u)) & ((1u << take) - 1u)) << got);
-        nb -= take; got += take; p += take;
-        if (consume) d.pos = p;
+    if (d.total_bits < 8u) {                                // literal: byte-bounded pieces, each tested against the length
+        int num = 0;
+        uint32_t got = 0, p = d.pos;
+        while (nb) {
+            const uint32_t room = 8u - (p & 7u), take = room < nb ? room : nb;
+            if (take > d.total_bits) return kDecoderOutOfData;
+            num |= (int)(((entropy_byte(d, p >> 3) >> (p & 7u)) & ((1u << take) - 1u)) << got);
+            nb -= take; got += take; p += take;
+            if (consume) d.pos = p;
+        }
+        return num;
     }
+    entropy_fill(d);
+    const int num = (int)((uint32_t)d.win & ((1u << nb) - 1u));
+    if (consume) { d.win >>= nb; d.win_bits -= nb; d.pos += nb; }
     return num;
 }
 ICER_HD uint32_t reverse_low_bits(uint32_t v, uint32_t n)            // icer_reverse_bits, icer.h:601-610 (16-bit)
@@ -117,12 +144,17 @@ ICER_HD uint32_t reverse_low_bits(uint32_t v, uint32_t n)            // icer_rev
     for (uint32_t k = 0; k < n; k++) { r = (r << 1) | (v & 1u); v >>= 1; }
     return r & 0xFFFFu;
 }
-ICER_HD int pick_bin_plain(const DecoderTables &t, uint32_t zero, uint32_t total)     // icer_compute_bin, icer_util.c:48-56
+// icer_compute_bin, icer_util.c:48-56: the highest bin whose cut-off the probability of a zero reaches (the cut-offs
+// ascend, so a binary search finds it)
+ICER_HD int pick_bin_plain(const DecoderTables &t, uint32_t zero, uint32_t total)
 {
     const uint32_t lhs = zero * 65536u;
-    for (int b = 16; b >= 1; b--)
-        if (lhs >= total * t.cut[b - 1]) return b;
-    return 0;
+    int b = 0;
+    for (int step = 16; step >= 1; step >>= 1) {
+        const int nb = b + step;
+        if (nb <= 16 && lhs >= total * t.cut[nb - 1]) b = nb;
+    }
+    return b;
 }
 
 // icer_decode_bit, icer_decoding.c:108-194
