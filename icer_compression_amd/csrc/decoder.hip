@@ -1,7 +1,9 @@
-// decoder.hip -- C ABI of libicer_hip_dec.so (include/icer_hip_dec.h) and the host-side pipeline of the decoder:
-//   stream -> device | header candidates (one thread per byte offset) | payload CRCs (one thread per candidate)
-//   | host: packet walk, table, chains (decoder_plan.hpp) | decode kernel (one thread per chain = segment, planes
-//   top-down) | sign-magnitude removal + LL mean | inverse DWT, one level at a time (one thread per line)
+// decoder.hip -- C ABI of libicer_hip_dec.so (include/icer_hip_dec.h) and the host-side pipeline of the decoder, for
+// a BATCH of streams (the lib_icer-shaped entry points are batches of one):
+//   streams -> device | header candidates (one thread per byte offset, grid.y = stream) | payload CRCs (one thread per
+//   candidate) | host: per stream the packet walk, table and chains (decoder_plan.hpp) | decode kernel over the
+//   chains of all streams (one thread per chain, or one wavefront per chain with ICER_DEC_WAVE=1) | sign-magnitude
+//   removal + LL mean | inverse DWT, one level at a time, one thread per line, all frames of a geometry per launch
 //   | clamp, narrow, copy back.
 // First version: correctness before speed; every loop is bounded by the stream / image size and no
 // kernel waits on another thread.
@@ -51,73 +53,89 @@ int fail(const char *fmt, ...)
     } while (0)
 
 // ------------------------------------------------------------------------------------------ kernels
+// what the kernels need to know about one stream / image of the batch
+struct FrameInfo {
+    uint32_t stream_off, stream_len;     // its bytes in the batch buffer
+    uint32_t w, h, ll_w, ll_h;           // image and deepest-LL size
+    uint16_t mean[4];
+    uint32_t transform;                  // the run reaches sign-magnitude removal / mean / inverse DWT / clamping
+};
+
 __global__ void __launch_bounds__(256)
-count_headers_kernel(const uint8_t *__restrict__ stream, uint32_t len, const uint32_t *__restrict__ crc_tab,
-                     PacketCandidate *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count)
+count_headers_kernel(const uint8_t *__restrict__ data, const FrameInfo *__restrict__ frames,
+                     const uint32_t *__restrict__ crc_tab, PacketCandidate *__restrict__ out, uint32_t cap,
+                     uint32_t *__restrict__ count)
 {
+    const FrameInfo f = frames[blockIdx.y];
     const uint32_t off = blockIdx.x * blockDim.x + threadIdx.x;
-    if (off >= len) return;
+    if (off >= f.stream_len) return;
     PacketCandidate c;
-    if (!header_candidate(crc_tab, stream, len, off, &c)) return;
+    if (!header_candidate(crc_tab, data + f.stream_off, f.stream_len, off, &c)) return;
+    c.frame = blockIdx.y;
     const uint32_t at = atomicAdd(count, 1u);
     if (at < cap) out[at] = c;
 }
 
 __global__ void __launch_bounds__(64)
-check_payloads_kernel(const uint8_t *__restrict__ stream, const uint32_t *__restrict__ crc_tab,
-                      PacketCandidate *__restrict__ cands, uint32_t n)
+check_payloads_kernel(const uint8_t *__restrict__ data, const FrameInfo *__restrict__ frames,
+                      const uint32_t *__restrict__ crc_tab, PacketCandidate *__restrict__ cands, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) check_payload(crc_tab, stream, &cands[i]);
+    if (i < n) check_payload(crc_tab, data + frames[cands[i].frame].stream_off, &cands[i]);
 }
 
+// plane of channel `chan` of frame `frame`: planes + (frame * channels + chan) * frame_stride, rows of the frame's width
 __global__ void __launch_bounds__(64)
-decode_chains_kernel(uint16_t *__restrict__ planes, size_t plane_samples, uint32_t image_w,
-                     const ChainDesc *__restrict__ chains, const uint8_t *__restrict__ subbands, uint32_t n,
-                     const uint8_t *__restrict__ stream, uint32_t len, const DecoderTables *__restrict__ tables,
-                     int nplanes, int sign_bit)
+decode_chains_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels,
+                     const ChainDesc *__restrict__ chains, uint32_t n, const uint8_t *__restrict__ data,
+                     const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes, int sign_bit)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ChainDesc c = chains[i];
-    decode_chain(planes + (size_t)c.chan * plane_samples, image_w, c, subbands[i], stream, len, *tables, nplanes, sign_bit);
+    const FrameInfo f = frames[c.frame];
+    decode_chain(planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband, data + f.stream_off,
+                 f.stream_len, *tables, nplanes, sign_bit);
 }
 
 // the same with one wavefront per chain and one lane per packet (decoder_wave.hpp); dynamic LDS = the row ring
 __global__ void __launch_bounds__(64)
-decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t plane_samples, uint32_t image_w,
-                          const ChainDesc *__restrict__ chains, const uint8_t *__restrict__ subbands,
-                          const uint8_t *__restrict__ stream, uint32_t len, const DecoderTables *__restrict__ tables,
-                          int nplanes, int sign_bit, uint32_t pitch)
+decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels,
+                          const ChainDesc *__restrict__ chains, const uint8_t *__restrict__ data,
+                          const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes,
+                          int sign_bit, uint32_t pitch)
 {
     ICER_DYNAMIC_LDS(uint16_t, ring);
     const ChainDesc c = chains[blockIdx.x];
-    decode_chain_wave(ring, pitch, planes + (size_t)c.chan * plane_samples, image_w, c, subbands[blockIdx.x], stream, len,
-                      *tables, nplanes, sign_bit, nullptr);
+    const FrameInfo f = frames[c.frame];
+    decode_chain_wave(ring, pitch, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
+                      data + f.stream_off, f.stream_len, *tables, nplanes, sign_bit, nullptr);
 }
 
-// sign-magnitude words -> int16, LL mean back in (grid.y = channel)
+// sign-magnitude words -> int16, LL mean back in (grid.y = frame * channels + channel)
 __global__ void __launch_bounds__(256)
-unsign_kernel(uint16_t *__restrict__ planes, size_t plane_samples, uint32_t image_w, uint32_t ll_w, uint32_t ll_h,
-              uint16_t mean0, uint16_t mean1, uint16_t mean2, int sign_bit, int bits)
+unsign_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels, const FrameInfo *__restrict__ frames,
+              int sign_bit, int bits)
 {
+    const FrameInfo f = frames[blockIdx.y / (unsigned)channels];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= plane_samples) return;
-    const uint32_t ch = blockIdx.y;
-    uint16_t *p = planes + (size_t)ch * plane_samples;
+    if (!f.transform || i >= (size_t)f.w * f.h) return;
+    uint16_t *p = planes + (size_t)blockIdx.y * frame_stride;
     int16_t s = from_sign_magnitude(p[i], sign_bit);
-    const uint32_t x = (uint32_t)(i % image_w), y = (uint32_t)(i / image_w);
-    if (x < ll_w && y < ll_h) s = add_ll_mean(s, ch == 0 ? mean0 : ch == 1 ? mean1 : mean2, bits);
+    const uint32_t x = (uint32_t)(i % f.w), y = (uint32_t)(i / f.w);
+    if (x < f.ll_w && y < f.ll_h) s = add_ll_mean(s, f.mean[blockIdx.y % (unsigned)channels], bits);
     p[i] = (uint16_t)s;
 }
 
-// one thread per column (rows = false) or per row (rows = true) of a level's region; grid.y = channel
+// one thread per column (rows = false) or per row (rows = true) of a level's region; grid.y walks the channels of the
+// frames in `list` (all of the same size)
 __global__ void __launch_bounds__(64)
-idwt_lines_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t plane_samples, uint32_t image_w,
-                  uint32_t cw, uint32_t ch_rows, FilterTaps taps, int bits, const uint32_t *__restrict__ pos_of, bool rows)
+idwt_lines_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t frame_stride, int channels,
+                  const uint32_t *__restrict__ list, uint32_t image_w, uint32_t cw, uint32_t ch_rows, FilterTaps taps,
+                  int bits, const uint32_t *__restrict__ pos_of, bool rows)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t base = (size_t)blockIdx.y * plane_samples;
+    const size_t base = ((size_t)list[blockIdx.y / (unsigned)channels] * channels + blockIdx.y % (unsigned)channels) * frame_stride;
     if (rows) {
         if (i < ch_rows) idwt_line(src + base + (size_t)i * image_w, dst + base + (size_t)i * image_w, cw, 1, taps, bits, pos_of);
     } else {
@@ -125,170 +143,244 @@ idwt_lines_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst, si
     }
 }
 
-// icer_remove_negative_* (icer_util.c:70-91); `out8` != null: also narrow to bytes
+// icer_remove_negative_* (icer_util.c:70-91) for the frames that were transformed; `out8` != null: narrow to bytes
+// (every frame: a frame that stopped early keeps its sign-magnitude words, narrowed like the reference's uint8 planes)
 __global__ void __launch_bounds__(256)
-clamp_kernel(uint16_t *__restrict__ planes, size_t total, uint8_t *__restrict__ out8)
+finish_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels, const FrameInfo *__restrict__ frames,
+              uint8_t *__restrict__ out8)
 {
+    const FrameInfo f = frames[blockIdx.y / (unsigned)channels];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int16_t s = (int16_t)planes[i];
-    if (s < 0) s = 0;
-    planes[i] = (uint16_t)s;
-    if (out8) out8[i] = (uint8_t)s;
+    if (i >= (size_t)f.w * f.h) return;
+    const size_t at = (size_t)blockIdx.y * frame_stride + i;
+    int16_t s = (int16_t)planes[at];
+    if (f.transform && s < 0) s = 0;
+    planes[at] = (uint16_t)s;
+    if (out8) out8[at] = (uint8_t)s;
 }
 
-__global__ void __launch_bounds__(256)
-narrow_kernel(const uint16_t *__restrict__ planes, size_t total, uint8_t *__restrict__ out8)
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ decoder object
+struct icerx_decoder {
+    int device = 0, channels = 1, stages = 1, filt = 0, bits = 16;
+    unsigned segments = 1;
+    DecoderTables tables;
+    uint32_t crc_tab[256];
+    // device buffers, grown on demand and kept
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list;
+};
+
+namespace {
+
+hipError_t ensure(icerx_decoder::Buf &b, size_t bytes)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) out8[i] = (uint8_t)planes[i];
+    if (bytes <= b.cap) return hipSuccess;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    const hipError_t e = hipMalloc(&b.p, bytes);
+    if (e == hipSuccess) b.cap = bytes;
+    return e;
 }
 
-// ------------------------------------------------------------------------------------------ host pipeline
-int decompress_planes(void *const planes[], int channels, size_t *image_w, size_t *image_h, size_t bufsize,
-                      const uint8_t *data, size_t data_length, int stages, int filt, unsigned segments, int bits)
+// n streams: stream k = bytes [offsets[k], offsets[k] + lens[k]) of `data` (host memory, or device memory when
+// data_on_device).  Results: rcs[k], ws[k] / hs[k] (in: the values kept when stream k holds no valid packet).  Frame k's
+// channel c goes to host_out[k * channels + c] (host pointers, >= frame_stride samples each) or, when host_out is null, to
+// dev_out + (k * channels + c) * frame_stride samples (device memory; uint16 or uint8 samples by sample_bits).
+int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_device, const size_t *offsets, const size_t *lens,
+                 void *const *host_out, void *dev_out, size_t frame_stride, int *rcs, size_t *ws, size_t *hs)
 {
     g_error.clear();
-    if (!image_w || !image_h || (!data && data_length) || (filt < 0 || filt > 6)) return ICER_INVALID_INPUT;
-    for (int c = 0; c < channels; c++)
-        if (!planes[c]) return ICER_INVALID_INPUT;
-    if (data_length >= 0xFFFFFFFFull - 64u) return fail("stream of %zu bytes: 32-bit offsets only", data_length);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no usable HIP device");
-
+    if (!d || n < 0 || (n && (!offsets || !lens || !rcs || !ws || !hs)) || (!host_out && !dev_out && n)) return ICER_INVALID_INPUT;
+    if (n == 0) return ICER_RESULT_OK;
     int rc = ICER_RESULT_OK;
-    const uint32_t len = (uint32_t)data_length;
-    uint8_t *d_stream = nullptr, *d_sub = nullptr, *d_out8 = nullptr;
-    uint32_t *d_crc = nullptr, *d_count = nullptr, *d_pos = nullptr;
-    PacketCandidate *d_cands = nullptr;
-    ChainDesc *d_chains = nullptr;
-    DecoderTables *d_tables = nullptr;
-    uint16_t *d_planes = nullptr, *d_tmp = nullptr;
+    const int channels = d->channels, bits = d->bits, stages = d->stages;
+    const int nplanes = bits == 8 ? kPlanes8 : kPlanes, sign_bit = bits == 8 ? 7 : 15;
+    size_t total_len = 0, max_len = 0;
+    for (int k = 0; k < n; k++) {
+        if (lens[k] && !data) return ICER_INVALID_INPUT;
+        total_len = std::max(total_len, offsets[k] + lens[k]);
+        max_len = std::max(max_len, lens[k]);
+    }
+    if (total_len >= 0xFFFFFFFFull - 64u) return fail("batch of %zu stream bytes: 32-bit offsets only", total_len);
+    const size_t planes_total = (size_t)n * channels * frame_stride;
+    if (frame_stride > 0xFFFFFFFFull) return fail("frames of %zu samples: 32-bit indices only", frame_stride);
+
+    std::vector<FrameInfo> frames((size_t)n);
     std::vector<PacketCandidate> cands;
-    DecodePlan pl;
-    uint32_t crc_tab[256];
-    build_crc32_table(crc_tab);
+    std::vector<DecodePlan> plans((size_t)n);
+    std::vector<ChainDesc> chains;
+    const uint8_t *d_data = nullptr;
+    uint16_t *d_planes = nullptr;
+    uint8_t *d_out8 = nullptr;
+    FrameInfo *d_frames = nullptr;
+
+    for (int k = 0; k < n; k++) {
+        memset(&frames[k], 0, sizeof(FrameInfo));
+        frames[k].stream_off = (uint32_t)offsets[k];
+        frames[k].stream_len = (uint32_t)lens[k];
+    }
+    HIP_TRY(ensure(d->frames, sizeof(FrameInfo) * n));
+    d_frames = (FrameInfo *)d->frames.p;
+    HIP_TRY(hipMemcpy(d_frames, frames.data(), sizeof(FrameInfo) * n, hipMemcpyHostToDevice));
 
     // 1. packets
-    if (len) {
-        HIP_TRY(hipMalloc(&d_stream, len));
-        HIP_TRY(hipMemcpy(d_stream, data, len, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&d_crc, sizeof crc_tab));
-        HIP_TRY(hipMemcpy(d_crc, crc_tab, sizeof crc_tab, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&d_count, sizeof(uint32_t)));
-        uint32_t cap = len / 64u + 1024u, count = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            if (d_cands) { HIP_TRY(hipFree(d_cands)); d_cands = nullptr; }
-            HIP_TRY(hipMalloc(&d_cands, sizeof(PacketCandidate) * cap));
-            HIP_TRY(hipMemset(d_count, 0, sizeof(uint32_t)));
-            ICER_LAUNCH(count_headers_kernel, (len + 255u) / 256u, 256, 0, d_stream, len, d_crc, d_cands, cap, d_count);
+    if (total_len) {
+        if (data_on_device) d_data = data;
+        else {
+            HIP_TRY(ensure(d->data, total_len));
+            HIP_TRY(hipMemcpy(d->data.p, data, total_len, hipMemcpyHostToDevice));
+            d_data = (const uint8_t *)d->data.p;
+        }
+        HIP_TRY(ensure(d->count, sizeof(uint32_t)));
+        uint32_t cap = (uint32_t)(total_len / 64u) + 1024u, count = 0;
+        for (int attempt = 0; attempt < 2 && max_len; attempt++) {
+            HIP_TRY(ensure(d->cands, sizeof(PacketCandidate) * cap));
+            HIP_TRY(hipMemset(d->count.p, 0, sizeof(uint32_t)));
+            ICER_LAUNCH(count_headers_kernel, dim3((unsigned)((max_len + 255u) / 256u), (unsigned)n), 256, 0, d_data, d_frames,
+                        (const uint32_t *)d->crc.p, (PacketCandidate *)d->cands.p, cap, (uint32_t *)d->count.p);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpy(&count, d_count, sizeof count, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&count, d->count.p, sizeof count, hipMemcpyDeviceToHost));
             if (count <= cap) break;
             cap = count;                                    // (more header look-alikes than expected: once more, all of them)
         }
         if (count) {
-            ICER_LAUNCH(check_payloads_kernel, (count + 63u) / 64u, 64, 0, d_stream, d_crc, d_cands, count);
+            ICER_LAUNCH(check_payloads_kernel, (count + 63u) / 64u, 64, 0, d_data, d_frames, (const uint32_t *)d->crc.p,
+                        (PacketCandidate *)d->cands.p, count);
             HIP_TRY(hipGetLastError());
             cands.resize(count);
-            HIP_TRY(hipMemcpy(cands.data(), d_cands, sizeof(PacketCandidate) * count, hipMemcpyDeviceToHost));
-            std::sort(cands.begin(), cands.end(), [](const PacketCandidate &a, const PacketCandidate &b) { return a.off < b.off; });
+            HIP_TRY(hipMemcpy(cands.data(), d->cands.p, sizeof(PacketCandidate) * count, hipMemcpyDeviceToHost));
+            std::sort(cands.begin(), cands.end(), [](const PacketCandidate &a, const PacketCandidate &b) {
+                return a.frame != b.frame ? a.frame < b.frame : a.off < b.off;
+            });
         }
     }
 
-    // 2. plan
-    plan_decode(&pl, data, cands, channels, stages, segments, bits, *image_w, *image_h, bufsize);
-    *image_w = pl.w;
-    *image_h = pl.h;
-    rc = pl.rc;
-    if (rc == kInvalidInput || rc == kTooManyStages || rc == kByteQuotaExceeded) goto done;
+    // 2. plans
     {
-        const size_t W = pl.w, H = pl.h, samples = W * H, total = samples * (size_t)channels;
-        const int nplanes = bits == 8 ? kPlanes8 : kPlanes, sign_bit = bits == 8 ? 7 : 15;
-        if (total == 0) goto done;
-        if (W > 0xFFFFFFFFull || samples > 0xFFFFFFFFull) { rc = fail("image of %zu x %zu samples: 32-bit indices only", W, H); goto done; }
-        HIP_TRY(hipMalloc(&d_planes, sizeof(uint16_t) * total));
-        HIP_TRY(hipMemset(d_planes, 0, sizeof(uint16_t) * total));
-
-        // 3. bit planes
-        if (!pl.chains.empty()) {
-            CoderTables ct;
-            DecoderTables dt;
-            build_coder_tables(&ct);
-            build_decoder_tables(&dt, ct);
-            const uint32_t n = (uint32_t)pl.chains.size();
-            HIP_TRY(hipMalloc(&d_tables, sizeof dt));
-            HIP_TRY(hipMemcpy(d_tables, &dt, sizeof dt, hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc(&d_chains, sizeof(ChainDesc) * n));
-            HIP_TRY(hipMemcpy(d_chains, pl.chains.data(), sizeof(ChainDesc) * n, hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc(&d_sub, n));
-            HIP_TRY(hipMemcpy(d_sub, pl.chain_subband.data(), n, hipMemcpyHostToDevice));
-            // ICER_DEC_WAVE=1: the planes of a segment side by side (one wavefront per chain), if its rows fit the LDS ring
-            uint32_t pitch = 2;
-            for (const ChainDesc &c : pl.chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
-            const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t);
-            const char *mode = getenv("ICER_DEC_WAVE");
-            if (mode && mode[0] == '1' && ring_bytes <= 65536u) {
-                ICER_LAUNCH_WAVE(decode_chains_wave_kernel, n, ring_bytes, d_planes, samples, (uint32_t)W, d_chains, d_sub, d_stream, len,
-                                 d_tables, nplanes, sign_bit, pitch);
-            } else {
-                ICER_LAUNCH(decode_chains_kernel, (n + 63u) / 64u, 64, 0, d_planes, samples, (uint32_t)W, d_chains, d_sub, n, d_stream, len,
-                            d_tables, nplanes, sign_bit);
-            }
-            HIP_TRY(hipGetLastError());
+        size_t at = 0;
+        std::vector<PacketCandidate> mine;
+        for (int k = 0; k < n; k++) {
+            mine.clear();
+            while (at < cands.size() && cands[at].frame == (uint32_t)k) mine.push_back(cands[at++]);
+            DecodePlan &pl = plans[k];
+            plan_decode(&pl, mine, channels, stages, d->segments, bits, ws[k], hs[k], frame_stride);
+            ws[k] = pl.w; hs[k] = pl.h; rcs[k] = pl.rc;
+            const bool runs = !(pl.rc == kInvalidInput || pl.rc == kTooManyStages || pl.rc == kByteQuotaExceeded) && pl.w * pl.h > 0;
+            frames[k].w = runs ? (uint32_t)pl.w : 0u;
+            frames[k].h = runs ? (uint32_t)pl.h : 0u;
+            frames[k].ll_w = (uint32_t)dim_low(pl.w, stages); frames[k].ll_h = (uint32_t)dim_low(pl.h, stages);
+            for (int c = 0; c < 3; c++) frames[k].mean[c] = pl.mean[c];
+            frames[k].transform = (runs && pl.transform) ? 1u : 0u;
+            if (!runs) continue;
+            for (ChainDesc c : pl.chains) { c.frame = (uint32_t)k; chains.push_back(c); }
         }
+    }
+    HIP_TRY(hipMemcpy(d_frames, frames.data(), sizeof(FrameInfo) * n, hipMemcpyHostToDevice));
 
-        // 4. samples
-        if (pl.transform) {
-            const dim3 grid_all((unsigned)((samples + 255u) / 256u), (unsigned)channels);
-            ICER_LAUNCH(unsign_kernel, grid_all, 256, 0, d_planes, samples, (uint32_t)W, (uint32_t)dim_low(W, stages),
-                        (uint32_t)dim_low(H, stages), pl.mean[0], pl.mean[1], pl.mean[2], sign_bit, bits);
-            HIP_TRY(hipGetLastError());
-            if (!pl.levels.empty()) {
-                const FilterTaps taps = filter_taps(filt);
-                HIP_TRY(hipMalloc(&d_tmp, sizeof(uint16_t) * total));
-                HIP_TRY(hipMalloc(&d_pos, sizeof(uint32_t) * (W > H ? W : H)));
-                std::vector<uint32_t> pos;
-                for (const DecodeLevel &lv : pl.levels) {
-                    // columns: d_planes -> d_tmp, rows: d_tmp -> d_planes (only the level's region is touched)
-                    pos.resize(lv.ch);
-                    interleave_positions(lv.ch, bits, pos.data());
-                    HIP_TRY(hipMemcpy(d_pos, pos.data(), sizeof(uint32_t) * lv.ch, hipMemcpyHostToDevice));
-                    ICER_LAUNCH(idwt_lines_kernel, dim3((lv.cw + 63u) / 64u, (unsigned)channels), 64, 0,
-                                (const int16_t *)d_planes, (int16_t *)d_tmp, samples, (uint32_t)W, lv.cw, lv.ch, taps, bits, d_pos, false);
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipDeviceSynchronize());            // (d_pos is reused for the rows)
-                    pos.resize(lv.cw);
-                    interleave_positions(lv.cw, bits, pos.data());
-                    HIP_TRY(hipMemcpy(d_pos, pos.data(), sizeof(uint32_t) * lv.cw, hipMemcpyHostToDevice));
-                    ICER_LAUNCH(idwt_lines_kernel, dim3((lv.ch + 63u) / 64u, (unsigned)channels), 64, 0,
-                                (const int16_t *)d_tmp, (int16_t *)d_planes, samples, (uint32_t)W, lv.cw, lv.ch, taps, bits, d_pos, true);
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipDeviceSynchronize());
-                }
+    // 3. bit planes: into the caller's device buffer when that holds uint16 samples, else into a work buffer
+    if (planes_total == 0) goto done;
+    if (dev_out && !host_out && bits == 16) d_planes = (uint16_t *)dev_out;
+    else { HIP_TRY(ensure(d->work, sizeof(uint16_t) * planes_total)); d_planes = (uint16_t *)d->work.p; }
+    // (only the w * h samples of a frame are defined results; the rest of its slot is scratch)
+    HIP_TRY(hipMemset(d_planes, 0, sizeof(uint16_t) * planes_total));
+    if (!chains.empty()) {
+        const uint32_t nc = (uint32_t)chains.size();
+        HIP_TRY(ensure(d->chains, sizeof(ChainDesc) * nc));
+        HIP_TRY(hipMemcpy(d->chains.p, chains.data(), sizeof(ChainDesc) * nc, hipMemcpyHostToDevice));
+        // ICER_DEC_WAVE=1: the planes of a segment side by side (one wavefront per chain), if its rows fit the LDS ring
+        uint32_t pitch = 2;
+        for (const ChainDesc &c : chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
+        const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t);
+        const char *mode = getenv("ICER_DEC_WAVE");
+        if (mode && mode[0] == '1' && ring_bytes <= 65536u) {
+            ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nc, ring_bytes, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
+                             d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit, pitch);
+        } else {
+            ICER_LAUNCH(decode_chains_kernel, (nc + 63u) / 64u, 64, 0, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
+                        nc, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+
+    // 4. samples
+    {
+        const dim3 grid_all((unsigned)((frame_stride + 255u) / 256u), (unsigned)(n * channels));
+        ICER_LAUNCH(unsign_kernel, grid_all, 256, 0, d_planes, frame_stride, channels, d_frames, sign_bit, bits);
+        HIP_TRY(hipGetLastError());
+        // inverse DWT: the frames of one size together
+        std::vector<char> done((size_t)n, 0);
+        const FilterTaps taps = filter_taps(d->filt);
+        for (int k = 0; k < n; k++) {
+            if (done[k] || !frames[k].transform || plans[k].levels.empty()) continue;
+            std::vector<uint32_t> list, pos, tab;
+            for (int j = k; j < n; j++)
+                if (!done[j] && frames[j].transform && frames[j].w == frames[k].w && frames[j].h == frames[k].h) { list.push_back((uint32_t)j); done[j] = 1; }
+            const uint32_t W = frames[k].w;
+            std::vector<size_t> col_at, row_at;              // where each level's position tables start
+            for (const DecodeLevel &lv : plans[k].levels) {
+                col_at.push_back(tab.size());
+                pos.resize(lv.ch); interleave_positions(lv.ch, bits, pos.data()); tab.insert(tab.end(), pos.begin(), pos.end());
+                row_at.push_back(tab.size());
+                pos.resize(lv.cw); interleave_positions(lv.cw, bits, pos.data()); tab.insert(tab.end(), pos.begin(), pos.end());
             }
+            HIP_TRY(ensure(d->tmp, sizeof(uint16_t) * planes_total));
+            HIP_TRY(ensure(d->pos, sizeof(uint32_t) * tab.size()));
+            HIP_TRY(hipMemcpy(d->pos.p, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
+            HIP_TRY(ensure(d->list, sizeof(uint32_t) * list.size()));
+            HIP_TRY(hipMemcpy(d->list.p, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice));
+            const unsigned gy = (unsigned)(list.size() * (size_t)channels);
+            for (size_t li = 0; li < plans[k].levels.size(); li++) {
+                const DecodeLevel &lv = plans[k].levels[li];
+                // columns: planes -> tmp, rows: tmp -> planes (only the level's region is touched)
+                ICER_LAUNCH(idwt_lines_kernel, dim3((lv.cw + 63u) / 64u, gy), 64, 0, (const int16_t *)d_planes, (int16_t *)d->tmp.p,
+                            frame_stride, channels, (const uint32_t *)d->list.p, W, lv.cw, lv.ch, taps, bits,
+                            (const uint32_t *)d->pos.p + col_at[li], false);
+                HIP_TRY(hipGetLastError());
+                ICER_LAUNCH(idwt_lines_kernel, dim3((lv.ch + 63u) / 64u, gy), 64, 0, (const int16_t *)d->tmp.p, (int16_t *)d_planes,
+                            frame_stride, channels, (const uint32_t *)d->list.p, W, lv.cw, lv.ch, taps, bits,
+                            (const uint32_t *)d->pos.p + row_at[li], true);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipDeviceSynchronize());                 // (the position tables and the list are reused by the next size)
         }
 
         // 5. results
-        if (bits == 8) HIP_TRY(hipMalloc(&d_out8, total));
-        if (pl.transform) {
-            ICER_LAUNCH(clamp_kernel, (unsigned)((total + 255u) / 256u), 256, 0, d_planes, total, d_out8);
-            HIP_TRY(hipGetLastError());
-        } else if (bits == 8) {
-            ICER_LAUNCH(narrow_kernel, (unsigned)((total + 255u) / 256u), 256, 0, d_planes, total, d_out8);
-            HIP_TRY(hipGetLastError());
+        if (bits == 8) {
+            if (dev_out && !host_out) d_out8 = (uint8_t *)dev_out;
+            else { HIP_TRY(ensure(d->out8, planes_total)); d_out8 = (uint8_t *)d->out8.p; }
         }
+        ICER_LAUNCH(finish_kernel, grid_all, 256, 0, d_planes, frame_stride, channels, d_frames, d_out8);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
-        for (int c = 0; c < channels; c++) {
-            if (bits == 8) HIP_TRY(hipMemcpy(planes[c], d_out8 + (size_t)c * samples, samples, hipMemcpyDeviceToHost));
-            else HIP_TRY(hipMemcpy(planes[c], d_planes + (size_t)c * samples, sizeof(uint16_t) * samples, hipMemcpyDeviceToHost));
-        }
+        if (host_out)
+            for (int k = 0; k < n; k++) {
+                const size_t samples = (size_t)frames[k].w * frames[k].h;
+                for (int c = 0; c < channels && samples; c++) {
+                    const size_t at = ((size_t)k * channels + c) * frame_stride;
+                    if (bits == 8) HIP_TRY(hipMemcpy(host_out[k * channels + c], d_out8 + at, samples, hipMemcpyDeviceToHost));
+                    else HIP_TRY(hipMemcpy(host_out[k * channels + c], d_planes + at, sizeof(uint16_t) * samples, hipMemcpyDeviceToHost));
+                }
+            }
     }
 done:
-    for (void *p : {(void *)d_stream, (void *)d_crc, (void *)d_count, (void *)d_cands, (void *)d_chains, (void *)d_sub,
-                    (void *)d_tables, (void *)d_planes, (void *)d_tmp, (void *)d_pos, (void *)d_out8})
-        if (p) (void)hipFree(p);
     return rc;
+}
+
+int decompress_planes(void *const planes[], int channels, size_t *image_w, size_t *image_h, size_t bufsize,
+                      const uint8_t *data, size_t data_length, int stages, int filt, unsigned segments, int bits)
+{
+    if (!image_w || !image_h || (!data && data_length)) return ICER_INVALID_INPUT;
+    for (int c = 0; c < channels; c++)
+        if (!planes[c]) return ICER_INVALID_INPUT;
+    icerx_decoder *d = nullptr;
+    int rc = icerx_decoder_create(&d, -1, channels, stages, filt, segments, bits);
+    if (rc != ICER_RESULT_OK) return rc;
+    const size_t off = 0;
+    int frame_rc = ICER_RESULT_OK;
+    rc = decode_batch(d, 1, data, false, &off, &data_length, planes, nullptr, bufsize, &frame_rc, image_w, image_h);
+    icerx_decoder_destroy(d);
+    return rc != ICER_RESULT_OK ? rc : frame_rc;
 }
 
 }  // namespace
@@ -296,6 +388,62 @@ done:
 extern "C" {
 
 const char *icerx_decoder_last_error(void) { return g_error.c_str(); }
+
+int icerx_decoder_create(icerx_decoder **out, int device, int channels, int stages, int filt, unsigned segments, int sample_bits)
+{
+    g_error.clear();
+    if (!out) return ICER_INVALID_INPUT;
+    *out = nullptr;
+    if ((channels != 1 && channels != 3) || filt < 0 || filt > 6 || (sample_bits != 8 && sample_bits != 16)) return ICER_INVALID_INPUT;
+    if (stages < 1 || stages > kMaxStages) return ICER_TOO_MANY_STAGES;        // (reference: out-of-bounds table)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no usable HIP device");
+#ifndef ICER_HOST_MOCK
+    if (device >= 0) {
+        if (device >= ndev) return fail("device %d of %d", device, ndev);
+        if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice(%d) failed", device);
+    }
+#endif
+    icerx_decoder *d = new icerx_decoder;
+    d->device = device; d->channels = channels; d->stages = stages; d->filt = filt; d->bits = sample_bits; d->segments = segments;
+    CoderTables ct;
+    build_coder_tables(&ct);
+    build_decoder_tables(&d->tables, ct);
+    build_crc32_table(d->crc_tab);
+    int rc = ICER_RESULT_OK;
+    HIP_TRY(ensure(d->crc, sizeof d->crc_tab));
+    HIP_TRY(hipMemcpy(d->crc.p, d->crc_tab, sizeof d->crc_tab, hipMemcpyHostToDevice));
+    HIP_TRY(ensure(d->dtables, sizeof d->tables));
+    HIP_TRY(hipMemcpy(d->dtables.p, &d->tables, sizeof d->tables, hipMemcpyHostToDevice));
+    *out = d;
+    return ICER_RESULT_OK;
+done:
+    icerx_decoder_destroy(d);
+    return rc;
+}
+
+void icerx_decoder_destroy(icerx_decoder *d)
+{
+    if (!d) return;
+    for (icerx_decoder::Buf *b : {&d->data, &d->frames, &d->crc, &d->dtables, &d->count, &d->cands, &d->chains, &d->work, &d->tmp,
+                                  &d->out8, &d->pos, &d->list})
+        if (b->p) (void)hipFree(b->p);
+    delete d;
+}
+
+int icerx_decode_host(icerx_decoder *dec, int n, const uint8_t *data, const size_t *offsets, const size_t *lens,
+                      void *const *planes_out, size_t frame_stride, int *rcs, size_t *ws, size_t *hs)
+{
+    if (!planes_out && n) return ICER_INVALID_INPUT;
+    return decode_batch(dec, n, data, false, offsets, lens, planes_out, nullptr, frame_stride, rcs, ws, hs);
+}
+
+int icerx_decode_device(icerx_decoder *dec, int n, const void *d_data, const size_t *offsets, const size_t *lens,
+                        void *d_out, size_t frame_stride, int *rcs, size_t *ws, size_t *hs)
+{
+    if (!d_out && n) return ICER_INVALID_INPUT;
+    return decode_batch(dec, n, (const uint8_t *)d_data, true, offsets, lens, nullptr, d_out, frame_stride, rcs, ws, hs);
+}
 
 int icer_get_image_dimensions(const uint8_t *datastream, size_t data_length, size_t *image_w, size_t *image_h)
 {

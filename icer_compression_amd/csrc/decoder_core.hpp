@@ -60,6 +60,8 @@ inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
 
 // one chain = one segment of one subband of one channel
 struct ChainDesc {
+    uint32_t frame;             // which stream / image of a batch
+    uint32_t subband;           // kLL .. kHH: selects the context tables
     uint32_t chan;              // channel plane the segment lives in
     uint32_t first;             // index of the segment's first sample in that plane
     uint16_t w, h;              // segment size

@@ -18,10 +18,12 @@ namespace icer {
 
 // a position in the stream where a packet header with the preamble and a matching header CRC starts
 struct PacketCandidate {
-    uint32_t off;           // byte offset of the header
+    uint32_t off;           // byte offset of the header in its stream
     uint32_t payload_bytes; // ceil(data_length / 8)
     uint32_t fits;          // the payload lies inside the stream
     uint32_t payload_ok;    // ... and its CRC-32 matches
+    uint32_t frame;         // which stream of a batch
+    uint8_t hdr[kHeaderBytes];  // copy of the header, so that the host planner never reads the (device-resident) stream
 };
 
 // reflected CRC-32 (zlib), byte at a time; `tab` = the usual 256-entry table
@@ -50,6 +52,8 @@ ICER_HD bool header_candidate(const uint32_t *tab, const uint8_t *s, uint32_t le
     if (load_le32(p + 24) != crc32_bytes(tab, p, 24)) return false;
     const uint32_t bits = load_le32(p + 16);
     out->off = off;
+    out->frame = 0;
+    for (int i = 0; i < kHeaderBytes; i++) out->hdr[i] = p[i];
     out->payload_bytes = bits / 8u + ((bits % 8u) ? 1u : 0u);
     out->fits = out->payload_bytes <= len - off - (uint32_t)kHeaderBytes;
     out->payload_ok = 0;
@@ -71,12 +75,11 @@ struct DecodePlan {
     size_t w = 0, h = 0;
     uint16_t mean[3] = {0, 0, 0};
     std::vector<ChainDesc> chains;
-    std::vector<uint8_t> chain_subband;
     std::vector<DecodeLevel> levels;            // empty when the deepest LL is thinner than 3 (ICER_TOO_MANY_STAGES, ignored)
 };
 
-// `cands` sorted by offset.  *w / *h: in = the caller's values (kept when the stream holds no valid packet).
-inline void plan_decode(DecodePlan *pl, const uint8_t *stream, const std::vector<PacketCandidate> &cands, int channels,
+// `cands`: the candidates of ONE stream, sorted by offset.  *w / *h: in = the caller's values (kept when the stream holds no valid packet).
+inline void plan_decode(DecodePlan *pl, const std::vector<PacketCandidate> &cands, int channels,
                         int stages, unsigned segments, int sample_bits, size_t w_in, size_t h_in, size_t bufsize)
 {
     const int planes = sample_bits == 8 ? kPlanes8 : kPlanes;
@@ -94,7 +97,7 @@ inline void plan_decode(DecodePlan *pl, const uint8_t *stream, const std::vector
     uint32_t cursor = 0;
     for (const PacketCandidate &c : cands) {
         if (c.off < cursor || !c.fits || !c.payload_ok) continue;
-        const uint8_t *p = stream + c.off;
+        const uint8_t *p = c.hdr;
         const int lv = p[4], sb = p[5], sg = p[6], lsb = p[7] & 15, ch = channels == 3 ? (p[7] >> 4) : 0;
         if (lv <= kMaxStages && sb < 4 && sg <= kMaxSegments && lsb < kPlanes && ch < 3) slot(ch, lv, sb, sg, lsb) = c.off;
         pl->w = load_le32(p + 8);
@@ -123,12 +126,13 @@ inline void plan_decode(DecodePlan *pl, const uint8_t *stream, const std::vector
                 for (size_t sg = 0; sg < rects.size() && sg <= (size_t)kMaxSegments; sg++) {
                     if (slot(ch, lv, sb, (int)sg, planes - 1) == kNoPacket) continue;
                     ChainDesc c;
+                    c.frame = 0;
+                    c.subband = (uint32_t)sb;
                     c.chan = (uint32_t)ch;
                     c.first = (uint32_t)((oy + rects[sg].y) * w + ox + rects[sg].x);
                     c.w = (uint16_t)rects[sg].w; c.h = (uint16_t)rects[sg].h;
                     for (int lsb = 0; lsb < kPlanes; lsb++) c.pkt[lsb] = lsb < planes ? slot(ch, lv, sb, (int)sg, lsb) : kNoPacket;
                     pl->chains.push_back(c);
-                    pl->chain_subband.push_back((uint8_t)sb);
                 }
             }
     if (pl->rc != kOk) return;

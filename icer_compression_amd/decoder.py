@@ -74,3 +74,58 @@ def decompress(stream: bytes, channels: int, stages: int, filt: int, segments: i
     w, h = _sz(0), _sz(0)
     rc = fn(*[p.ctypes.data for p in planes], C.byref(w), C.byref(h), bufsize, buf, len(stream), stages, filt, segments)
     return rc, w.value, h.value, planes
+
+
+class Decoder:
+    """Batch / device-resident extension (icerx_decoder_*, include/icer_hip_dec.h Part 2)."""
+
+    def __init__(self, channels: int, stages: int, filt: int, segments: int, bits: int = 16, device: int = -1, lib=None):
+        self.lib = lib or load_library()
+        self.channels, self.bits = channels, bits
+        self.lib.icerx_decoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int]
+        self.lib.icerx_decoder_destroy.argtypes = [C.c_void_p]
+        self.lib.icerx_decoder_destroy.restype = None
+        tail = [C.POINTER(_sz), C.POINTER(_sz), C.c_void_p, _sz, C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(_sz)]
+        self.lib.icerx_decode_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + tail
+        self.lib.icerx_decode_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + tail
+        self.handle = C.c_void_p()
+        rc = self.lib.icerx_decoder_create(C.byref(self.handle), device, channels, stages, filt, segments, bits)
+        if rc != 0:
+            raise RuntimeError(f"icerx_decoder_create: {rc} {self.lib.icerx_decoder_last_error().decode()}")
+
+    def close(self):
+        if self.handle:
+            self.lib.icerx_decoder_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _pack(self, streams):
+        lens = [len(s) for s in streams]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if streams else np.zeros(0, np.uint64)
+        blob = np.frombuffer(b"".join(streams), dtype=np.uint8).copy() if sum(lens) else np.zeros(1, np.uint8)
+        n = len(streams)
+        return blob, (_sz * n)(*[int(o) for o in offs]), (_sz * n)(*lens)
+
+    def decode_host(self, streams, frame_stride: int):
+        """-> (rc, [(rc_k, w_k, h_k, [flat planes])]) for a list of streams in host memory"""
+        n = len(streams)
+        blob, offs, lens = self._pack(streams)
+        dt = np.uint16 if self.bits == 16 else np.uint8
+        planes = [np.zeros(max(frame_stride, 1), dt) for _ in range(n * self.channels)]
+        ptrs = (C.c_void_p * max(len(planes), 1))(*[p.ctypes.data for p in planes])
+        rcs, ws, hs = (C.c_int * max(n, 1))(), (_sz * max(n, 1))(), (_sz * max(n, 1))()
+        rc = self.lib.icerx_decode_host(self.handle, n, blob.ctypes.data, offs, lens, ptrs, frame_stride, rcs, ws, hs)
+        return rc, [(rcs[k], ws[k], hs[k], planes[k * self.channels: (k + 1) * self.channels]) for k in range(n)]
+
+    def decode_device(self, n: int, d_data: int, offsets, lens, d_out: int, frame_stride: int):
+        """raw device pointers (e.g. torch tensors' data_ptr()); -> (rc, rcs, ws, hs)"""
+        offs = (_sz * max(n, 1))(*[int(o) for o in offsets])
+        ln = (_sz * max(n, 1))(*[int(x) for x in lens])
+        rcs, ws, hs = (C.c_int * max(n, 1))(), (_sz * max(n, 1))(), (_sz * max(n, 1))()
+        rc = self.lib.icerx_decode_device(self.handle, n, d_data, offs, ln, d_out, frame_stride, rcs, ws, hs)
+        return rc, list(rcs)[:n], list(ws)[:n], list(hs)[:n]

@@ -48,6 +48,28 @@ int icer_decompress_image_yuv_uint8(uint8_t *y_channel, uint8_t *u_channel, uint
                                     size_t *image_h, size_t image_bufsize, const uint8_t *datastream,
                                     size_t data_length, uint8_t stages, enum icer_filter_types filt, uint8_t segments);
 
+/* ---- Part 2: batches and device-resident buffers (our extension; what a decode benchmark times) -------------------
+ * One decoder per (channels, stages, filter, segments, sample width); its device buffers grow on demand and are kept.
+ * Every frame's image, size and return code equal those of a per-frame call of the Part-1 function. */
+typedef struct icerx_decoder icerx_decoder;
+
+/* device < 0: the current HIP device.  sample_bits: 16 or 8. */
+int icerx_decoder_create(icerx_decoder **out, int device, int channels, int stages, int filt, unsigned segments,
+                         int sample_bits);
+void icerx_decoder_destroy(icerx_decoder *dec);
+
+/* n streams in one host buffer: stream k = data[offsets[k] .. offsets[k] + lens[k]).  Frame k's channel c is written to
+ * planes_out[k * channels + c] (host memory, frame_stride samples each: uint16 or uint8 by sample_bits).  Per frame:
+ * rcs[k] = the Part-1 return code, ws[k] / hs[k] = the image size (in: the values kept when the stream holds no valid
+ * packet).  Returns ICER_RESULT_OK, or ICER_FATAL_ERROR / ICER_INVALID_INPUT for the call as a whole. */
+int icerx_decode_host(icerx_decoder *dec, int n, const uint8_t *data, const size_t *offsets, const size_t *lens,
+                      void *const *planes_out, size_t frame_stride, int *rcs, size_t *ws, size_t *hs);
+
+/* the same with the streams and the images in device memory: frame k's channel c at
+ * d_out + (k * channels + c) * frame_stride samples; only its first ws[k] * hs[k] samples are results.  Synchronous. */
+int icerx_decode_device(icerx_decoder *dec, int n, const void *d_data, const size_t *offsets, const size_t *lens,
+                        void *d_out, size_t frame_stride, int *rcs, size_t *ws, size_t *hs);
+
 /* last error message of this thread's most recent failing call ("" if none) */
 const char *icerx_decoder_last_error(void);
 

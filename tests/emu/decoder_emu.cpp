@@ -76,7 +76,7 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     }
     for (PacketCandidate &c : cands) check_payload(crc_tab, data, &c);
     DecodePlan pl;
-    plan_decode(&pl, data, cands, channels, stages, segments, sample_bits, *w, *h, bufsize);
+    plan_decode(&pl, cands, channels, stages, segments, sample_bits, *w, *h, bufsize);
     *w = pl.w; *h = pl.h;
     if (pl.rc == kInvalidInput || pl.rc == kTooManyStages || pl.rc == kByteQuotaExceeded) return pl.rc;
     const size_t W = pl.w, H = pl.h;
@@ -91,9 +91,9 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     for (const ChainDesc &c : pl.chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
     std::vector<uint16_t> ring((size_t)kRingRows * pitch);
     for (size_t i = 0; i < pl.chains.size(); i++) {
-        if (g_lockstep == 3) decode_chain_wave(ring.data(), pitch, planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
-        else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
-        else decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], pl.chain_subband[i], data, (uint32_t)len, dt, nplanes, sign_bit);
+        if (g_lockstep == 3) decode_chain_wave(ring.data(), pitch, planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        else decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit);
     }
     if (!pl.transform) return pl.rc;
     const FilterTaps taps = filter_taps(filt);

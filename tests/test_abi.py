@@ -33,7 +33,8 @@ def test_decoder_library_exports_every_declared_symbol_and_has_no_cpu_fallback()
     lib = decoder.load_library()
     names = _declared_functions("icer_hip_dec.h")
     assert {"icer_get_image_dimensions", "icer_decompress_image_uint16", "icer_decompress_image_yuv_uint16",
-            "icer_decompress_image_uint8", "icer_decompress_image_yuv_uint8"} <= set(names)
+            "icer_decompress_image_uint8", "icer_decompress_image_yuv_uint8", "icerx_decoder_create", "icerx_decode_host",
+            "icerx_decode_device"} <= set(names)
     for n in names:
         assert hasattr(lib, n), n
     # host-only entry point: size fields of the first CRC-valid packet (icer_compress.c:541-566)

@@ -197,6 +197,45 @@ def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
                             orc.decompress(s, 1, 3, 1, 5, bufsize=160 * 120)), len(s)
         assert decoder.decompress(stream, 1, 3, 1, 5, bufsize=160 * 120 - 1, lib=lib)[0] == -5
         assert decoder.decompress(stream, 1, 3, 1, 5, lib=lib)[1:3] == (160, 120)
+        # batches (Part 2): streams of different sizes, one that stops on a grid error, an empty one, one that does not
+        # fit the frame stride; host and "device" (= host, in the mock) buffers, 16- and 8-bit
+        for bits in (16, 8):
+            top = 200 if bits == 16 else 50
+            comp = orc.compress if bits == 16 else orc.compress_u8
+            dt = np.uint16 if bits == 16 else np.uint8
+            imgs = [rng.integers(0, top, shp).astype(dt) for shp in ((64, 96), (64, 96), (40, 56), (96, 128), (64, 96))]
+            streams = [comp([im], 2, 0, 6, 4 * im.size)[1] for im in imgs]
+            streams[1] = b""
+            stride = 64 * 96 + 11
+            want = [orc.decompress(s_, 1, 2, 0, 6, bufsize=stride, bits=bits) for s_ in streams]
+            assert [w_[0] for w_ in want] == [0, -3, 0, -5, 0]        # (an empty stream: no size, so no segment grid)
+            for mode in ("0", "1"):
+                os.environ["ICER_DEC_WAVE"] = mode
+                dec = decoder.Decoder(1, 2, 0, 6, bits=bits, lib=lib)
+                rc, res = dec.decode_host(streams, stride)
+                assert rc == 0
+                for (rk, wk, hk, pk), wnt in zip(res, want):
+                    assert (rk, wk, hk) == wnt[:3]
+                    assert np.array_equal(pk[0][: wk * hk], wnt[3][0][: wk * hk]) or rk == -5
+                blob, offs, lens = dec._pack(streams)
+                out = np.full(len(streams) * stride, 7, dt)
+                rc, rcs, ws, hs = dec.decode_device(len(streams), blob.ctypes.data, offs, lens, out.ctypes.data, stride)
+                assert rc == 0 and rcs == [w_[0] for w_ in want]
+                for k, wnt in enumerate(want):
+                    if rcs[k] == 0:
+                        assert np.array_equal(out[k * stride: k * stride + ws[k] * hs[k]], wnt[3][0][: ws[k] * hs[k]]), (bits, mode, k)
+                dec.close()
+        # a batch in which a frame stops with ICER_TOO_MANY_SEGMENTS (decoded with more segments than its subbands hold)
+        small = rng.integers(0, 100, (24, 24)).astype(np.uint16)
+        s_small = orc.compress([small], 3, 0, 2, 4 * small.size)[1]
+        s_ok = orc.compress([imgs16 := rng.integers(0, 100, (24, 24)).astype(np.uint16)], 3, 0, 2, 4 * 576)[1]
+        dec = decoder.Decoder(1, 3, 0, 20, lib=lib)
+        rc, res = dec.decode_host([s_small, s_ok], 576)
+        wnt = [orc.decompress(s_, 1, 3, 0, 20, bufsize=576) for s_ in (s_small, s_ok)]
+        assert rc == 0 and [r[0] for r in res] == [w_[0] for w_ in wnt] and -3 in [r[0] for r in res]
+        for r, w_ in zip(res, wnt):
+            assert np.array_equal(r[3][0][:576], w_[3][0][:576])
+        dec.close()
         os.environ["ICER_MOCK_NO_DEVICE"] = "1"
         assert decoder.decompress(stream, 1, 3, 1, 5, lib=lib)[0] == -10
     finally:
