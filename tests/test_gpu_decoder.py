@@ -100,3 +100,35 @@ def test_error_paths(dec, orc, kernel):
     assert dec.decompress(stream, 1, 3, 1, 5, bufsize=160 * 120 - 1)[0] == -5
     for s in (b"", stream[: len(stream) // 2], stream[5:], b"\x00" * 9 + stream + b"\x5b\x60\x00"):
         assert same(dec.decompress(s, 1, 3, 1, 5, bufsize=160 * 120), orc.decompress(s, 1, 3, 1, 5, bufsize=160 * 120)), len(s)
+
+
+@pytest.mark.timeout(600)
+def test_batch_decoder_object(dec, orc, kernel):
+    """Part 2: mixed sizes, an empty stream and an oversized frame in one batch; host buffers and device buffers (torch)"""
+    import torch
+    rng = np.random.default_rng(5)
+    for bits in (16, 8):
+        top = 200 if bits == 16 else 50
+        comp = orc.compress if bits == 16 else orc.compress_u8
+        dt = np.uint16 if bits == 16 else np.uint8
+        imgs = [rng.integers(0, top, shp).astype(dt) for shp in ((64, 96), (64, 96), (40, 56), (96, 128), (64, 96))]
+        streams = [comp([im], 2, 0, 6, 4 * im.size)[1] for im in imgs]
+        streams[1] = b""
+        stride = 64 * 96 + 11
+        want = [orc.decompress(s, 1, 2, 0, 6, bufsize=stride, bits=bits) for s in streams]
+        d = dec.Decoder(1, 2, 0, 6, bits=bits)
+        rc, res = d.decode_host(streams, stride)
+        assert rc == 0
+        for (rk, wk, hk, pk), wnt in zip(res, want):
+            assert (rk, wk, hk) == wnt[:3]
+            assert rk == -5 or np.array_equal(pk[0][: wk * hk], wnt[3][0][: wk * hk])
+        blob, offs, lens = d._pack(streams)
+        d_blob = torch.from_numpy(blob).cuda()
+        d_out = torch.zeros(len(streams) * stride, dtype=torch.int16 if bits == 16 else torch.uint8, device="cuda")
+        rc, rcs, ws, hs = d.decode_device(len(streams), d_blob.data_ptr(), offs, lens, d_out.data_ptr(), stride)
+        assert rc == 0 and rcs == [w_[0] for w_ in want]
+        out = d_out.cpu().numpy().view(dt)
+        for k, wnt in enumerate(want):
+            if rcs[k] == 0:
+                assert np.array_equal(out[k * stride: k * stride + ws[k] * hs[k]], wnt[3][0][: ws[k] * hs[k]])
+        d.close()
