@@ -53,6 +53,41 @@ def test_decoder_library_exports_every_declared_symbol_and_has_no_cpu_fallback()
         assert rc == api.ICER_FATAL_ERROR and b"no usable HIP device" in lib.icerx_decoder_last_error()
 
 
+def test_plain_c_decode_program_links(tmp_path):
+    """tests/c_abi/dropin_decode_example.c: the reference's decode call sequence against include/icer_hip_dec.h and
+    libicer_hip_dec.so.  Without a GPU the image call must fail loudly (exit code 10); with one, the images must equal the
+    decoder oracle's."""
+    import subprocess
+    from oracle.binding import Oracle
+    from icer_compression_amd import synth
+    from icer_compression_amd.build import build_decoder_library
+    exe = str(tmp_path / "dropin_decode_example")
+    libdir = os.path.dirname(build_decoder_library())
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "dropin_decode_example.c"),
+                           "-L", libdir, "-licer_hip_dec", "-Wl,-rpath," + libdir, "-o", exe])
+    orc = Oracle()
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    for planes, st, f, sg in [([synth.gray_frame(160, 120, 5, 1)], 3, 0, 5), (list(synth.color_frame_yuv(96, 64, 7)), 2, 1, 3)]:
+        rc, stream, _ = orc.compress(planes, st, f, sg, 1 << 20)
+        (tmp_path / "in.bin").write_bytes(stream)
+        if has_gpu and os.environ.get("ICER_GPU_DECODER_TESTS") != "1":
+            continue                                  # (the decoder's first hardware run is opt-in, see tests/test_gpu_decoder.py)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(len(planes)), str(st), str(f), str(sg), str(tmp_path / "out.raw")],
+                           capture_output=True, text=True)
+        if not has_gpu:
+            assert r.returncode == 10 and "rc=-10" in r.stdout and "no usable HIP device" in r.stderr, r.stdout + r.stderr
+            continue
+        h, w = planes[0].shape
+        want = orc.decompress(stream, len(planes), st, f, sg)
+        assert r.returncode == 0 and f"rc=0 w={w} h={h}" in r.stdout, r.stdout + r.stderr
+        got = np.fromfile(tmp_path / "out.raw", "<u2").reshape(len(planes), h * w)
+        assert all(np.array_equal(got[c], want[3][c]) for c in range(len(planes)))
+
+
 def test_output_struct_layout_and_init():
     # icer.h:307-312: four 8-byte fields
     assert C.sizeof(api.icer_output_data_buf_typedef) == 32
