@@ -90,11 +90,14 @@ decode_chains_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int cha
                      const ChainDesc *__restrict__ chains, uint32_t n, const uint8_t *__restrict__ data,
                      const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes, int sign_bit)
 {
+    ICER_DYNAMIC_LDS(uint8_t, state);                     // plane_block_bytes(64): the threads' per-bin arrays
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ChainDesc c = chains[i];
     const FrameInfo f = frames[c.frame];
-    decode_chain(planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband, data + f.stream_off,
+    PlaneDecoder job;
+    plane_attach_columns(job, state, 64u, threadIdx.x);
+    decode_chain(job, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband, data + f.stream_off,
                  f.stream_len, *tables, nplanes, sign_bit);
 }
 
@@ -105,11 +108,12 @@ decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t frame_stride, in
                           const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes,
                           int sign_bit, uint32_t pitch)
 {
-    ICER_DYNAMIC_LDS(uint16_t, ring);
+    ICER_DYNAMIC_LDS(uint16_t, ring);                     // the row ring, then the lanes' per-bin arrays
     const ChainDesc c = chains[blockIdx.x];
     const FrameInfo f = frames[c.frame];
+    uint8_t *state = reinterpret_cast<uint8_t *>(ring + (size_t)kRingRows * pitch);
     decode_chain_wave(ring, pitch, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
-                      data + f.stream_off, f.stream_len, *tables, nplanes, sign_bit, nullptr);
+                      data + f.stream_off, f.stream_len, *tables, nplanes, sign_bit, nullptr, state);
 }
 
 // sign-magnitude words -> int16, LL mean back in (grid.y = frame * channels + channel)
@@ -291,13 +295,13 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         // ICER_DEC_WAVE=1: the planes of a segment side by side (one wavefront per chain), if its rows fit the LDS ring
         uint32_t pitch = 2;
         for (const ChainDesc &c : chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
-        const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t);
+        const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t) + plane_block_bytes(kStateColumns);
         const char *mode = getenv("ICER_DEC_WAVE");
         if (mode && mode[0] == '1' && ring_bytes <= 65536u) {
             ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nc, ring_bytes, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
                              d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit, pitch);
         } else {
-            ICER_LAUNCH(decode_chains_kernel, (nc + 63u) / 64u, 64, 0, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
+            ICER_LAUNCH(decode_chains_kernel, (nc + 63u) / 64u, 64, plane_block_bytes(64u), d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
                         nc, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
         }
         HIP_TRY(hipGetLastError());

@@ -79,16 +79,18 @@ struct EntropyDecoder {
     uint64_t win;               // (packets of >= 8 bits) the next win_bits bits of the payload, from `pos` on
     uint32_t win_bits;
     uint32_t win_next;          // next payload byte to load into the window
-    int16_t n[kNumBins];        // bits pending per bin, served from the top
-    uint8_t bits[kNumBins];     // bins 0..7: the pending pattern (bit k = k-th from the bottom); bins 8..16: bottom bit
-    uint32_t index[kNumBins];   // `words` when the bin's last code word was read
+    // per-bin state, entry b at [b * ss]: in the thread's own memory (ss = 1) or a column of an LDS block (plane_attach_*)
+    int16_t *n;                 // bits pending per bin, served from the top
+    uint8_t *bits;              // bins 0..7: the pending pattern (bit k = k-th from the bottom); bins 8..16: bottom bit
+    uint32_t *index;            // `words` when the bin's last code word was read
+    uint32_t ss;
 };
 
 ICER_HD void entropy_init(EntropyDecoder &d, const uint8_t *stream, uint32_t stream_len, uint32_t base, uint32_t total_bits)
 {
     d.stream = stream; d.stream_len = stream_len; d.base = base; d.total_bits = total_bits; d.pos = 0; d.words = 0;
     d.win = 0; d.win_bits = 0; d.win_next = 0;
-    for (int b = 0; b < kNumBins; b++) { d.n[b] = 0; d.bits[b] = 0; d.index[b] = 0; }
+    for (uint32_t b = 0; b < (uint32_t)kNumBins; b++) { d.n[b * d.ss] = 0; d.bits[b * d.ss] = 0; d.index[b * d.ss] = 0; }
 }
 ICER_HD uint32_t entropy_byte(const EntropyDecoder &d, uint32_t i)
 {
@@ -165,16 +167,17 @@ ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *
     bool inv = false;
     if (zero < (total >> 1)) { zero = total - zero; inv = true; }
     const int bin = pick_bin_plain(t, zero, total);
+    const uint32_t at = (uint32_t)bin * d.ss;
     // a new code word is due when nothing is pending, or when kRingWords code words have been read since this bin's
     // last one: the encoder's ring was full then and it force-completed the bin's word (:128)
-    if (d.n[bin] <= 0 || d.words - d.index[bin] >= (uint32_t)kRingWords) {
-        d.n[bin] = 0;
-        d.bits[bin] = 0;
+    if (d.n[at] <= 0 || d.words - d.index[at] >= (uint32_t)kRingWords) {
+        d.n[at] = 0;
+        d.bits[at] = 0;
         if (bin >= 8) {
             const uint32_t m = t.gm[bin], l = t.gl[bin], gi = t.gi[bin];
             if (entropy_peek(d, 1)) {                              // "1": a full run of m zeros
                 entropy_read(d, 1, true);
-                d.n[bin] = (int16_t)m;
+                d.n[at] = (int16_t)m;
             } else {
                 // (QUIRK: an out-of-data result is used as a number; only reachable with a packet shorter than one
                 // code word, which no encoder writes)
@@ -185,9 +188,9 @@ ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *
                     k = reverse_low_bits((uint32_t)entropy_read(d, l + 1u, true) & 0xFFFFu, l + 1u);
                     k = (k - gi) & 0xFFFFu;
                 }
-                d.bits[bin] = 1;                                   // a one at the bottom, k zeros on top of it
+                d.bits[at] = 1;                                   // a one at the bottom, k zeros on top of it
                 const uint32_t cnt = 1u + k;
-                d.n[bin] = (int16_t)(cnt > 32767u ? 32767u : cnt);
+                d.n[at] = (int16_t)(cnt > 32767u ? 32767u : cnt);
             }
         } else if (bin >= 1) {
             uint32_t code = 0, nb = 0;
@@ -200,8 +203,8 @@ ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *
                 if (code >= 32u) return kDecodedInvalidData;
                 const uint32_t e = t.dec[bin][code];
                 if ((e & 15u) == nb) {
-                    d.bits[bin] = (uint8_t)(e >> 8);
-                    d.n[bin] = (int16_t)((e >> 4) & 15u);
+                    d.bits[at] = (uint8_t)(e >> 8);
+                    d.n[at] = (int16_t)((e >> 4) & 15u);
                     if ((int)code != entropy_read(d, nb, true)) return kDecodedInvalidData;
                     break;
                 }
@@ -209,22 +212,22 @@ ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *
         } else {
             const int b = entropy_read(d, 1, true);
             if (b == kDecoderOutOfData) return kDecoderOutOfData;
-            d.bits[bin] = (uint8_t)(b != 0);
-            d.n[bin] = 1;
+            d.bits[at] = (uint8_t)(b != 0);
+            d.n[at] = 1;
         }
         d.words++;
-        d.index[bin] = d.words;
+        d.index[at] = d.words;
     }
     // serve the top pending bit (:186-190).  Golomb bins hold zeros above one bottom bit; the reference's shift by -1 at
     // multiples of 32 pending bits reads a zero, which is what lies there; after a code word that matched nothing the
     // count goes to -1 and a zero is served.
     uint32_t b = 0;
-    const int n = d.n[bin];
+    const int n = d.n[at];
     if (n > 0) {
-        if (bin >= 8) b = (n == 1) ? d.bits[bin] : 0u;
-        else b = (d.bits[bin] >> (n - 1)) & 1u;
+        if (bin >= 8) b = (n == 1) ? d.bits[at] : 0u;
+        else b = (d.bits[at] >> (n - 1)) & 1u;
     }
-    d.n[bin] = (int16_t)(n - 1);
+    d.n[at] = (int16_t)(n - 1);
     *bit = inv ? (b ^ 1u) : b;
     return kOk;
 }
@@ -273,7 +276,7 @@ ICER_HD void dec_model_update(uint16_t &zero, uint16_t &total, bool was_zero)
 // plane `lsb` -- and its sign, when the sample becomes significant -- to the sign-magnitude word (sign at `sign_bit`).
 struct PlaneDecoder {
     EntropyDecoder d;
-    uint16_t zero[kNumContexts], total[kNumContexts];      // context model (icer_init_context_model_vals :607-613)
+    uint16_t *zero, *total;     // context model (icer_init_context_model_vals :607-613), entry k at [k * d.ss]
     uint32_t r, c;              // next sample
     uint32_t left;              // the sample to the left, this plane already decoded
     uint32_t done;              // samples finished (= r * w + c)
@@ -281,9 +284,35 @@ struct PlaneDecoder {
     int status;                 // 1 = running, 0 = finished (kOk), < 0 = failed with that code, 2 = not started
 };
 
+// where a plane job keeps its per-bin / per-context arrays: its own memory ...
+struct PlaneStorage {
+    uint32_t index[kNumBins];
+    int16_t n[kNumBins];
+    uint16_t zero[kNumContexts], total[kNumContexts];
+    uint8_t bits[kNumBins];
+};
+ICER_HD void plane_attach_local(PlaneDecoder &p, PlaneStorage &st)
+{
+    p.d.n = st.n; p.d.bits = st.bits; p.d.index = st.index; p.zero = st.zero; p.total = st.total; p.d.ss = 1;
+}
+// ... or column `col` of a block shared by `columns` jobs (LDS: dynamic indexing there beats the scratch memory that
+// per-thread arrays indexed by a run-time bin number end up in).  Block layout: index, n, zero, total, bits.
+ICER_HD size_t plane_block_bytes(uint32_t columns) { return (size_t)columns * (kNumBins * 7u + kNumContexts * 4u); }
+ICER_HD void plane_attach_columns(PlaneDecoder &p, uint8_t *block, uint32_t columns, uint32_t col)
+{
+    uint8_t *q = block;
+    p.d.index = reinterpret_cast<uint32_t *>(q) + col; q += (size_t)columns * kNumBins * 4u;
+    p.d.n = reinterpret_cast<int16_t *>(q) + col;      q += (size_t)columns * kNumBins * 2u;
+    p.zero = reinterpret_cast<uint16_t *>(q) + col;    q += (size_t)columns * kNumContexts * 2u;
+    p.total = reinterpret_cast<uint16_t *>(q) + col;   q += (size_t)columns * kNumContexts * 2u;
+    p.d.bits = q + col;
+    p.d.ss = columns;
+}
+
+// (attach the storage, then entropy_init, then plane_begin)
 ICER_HD void plane_begin(PlaneDecoder &p, int lsb, int sign_bit, uint32_t w, uint32_t h)
 {
-    for (int k = 0; k < kNumContexts; k++) { p.zero[k] = 2; p.total[k] = 4; }
+    for (uint32_t k = 0; k < (uint32_t)kNumContexts; k++) { p.zero[k * p.d.ss] = 2; p.total[k * p.d.ss] = 4; }
     p.r = 0; p.c = 0; p.left = 0; p.done = 0; p.lsb = lsb;
     p.status = (lsb + 1 >= sign_bit + 1) ? kBitplaneOutOfRange : ((w == 0 || h == 0) ? kOk : 1);
 }
@@ -329,9 +358,9 @@ ICER_HD void plane_step_img(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
                 ctx = subband == kHH ? dec_ctx_hh(hh + vv, dd) : dec_ctx_plain(hh, vv, dd);
             }
         }
-        if ((res = entropy_decode(p.d, t, &bit, p.zero[ctx], p.total[ctx])) != kOk) { p.status = res; return; }
+        if ((res = entropy_decode(p.d, t, &bit, p.zero[(uint32_t)ctx * p.d.ss], p.total[(uint32_t)ctx * p.d.ss])) != kOk) { p.status = res; return; }
         val = cur | (bit << lsb);
-        dec_model_update(p.zero[ctx], p.total[ctx], bit == 0);
+        dec_model_update(p.zero[(uint32_t)ctx * p.d.ss], p.total[(uint32_t)ctx * p.d.ss], bit == 0);
         if (cat == 0 && bit) {
             // sign: only negative significant neighbours count (QUIRK C6)
             auto sgn = [&](uint32_t v, int plane) { return (((v & mask) >> plane) != 0 && ((v >> sign_bit) & 1u)) ? -1 : 0; };
@@ -340,9 +369,9 @@ ICER_HD void plane_step_img(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
             if (subband == kHL) { const int x = sh; sh = sv; sv = x; }
             const int sctx = dec_sign_ctx(sh, sv);
             uint32_t agree;
-            if ((res = entropy_decode(p.d, t, &agree, p.zero[sctx], p.total[sctx])) != kOk) { img.put(r, c, val); p.status = res; return; }
+            if ((res = entropy_decode(p.d, t, &agree, p.zero[(uint32_t)sctx * p.d.ss], p.total[(uint32_t)sctx * p.d.ss])) != kOk) { img.put(r, c, val); p.status = res; return; }
             val |= ((agree ^ (uint32_t)dec_sign_pred(sh, sv)) & 1u) << sign_bit;
-            dec_model_update(p.zero[sctx], p.total[sctx], agree == 0);
+            dec_model_update(p.zero[(uint32_t)sctx * p.d.ss], p.total[(uint32_t)sctx * p.d.ss], agree == 0);
         }
     }
     img.put(r, c, val);
@@ -371,10 +400,10 @@ ICER_HD uint32_t packet_bits(const uint8_t *stream, uint32_t at)
 }
 
 // all planes of one chain, top plane first, until one is missing or fails (icer_partition.c:427-443)
-ICER_HD void decode_chain(uint16_t *plane, size_t stride, const ChainDesc &c, int subband, const uint8_t *stream,
+// `p`: a plane job with its storage attached (plane_attach_local / plane_attach_columns); it is reused plane after plane
+ICER_HD void decode_chain(PlaneDecoder &p, uint16_t *plane, size_t stride, const ChainDesc &c, int subband, const uint8_t *stream,
                           uint32_t stream_len, const DecoderTables &t, int planes, int sign_bit)
 {
-    PlaneDecoder p;
     for (int lsb = planes - 1; lsb >= 0; lsb--) {
         const uint32_t at = c.pkt[lsb];
         if (at == kNoPacket) break;

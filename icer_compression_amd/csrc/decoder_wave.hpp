@@ -27,6 +27,7 @@
 namespace icer {
 
 constexpr uint32_t kRingRows = 16;          // >= kPlanes + 3; power of two
+constexpr uint32_t kStateColumns = 16;      // >= kPlanes: lanes that keep their per-bin arrays in the LDS state block
 
 struct RingImage {
     uint16_t *ring; uint32_t pitch;
@@ -34,11 +35,12 @@ struct RingImage {
     ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { ring[(r & (kRingRows - 1u)) * pitch + c] = (uint16_t)v; }
 };
 
-// `ring`: kRingRows * pitch words of LDS (pitch >= c.w); `plane`: the channel plane (zero where not yet decoded).
+// `ring`: kRingRows * pitch words of LDS (pitch >= c.w); `plane`: the channel plane (zero where not yet decoded);
+// `state_block`: plane_block_bytes(kStateColumns) bytes of LDS for the lanes' per-bin arrays.
 // stats (tests): [0] iterations, [1] samples decoded, [2] roll-backs, [3] chains that ended with rows not retired.
 ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane, size_t stride, const ChainDesc &c,
                                 int subband, const uint8_t *stream, uint32_t stream_len, const DecoderTables &t,
-                                int planes, int sign_bit, unsigned long long *stats)
+                                int planes, int sign_bit, unsigned long long *stats, uint8_t *state_block)
 {
     DECL_LANE;
     const uint32_t w = c.w, h = c.h;
@@ -49,6 +51,8 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
     LANEVAR(PlaneDecoder, pd);
     FOR_LANES
     {
+        // (lanes that run no plane share a column they never touch)
+        plane_attach_columns(LV(pd), state_block, kStateColumns, (uint32_t)lane & (kStateColumns - 1u));
         for (uint32_t i = (uint32_t)lane; i < kRingRows * pitch; i += 64) ring[i] = 0;
         LV(pd).status = 2; LV(pd).done = 0; LV(pd).r = 0; LV(pd).c = 0; LV(pd).lsb = 0;
         if (lane < nrun) {

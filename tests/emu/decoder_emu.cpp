@@ -20,10 +20,12 @@ static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDes
                                   uint32_t stream_len, const DecoderTables &t, int planes, int sign_bit, unsigned long long *stats)
 {
     PlaneDecoder pd[kPlanes];
+    PlaneStorage store[kPlanes];
     bool chain_open = true;
     for (int j = 0; j < planes; j++) {
         const int lsb = planes - 1 - j;
         const uint32_t at = c.pkt[lsb];
+        plane_attach_local(pd[j], store[j]);
         pd[j].status = 2; pd[j].done = 0; pd[j].lsb = lsb;
         if (at == kNoPacket) chain_open = false;
         if (!chain_open) continue;
@@ -90,10 +92,16 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     uint32_t pitch = 2;
     for (const ChainDesc &c : pl.chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
     std::vector<uint16_t> ring((size_t)kRingRows * pitch);
+    std::vector<uint8_t> state(plane_block_bytes(kStateColumns));
     for (size_t i = 0; i < pl.chains.size(); i++) {
-        if (g_lockstep == 3) decode_chain_wave(ring.data(), pitch, planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        if (g_lockstep == 3) decode_chain_wave(ring.data(), pitch, planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats, state.data());
         else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
-        else decode_chain(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit);
+        else {
+            PlaneDecoder job;
+            PlaneStorage own;
+            plane_attach_local(job, own);
+            decode_chain(job, planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit);
+        }
     }
     if (!pl.transform) return pl.rc;
     const FilterTaps taps = filter_taps(filt);
