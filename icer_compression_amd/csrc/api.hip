@@ -347,6 +347,33 @@ void icerx_encoder_destroy(icerx_encoder *e)
     delete e;
 }
 
+// diagnostics of a unit time-out (rare error path): which unit, which wave at which wait, and the unit's hand-off counters
+// (the record code_units_kernel leaves in the failed unit's payload slot)
+static void report_timeouts(icerx_encoder *e, int n_frames)
+{
+    const size_t n_units = e->plan.units.size();
+    std::vector<uint32_t> bits((size_t)n_frames * n_units);
+    if (!n_units || hipMemcpy(bits.data(), e->unit_bits.p, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+    int shown = 0;
+    for (size_t i = 0; i < bits.size() && shown < 4; i++) {
+        if (bits[i] != kUnitFailed) continue;
+        const size_t frame = i / n_units, ui = i % n_units;
+        const UnitDesc &u = e->plan.units[ui];
+        uint32_t dbg[kFailWords] = {0};
+        if (u.cap_words >= kFailWords)
+            (void)hipMemcpy(dbg, e->slots.p + frame * e->plan.slot_bytes + u.slot_off + kHeaderBytes, sizeof dbg, hipMemcpyDeviceToHost);
+        fprintf(stderr, "libicer_hip: time-out in frame %zu unit %zu (chan %u level %u subband %u lsb %u seg %u, %u x %u)", frame, ui,
+                (unsigned)u.chan, (unsigned)u.level, (unsigned)u.subband, (unsigned)u.lsb, (unsigned)u.seg, (unsigned)u.w, (unsigned)u.h);
+        if (dbg[0] == kFailMagic)
+            fprintf(stderr, ": wave %u gave up at coder_core.hpp:%u; chunks %u, done pixel/count/compact/merge %u/%u/%u/%u, ring alloc/popped "
+                    "%u/%u, hold seq/ack %u/%u, generation %u (last exact %u), bitpos %u, flushed words %u, drain_exit %u",
+                    dbg[1] >> 16, dbg[1] & 0xFFFFu, dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[8], dbg[9], dbg[10], dbg[11],
+                    dbg[12], dbg[13], dbg[14], dbg[15]);
+        fprintf(stderr, "\n");
+        shown++;
+    }
+}
+
 // `stride_may_shrink`: the host wrappers size the output by min(quota, slot area); when a slot-bound retry
 // enlarges the slot area they must re-allocate, signalled by *regrow (the batch is then re-run by them).
 static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
@@ -388,6 +415,7 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
             // A wave of some coding unit waited longer than its spin bound (seconds) and gave the unit up; the frame's
             // return code is ICER_FATAL_ERROR.  Seen once in ~60 000 randomised encodes and not reproducible on the same
             // input, so the batch is simply run again, once, before the error is passed on.
+            report_timeouts(e, n_frames);
             if (timed_out_once) break;
             timed_out_once = true;
             fprintf(stderr, "libicer_hip: a coding unit timed out; re-running the batch once\n");

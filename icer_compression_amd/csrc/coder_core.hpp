@@ -88,7 +88,11 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define ICER_POLL_PAUSE(n) __builtin_amdgcn_s_sleep(n)
-#define ICER_SET_ABORT2() __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// (the first wave to give up also leaves its wave number and the source line of the wait: code_units_kernel passes them
+// on with the unit's counters, so that a time-out names the hand-off it happened in)
+#define ICER_SET_ABORT2() { if (__hip_atomic_load(&s.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2u)            \
+        __hip_atomic_store(&s.abort_site, (uint32_t)__LINE__ | ((uint32_t)(threadIdx.x >> 6) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    __hip_atomic_store(&s.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define ICER_FENCE_ACQ() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 #define ICER_FENCE_REL() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define ICER_STORE_CNT(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -156,6 +160,8 @@ namespace icer {
 constexpr uint32_t kStageWords = 1024;      // LDS bit stage (circular, 32-bit words)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kUnitFailed = 0xFFFFFFFEu;    // internal error (a bounded spin expired): reported as ICER_FATAL_ERROR
+constexpr uint32_t kFailMagic = 0x1CEBAD00u;     // first word of the diagnostic record a failed unit leaves in its payload slot
+constexpr uint32_t kFailWords = 16;
 constexpr uint32_t kSpinLimit = 1u << 25;
 constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
 constexpr int kUnitWaves = 8;               // pixel, count, compaction, walker, golomb, merge, records, drain
@@ -227,6 +233,7 @@ struct CoderShared {
     uint32_t nchunks;           // chunks of the unit
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
     uint32_t p_done, a_done, c_done, b_done, abort;
+    uint32_t abort_site;        // who set abort = 2: source line | wave << 16 (GPU build; diagnostics only)
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
     // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
     uint32_t exact_seq, last_exact;
@@ -1751,7 +1758,7 @@ ICER_DEV void unit_state_init(CoderShared &s)
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.gk[lane] = 0; }
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
-            s.p_done = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.exact_seq = 0; s.last_exact = 0;
+            s.p_done = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
             for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; }
         }
     }

@@ -198,7 +198,17 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         compact_wave_run(s, a, 0, nchunks);
     } else {
         uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
-        if (s.abort == 2u) bits = kUnitFailed;        // a bounded spin expired: internal error, never a silent hang
+        if (s.abort == 2u) {                          // a bounded spin expired: internal error, never a silent hang
+            bits = kUnitFailed;
+            // leave the unit's hand-off counters where its payload would have been (api.hip prints them)
+            if ((threadIdx.x & 63) == 0 && u.cap_words >= kFailWords) {
+                uint32_t *dbg = slot_words + kHeaderBytes / 4;
+                dbg[0] = kFailMagic; dbg[1] = s.abort_site; dbg[2] = nchunks; dbg[3] = s.p_done; dbg[4] = s.a_done;
+                dbg[5] = s.c_done; dbg[6] = s.b_done; dbg[7] = s.alloc; dbg[8] = s.popped; dbg[9] = s.hold_seq;
+                dbg[10] = s.hold_ack; dbg[11] = s.exact_seq; dbg[12] = s.last_exact; dbg[13] = s.bitpos;
+                dbg[14] = s.flushed_words; dbg[15] = s.drain_exit;
+            }
+        }
         if (s.abort == 3u) bits = 0;                  // progressive mode: stopped, the quota cut lies before this unit
         if (bits != kUnitTooBig && bits != kUnitFailed) {
             // make this wave's payload stores visible to its own loads before the CRC pass reads them
