@@ -27,6 +27,7 @@
 namespace icer {
 
 constexpr uint32_t kRingRows = 16;          // >= kPlanes + 3; power of two
+constexpr uint32_t kBurst = 8;              // samples a plane may take per look at its neighbours
 constexpr uint32_t kStateColumns = 16;      // >= kPlanes: lanes that keep their per-bin arrays in the LDS state block
 
 struct RingImage {
@@ -78,10 +79,12 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
             const int above = (int)st_u[j - 1];
             if (st_u[j] == 1u && (above < 0 || above == 2)) st_u[j] = 2u;
         }
-        LANEVAR(uint32_t, go);
+        // how many samples each plane may take before the next look (kBurst at most): its upper neighbour has to stay
+        // w + 2 samples ahead of the last one -- plane_needs(), rounded up -- and the row below must have its ring slot
+        LANEVAR(uint32_t, grant);
         FOR_LANES
         {
-            bool g = false;
+            uint32_t g = 0;
             if (lane < nrun) {
                 uint32_t mine = 0;
                 int above_status = kOk;
@@ -92,27 +95,42 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
                         if (j > 0) { above_status = (int)st_u[j - 1]; above_done = dn_u[j - 1]; }
                     }
                 if (LV(pd).status == 1 && mine == 2u) LV(pd).status = 2;
-                g = lane == 0 ? LV(pd).status == 1 : plane_ready(LV(pd), above_status, above_done, w, h);
-                g = g && LV(pd).r + 1u < retired + kRingRows;            // row r + 1 has its slot
+                if (LV(pd).status == 1) {
+                    g = kBurst;
+                    if (above_status == 1) {
+                        const uint32_t need = LV(pd).done + w + 2u;          // for the first sample of the burst
+                        g = above_done >= need ? (above_done - need + 1u < kBurst ? above_done - need + 1u : kBurst) : 0u;
+                    } else if (above_status != kOk) g = 0;
+                    const uint32_t room_end = (retired + kRingRows - 1u) * w;       // samples of rows whose row below has a slot
+                    const uint32_t room = room_end > LV(pd).done ? room_end - LV(pd).done : 0u;
+                    if (room < g) g = room;
+                }
             }
-            LV(go) = g ? 1u : 0u;
+            LV(grant) = g;
         }
-        const uint64_t G = BALLOT(LV(go) != 0u);
+        const uint64_t G = BALLOT(LV(grant) != 0u);
         // rows below `limit` are dead: a running plane in row r still reads row r - 1
         uint32_t limit = h;
         for (int j = 0; j < nrun; j++)
             if (st_u[j] == 1u) { const uint32_t l = row_u[j] > 0u ? row_u[j] - 1u : 0u; if (l < limit) limit = l; }
         const bool retire = retired < limit;
         if (G == 0ull && !retire) break;
-        FOR_LANES
-        {
-            if (LV(go)) {
-                RingImage img{ring, pitch};
-                plane_step_img(LV(pd), img, w, h, subband, sign_bit, t);
+        uint32_t steps = 0;
+        for (uint32_t k = 0; k < kBurst; k++) {
+            const uint64_t A = BALLOT(k < LV(grant) && LV(pd).status == 1);
+            if (A == 0ull) break;
+            FOR_LANES
+            {
+                if (k < LV(grant) && LV(pd).status == 1) {
+                    RingImage img{ring, pitch};
+                    plane_step_img(LV(pd), img, w, h, subband, sign_bit, t);
+                }
             }
+            WAVE_SYNC();
+            steps += (uint32_t)popc64(A);
         }
-        WAVE_SYNC();
-        if (retire) {
+        // (rows that became dead before this burst; at most as many as the burst can open up again)
+        for (uint32_t k = 0; k < kBurst / 4u + 1u && retired < limit; k++) {
             uint16_t *slot = ring + (retired & (kRingRows - 1u)) * pitch;
             FOR_LANES
             {
@@ -120,7 +138,8 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
             }
             retired++;
         }
-        if (stats) { stats[0]++; stats[1] += (unsigned long long)popc64(G); }
+        WAVE_SYNC();
+        if (stats) { stats[0]++; stats[1] += (unsigned long long)steps; }
     }
     if (stats && retired != h) stats[3]++;
     // a failed plane: the planes below it are taken back (chain_rollback), on the written-back samples
