@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity stress on a GPU (not collected by pytest): random geometries, filters, segment counts,
 quotas and content, HIP path through the C ABI vs the oracle.  Meant to shake out rare cross-wave races.
-   python tests/stress_gpu.py [seconds] [seed]"""
+   python tests/stress_gpu.py [seconds] [seed]
+With ICER_STRESS_DECODE=1 every stream the encoder produced is also decoded by libicer_hip_dec.so (both decode kernels)
+and compared with the decoder oracle."""
 import os
 import sys
 import time
@@ -14,10 +16,22 @@ from icer_compression_amd import api, synth  # noqa: E402
 from oracle.binding import Oracle  # noqa: E402
 
 
+def _packets(stream):
+    out, off = [], 0
+    while off + 28 <= len(stream):
+        n = 28 + (int.from_bytes(stream[off + 16: off + 20], "little") + 7) // 8
+        out.append(stream[off: off + n])
+        off += n
+    return out
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     orc = Oracle()
+    decode = os.environ.get("ICER_STRESS_DECODE") == "1"
+    if decode:
+        from icer_compression_amd import decoder
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
         big = rng.random() < 0.03                       # now and then a large frame (long coding units, deep queues)
@@ -52,6 +66,16 @@ def main():
         b = (orc.compress_u8 if u8 else orc.compress)(planes, st, filt, sg, quota)
         same = a[0] == b[0] and a[1] == b[1] and (a[0] not in (0, -5) or all(np.array_equal(p, q) for p, q in zip(a[2], b[2])))
         n += 1
+        if decode and same and a[1] and len({p[7] >> 4 for p in _packets(a[1])}) >= len(planes):
+            bits = 8 if u8 else 16
+            want = orc.decompress(a[1], len(planes), st, filt, sg, bufsize=w * h, bits=bits)
+            for mode in ("0", "1"):
+                os.environ["ICER_DEC_WAVE"] = mode
+                got = decoder.decompress(a[1], len(planes), st, filt, sg, bufsize=w * h, bits=bits)
+                if not (got[0] == want[0] and got[1:3] == want[1:3] and all(np.array_equal(x, y) for x, y in zip(got[3], want[3]))):
+                    bad += 1
+                    print("DECODE MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color),
+                                                  u8=bool(u8), kernel=mode), "rc", got[0], want[0], flush=True)
         if not same:
             bad += 1
             print("MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color), u8=bool(u8)),
