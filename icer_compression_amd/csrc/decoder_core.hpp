@@ -2,8 +2,8 @@
 // encoder hot path writes.  Plain per-thread code, shared between the gfx950 build (decoder.hip) and a g++ build
 // for tests/emu (the authoring container has no GPU); no wave-level cooperation yet.
 //
-// STATUS: first correct version.  Checked bit-for-bit against the decoder oracle on the CPU build; cross-compiled for
-// gfx950; NOT yet run or measured on a GPU.  It is not part of libicer_hip.so.
+// STATUS: first correct version.  Checked bit-for-bit against the decoder oracle on the CPU build and, briefly, on an
+// MI355X (16-bit gray frames up to 4096 x 4096); not yet profiled.  It is not part of libicer_hip.so.
 //
 // Restates, per segment ("chain": the bit planes of one segment of one subband of one channel, top plane first):
 //   entropy decoder        icer_decode_bit + bit readers            lib_icer/src/icer_decoding.c:12-194

@@ -1,9 +1,10 @@
 /*
  * icer_hip_dec.h -- C ABI of libicer_hip_dec.so, the MI355X (gfx950) ICER *decoder* (SURVEY.md 8f, row next-1).
  *
- * STATUS: first version.  The device code is checked bit-for-bit against the decoder oracle in its CPU build
- * (tests/test_emu_decoder.py) and cross-compiles for gfx950, but it has NOT yet been run or measured on a GPU; it is a
- * separate library so that libicer_hip.so (the measured encoder) is unaffected.  See DESIGN.md 6b.
+ * STATUS: first version.  The device code is checked bit-for-bit against the decoder oracle in its CPU builds
+ * (tests/test_emu_decoder.py) and has had a first, short hardware run: bit-exact for 16-bit gray frames up to 4096 x 4096
+ * (profiles/r01_decoder_first_gpu_*.log); not yet profiled or tuned.  It is a separate library so that libicer_hip.so (the
+ * measured encoder) is unaffected.  See DESIGN.md 6b.
  *
  * Same names, argument meaning and return codes as the decoding entry points of lib_icer
  * (TheRealOrange/icer_compression, lib_icer/inc/icer.h); the work runs on the GPU and there is no CPU fallback
