@@ -9,14 +9,15 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libicer_hip.so")
 SOURCES = ["api.hip"]
-HEADERS = ["kernels.hpp", "coder_core.hpp", "assemble_core.hpp", "dwt_core.hpp", "plan.hpp", "icer_tables.hpp", "wave.hpp"]
+# the decoder's own sources do not go into libicer_hip.so; every other file under csrc/ is a dependency
+DEC_ONLY = {"decoder.hip", "decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp"}
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(PKG, "..", "include", "icer_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f not in DEC_ONLY] + [os.path.join(PKG, "..", "include", "icer_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

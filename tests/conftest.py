@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first():
+    """torch ships its own HIP runtime; when it is initialised AFTER libicer_hip*.so (which link the system one) it finds
+    no device.  On a GPU box bring torch's runtime up first, so both see the GPU in one process (bench.py does the same)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:                                   # noqa: BLE001  (no torch / no GPU: nothing to order)
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.binding import Oracle

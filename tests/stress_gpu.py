@@ -34,7 +34,7 @@ def main():
         from icer_compression_amd import decoder
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
-        big = rng.random() < 0.03                       # now and then a large frame (long coding units, deep queues)
+        big = rng.random() < float(os.environ.get('ICER_STRESS_BIG', '0.03'))                       # now and then a large frame (long coding units, deep queues)
         w, h = (int(rng.integers(700, 2200)), int(rng.integers(700, 2200))) if big else (int(rng.integers(5, 700)), int(rng.integers(5, 700)))
         st = int(rng.integers(1, 7))
         while ((w + (1 << st) - 1) >> st) < 3 or ((h + (1 << st) - 1) >> st) < 3:

@@ -74,8 +74,6 @@ def test_plain_c_decode_program_links(tmp_path):
     for planes, st, f, sg in [([synth.gray_frame(160, 120, 5, 1)], 3, 0, 5), (list(synth.color_frame_yuv(96, 64, 7)), 2, 1, 3)]:
         rc, stream, _ = orc.compress(planes, st, f, sg, 1 << 20)
         (tmp_path / "in.bin").write_bytes(stream)
-        if has_gpu and os.environ.get("ICER_GPU_DECODER_TESTS") != "1":
-            continue                                  # (the decoder's first hardware run is opt-in, see tests/test_gpu_decoder.py)
         r = subprocess.run([exe, str(tmp_path / "in.bin"), str(len(planes)), str(st), str(f), str(sg), str(tmp_path / "out.raw")],
                            capture_output=True, text=True)
         if not has_gpu:

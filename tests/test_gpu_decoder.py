@@ -1,8 +1,7 @@
-"""GPU parity tests of the decoder (libicer_hip_dec.so through its C ABI) against the decoder oracle.
-
-OPT-IN (set ICER_GPU_DECODER_TESTS=1): the decoder's device code has so far only been run in its CPU build
-(tests/test_emu_decoder.py); these tests are what its first GPU run executes, and they join the default `-m gpu` set
-once they have passed on hardware.  See DESIGN.md 6b.
+"""GPU parity tests of the decoder (libicer_hip_dec.so through its C ABI) against the decoder oracle: random gray / YUV,
+uint16 / uint8 streams incl. quota-cut ones, wrong decode parameters, damaged / truncated / re-ordered streams, the golden
+decoder digests up to 4096 x 4096 and the batch decoder object, for both decode kernels.  First hardware run:
+profiles/r02_decoder_gpu_tests.log.  See DESIGN.md 6b.
 """
 import hashlib
 import json
@@ -15,9 +14,7 @@ from icer_compression_amd import synth
 from oracle.binding import Oracle
 from tests.test_oracle_decoder import random_case
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("ICER_GPU_DECODER_TESTS") != "1",
-                                 reason="decoder not yet validated on hardware: opt in with ICER_GPU_DECODER_TESTS=1")]
+pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
 
