@@ -54,7 +54,7 @@
 // waves' register state is an array and the region a loop over it.)
 #ifdef ICER_WAVE_EMU
 #include <assert.h>
-#define WG_REGS(T, name) T name[ICER_WG_WAVES]
+#define WG_REGS_PARAM(T, name) T (&name)[ICER_WG_WAVES]
 #define WG_EACH_WAVE for (uint32_t w = 0; w < (uint32_t)ICER_WG_WAVES; ++w) { auto &R = regs[w];
 #define WG_BARRIER }
 #define WG_UNIFORM(field) (regs[0].field)
@@ -62,7 +62,7 @@
 #define WG_GLOBAL_RELEASE()
 #define WG_GLOBAL_ACQUIRE()
 #else
-#define WG_REGS(T, name) T name
+#define WG_REGS_PARAM(T, name) T &name
 #define WG_EACH_WAVE { const uint32_t w = threadIdx.x >> 6; auto &R = regs;
 #define WG_BARRIER } __syncthreads();
 #define WG_UNIFORM(field) (regs.field)
@@ -72,6 +72,7 @@
 #endif
 
 namespace icer {
+namespace wg {
 
 constexpr uint32_t kWgWaves = ICER_WG_WAVES;
 static_assert(kWgWaves * 128u <= (uint32_t)kRingWords, "a window must not be able to open more words than the ring holds (E5 test)");
@@ -1334,7 +1335,7 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
 // Returns the payload length in bits, kUnitTooBig (payload slot too small) or kUnitStopped (progressive mode).
 // GPU: called by all kWgWaves * 64 threads of the workgroup, `regs` in registers; Shared initialised (unit_state_init,
 // tables) and a barrier passed.
-ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS(Wave, &regs))
+ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave, regs))
 {
     DECL_LANE;
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
@@ -1406,7 +1407,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS(Wave, &regs
                     const uint64_t L0 = BALLOT(LV(wd) & (1u << 11)), L1 = BALLOT(LV(wd) & (2u << 11)), L2 = BALLOT(LV(wd) & (4u << 11)), L3 = BALLOT(LV(wd) & (8u << 11));
                     FOR_LANES { if (lane == 0) s.wl[w].segtot = (uint32_t)(popc64(L0) + 2 * popc64(L1) + 4 * popc64(L2) + 8 * popc64(L3)); }
                     // (kept for the second half)
-                    LV(R.c.sp1) = LV(wd);
+                    FOR_LANES { LV(R.c.sp1) = LV(wd); }
                 WG_BARRIER
                 const uint32_t n = WG_UNIFORM(nflush);
                 WG_EACH_WAVE
@@ -1477,6 +1478,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS(Wave, &regs
     // end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455)
     uint32_t bits = kUnitTooBig;
     WG_EACH_WAVE
+        (void)R;
         WG_GLOBAL_RELEASE();
     WG_BARRIER
     WG_EACH_WAVE
@@ -1500,4 +1502,5 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS(Wave, &regs
     return bits;
 }
 
+}  // namespace wg
 }  // namespace icer

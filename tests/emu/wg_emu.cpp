@@ -1,0 +1,40 @@
+// TESTS ONLY: the barrier-only workgroup coder (csrc/coder_wg.hpp) as a CPU lane-loop build (-DICER_WAVE_EMU, see
+// csrc/wave.hpp): the waves of a workgroup become an array of register states, a barrier-closed region a loop over
+// them.  Compared with the oracle by tests/test_emu_wg.py.  Not part of the product library.
+#define ICER_WAVE_EMU 1
+#ifndef ICER_WG_WAVES
+#define ICER_WG_WAVES 16
+#endif
+#include "../../icer_compression_amd/csrc/coder_wg.hpp"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace icer;
+
+static wg::Shared g_sh;
+
+extern "C" int emu_wg_waves(void) { return (int)wg::kWgWaves; }
+
+// one coding unit; returns the payload length in bits, -5 slot too small, -3 stopped (progressive mode)
+extern "C" long emu_wg_code_unit(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
+                                 uint8_t *out, size_t cap_bytes, int stop_flag)
+{
+    memset(&g_sh, 0xA5, sizeof g_sh);             // the kernel must not depend on LDS contents
+    build_coder_tables(&g_sh.tab);
+    wg::UnitArgs a;
+    a.seg = seg; a.stride = (uint32_t)stride; a.w = (uint32_t)w; a.h = (uint32_t)h;
+    a.subband = subband; a.lsb = lsb;
+    a.cap_words = (uint32_t)(cap_bytes / 4);
+    std::vector<uint32_t> words(a.cap_words + 1, 0);
+    a.out_words = words.data();
+    uint32_t flag = stop_flag ? 1u : 0u;
+    a.done_bytes = &flag; a.prio_index = 0; a.early_quota = stop_flag ? 1u : 0u;
+    static wg::Wave regs[ICER_WG_WAVES];
+    memset(regs, 0x5A, sizeof regs);
+    { wg::Wave &R = regs[0]; (void)R; wg::unit_state_init(g_sh, a); }
+    const uint32_t bits = wg::code_unit_wg(g_sh, a, regs);
+    long res = bits == wg::kUnitTooBig ? -5 : bits == wg::kUnitStopped ? -3 : (long)bits;
+    if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
+    return res;
+}
