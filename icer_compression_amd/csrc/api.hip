@@ -74,6 +74,7 @@ struct icerx_encoder {
     size_t slot_quota = (size_t)-1;     // quota the current slot table was built for
     unsigned bits_per_pixel = 3;        // slot bound; doubled on overflow
     bool units_uploaded = false;
+    bool coder_wg = true;               // coding units by code_units_wg_kernel (barrier-only windows); ICER_HIP_CODER=pipe: the eight-wave pipeline
 
     DevBuf<int16_t> coef, tmp;
     DevBuf<unsigned long long> sums;
@@ -235,6 +236,12 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
+    if (e->coder_wg)
+        hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
+                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+    else
     hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64 * kUnitWaves), 0, st,
                        reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                        progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
@@ -298,6 +305,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const int rc = build_plan(&e->plan, w, h, channels, stages, segments, sample_bits);
     if (rc != kOk) { delete e; return rc; }
     // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
+    if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_wg = strcmp(cd, "pipe") != 0;
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -322,6 +330,8 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         return ICER_FATAL_ERROR;
     }
     HIP_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
+    // the workgroup coder's LDS block is above the 64 KiB a kernel gets without asking
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)));
 #ifdef ICER_PHASE_TIMERS
     if (e->prof.ensure(kProfWords)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
     HIP_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));

@@ -37,7 +37,7 @@ ICER_DEV uint32_t gf_xpow_bytes(const uint32_t *x2n, uint32_t nbytes)
     return p;
 }
 
-ICER_DEV void build_crc_table(CoderShared &s)
+template <class SharedT> ICER_DEV void build_crc_table(SharedT &s)
 {
     DECL_LANE;
     FOR_LANES
@@ -59,7 +59,7 @@ struct FinishArgs {
 
 // CRC-32 of the payload: every lane takes a contiguous piece, the 64 piece CRCs are combined with
 // crc(A||B) = crc(A) * x^(8|B|) + crc(B)  (valid for the init/final-xor form, cf. zlib crc32_combine)
-ICER_DEV void finish_unit_wave(CoderShared &s, const FinishArgs &f)
+template <class SharedT> ICER_DEV void finish_unit_wave(SharedT &s, const FinishArgs &f)
 {
     DECL_LANE;
     const uint32_t n = (f.bits + 7u) >> 3;

@@ -54,11 +54,14 @@
 // waves' register state is an array and the region a loop over it.)
 #ifdef ICER_WAVE_EMU
 #include <assert.h>
+#include <stdio.h>
+#include <stdlib.h>
 #define WG_REGS_PARAM(T, name) T (&name)[ICER_WG_WAVES]
-#define WG_EACH_WAVE for (uint32_t w = 0; w < (uint32_t)ICER_WG_WAVES; ++w) { auto &R = regs[w];
+// (the order in which the waves run a region must not matter: g_wg_order = 1 runs them backwards, >= 2 shuffled)
+#define WG_EACH_WAVE for (uint32_t wi_ = 0; wi_ < (uint32_t)ICER_WG_WAVES; ++wi_) { const uint32_t w = icer::wg::wg_wave_order(wi_); auto &R = regs[w];
 #define WG_BARRIER }
 #define WG_UNIFORM(field) (regs[0].field)
-#define WG_ASSERT(x) assert(x)
+#define WG_ASSERT(x) do { if (!(x)) { wg_assert_fail(#x, __LINE__); } } while (0)
 #define WG_GLOBAL_RELEASE()
 #define WG_GLOBAL_ACQUIRE()
 #else
@@ -67,12 +70,37 @@
 #define WG_BARRIER } __syncthreads();
 #define WG_UNIFORM(field) (regs.field)
 #define WG_ASSERT(x)
+#define WG_STAT(i)
 #define WG_GLOBAL_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#ifdef ICER_PHASE_TIMERS
+// profiling build only (libicer_hip_prof.so): cycles since the previous tick go to bucket k of this wave
+#define WG_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); R.tacc[k] += (uint32_t)(t_ - R.tlast); R.tlast = t_; }
+#endif
 #define WG_GLOBAL_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
+#ifndef WG_TICK
+#define WG_TICK(k)
 #endif
 
 namespace icer {
 namespace wg {
+#ifdef ICER_WAVE_EMU
+// tests only: set by a failed WG_ASSERT (the run goes on, so that a test can report it instead of aborting)
+static int g_wg_assert_line = 0;
+static unsigned g_wg_order = 0, g_wg_order_state = 1;
+static unsigned long long g_wg_stats[8] = {0};   // windows, detailed flush tests, exact chunks, forced flushes
+#define WG_STAT(i) (icer::wg::g_wg_stats[i]++)
+static inline uint32_t wg_wave_order(uint32_t i)
+{
+    const uint32_t n = (uint32_t)ICER_WG_WAVES;
+    if (g_wg_order == 0) return i;
+    if (g_wg_order == 1) return n - 1u - i;
+    if (i == 0) g_wg_order_state = g_wg_order_state * 1664525u + 1013904223u;     // a new permutation per region
+    const uint32_t mul = ((g_wg_order_state >> 8) | 1u) % n, add = (g_wg_order_state >> 16) % n;   // odd multiplier: a bijection mod 2^k
+    return (i * (mul | 1u) + add) % n;
+}
+static inline void wg_assert_fail(const char *what, int line) { if (!g_wg_assert_line) { g_wg_assert_line = line; if (getenv("ICER_WG_TRACE")) fprintf(stderr, "WG_ASSERT line %d: %s\n", line, what); } }
+#endif
 
 constexpr uint32_t kWgWaves = ICER_WG_WAVES;
 static_assert(kWgWaves * 128u <= (uint32_t)kRingWords, "a window must not be able to open more words than the ring holds (E5 test)");
@@ -81,8 +109,9 @@ constexpr uint32_t kStageWords = 2048;              // LDS bit stage (circular, 
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kUnitStopped = 0xFFFFFFFDu;      // progressive mode: the quota cut lies before this unit
 
-// ring word: open  -> owner bin (bit 15 clear)
-//            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)
+// ring word: 0 while its code word is unfinished (a slot is cleared when it is popped; which bin an open word
+//            belongs to follows from the bins' open slots), 0x8000 | nbits << 11 | code (<= 10 bits) once it is finished.
+//            Only END events store to the ring, so no two waves ever store to the same slot.
 constexpr uint32_t kWordDone = 0x8000u;
 
 struct UnitArgs {
@@ -97,6 +126,7 @@ struct UnitArgs {
     const uint32_t *done_bytes;
     uint32_t prio_index;
     uint64_t early_quota;
+    uint64_t *timers;           // profiling build: per-phase cycle counters (null otherwise)
 };
 
 struct WaveLds {                // per-wave LDS: the chunk's summaries and scratch
@@ -161,14 +191,14 @@ ICER_DEV bool quota_already_spent(const UnitArgs &a)
 ICER_DEV bool quota_already_spent(const UnitArgs &a) { return a.early_quota && a.done_bytes && a.done_bytes[0] != 0u; }
 #endif
 
-#define RING_LD(i) ((uint32_t)s.ring[(i) & (kPhysRing - 1)])
-#define RING_ST(i, v) (s.ring[(i) & (kPhysRing - 1)] = (uint16_t)(v))
+#define WRING_LD(i) ((uint32_t)s.ring[(i) & (kPhysRing - 1)])
+#define WRING_ST(i, v) (s.ring[(i) & (kPhysRing - 1)] = (uint16_t)(v))
 
 // ------------------------------------------------------------------------------------------
 // exact coder steps (restatement of E1-E6)
 // ------------------------------------------------------------------------------------------
 // Golomb codeword for a run of k zeros ended by a one (icer_encoding.c:73-80)
-ICER_DEV uint32_t golomb_word(const CoderTables &t, int bin, uint32_t k)
+ICER_DEV uint32_t wg_golomb_word(const CoderTables &t, int bin, uint32_t k)
 {
     const uint32_t gi = t.gi[bin];
     const uint32_t code = k + (k >= gi ? gi : 0u);
@@ -186,25 +216,24 @@ ICER_DEV uint32_t st_pack(uint32_t op, uint32_t acc, uint32_t nin) { return op |
 ICER_DEV void seq_complete_head(Shared &s)
 {
     const uint32_t head = s.popped;
-    const uint32_t w = RING_LD(head);
-    if (!(w & kWordDone)) {
-        const int bin = (int)(w & 31u);
-        if (bin >= 8) {
-            const uint32_t k = st_acc(s.bin_state[bin]);
-            RING_ST(head, (k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u) : golomb_word(s.tab, bin, k));
-            s.bin_state[bin] = 0;
-            s.bin_slot[bin] = -1;
-        } else if (bin >= 1) {
-            const uint32_t nin = st_nin(s.bin_state[bin]), acc = st_acc(s.bin_state[bin]);
-            const uint32_t pv = acc > 8u ? 8u : acc;                                // partial values are <= 8
-            const uint32_t f = s.tab.v2v_flush[bin][pv][nin > 5u ? 5u : nin];
-            const uint32_t pre = (acc | ((f & 15u) << nin)) & 31u;
-            const uint32_t e = s.tab.v2v[bin][pre];
-            // QUIRK (kept): the completed input is not checked to be a real code word
-            RING_ST(head, (kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8)));
-            s.bin_state[bin] = 0;
-            s.bin_slot[bin] = -1;
-        }
+    // the oldest word is open (everything finished has been popped): it is the open word of the bin whose slot it is
+    int bin = 0;
+    for (int b = 1; b < kNumBins; b++) if (s.bin_slot[b] == (int32_t)head) bin = b;
+    if (bin >= 8) {
+        const uint32_t k = st_acc(s.bin_state[bin]);
+        WRING_ST(head, (k == (uint32_t)s.tab.gm[bin] - 1u) ? (kWordDone | (1u << 11) | 1u) : wg_golomb_word(s.tab, bin, k));
+        s.bin_state[bin] = 0;
+        s.bin_slot[bin] = -1;
+    } else if (bin >= 1) {
+        const uint32_t nin = st_nin(s.bin_state[bin]), acc = st_acc(s.bin_state[bin]);
+        const uint32_t pv = acc > 8u ? 8u : acc;                                // partial values are <= 8
+        const uint32_t f = s.tab.v2v_flush[bin][pv][nin > 5u ? 5u : nin];
+        const uint32_t pre = (acc | ((f & 15u) << nin)) & 31u;
+        const uint32_t e = s.tab.v2v[bin][pre];
+        // QUIRK (kept): the completed input is not checked to be a real code word
+        WRING_ST(head, (kWordDone | (((e >> 4) & 15u) << 11) | (e >> 8)));
+        s.bin_state[bin] = 0;
+        s.bin_slot[bin] = -1;
     }
 }
 
@@ -250,6 +279,7 @@ ICER_DEV uint32_t pick_bin(const uint32_t *binlut, uint32_t zero, uint32_t total
 // Adaptive counts for every event of context C in this chunk when the context is rescaled inside the chunk.  A context
 // is rescaled when its total reaches 500 (-> 250); with at most 64 events per context and chunk that can happen at
 // most once per chunk.  QUIRK C5: at a rescale `zero` is halved only if it exceeds the halved total.
+#undef ICER_CTX_STEP
 #define ICER_CTX_STEP(C, PRED, ISZERO, ZOUT, TOUT)                                                    \
     {                                                                                                 \
         const uint64_t m_ = BALLOT(PRED);                                                             \
@@ -322,7 +352,7 @@ ICER_DEV uint32_t wave_drain(Shared &s, uint32_t limit)
         LANEVAR(uint32_t, w); LANEVAR(uint32_t, len); LANEVAR(uint32_t, off);
         FOR_LANES
         {
-            LV(w) = (uint32_t)lane < used ? RING_LD(head + (uint32_t)lane) : 0u;
+            LV(w) = (uint32_t)lane < used ? WRING_LD(head + (uint32_t)lane) : 0u;
         }
         const uint64_t done = BALLOT((LV(w) & kWordDone) != 0u);
         const uint32_t n = (uint32_t)ffs64(~done);               // leading finished words
@@ -346,6 +376,10 @@ ICER_DEV uint32_t wave_drain(Shared &s, uint32_t limit)
                 LDS_OR(s.stage[wi], code << sh);
                 if (sh + LV(len) > 32u) LDS_OR(s.stage[(wi + 1) & (kStageWords - 1)], code >> (32u - sh));
             }
+        }
+        FOR_LANES
+        {
+            if ((uint32_t)lane < n) WRING_ST(head + (uint32_t)lane, 0u);          // popped: the slot is free again
         }
         bitpos += total;
         head += n;
@@ -421,6 +455,8 @@ struct Wave {
     LANEVAR(uint32_t, stl0); LANEVAR(uint32_t, stl1); LANEVAR(uint32_t, stl2); LANEVAR(uint32_t, stl3); LANEVAR(uint32_t, wnode);
     LANEVAR(uint32_t, cb); LANEVAR(uint32_t, ce);       // candidate lanes: their bin and the (compact) node they assume
     LANEVAR(uint32_t, slot);                            // lane b: ring slot of bin b's open word at chunk start / after it
+    LANEVAR(uint32_t, slot0);                           // lane b: ring slot of bin b's open word before the pending chunks, ~0 if none
+    LANEVAR(uint32_t, dw);                              // drain: this lane's ring word between the two halves of a round
     MergeChunk c;
     uint32_t blank, has_v2v;
     // uniform (the same value in every wave)
@@ -429,6 +465,10 @@ struct Wave {
     uint32_t wL;                                        // first chunk of the pending ones that needs exact_chunk (or nwin)
     uint32_t nflush;                                    // drain: words to pop
     uint32_t too_big;
+#if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
+    uint32_t tacc[24];
+    uint64_t tlast;
+#endif
 };
 
 // ==========================================================================================
@@ -471,7 +511,15 @@ ICER_DEV void wave_init(Shared &s, const UnitArgs &a, Wave &R, uint32_t w)
         LV(R.cb) = (lane >= 8) ? (uint32_t)s.tab.cand_bin[lane] : 0u;
         LV(R.ce) = LV(R.cb) ? (uint32_t)s.tab.node_c[LV(R.cb) & 7u][s.tab.cand_node[lane]] & 7u : 0u;
     }
+    FOR_LANES
+    {
+        for (uint32_t i = w * 64u + (uint32_t)lane; i < kPhysRing / 2u; i += 64u * kWgWaves) reinterpret_cast<uint32_t *>(s.ring)[i] = 0u;
+    }
     R.tail = 0; R.popped = 0; R.bitpos = 0; R.flushed_words = 0; R.too_big = 0;
+#if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
+    for (int i_ = 0; i_ < 24; i_++) R.tacc[i_] = 0;
+    R.tlast = __builtin_amdgcn_s_memtime();
+#endif
     fetch_window(a, R, w * 64u, dq, dr);
 }
 
@@ -1037,7 +1085,7 @@ ICER_DEV void phase_de(Shared &s, Wave &R, uint32_t w, uint32_t wbase)
                     const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
                     const uint32_t bit_ = ((EV) >> 5) & 1u;                                                     \
                     FL = (kb_ == 0u ? 1u : 0u) | ((bit_ || kb_ + 1u == m) ? 2u : 0u);                           \
-                    WD = bit_ ? golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);               \
+                    WD = bit_ ? wg_golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);               \
                     const uint32_t before_ = cnt_lt_own(m1_, m2_, lane, (SLOT));                                \
                     if (before_ + 1u == (uint32_t)(popc64(m1_) + popc64(m2_))) KA = (FL & 2u) ? 0u : kb_ + 1u;  \
                 }
@@ -1111,7 +1159,7 @@ ICER_DEV void first_ends(Shared &s, Wave &R, uint32_t w)
 ICER_DEV void phase_f_scan(Shared &s, Wave &R, uint32_t w, uint32_t wbase, uint32_t nwin)
 {
     DECL_LANE;
-    FOR_LANES { LV(R.slot) = lane < 17 ? (uint32_t)s.bin_slot[lane] : ~0u; }
+    FOR_LANES { LV(R.slot) = LV(R.slot0); }
     uint32_t run = R.tail;
     for (uint32_t v = wbase; v < w && v < nwin; v++) {
         const WaveLds &p = s.wl[v];
@@ -1137,7 +1185,10 @@ ICER_DEV bool flush_possible(Shared &s, Wave &R, uint32_t wbase, uint32_t nwin, 
     uint32_t total = 0;
     for (uint32_t v = wbase; v < nwin; v++) total += s.wl[v].nst;
     *total_out = total;
-    const uint64_t open = BALLOT(lane < 17 && s.bin_slot[lane] >= 0 && R.tail + total - (uint32_t)s.bin_slot[lane] > (uint32_t)kRingWords);
+    // (the bins' open slots are taken into registers here: the commit that follows a barrier later overwrites them
+    // while other waves still need the old values)
+    FOR_LANES { LV(R.slot0) = lane < 17 ? (uint32_t)s.bin_slot[lane] : ~0u; }
+    const uint64_t open = BALLOT(lane < 17 && (int32_t)LV(R.slot0) >= 0 && R.tail + total - LV(R.slot0) > (uint32_t)kRingWords);
     return open != 0ull;
 }
 
@@ -1149,9 +1200,9 @@ ICER_DEV uint32_t flush_chunk(Shared &s, Wave &R, uint32_t wbase, uint32_t nwin,
     FOR_LANES
     {
         LV(cand) = nwin;
-        if (lane < 17 && s.bin_slot[lane] >= 0) {
+        if (lane < 17 && (int32_t)LV(R.slot0) >= 0) {
             // the word start that would allocate slot s_b + 2048 is the trig-th start of the pending chunks
-            const uint32_t trig = (uint32_t)s.bin_slot[lane] + (uint32_t)kRingWords - R.tail;
+            const uint32_t trig = LV(R.slot0) + (uint32_t)kRingWords - R.tail;
             if (trig < total) {
                 uint32_t cum = 0, wT = nwin, wE = nwin;
                 for (uint32_t v = wbase; v < nwin; v++) {
@@ -1186,8 +1237,7 @@ ICER_DEV void commit_bins(Shared &s, MergeChunk &c, uint32_t tail)
     }
 }
 
-// ring stores for the chunk's events at positions [lo, hi): open markers of the words that start there, finished
-// words of the ones that end there (slot of a word = tail0 + number of word starts before its first event, E2).
+// ring stores for the chunk's events at positions [lo, hi): the finished words of the code words that end there (slot of a word = tail0 + number of word starts before its first event, E2).
 // `bslot` = the bins' open slots at chunk start.
 ICER_DEV void commit_range(Shared &s, MergeChunk &c, const int32_t *bslot, uint32_t tail0, uint32_t lo, uint32_t hi)
 {
@@ -1196,20 +1246,13 @@ ICER_DEV void commit_range(Shared &s, MergeChunk &c, const int32_t *bslot, uint3
     FOR_LANES
     {
         const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
-        if ((LV(c.fl1) & 1u) && p1 >= lo && p1 < hi) RING_ST(tail0 + cnt_lt_own(S1, S2, lane, 0u), (LV(c.ev1) & 31u));
-        if ((LV(c.fl2) & 1u) && p2 >= lo && p2 < hi) RING_ST(tail0 + cnt_lt_own(S1, S2, lane, 1u), (LV(c.ev2) & 31u));
-    }
-    WAVE_SYNC();
-    FOR_LANES
-    {
-        const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
         if ((LV(c.fl1) & 2u) && p1 >= lo && p1 < hi) {
             const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)bslot[LV(c.ev1) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp1)));
-            RING_ST(slot, LV(c.wd1));
+            WRING_ST(slot, LV(c.wd1));
         }
         if ((LV(c.fl2) & 2u) && p2 >= lo && p2 < hi) {
             const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)bslot[LV(c.ev2) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp2)));
-            RING_ST(slot, LV(c.wd2));
+            WRING_ST(slot, LV(c.wd2));
         }
     }
     WAVE_SYNC();
@@ -1249,7 +1292,10 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
         if (alloc - s.popped == (uint32_t)kRingWords) {
             // still full: the head word is open.  Its bin, and that bin's state just before P:
             const uint32_t head = s.popped;
-            const uint32_t hb = RING_LD(head) & 31u;
+            // (the ring holds kRingWords words and a chunk opens at most 128: the head was open before this chunk)
+            const uint32_t hb = (uint32_t)ffs64(BALLOT(lane >= 1 && lane < kNumBins && s.bin_slot[lane] == (int32_t)head));
+            WG_ASSERT(hb >= 1u && hb < (uint32_t)kNumBins);
+            WG_STAT(3);
             const uint64_t E1 = BALLOT((LV(c.ev1) & 0x9Fu) == (0x80u | hb)), E2 = BALLOT((LV(c.ev2) & 0x9Fu) == (0x80u | hb));
             const int x = last_lt(S1 & E1, S2 & E2, P);                           // first event of the open word, -1: carried in
             const uint32_t lo = x < 0 ? 0u : (uint32_t)x;
@@ -1259,7 +1305,7 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
             uint32_t word;
             if (hb >= 8u) {
                 hacc += (uint32_t)(popc64(R1) + popc64(R2));                       // all zeros, or the word would have ended
-                word = (hacc == (uint32_t)s.tab.gm[hb] - 1u) ? (kWordDone | (1u << 11) | 1u) : golomb_word(s.tab, (int)hb, hacc);
+                word = (hacc == (uint32_t)s.tab.gm[hb] - 1u) ? (kWordDone | (1u << 11) | 1u) : wg_golomb_word(s.tab, (int)hb, hacc);
             } else {
                 while (R1 | R2) {
                     uint32_t q, v;
@@ -1274,7 +1320,7 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
             }
             FOR_LANES
             {
-                if (lane == 0) { RING_ST(head, word); s.bin_slot[hb] = -1; }
+                if (lane == 0) { WRING_ST(head, word); s.bin_slot[hb] = -1; }
             }
             WAVE_SYNC();
             // bin hb starts afresh at P: replay its remaining events of the chunk
@@ -1290,7 +1336,7 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
                 uint32_t wd = 0;
                 bool close = false;
                 if (hb >= 8u) {
-                    if (bit) { wd = golomb_word(s.tab, (int)hb, acc); close = true; }
+                    if (bit) { wd = wg_golomb_word(s.tab, (int)hb, acc); close = true; }
                     else if (acc + 1u >= s.tab.gm[hb]) { wd = kWordDone | (1u << 11) | 1u; close = true; }
                     else acc++;
                 } else if (hb >= 1u) {
@@ -1345,32 +1391,43 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
     uint32_t windows = 0;
     for (uint32_t j0 = 0; j0 < nchunks; j0 += kWgWaves, windows++) {
         const uint32_t nwin = nchunks - j0 < kWgWaves ? nchunks - j0 : kWgWaves;
+        WG_STAT(0);
         // progressive mode: has the byte quota been used up by units of higher priority in the meantime?
         const bool check_stop = a.early_quota && (windows & 15u) == 15u;
         WG_EACH_WAVE
+            WG_TICK(0)
             if (check_stop && w == 0 && quota_already_spent(a)) { FOR_LANES { if (lane == 0) s.stop = 1u; } }
             phase_a(s, a, R, w, j0 + w);
+            WG_TICK(1)
         WG_BARRIER
         if (s.stop) return kUnitStopped;
         WG_EACH_WAVE
+            WG_TICK(0)
             phase_b(s, R, w);
+            WG_TICK(2)
             phase_c(s, R, w);
+            WG_TICK(3)
         WG_BARRIER
         for (uint32_t wbase = 0; wbase < nwin;) {
             WG_EACH_WAVE
+                WG_TICK(0)
                 if (w >= wbase) phase_de(s, R, w, wbase);
+                WG_TICK(4)
             WG_BARRIER
             bool detailed = false;
             WG_EACH_WAVE
+                WG_TICK(0)
                 uint32_t total;
                 const bool fp = flush_possible(s, R, wbase, nwin, &total);
                 R.nflush = total;
                 R.wL = nwin;
                 detailed = fp;
                 if (fp && w >= wbase && w < nwin) first_ends(s, R, w);
+                WG_TICK(5)
             WG_BARRIER
             WG_EACH_WAVE
-                if (detailed) R.wL = flush_chunk(s, R, wbase, nwin, R.nflush);
+                WG_TICK(0)
+                if (detailed) { R.wL = flush_chunk(s, R, wbase, nwin, R.nflush); if (w == 0) WG_STAT(1); }
                 const uint32_t wL = R.wL;
                 phase_f_scan(s, R, w, wbase, wL);
                 if (w >= wbase && w < wL) {
@@ -1390,10 +1447,12 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                 }
                 // (uniform) allocation count after the committed chunks
                 { uint32_t t = R.tail; for (uint32_t v = wbase; v < wL; v++) t += s.wl[v].nst; R.tail = t; }
+                WG_TICK(6)
             WG_BARRIER
             // ---- drain: everything before the oldest open word is finished ------------------------------------
             for (;;) {
                 WG_EACH_WAVE
+                    WG_TICK(0)
                     LANEVAR(uint32_t, bs);
                     FOR_LANES { LV(bs) = (lane >= 1 && lane < 17) ? (uint32_t)s.bin_slot[lane] : ~0u; }
                     uint32_t head = R.tail;
@@ -1403,18 +1462,20 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     R.nflush = n;
                     // this wave's 64 ring words: lengths, their sum
                     LANEVAR(uint32_t, wd);
-                    FOR_LANES { LV(wd) = (w * 64u + (uint32_t)lane) < n ? RING_LD(R.popped + w * 64u + (uint32_t)lane) : 0u; WG_ASSERT((w * 64u + (uint32_t)lane) >= n || (LV(wd) & kWordDone)); }
+                    FOR_LANES { LV(wd) = (w * 64u + (uint32_t)lane) < n ? WRING_LD(R.popped + w * 64u + (uint32_t)lane) : 0u; WG_ASSERT((w * 64u + (uint32_t)lane) >= n || (LV(wd) & kWordDone)); }
                     const uint64_t L0 = BALLOT(LV(wd) & (1u << 11)), L1 = BALLOT(LV(wd) & (2u << 11)), L2 = BALLOT(LV(wd) & (4u << 11)), L3 = BALLOT(LV(wd) & (8u << 11));
                     FOR_LANES { if (lane == 0) s.wl[w].segtot = (uint32_t)(popc64(L0) + 2 * popc64(L1) + 4 * popc64(L2) + 8 * popc64(L3)); }
                     // (kept for the second half)
-                    FOR_LANES { LV(R.c.sp1) = LV(wd); }
+                    FOR_LANES { LV(R.dw) = LV(wd); }
+                    WG_TICK(7)
                 WG_BARRIER
                 const uint32_t n = WG_UNIFORM(nflush);
                 WG_EACH_WAVE
+                    WG_TICK(0)
                     uint32_t before = 0, total = 0;
                     for (uint32_t v = 0; v < kWgWaves; v++) { const uint32_t tsum = s.wl[v].segtot; if (v < w) before += tsum; total += tsum; }
                     LANEVAR(uint32_t, wd);
-                    FOR_LANES { LV(wd) = LV(R.c.sp1); }
+                    FOR_LANES { LV(wd) = LV(R.dw); if ((w * 64u + (uint32_t)lane) < n) WRING_ST(R.popped + w * 64u + (uint32_t)lane, 0u); }
                     const uint64_t L0 = BALLOT(LV(wd) & (1u << 11)), L1 = BALLOT(LV(wd) & (2u << 11)), L2 = BALLOT(LV(wd) & (4u << 11)), L3 = BALLOT(LV(wd) & (8u << 11));
                     FOR_LANES
                     {
@@ -1429,9 +1490,11 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     }
                     R.bitpos += total;
                     R.popped += n;
+                    WG_TICK(8)
                 WG_BARRIER
                 // complete 32-bit words of the bit stage -> HBM (every word is stored exactly once)
                 WG_EACH_WAVE
+                    WG_TICK(0)
                     const uint32_t first = R.flushed_words, last = R.bitpos >> 5;
                     const bool fits = last <= a.cap_words;
                     const uint32_t stop = fits ? last : a.cap_words;
@@ -1446,6 +1509,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     R.flushed_words = last;
                     // a unit whose complete bytes reach the capacity can never fit (see P3 in DESIGN.md)
                     if (!(fits && (R.bitpos >> 3) < a.cap_words * 4u)) R.too_big = 1u;
+                    WG_TICK(9)
                 WG_BARRIER
                 if (WG_UNIFORM(too_big)) return kUnitTooBig;
                 if (n < 64u * kWgWaves) break;
@@ -1454,14 +1518,17 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
             if (wL < nwin) {
                 // ---- the chunk in which a word start may find the ring full: its wave alone -------------------
                 WG_EACH_WAVE
+                    WG_TICK(0)
                     if (w == wL) {
                         FOR_LANES { if (lane == 0) { s.alloc = R.tail; s.popped = R.popped; s.bitpos = R.bitpos; s.flushed_words = R.flushed_words; } }
                         WAVE_SYNC();
+                        WG_STAT(2);
                         exact_chunk(s, R.c, R.tail);
                         const uint32_t nst = (uint32_t)(popc64(R.c.S1) + popc64(R.c.S2));
                         const bool ok = flush_stage(s, a, false);
                         FOR_LANES { if (lane == 0) { s.alloc = R.tail + nst; if (!ok) s.stop = 2u; } }
                     }
+                    WG_TICK(10)
                 WG_BARRIER
                 if (s.stop == 2u) return kUnitTooBig;
                 WG_EACH_WAVE
@@ -1480,6 +1547,10 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
     WG_EACH_WAVE
         (void)R;
         WG_GLOBAL_RELEASE();
+#if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
+        R.tacc[11] = windows;
+        if (a.timers && lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd((unsigned long long *)&a.timers[i_], (unsigned long long)R.tacc[i_]);
+#endif
     WG_BARRIER
     WG_EACH_WAVE
         if (w == 0) {

@@ -12,6 +12,7 @@
 
 #include "assemble_core.hpp"
 #include "coder_core.hpp"
+#include "coder_wg.hpp"
 #include "dwt_core.hpp"
 #include "dwt_tile.hpp"
 #include "plan.hpp"
@@ -233,6 +234,88 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
 #ifdef ICER_PHASE_TIMERS
         if (trace && (threadIdx.x & 63) == 0) trace[1] = wall_clock64();
 #endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------ coder (workgroup windows)
+// One workgroup of wg::kWgWaves wavefronts = one coding unit of one frame; the unit is coded in windows of kWgWaves
+// chunks of 64 pixels, one chunk per wave, the waves meeting at workgroup barriers only (coder_wg.hpp): no wave ever
+// waits on a flag, so there is no hand-off that could stall.  grid = (units, frames), block = 64 * kWgWaves, LDS =
+// sizeof(wg::Shared) (dynamic: above the 64 KiB static limit).
+__global__ void __launch_bounds__(64 * wg::kWgWaves)
+code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
+                     const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
+                     const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
+                     const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
+                     size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
+                     uint32_t *__restrict__ done_bytes, uint64_t early_quota)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
+    wg::Shared &s = *reinterpret_cast<wg::Shared *>(wg_lds);
+    const uint32_t frame = blockIdx.y;
+    const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
+    const uint32_t wave = threadIdx.x >> 6;
+    if (frame_skip[frame]) {                      // DWT / mean overflow: the reference emits nothing
+        if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
+        return;
+    }
+    const UnitDesc u = units[ui];
+    uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
+    wg::UnitArgs a;
+    a.seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
+    a.stride = img_w;
+    a.w = u.w; a.h = u.h;
+    a.subband = (int)u.subband; a.lsb = (int)u.lsb;
+    a.out_words = slot_words + kHeaderBytes / 4;
+    a.cap_words = u.cap_words;
+    a.done_bytes = early_quota ? done_bytes + (size_t)frame * n_units : nullptr;
+    a.prio_index = ui;
+    a.early_quota = early_quota;
+    // profiling build: per-phase cycle counters of the level-1 (largest) units, one row per bit plane
+    a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
+    {   // tables -> LDS
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
+        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * wg::kWgWaves) dst[i] = src[i];
+    }
+    if (wave == 0) {
+        wg::unit_state_init(s, a);
+        // progressive mode: a unit whose finished higher-priority predecessors have already used up the quota can not
+        // be in the stream (quota_already_spent)
+        if (early_quota && wg::quota_already_spent(a) && threadIdx.x == 0) s.stop = 1u;
+    }
+    if (wave == 1) build_crc_table(s);
+    __syncthreads();
+    uint32_t bits;
+    if (s.stop) bits = wg::kUnitStopped;
+    else {
+        wg::Wave regs;
+        bits = wg::code_unit_wg(s, a, regs);
+    }
+    const bool stopped = bits == wg::kUnitStopped;
+    if (stopped) bits = 0;                        // the quota cut lies before this unit
+    if (wave == 0) {
+        if (bits != kUnitTooBig) {
+            // the payload words were stored by every wave of the workgroup (released before the last barrier): the CRC
+            // pass below must see them
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            FinishArgs f;
+            f.slot_words = slot_words;
+            f.bits = bits;
+            f.mean = means[(size_t)frame * channels + u.chan];
+            f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
+            f.image_w = img_w; f.image_h = img_h;
+            finish_unit_wave(s, f);
+        }
+        if (threadIdx.x == 0) {
+            unit_bits[(size_t)frame * n_units + ui] = bits;
+            if (early_quota && !stopped) {
+                // a unit that outgrew a slot sized by the quota can not fit; one that outgrew the bits-per-pixel bound is
+                // unknown (the batch is redone with larger slots if it matters)
+                const uint32_t d = bits == kUnitTooBig ? (u.cap_is_bound ? 0u : ~0u) : kHeaderBytes + ((bits + 7u) >> 3);
+                __hip_atomic_store(&done_bytes[(size_t)frame * n_units + ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

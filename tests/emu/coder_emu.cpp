@@ -5,6 +5,7 @@
 #define ICER_WAVE_EMU 1
 #include "../../icer_compression_amd/csrc/assemble_core.hpp"
 #include "../../icer_compression_amd/csrc/coder_core.hpp"
+#include "../../icer_compression_amd/csrc/coder_wg.hpp"
 #include "../../icer_compression_amd/csrc/dwt_core.hpp"
 #include "../../icer_compression_amd/csrc/dwt_tile.hpp"
 #include "../../icer_compression_amd/csrc/plan.hpp"
@@ -15,6 +16,25 @@
 using namespace icer;
 
 static CoderShared g_sh;
+// which coder the whole-frame pipeline below uses: 0 = the eight-wave pipeline (coder_core.hpp), 1 = the workgroup-window
+// coder (coder_wg.hpp; `order`: 0 the waves run a region in order, 1 backwards, >= 2 shuffled)
+static int g_use_wg = 0;
+static wg::Shared g_wsh;
+extern "C" void emu_set_coder(int use_wg, unsigned order) { g_use_wg = use_wg; wg::g_wg_order = order; wg::g_wg_order_state = order; }
+extern "C" int emu_wg_assert_line(void) { const int l = wg::g_wg_assert_line; wg::g_wg_assert_line = 0; return l; }
+static uint32_t wg_unit(const UnitArgs &a0)
+{
+    memset(&g_wsh, 0xA5, sizeof g_wsh);
+    build_coder_tables(&g_wsh.tab);
+    wg::UnitArgs a;
+    a.seg = a0.seg; a.stride = a0.stride; a.w = a0.w; a.h = a0.h; a.subband = a0.subband; a.lsb = a0.lsb;
+    a.out_words = a0.out_words; a.cap_words = a0.cap_words;
+    a.done_bytes = nullptr; a.prio_index = 0; a.early_quota = 0; a.timers = nullptr;
+    static wg::Wave regs[ICER_WG_WAVES];
+    memset(regs, 0x5A, sizeof regs);
+    wg::unit_state_init(g_wsh, a);
+    return wg::code_unit_wg(g_wsh, a, regs);
+}
 unsigned long long g_emu_chunks[2] = {0, 0};
 extern "C" void emu_chunk_stats(unsigned long long *out, int reset) { out[0] = g_emu_chunks[0]; out[1] = g_emu_chunks[1]; if (reset) g_emu_chunks[0] = g_emu_chunks[1] = 0; }
 
@@ -156,7 +176,7 @@ extern "C" int emu_compress_bits(uint16_t *const planes[], int channels, size_t 
         a.out_words = slot_words + kHeaderBytes / 4;
         a.cap_words = u.cap_words;
         a.timers = nullptr;
-        const uint32_t bits = code_unit_emu(g_sh, a);
+        const uint32_t bits = g_use_wg ? wg_unit(a) : code_unit_emu(g_sh, a);
         if (bits != kUnitTooBig) {
             FinishArgs f;
             f.slot_words = slot_words; f.bits = bits; f.mean = means[u.chan];

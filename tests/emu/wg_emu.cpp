@@ -15,6 +15,10 @@ using namespace icer;
 static wg::Shared g_sh;
 
 extern "C" int emu_wg_waves(void) { return (int)wg::kWgWaves; }
+// 0: the waves run every region in order, 1: backwards, >= 2: shuffled (seed)
+extern "C" void emu_wg_set_order(unsigned order) { wg::g_wg_order = order; wg::g_wg_order_state = order; }
+extern "C" void emu_wg_stats(unsigned long long *out, int reset) { for (int i = 0; i < 8; i++) { out[i] = wg::g_wg_stats[i]; if (reset) wg::g_wg_stats[i] = 0; } }
+extern "C" int emu_wg_assert_line(void) { const int l = wg::g_wg_assert_line; wg::g_wg_assert_line = 0; return l; }
 
 // one coding unit; returns the payload length in bits, -5 slot too small, -3 stopped (progressive mode)
 extern "C" long emu_wg_code_unit(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
@@ -29,7 +33,7 @@ extern "C" long emu_wg_code_unit(const uint16_t *seg, size_t w, size_t h, size_t
     std::vector<uint32_t> words(a.cap_words + 1, 0);
     a.out_words = words.data();
     uint32_t flag = stop_flag ? 1u : 0u;
-    a.done_bytes = &flag; a.prio_index = 0; a.early_quota = stop_flag ? 1u : 0u;
+    a.done_bytes = &flag; a.prio_index = 0; a.early_quota = stop_flag ? 1u : 0u; a.timers = nullptr;
     static wg::Wave regs[ICER_WG_WAVES];
     memset(regs, 0x5A, sizeof regs);
     { wg::Wave &R = regs[0]; (void)R; wg::unit_state_init(g_sh, a); }
