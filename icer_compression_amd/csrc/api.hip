@@ -84,6 +84,7 @@ struct icerx_encoder {
     DevBuf<uint32_t> work_order, final_order, unit_bits, done_bytes;
     DevBuf<uint64_t> final_off;
     DevBuf<uint8_t> slots;
+    DevBuf<uint8_t> sig;                // chunk tables (chunk_sig_kernel), max_frames * plan.sig_bytes
     DevBuf<CoderTables> tables;
     // host-API staging
     DevBuf<uint16_t> in;
@@ -236,11 +237,18 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
+    if (e->coder_wg) {
+        uint32_t max_chunks = 1;
+        for (const UnitDesc &u : e->plan.units) max_chunks = std::max(max_chunks, (u.w * u.h + 63u) / 64u);
+        hipLaunchKernelGGL(chunk_sig_kernel, dim3((max_chunks + 63u) / 64u, n_units, n_frames), dim3(256), 0, st,
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, skip, e->sig.p, e->plan.sig_bytes);
+    }
     if (e->coder_wg)
         hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
+                           e->sig.p, e->plan.sig_bytes);
     else
     hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64 * kUnitWaves), 0, st,
                        reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
@@ -323,7 +331,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
-        e->done_bytes.ensure((size_t)max_frames * n_units) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -348,7 +356,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
-    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);

@@ -60,6 +60,7 @@
 // (the order in which the waves run a region must not matter: g_wg_order = 1 runs them backwards, >= 2 shuffled)
 #define WG_EACH_WAVE for (uint32_t wi_ = 0; wi_ < (uint32_t)ICER_WG_WAVES; ++wi_) { const uint32_t w = icer::wg::wg_wave_order(wi_); auto &R = regs[w];
 #define WG_BARRIER }
+#define WG_BARRIER_NONE }
 #define WG_UNIFORM(field) (regs[0].field)
 #define WG_ASSERT(x) do { if (!(x)) { wg_assert_fail(#x, __LINE__); } } while (0)
 #define WG_GLOBAL_RELEASE()
@@ -68,6 +69,7 @@
 #define WG_REGS_PARAM(T, name) T &name
 #define WG_EACH_WAVE { const uint32_t w = threadIdx.x >> 6; auto &R = regs;
 #define WG_BARRIER } __syncthreads();
+#define WG_BARRIER_NONE }                     // closes a region that only touches this wave's registers
 #define WG_UNIFORM(field) (regs.field)
 #define WG_ASSERT(x)
 #define WG_STAT(i)
@@ -106,6 +108,7 @@ constexpr uint32_t kWgWaves = ICER_WG_WAVES;
 static_assert(kWgWaves * 128u <= (uint32_t)kRingWords, "a window must not be able to open more words than the ring holds (E5 test)");
 constexpr uint32_t kPhysRing = 2u * kRingWords;     // physical ring entries: ring occupancy + one window of new words
 constexpr uint32_t kStageWords = 2048;              // LDS bit stage (circular, 32-bit words): one full drain of the physical ring
+constexpr uint32_t kBlankRunMin = 2, kBlankRunMax = 32;   // blank chunks coded in closed form at a time (blank_run)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kUnitStopped = 0xFFFFFFFDu;      // progressive mode: the quota cut lies before this unit
 
@@ -127,6 +130,7 @@ struct UnitArgs {
     uint32_t prio_index;
     uint64_t early_quota;
     uint64_t *timers;           // profiling build: per-phase cycle counters (null otherwise)
+    const uint8_t *sig;         // chunk table of the unit's family: chunk j is blank at every plane >= sig[j] (chunk_blank_plane); null: none
 };
 
 struct WaveLds {                // per-wave LDS: the chunk's summaries and scratch
@@ -156,7 +160,7 @@ struct Shared {
     uint32_t crc_tab[256];
     WaveLds wl[kWgWaves];
     // coder state as of the first chunk that is not committed yet
-    uint32_t ctot[20], czer[20];    // adaptive counts (icer_context_model_typedef, icer.h:195-199), as of the window start
+    uint32_t ctot[2][20], czer[2][20];  // adaptive counts (icer_context_model_typedef, icer.h:195-199) as of the window start; [window parity]
     uint32_t bin_state[20];         // as WaveLds::binst (bits 0..7 unused)
     int32_t bin_slot[20];           // ring slot (allocation count) of the bin's open word, -1 if none
     uint8_t ctx_tab[48];            // context table of the unit's subband (phase A)
@@ -165,6 +169,7 @@ struct Shared {
     // works alone (exact_chunk, end of unit).
     uint32_t alloc, popped, bitpos, flushed_words;
     uint32_t stop;                  // progressive mode: the unit was abandoned
+    uint32_t run_tail[2];           // blank_run: allocation count after the run, [counts copy the run started from]
 };
 
 // Progressive mode.  The stream keeps units in priority order until the first one that does not fit the byte quota
@@ -425,6 +430,48 @@ ICER_DEV bool flush_stage(Shared &s, const UnitArgs &a, bool final_partial)
 }
 
 // ==========================================================================================
+// chunk tables
+// ==========================================================================================
+// A chunk is BLANK at a bit plane when its 64 pixels are and stay insignificant there and have no significant
+// neighbour: 64 zero events of context 0, no sign event (icer_compress_bitplane_uint16, icer_context_modeller.c:312-457:
+// category 0, bit 0, h = v = d = 0).  With pixel magnitude m that is  m >> lsb == 0  for the pixel and its W, N, NW, NE
+// neighbours (judged at this plane) and  m >> (lsb + 1) == 0  for E, S, SW, SE (judged one plane up), so a chunk is blank
+// at every plane >= T and at none below, T = max(bitlen(pixels, W, N, NW, NE), bitlen(E, S, SW, SE) - 1); T = 255 for a
+// chunk with fewer than 64 pixels (never blank).  One wavefront, chunk j of the segment; wave-uniform result.  It
+// depends on the coefficients only, so it is computed once per (channel, level, subband, segment) for all bit planes.
+ICER_DEV uint32_t chunk_blank_plane(const uint16_t *seg, uint32_t stride, uint32_t sw, uint32_t sh, uint32_t j)
+{
+    DECL_LANE;
+    const uint32_t npix = sw * sh;
+    LANEVAR(uint32_t, t);
+    FOR_LANES
+    {
+        const uint32_t np = j * 64u + (uint32_t)lane;
+        const bool in_ = np < npix;
+        const uint32_t r_ = in_ ? np / sw : 0u, c_ = in_ ? np - r_ * sw : 0u;
+        const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < sw, hasN_ = r_ > 0, hasS_ = r_ + 1 < sh;
+        const uint32_t cW_ = hasW_ ? c_ - 1u : c_, cE_ = hasE_ ? c_ + 1u : c_;
+        const uint16_t *pC_ = seg + (size_t)r_ * stride;
+        const uint16_t *pN_ = hasN_ ? pC_ - stride : pC_, *pS_ = hasS_ ? pC_ + stride : pC_;
+        // (clamped positions repeat a pixel that is in the right group already, or, for E / S, one of the other group:
+        // those are masked)
+        uint32_t a_ = pC_[c_] & 0x7FFFu;
+        a_ |= pC_[cW_] & 0x7FFFu;                                   // OR keeps the bit length of the maximum
+        a_ |= pN_[c_] & 0x7FFFu; a_ |= pN_[cW_] & 0x7FFFu;
+        a_ |= (hasN_ && hasE_) ? (pN_[cE_] & 0x7FFFu) : 0u;
+        uint32_t b_ = hasE_ ? (pC_[cE_] & 0x7FFFu) : 0u;
+        b_ |= hasS_ ? (pS_[c_] & 0x7FFFu) : 0u;
+        b_ |= (hasS_ && hasW_) ? (pS_[cW_] & 0x7FFFu) : 0u;
+        b_ |= (hasS_ && hasE_) ? (pS_[cE_] & 0x7FFFu) : 0u;
+        const uint32_t la_ = 32u - (uint32_t)clz32(a_), lb_ = 32u - (uint32_t)clz32(b_);
+        LV(t) = in_ ? (la_ > lb_ - (lb_ ? 1u : 0u) ? la_ : lb_ - (lb_ ? 1u : 0u)) : 255u;
+    }
+    uint32_t tmax;
+    WAVE_MAX(tmax, t)
+    return tmax;
+}
+
+// ==========================================================================================
 // per-wave register state
 // ==========================================================================================
 struct MergeChunk {             // one chunk's events with their code-word roles, one pixel per lane
@@ -441,7 +488,7 @@ struct Wave {
     LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
     LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
     LANEVAR(uint32_t, has);                             // which neighbours exist: bit 0 W, 1 E, 2 N, 3 S
-    LANEVAR(uint32_t, row); LANEVAR(uint32_t, col);     // raster coordinates of this lane's pixel in the next window
+    uint32_t pf;                                        // the chunk these belong to (~0: none)
     // phase A -> B: per pixel, word 1 the magnitude-bit event, word 2 the sign event:
     //   bits 0..7   0x80 | bit << 5 | context (31 = uncoded), 0 = none; the sign event's bit is the agreement bit
     //   bits 8..15  rank of the event among the chunk's events of the same context (coding order)
@@ -474,15 +521,16 @@ struct Wave {
 // ==========================================================================================
 // phase A: pixels -> events
 // ==========================================================================================
-// fetch the 3x3 windows of this lane's pixel (R.row, R.col); then advance to the same lane `step` pixels further on
-ICER_DEV void fetch_window(const UnitArgs &a, Wave &R, uint32_t base, uint32_t dq, uint32_t dr)
+// fetch the 3x3 windows of the pixels of chunk j (one pixel per lane) into the prefetch registers; R.pf = j
+ICER_DEV void fetch_window(const UnitArgs &a, Wave &R, uint32_t j)
 {
     DECL_LANE;
     const uint32_t npix = a.w * a.h;
     FOR_LANES
     {
-        const bool in_ = base + (uint32_t)lane < npix;
-        const uint32_t r_ = in_ ? LV(R.row) : 0u, c_ = in_ ? LV(R.col) : 0u;
+        const uint32_t np = j * 64u + (uint32_t)lane;
+        const bool in_ = np < npix;
+        const uint32_t r_ = in_ ? np / a.w : 0u, c_ = in_ ? np - r_ * a.w : 0u;
         const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < a.w, hasN_ = r_ > 0, hasS_ = r_ + 1 < a.h;
         /* nine unconditional loads from clamped (always valid) positions, then selects: no divergent branches */
         const uint32_t cW_ = hasW_ ? c_ - 1u : c_, cE_ = hasE_ ? c_ + 1u : c_;
@@ -491,23 +539,24 @@ ICER_DEV void fetch_window(const UnitArgs &a, Wave &R, uint32_t base, uint32_t d
         LV(R.nC) = pC_[c_]; LV(R.nW) = pC_[cW_]; LV(R.nE) = pC_[cE_];
         LV(R.nN) = pN_[c_]; LV(R.nNW) = pN_[cW_]; LV(R.nNE) = pN_[cE_];
         LV(R.nS) = pS_[c_]; LV(R.nSW) = pS_[cW_]; LV(R.nSE) = pS_[cE_];
-        /* the loaded values are not touched before the next window needs them (the loads stay in flight meanwhile):
+        /* the loaded values are not touched before the chunk is processed (the loads stay in flight meanwhile):
          * which neighbours exist is kept as a mask and applied then */
         LV(R.has) = (hasW_ ? 1u : 0u) | (hasE_ ? 2u : 0u) | (hasN_ ? 4u : 0u) | (hasS_ ? 8u : 0u);
-        uint32_t nc_ = LV(R.col) + dr, nr_ = LV(R.row) + dq;
-        if (nc_ >= a.w) { nc_ -= a.w; nr_++; }
-        LV(R.col) = nc_; LV(R.row) = nr_;
     }
+    R.pf = j;
+}
+
+// is chunk j blank at this unit's bit plane, going by the family's chunk table (false without a table)
+ICER_DEV bool table_says_blank(const UnitArgs &a, uint32_t j)
+{
+    return a.sig != nullptr && (uint32_t)a.lsb >= (uint32_t)a.sig[j];
 }
 
 ICER_DEV void wave_init(Shared &s, const UnitArgs &a, Wave &R, uint32_t w)
 {
     DECL_LANE;
-    const uint32_t dq = (64u * kWgWaves) / a.w, dr = (64u * kWgWaves) % a.w;
     FOR_LANES
     {
-        const uint32_t np = w * 64u + (uint32_t)lane;
-        LV(R.row) = np / a.w; LV(R.col) = np - LV(R.row) * a.w;
         LV(R.cb) = (lane >= 8) ? (uint32_t)s.tab.cand_bin[lane] : 0u;
         LV(R.ce) = LV(R.cb) ? (uint32_t)s.tab.node_c[LV(R.cb) & 7u][s.tab.cand_node[lane]] & 7u : 0u;
     }
@@ -520,7 +569,9 @@ ICER_DEV void wave_init(Shared &s, const UnitArgs &a, Wave &R, uint32_t w)
     for (int i_ = 0; i_ < 24; i_++) R.tacc[i_] = 0;
     R.tlast = __builtin_amdgcn_s_memtime();
 #endif
-    fetch_window(a, R, w * 64u, dq, dr);
+    R.pf = ~0u;
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    if (w < nchunks && !table_says_blank(a, w)) fetch_window(a, R, w);
 }
 
 // state every wave relies on; run by ONE wave before the others start (a workgroup barrier follows)
@@ -531,7 +582,7 @@ ICER_DEV void unit_state_init(Shared &s, const UnitArgs &a)
     FOR_LANES
     {
         for (uint32_t i = (uint32_t)lane; i < kStageWords; i += 64) s.stage[i] = 0;
-        if (lane < 20) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.czer[lane] = 2u; s.ctot[lane] = 4u; }   // icer_context_modeller.c:607-613
+        if (lane < 20) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.czer[0][lane] = 2u; s.ctot[0][lane] = 4u; }   // icer_context_modeller.c:607-613
         // context of a not-yet-significant pixel by neighbour counts (icer_config.c:26-67): HH indexed
         // (h + v) * 5 + d, the other subbands (h * 3 + v) * 5 + d with h, v <= 2, d <= 4
         if (lane < 45) s.ctx_tab[lane] = (uint8_t)(is_hh ? ctx_hh((uint32_t)lane / 5u, (uint32_t)lane % 5u)
@@ -554,20 +605,31 @@ ICER_DEV void phase_a(Shared &s, const UnitArgs &a, Wave &R, uint32_t w, uint32_
     LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
     LANEVAR(uint32_t, cC); LANEVAR(uint32_t, cW); LANEVAR(uint32_t, cE); LANEVAR(uint32_t, cN); LANEVAR(uint32_t, cS);
     LANEVAR(uint32_t, cNW); LANEVAR(uint32_t, cNE); LANEVAR(uint32_t, cSW); LANEVAR(uint32_t, cSE);
+    // A chunk that the family's chunk table says is blank needs no pixels at all.
+    const bool tblank = base + 64u <= npix && table_says_blank(a, j);
+#ifdef ICER_WAVE_EMU
+    const bool tskip = false;                         // (tests: the pixels are always read and the chunk table is checked against them)
+#else
+    const bool tskip = tblank;
+#endif
+    if (!tskip && R.pf != j) fetch_window(a, R, j);                    // (not prefetched: the windows did not follow each other)
     FOR_LANES
     {
-        const uint32_t hm = LV(R.has);
+        const uint32_t hm = tskip ? 0u : LV(R.has);
         const bool hW = hm & 1u, hE = hm & 2u, hN = hm & 4u, hS = hm & 8u;
-        LV(cC) = LV(R.nC); LV(cW) = hW ? LV(R.nW) : 0u; LV(cE) = hE ? LV(R.nE) : 0u;
+        LV(cC) = tskip ? 0u : LV(R.nC); LV(cW) = hW ? LV(R.nW) : 0u; LV(cE) = hE ? LV(R.nE) : 0u;
         LV(cN) = hN ? LV(R.nN) : 0u; LV(cS) = hS ? LV(R.nS) : 0u;
         LV(cNW) = (hN && hW) ? LV(R.nNW) : 0u; LV(cNE) = (hN && hE) ? LV(R.nNE) : 0u;
         LV(cSW) = (hS && hW) ? LV(R.nSW) : 0u; LV(cSE) = (hS && hE) ? LV(R.nSE) : 0u;
     }
     // this wave's chunk of the next window is fetched while this one is processed
-    if (base + 64u * kWgWaves < npix) fetch_window(a, R, base + 64u * kWgWaves, (64u * kWgWaves) / a.w, (64u * kWgWaves) % a.w);
+    {
+        const uint32_t jn = j + kWgWaves;
+        if (jn * 64u < npix && !table_says_blank(a, jn)) fetch_window(a, R, jn);
+    }
 
     // ---- context formation (C1-C6) ------------------------------------------------------------
-    FOR_LANES
+    if (!tskip) FOR_LANES
     {
         const bool valid = base + (uint32_t)lane < npix;
         const uint32_t x = LV(cC), xW = LV(cW), xE = LV(cE), xN = LV(cN), xS = LV(cS);
@@ -615,7 +677,12 @@ ICER_DEV void phase_a(Shared &s, const UnitArgs &a, Wave &R, uint32_t w, uint32_
     // A blank chunk -- 64 pixels that are and stay insignificant with no significant neighbour, i.e. 64 zero events
     // of context 0 and no sign event; more than half of all chunks, the high planes mostly -- needs no matching:
     // the rank of an event is its lane number and so is the number of zeros before it.
+#ifdef ICER_WAVE_EMU
     const bool blank = BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull;
+    WG_ASSERT(a.sig == nullptr || blank == tblank);
+#else
+    const bool blank = tblank || BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull;
+#endif
     R.blank = blank ? 1u : 0u;
     if (blank) {
         FOR_LANES
@@ -670,15 +737,15 @@ ICER_DEV void phase_a(Shared &s, const UnitArgs &a, Wave &R, uint32_t w, uint32_
 // ==========================================================================================
 // phase B: adaptive counts (C5), probability fold + bin (E1)
 // ==========================================================================================
-ICER_DEV void phase_b(Shared &s, Wave &R, uint32_t w)
+ICER_DEV void phase_b(Shared &s, Wave &R, uint32_t w, uint32_t par)
 {
     DECL_LANE;
     LANEVAR(uint32_t, czer); LANEVAR(uint32_t, ctot);
     // counts at the start of this wave's chunk = counts at the window start advanced over the chunks before it
     FOR_LANES
     {
-        LV(ctot) = lane < 17 ? s.ctot[lane] : 0u;
-        LV(czer) = lane < 17 ? s.czer[lane] : 0u;
+        LV(ctot) = lane < 17 ? s.ctot[par][lane] : 0u;
+        LV(czer) = lane < 17 ? s.czer[par][lane] : 0u;
     }
     for (uint32_t v = 0; v < w; v++) {
         const WaveLds &p = s.wl[v];
@@ -1185,9 +1252,6 @@ ICER_DEV bool flush_possible(Shared &s, Wave &R, uint32_t wbase, uint32_t nwin, 
     uint32_t total = 0;
     for (uint32_t v = wbase; v < nwin; v++) total += s.wl[v].nst;
     *total_out = total;
-    // (the bins' open slots are taken into registers here: the commit that follows a barrier later overwrites them
-    // while other waves still need the old values)
-    FOR_LANES { LV(R.slot0) = lane < 17 ? (uint32_t)s.bin_slot[lane] : ~0u; }
     const uint64_t open = BALLOT(lane < 17 && (int32_t)LV(R.slot0) >= 0 && R.tail + total - LV(R.slot0) > (uint32_t)kRingWords);
     return open != 0ull;
 }
@@ -1381,6 +1445,130 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
 // Returns the payload length in bits, kUnitTooBig (payload slot too small) or kUnitStopped (progressive mode).
 // GPU: called by all kWgWaves * 64 threads of the workgroup, `regs` in registers; Shared initialised (unit_state_init,
 // tables) and a barrier passed.
+//
+// Barriers per window (no forced flush in sight): A | B C | D E | F | drain 1 | drain 2 -- the store of the drained
+// payload words (drain 3) is done by the next region that comes along.
+
+// phase F of one wave: the first pending chunk that may hit a full ring (detailed test only), ring slots, ring stores
+// of the chunks before it, the coder state they leave, the allocation count
+ICER_DEV void phase_f_commit(Shared &s, Wave &R, uint32_t w, uint32_t wbase, uint32_t nwin, bool detailed)
+{
+    DECL_LANE;
+    if (detailed) { R.wL = flush_chunk(s, R, wbase, nwin, R.nflush); if (w == 0) WG_STAT(1); }
+    const uint32_t wL = R.wL;
+    phase_f_scan(s, R, w, wbase, wL);
+    if (w >= wbase && w < wL) {
+        commit_range(s, R.c, s.wl[w].bslot, R.tailw, 0u, 128u);
+        if (w + 1u == wL) {
+            // the last committed chunk leaves the coder state (the next chunk's start state)
+            const MergeChunk &c = R.c;
+            FOR_LANES
+            {
+                if (lane >= 1 && lane < kNumBins) {
+                    const uint32_t op = LV(c.st) & 255u;
+                    s.bin_slot[lane] = op == 254u ? -1 : op < 128u ? (int32_t)(R.tailw + cnt_lt(c.S1, c.S2, op)) : (int32_t)LV(R.slot);
+                    s.bin_state[lane] = LV(c.st);
+                }
+            }
+        }
+    }
+    // (uniform) allocation count after the committed chunks
+    { uint32_t t = R.tail; for (uint32_t v = wbase; v < wL; v++) t += s.wl[v].nst; R.tail = t; }
+}
+
+// ---- runs of blank chunks in closed form ------------------------------------------------------------------
+// nev = 64 * (number of blank chunks) zero events of context 0 and nothing else.  Their bins follow from the context's
+// counts alone -- the estimate zero / total only rises from event to event, except for a slight drop where the counts are
+// halved (at most one bin down) --, so the events fall into a few SEGMENTS of one Golomb bin each, ending where the
+// estimate crosses the bin's upper cut-off or the counts are rescaled; and n zero events of a Golomb bin with parameter
+// m just fill up words of m zeros (code word "1", icer_encoding.c:68-72).  blank_run_ok: the closed form applies -- the
+// estimate is not folded, every bin on the way is a Golomb bin, and no word start can find the ring full whatever the
+// segments turn out to be (an upper bound of the words they open; also keeps the physical ring from overflowing, since
+// nothing is popped here).  Every wave evaluates it (wave-uniform, same answer).
+ICER_DEV bool blank_run_ok(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
+{
+    const uint32_t z = s.czer[par][0], t = s.ctot[par][0];
+    if (z < (t >> 1)) return false;
+    if (pick_bin(s.tab.binlut, z, t) < 9u) return false;
+    return R.tail + nev / 5u + 2u - R.popped <= (uint32_t)kRingWords;      // (5 = the smallest Golomb parameter)
+}
+
+// One wave; the others wait at the barrier that follows.  Leaves the counts in the OTHER copy (the caller flips `par`)
+// and the allocation count in Shared::run_tail[par].
+ICER_DEV void blank_run(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
+{
+    DECL_LANE;
+    uint32_t z = s.czer[par][0], t = s.ctot[par][0], tail = R.tail;
+    const uint32_t one_word = kWordDone | (1u << 11) | 1u;
+    while (nev) {
+        const uint32_t b = pick_bin(s.tab.binlut, z, t);
+        WG_ASSERT(b >= 8u && z >= (t >> 1));
+        uint32_t n = kRescaleCap - t;                 // events up to and including the one that triggers the rescale
+        if (b < 16u) {
+            // first event that sees the next bin: (z + i) * 65536 >= (t + i) * cut
+            const uint32_t cut = s.tab.cut[b], num = t * cut - (z << 16), den = 65536u - cut;
+            const uint32_t nb = (num + den - 1u) / den;
+            n = nb < n ? nb : n;
+        }
+        n = nev < n ? nev : n;
+        const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b];
+        uint32_t k = st_acc(s.bin_state[b]);
+        int32_t slot = s.bin_slot[b];
+        WAVE_SYNC();
+        uint32_t left = n;
+        if (slot < 0) { slot = (int32_t)tail++; k = 0; }                     // a word starts at the segment's first event
+        if (left >= m - k) {
+            left -= m - k;                                                   // the open word is filled up ...
+            const uint32_t q = (left * inv) >> 20;                           // ... then q whole words, each started by the next event
+            left -= q * m;
+            FOR_LANES
+            {
+                if (lane == 0) WRING_ST((uint32_t)slot, one_word);
+                for (uint32_t i = (uint32_t)lane; i < q; i += 64u) WRING_ST(tail + i, one_word);
+            }
+            tail += q;
+            if (left) { slot = (int32_t)tail++; k = left; }
+            else { slot = -1; k = 0; }
+        } else k += left;
+        FOR_LANES
+        {
+            if (lane == 0) { s.bin_state[b] = st_pack(0u, k, 0u); s.bin_slot[b] = slot; }
+        }
+        WAVE_SYNC();
+        z += n; t += n;
+        if (t >= kRescaleCap) { t = kRescaleCap / 2; if (z > kRescaleCap / 2) z >>= 1; }     // QUIRK C5
+        nev -= n;
+    }
+    // results go where nobody is reading: the other copy of the counts (a slower wave may still be evaluating
+    // blank_run_ok on this one) and this run's copy of the allocation count
+    FOR_LANES
+    {
+        if (lane < 17) { s.czer[par ^ 1u][lane] = lane ? s.czer[par][lane] : z; s.ctot[par ^ 1u][lane] = lane ? s.ctot[par][lane] : t; }
+        if (lane == 0) s.run_tail[par] = tail;
+    }
+    WAVE_SYNC();
+}
+
+// drain 3: complete 32-bit words of the bit stage -> HBM (every word is stored exactly once, by the whole workgroup)
+ICER_DEV void store_stage_words(Shared &s, const UnitArgs &a, Wave &R, uint32_t w)
+{
+    DECL_LANE;
+    const uint32_t first = R.flushed_words, last = R.bitpos >> 5;
+    const bool fits = last <= a.cap_words;
+    const uint32_t stop = fits ? last : a.cap_words;
+    FOR_LANES
+    {
+        for (uint32_t wi = first + w * 64u + (uint32_t)lane; wi < last; wi += 64u * kWgWaves) {
+            const uint32_t v = s.stage[wi & (kStageWords - 1)];
+            if (wi < stop) a.out_words[wi] = v;
+            s.stage[wi & (kStageWords - 1)] = 0;
+        }
+    }
+    R.flushed_words = last;
+    // a unit whose complete bytes reach the capacity can never fit (see P3 in DESIGN.md)
+    if (!(fits && (R.bitpos >> 3) < a.cap_words * 4u)) R.too_big = 1u;
+}
+
 ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave, regs))
 {
     DECL_LANE;
@@ -1388,22 +1576,64 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
     WG_EACH_WAVE
         wave_init(s, a, R, w);
     WG_BARRIER
-    uint32_t windows = 0;
-    for (uint32_t j0 = 0; j0 < nchunks; j0 += kWgWaves, windows++) {
-        const uint32_t nwin = nchunks - j0 < kWgWaves ? nchunks - j0 : kWgWaves;
-        WG_STAT(0);
+    uint32_t windows = 0, par = 0;
+    bool store_pending = false;          // (uniform) drained payload words are waiting in the bit stage
+    const uint32_t nfull = (a.w * a.h) / 64u;                    // (a last chunk with fewer than 64 pixels is never blank)
+    for (uint32_t j0 = 0; j0 < nchunks; windows++) {
         // progressive mode: has the byte quota been used up by units of higher priority in the meantime?
         const bool check_stop = a.early_quota && (windows & 15u) == 15u;
+        // ---- a run of blank chunks (chunk table) is coded in closed form by one wave
+        if (a.sig) {
+            uint32_t nb;
+            {
+                const uint64_t bm = BALLOT(j0 + (uint32_t)lane < nfull && (uint32_t)a.lsb >= (uint32_t)a.sig[j0 + (uint32_t)lane < nfull ? j0 + (uint32_t)lane : 0u]);
+                nb = (uint32_t)ffs64(~bm);
+            }
+            if (nb > kBlankRunMax) nb = kBlankRunMax;
+            bool ok = false;
+            WG_EACH_WAVE
+                (void)w;
+                ok = nb >= kBlankRunMin && blank_run_ok(s, R, par, nb * 64u);
+            WG_BARRIER_NONE
+            if (ok) {
+                WG_EACH_WAVE
+                    WG_TICK(0)
+                    if (w == 0) {
+                        if (check_stop && quota_already_spent(a)) { FOR_LANES { if (lane == 0) s.stop = 1u; } }
+                        blank_run(s, R, par, nb * 64u);
+                        WG_STAT(4);
+                    }
+                    WG_TICK(12)
+                WG_BARRIER
+                if (s.stop) return kUnitStopped;
+                WG_EACH_WAVE
+                    (void)w;
+                    R.tail = s.run_tail[par];
+                WG_BARRIER_NONE
+                par ^= 1u;
+                j0 += nb;
+                continue;
+            }
+        }
+        const uint32_t nwin = nchunks - j0 < kWgWaves ? nchunks - j0 : kWgWaves;
+        WG_STAT(0);
         WG_EACH_WAVE
             WG_TICK(0)
+            if (store_pending) store_stage_words(s, a, R, w);
+            WG_TICK(9)
             if (check_stop && w == 0 && quota_already_spent(a)) { FOR_LANES { if (lane == 0) s.stop = 1u; } }
             phase_a(s, a, R, w, j0 + w);
             WG_TICK(1)
         WG_BARRIER
+        store_pending = false;
         if (s.stop) return kUnitStopped;
+        if (WG_UNIFORM(too_big)) return kUnitTooBig;
         WG_EACH_WAVE
             WG_TICK(0)
-            phase_b(s, R, w);
+            phase_b(s, R, w, par);
+            // the adaptive counts after the window: where phase B of the next window starts (the other copy: waves are
+            // still reading this window's)
+            if (w + 1u == nwin) { FOR_LANES { if (lane < 17) { s.ctot[par ^ 1u][lane] = LV(R.ctot); s.czer[par ^ 1u][lane] = LV(R.czer); } } }
             WG_TICK(2)
             phase_c(s, R, w);
             WG_TICK(3)
@@ -1411,9 +1641,14 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
         for (uint32_t wbase = 0; wbase < nwin;) {
             WG_EACH_WAVE
                 WG_TICK(0)
+                // (the bins' open slots as of chunk wbase are taken into registers here: the commit two regions further on
+                // overwrites them while other waves may still be at the forced-flush test)
+                FOR_LANES { LV(R.slot0) = lane < 17 ? (uint32_t)s.bin_slot[lane] : ~0u; }
                 if (w >= wbase) phase_de(s, R, w, wbase);
                 WG_TICK(4)
             WG_BARRIER
+            // forced-flush test: quick (uniform, every wave computes it) -- only if it can not exclude a flush do the
+            // waves publish their first end events and meet once more
             bool detailed = false;
             WG_EACH_WAVE
                 WG_TICK(0)
@@ -1424,35 +1659,22 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                 detailed = fp;
                 if (fp && w >= wbase && w < nwin) first_ends(s, R, w);
                 WG_TICK(5)
-            WG_BARRIER
-            WG_EACH_WAVE
-                WG_TICK(0)
-                if (detailed) { R.wL = flush_chunk(s, R, wbase, nwin, R.nflush); if (w == 0) WG_STAT(1); }
-                const uint32_t wL = R.wL;
-                phase_f_scan(s, R, w, wbase, wL);
-                if (w >= wbase && w < wL) {
-                    commit_range(s, R.c, s.wl[w].bslot, R.tailw, 0u, 128u);
-                    if (w + 1u == wL) {
-                        // the last committed chunk leaves the coder state (the next chunk's start state)
-                        const MergeChunk &c = R.c;
-                        FOR_LANES
-                        {
-                            if (lane >= 1 && lane < kNumBins) {
-                                const uint32_t op = LV(c.st) & 255u;
-                                s.bin_slot[lane] = op == 254u ? -1 : op < 128u ? (int32_t)(R.tailw + cnt_lt(c.S1, c.S2, op)) : (int32_t)LV(R.slot);
-                                s.bin_state[lane] = LV(c.st);
-                            }
-                        }
-                    }
-                }
-                // (uniform) allocation count after the committed chunks
-                { uint32_t t = R.tail; for (uint32_t v = wbase; v < wL; v++) t += s.wl[v].nst; R.tail = t; }
+                if (!fp) phase_f_commit(s, R, w, wbase, nwin, false);
                 WG_TICK(6)
             WG_BARRIER
+            if (detailed) {
+                WG_EACH_WAVE
+                    WG_TICK(0)
+                    phase_f_commit(s, R, w, wbase, nwin, true);
+                    WG_TICK(6)
+                WG_BARRIER
+            }
+            const uint32_t wL = WG_UNIFORM(wL);
             // ---- drain: everything before the oldest open word is finished ------------------------------------
             for (;;) {
                 WG_EACH_WAVE
                     WG_TICK(0)
+                    if (store_pending) store_stage_words(s, a, R, w);          // (a second round: the stage must be free again)
                     LANEVAR(uint32_t, bs);
                     FOR_LANES { LV(bs) = (lane >= 1 && lane < 17) ? (uint32_t)s.bin_slot[lane] : ~0u; }
                     uint32_t head = R.tail;
@@ -1469,6 +1691,8 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     FOR_LANES { LV(R.dw) = LV(wd); }
                     WG_TICK(7)
                 WG_BARRIER
+                store_pending = false;
+                if (WG_UNIFORM(too_big)) return kUnitTooBig;
                 const uint32_t n = WG_UNIFORM(nflush);
                 WG_EACH_WAVE
                     WG_TICK(0)
@@ -1492,31 +1716,18 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     R.popped += n;
                     WG_TICK(8)
                 WG_BARRIER
-                // complete 32-bit words of the bit stage -> HBM (every word is stored exactly once)
-                WG_EACH_WAVE
-                    WG_TICK(0)
-                    const uint32_t first = R.flushed_words, last = R.bitpos >> 5;
-                    const bool fits = last <= a.cap_words;
-                    const uint32_t stop = fits ? last : a.cap_words;
-                    FOR_LANES
-                    {
-                        for (uint32_t wi = first + w * 64u + (uint32_t)lane; wi < last; wi += 64u * kWgWaves) {
-                            const uint32_t v = s.stage[wi & (kStageWords - 1)];
-                            if (wi < stop) a.out_words[wi] = v;
-                            s.stage[wi & (kStageWords - 1)] = 0;
-                        }
-                    }
-                    R.flushed_words = last;
-                    // a unit whose complete bytes reach the capacity can never fit (see P3 in DESIGN.md)
-                    if (!(fits && (R.bitpos >> 3) < a.cap_words * 4u)) R.too_big = 1u;
-                    WG_TICK(9)
-                WG_BARRIER
-                if (WG_UNIFORM(too_big)) return kUnitTooBig;
+                store_pending = true;
                 if (n < 64u * kWgWaves) break;
             }
-            const uint32_t wL = WG_UNIFORM(wL);
             if (wL < nwin) {
                 // ---- the chunk in which a word start may find the ring full: its wave alone -------------------
+                WG_EACH_WAVE
+                    WG_TICK(0)
+                    store_stage_words(s, a, R, w);
+                    WG_TICK(9)
+                WG_BARRIER
+                store_pending = false;
+                if (WG_UNIFORM(too_big)) return kUnitTooBig;
                 WG_EACH_WAVE
                     WG_TICK(0)
                     if (w == wL) {
@@ -1537,21 +1748,20 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
             }
             wbase = wL + 1u;
         }
-        // the adaptive counts after the window (phase B of the next window starts from them)
-        WG_EACH_WAVE
-            if (w + 1u == nwin) { FOR_LANES { if (lane < 17) { s.ctot[lane] = LV(R.ctot); s.czer[lane] = LV(R.czer); } } }
-        WG_BARRIER
+        par ^= 1u;
+        j0 += kWgWaves;
     }
     // end of unit: force-complete whatever is still open (C8, icer_context_modeller.c:452-455)
     uint32_t bits = kUnitTooBig;
     WG_EACH_WAVE
-        (void)R;
+        if (store_pending) store_stage_words(s, a, R, w);
         WG_GLOBAL_RELEASE();
 #if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
         R.tacc[11] = windows;
-        if (a.timers && lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd((unsigned long long *)&a.timers[i_], (unsigned long long)R.tacc[i_]);
+        if (a.timers && lane == 0) for (int i_ = 0; i_ < 13; i_++) atomicAdd((unsigned long long *)&a.timers[i_], (unsigned long long)R.tacc[i_]);
 #endif
     WG_BARRIER
+    if (WG_UNIFORM(too_big)) return kUnitTooBig;
     WG_EACH_WAVE
         if (w == 0) {
             FOR_LANES { if (lane == 0) { s.alloc = R.tail; s.popped = R.popped; s.bitpos = R.bitpos; s.flushed_words = R.flushed_words; } }

@@ -237,6 +237,29 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     }
 }
 
+// ------------------------------------------------------------------------------------------ chunk tables
+// One byte per 64-pixel chunk of every (channel, level, subband, segment): the lowest bit plane from which the chunk
+// is blank (wg::chunk_blank_plane), for all bit planes of the family at once.  Launched over the units, of which the
+// plane-0 ones do the work: grid = (ceil(max chunks / 64), units, frames), block = 256 (16 chunks per wavefront).
+__global__ void __launch_bounds__(256)
+chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, int channels,
+                 const UnitDesc *__restrict__ units, const int *__restrict__ frame_skip,
+                 uint8_t *__restrict__ sig, size_t sig_frame_stride)
+{
+    const UnitDesc u = units[blockIdx.y];
+    const uint32_t frame = blockIdx.z, nchunks = (u.w * u.h + 63u) / 64u;
+    if (u.lsb != 0u || blockIdx.x * 64u >= nchunks || frame_skip[frame]) return;
+    const uint16_t *seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
+    uint8_t *out = sig + (size_t)frame * sig_frame_stride + u.sig_off;
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t i = 0; i < 16u; i++) {
+        const uint32_t j = blockIdx.x * 64u + wave * 16u + i;
+        if (j >= nchunks) break;
+        const uint32_t t = wg::chunk_blank_plane(seg, img_w, u.w, u.h, j);
+        if ((threadIdx.x & 63u) == 0u) out[j] = (uint8_t)t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ coder (workgroup windows)
 // One workgroup of wg::kWgWaves wavefronts = one coding unit of one frame; the unit is coded in windows of kWgWaves
 // chunks of 64 pixels, one chunk per wave, the waves meeting at workgroup barriers only (coder_wg.hpp): no wave ever
@@ -248,7 +271,8 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
                      const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                      const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                      size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                     uint32_t *__restrict__ done_bytes, uint64_t early_quota)
+                     uint32_t *__restrict__ done_bytes, uint64_t early_quota,
+                     const uint8_t *__restrict__ sig, size_t sig_frame_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     wg::Shared &s = *reinterpret_cast<wg::Shared *>(wg_lds);
@@ -273,6 +297,7 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
     a.early_quota = early_quota;
     // profiling build: per-phase cycle counters of the level-1 (largest) units, one row per bit plane
     a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
+    a.sig = sig ? sig + (size_t)frame * sig_frame_stride + u.sig_off : nullptr;
     {   // tables -> LDS
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);

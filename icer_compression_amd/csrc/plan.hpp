@@ -32,6 +32,8 @@ struct UnitDesc {
     uint32_t cap_words;             // payload capacity of the slot (32-bit words)
     uint32_t cap_is_bound;          // 1: capacity came from the bits-per-pixel bound, 0: from the byte quota
     uint32_t prio;                  // wave priority (s_setprio): the largest units form the critical path of a frame
+    uint32_t sig_off;               // byte offset of the chunk table of the unit's family -- (channel, level, subband, segment), shared by
+                                    // its bit planes -- in the frame's chunk-table area: one byte per 64-pixel chunk (chunk_blank_plane)
     uint64_t slot_off;              // byte offset of the slot (28-byte header + payload) in the frame's slot area
 };
 
@@ -146,6 +148,7 @@ struct Plan {
     std::vector<uint32_t> final_order;     // D7 order -> index into units
     std::vector<uint32_t> work_order;      // launch order (largest units first) -> index into units
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
+    size_t sig_bytes = 0;                  // per-frame chunk-table area (UnitDesc::sig_off)
 };
 
 // quarter-octave size class of a unit (launch order treats units of one class as equally large)
@@ -245,6 +248,17 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
             for (int x = 0; x < kXcds; x++)
                 if (k < lists[x].size()) p->work_order.push_back(lists[x][k]);
                 // (a shorter list simply stops contributing; the tail then drifts off the b % 8 pattern, harmless)
+    }
+    // chunk tables: one per family, in unit order
+    {
+        std::vector<int64_t> off_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
+        size_t off = 0;
+        for (UnitDesc &u : p->units) {
+            int64_t &o = off_of_family[((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg];
+            if (o < 0) { o = (int64_t)off; off += (((size_t)u.w * u.h + 63) / 64 + 3) & ~(size_t)3; }
+            u.sig_off = (uint32_t)o;
+        }
+        p->sig_bytes = off;
     }
     // the launch is latency-bound by its largest units: give their waves issue priority over the small ones
     const uint64_t biggest = p->units.empty() ? 1 : (uint64_t)p->units[p->work_order[0]].w * p->units[p->work_order[0]].h;

@@ -42,6 +42,7 @@ static inline uint32_t brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 
 #define WAVE_GATHER(DST, SRC, IDX) { uint32_t t_[64]; for (int l_ = 0; l_ < 64; ++l_) t_[l_] = SRC[l_]; for (int l_ = 0; l_ < 64; ++l_) DST[l_] = t_[IDX[l_] & 63u]; }
 // cross-lane reductions / scans over a lane variable
 #define WAVE_XOR(DST, X) { DST = 0; for (int l_ = 0; l_ < 64; ++l_) DST ^= X[l_]; }
+#define WAVE_MAX(DST, X) { DST = 0; for (int l_ = 0; l_ < 64; ++l_) DST = X[l_] > DST ? X[l_] : DST; }
 #define WAVE_EXCL_SCAN(T, OUT, IN, TOTAL) { T run_ = 0; for (int l_ = 0; l_ < 64; ++l_) { const T v_ = IN[l_]; OUT[l_] = run_; run_ += v_; } TOTAL = run_; }
 #else
 // ------------------------------------------------------------------ gfx950 (product)
@@ -71,6 +72,7 @@ static __device__ __forceinline__ uint32_t brev32(uint32_t v) { return __brev(v)
 #define READLANE(X, L) ((uint32_t)__builtin_amdgcn_readlane((int)(X), (int)(L)))
 #define WAVE_GATHER(DST, SRC, IDX) { DST = (uint32_t)__shfl((int)(SRC), (int)(IDX)); }
 #define WAVE_XOR(DST, X) { uint32_t t_ = (X); for (int o_ = 32; o_ > 0; o_ >>= 1) t_ ^= (uint32_t)__shfl_xor((int)t_, o_); DST = t_; }
+#define WAVE_MAX(DST, X) { uint32_t t_ = (X); for (int o_ = 32; o_ > 0; o_ >>= 1) { const uint32_t u_ = (uint32_t)__shfl_xor((int)t_, o_); t_ = u_ > t_ ? u_ : t_; } DST = t_; }
 #define WAVE_EXCL_SCAN(T, OUT, IN, TOTAL) { const T v_ = (IN); T s_ = v_; \
     for (int o_ = 1; o_ < 64; o_ <<= 1) { const T u_ = (T)__shfl_up(s_, o_); if (lane >= o_) s_ += u_; } \
     OUT = s_ - v_; TOTAL = (T)__shfl(s_, 63); }

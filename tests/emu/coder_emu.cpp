@@ -30,6 +30,9 @@ static uint32_t wg_unit(const UnitArgs &a0)
     a.seg = a0.seg; a.stride = a0.stride; a.w = a0.w; a.h = a0.h; a.subband = a0.subband; a.lsb = a0.lsb;
     a.out_words = a0.out_words; a.cap_words = a0.cap_words;
     a.done_bytes = nullptr; a.prio_index = 0; a.early_quota = 0; a.timers = nullptr;
+    std::vector<uint8_t> sig(((size_t)a.w * a.h + 63) / 64 + 4);
+    for (uint32_t j = 0; j < (a.w * a.h + 63u) / 64u; j++) sig[j] = (uint8_t)wg::chunk_blank_plane(a.seg, a.stride, a.w, a.h, j);
+    a.sig = sig.data();
     static wg::Wave regs[ICER_WG_WAVES];
     memset(regs, 0x5A, sizeof regs);
     wg::unit_state_init(g_wsh, a);

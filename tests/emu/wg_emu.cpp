@@ -13,6 +13,8 @@
 using namespace icer;
 
 static wg::Shared g_sh;
+static int g_no_table = 0;
+extern "C" void emu_wg_use_table(int on) { g_no_table = !on; }
 
 extern "C" int emu_wg_waves(void) { return (int)wg::kWgWaves; }
 // 0: the waves run every region in order, 1: backwards, >= 2: shuffled (seed)
@@ -34,6 +36,10 @@ extern "C" long emu_wg_code_unit(const uint16_t *seg, size_t w, size_t h, size_t
     a.out_words = words.data();
     uint32_t flag = stop_flag ? 1u : 0u;
     a.done_bytes = &flag; a.prio_index = 0; a.early_quota = stop_flag ? 1u : 0u; a.timers = nullptr;
+    // the family's chunk table (chunk_sig_kernel in the product); g_no_table: without, the general path only
+    std::vector<uint8_t> sig((w * h + 63) / 64 + 4);
+    for (uint32_t j = 0; j < (uint32_t)((w * h + 63) / 64); j++) sig[j] = (uint8_t)wg::chunk_blank_plane(seg, (uint32_t)stride, (uint32_t)w, (uint32_t)h, j);
+    a.sig = g_no_table ? nullptr : sig.data();
     static wg::Wave regs[ICER_WG_WAVES];
     memset(regs, 0x5A, sizeof regs);
     { wg::Wave &R = regs[0]; (void)R; wg::unit_state_init(g_sh, a); }

@@ -44,7 +44,7 @@ def wg():
         def stats(reset=True):
             buf = (C.c_ulonglong * 8)()
             L.emu_wg_stats(buf, 1 if reset else 0)
-            return dict(windows=buf[0], detailed=buf[1], exact_chunks=buf[2], forced_flushes=buf[3])
+            return dict(windows=buf[0], detailed=buf[1], exact_chunks=buf[2], forced_flushes=buf[3], blank_runs=buf[4])
     return Wg
 
 
@@ -93,6 +93,36 @@ def test_forced_flush_heavy_units(wg, oracle):
             assert wg.code_unit(plane, 0, 0, w, h, sb, lsb, order=trial) == oracle.code_unit(plane, 0, 0, w, h, sb, lsb), (trial, sb, lsb)
     st = wg.stats()
     assert st["forced_flushes"] > 200, st
+
+
+def test_blank_runs_in_closed_form(wg, oracle):
+    """runs of blank chunks (chunk table, blank_run): long empty stretches, stretches broken by single significant pixels,
+    units that end in a blank run, stale open words while a blank stretch fills the ring; with and without the table"""
+    rng = np.random.default_rng(11)
+    wg.stats()
+    for trial in range(14):
+        w, h = int(rng.integers(64, 500)), int(rng.integers(40, 400))
+        plane = np.zeros((h, w), np.uint16)
+        kind = trial % 4
+        if kind == 0:                                   # a busy top, then nothing
+            plane[: h // 5] = _sparse_plane(rng, w, h // 5, 200, 0.5)
+        elif kind == 1:                                 # isolated pixels
+            plane[rng.random((h, w)) < 0.0005] = int(rng.integers(1, 30000))
+        elif kind == 2:                                 # busy columns: every row leaves and re-enters blank chunks
+            plane[:, : w // 6] = _sparse_plane(rng, w // 6, h, 60, 0.8)
+        else:                                           # a few busy rows far apart
+            for r in rng.integers(0, h, 3):
+                plane[r] = _sparse_plane(rng, w, 1, 1000, 0.7)[0]
+        for sb, lsb in ((0, 0), (1, 2), (3, 5), (2, 8)):
+            want = oracle.code_unit(plane, 0, 0, w, h, sb, lsb)
+            assert wg.code_unit(plane, 0, 0, w, h, sb, lsb, order=trial) == want, (trial, sb, lsb)
+            wg.lib.emu_wg_use_table(0)
+            try:
+                assert wg.code_unit(plane, 0, 0, w, h, sb, lsb, order=trial) == want, (trial, sb, lsb, "no table")
+            finally:
+                wg.lib.emu_wg_use_table(1)
+    st = wg.stats()
+    assert st["blank_runs"] > 300 and st["forced_flushes"] > 0, st
 
 
 def test_slot_capacity_rule_and_stop(wg, oracle):

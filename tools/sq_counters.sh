@@ -14,10 +14,10 @@ cd "$root"
 python - "$tag" "$out" <<'PY'
 import json, sqlite3, sys
 tag, out = sys.argv[1], sys.argv[2]
-res = {"kernel": "code_units_kernel", "note": "rocprofv3 --pmc SQ_* passes on bench.py; averages per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_BUSY_CYCLES count quad-cycles summed over the chip's SQs"}
+res = {"kernel": "code_units(_wg)_kernel, whichever the run launched", "note": "rocprofv3 --pmc SQ_* passes on bench.py; averages per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_BUSY_CYCLES count quad-cycles summed over the chip's SQs"}
 for mode in ("single", "batch8"):
     cur = sqlite3.connect(f"{out}/{mode}/r_results.db").cursor()
-    q = "select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%code_units_kernel%' group by counter_name"
+    q = "select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%code_units%' group by counter_name"
     res[mode] = {n: round(v, 1) for n, v, _ in cur.execute(q)}
 json.dump(res, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from icer_compression_amd import api, build, synth  # noqa: E402
 
 NAMES = ["wait at barriers", "A pixels -> events", "B counts + bins", "C per-bin summaries, walks", "D+E states, records",
-         "flush test", "F slots + commit", "drain 1: lengths", "drain 2: pack", "drain 3: store", "exact chunk"]
+         "flush test", "F slots + commit", "drain 1: lengths", "drain 2: pack", "drain 3: store", "exact chunk", None, "blank runs (closed form)"]
 
 
 def main():
@@ -32,6 +32,8 @@ def main():
     print(" " * 34 + "  ".join(f"lsb{p}" for p in range(9)))
     tot = np.zeros(9)
     for k, name in enumerate(NAMES):
+        if name is None:
+            continue
         row = t[:, k] / np.maximum(t[:, 11], 1) / 1e3         # (each wave adds its window count to bucket 11)
         tot += row
         print(f"  {name:32s}" + "  ".join(f"{v:4.1f}" for v in row))
