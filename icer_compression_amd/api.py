@@ -85,6 +85,10 @@ def load_library() -> C.CDLL:
     L.icerx_timing_enable.argtypes = [C.c_void_p, C.c_int]
     L.icerx_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.icerx_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.icerx_encoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.icerx_process_stats.argtypes = [C.POINTER(C.c_uint64)]
+    L.icerx_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+    L.icerx_unpin_host.argtypes = [C.c_void_p]
     L.icerx_last_error.restype = C.c_char_p
     _lib = L
     return L
@@ -252,6 +256,15 @@ class Encoder:
             raise IcerHipError(f"icerx_encode_host rc={rc}: {self.lib.icerx_last_error().decode()}")
         return [(int(rcs[i]), bytes(out[i, : int(sizes[i])])) for i in range(n)]
 
+    def encode_host_into(self, frames: np.ndarray, byte_quota: int, out: np.ndarray, sizes: np.ndarray, rcs: np.ndarray) -> None:
+        """the same into caller-owned arrays (out: uint8 (n, stride), sizes: uint64 (n,), rcs: int32 (n,)) -- nothing is
+        allocated or copied on the Python side, so this is what a C caller of icerx_encode_host sees"""
+        n = frames.shape[0]
+        rc = self.lib.icerx_encode_host(self.handle, frames.ctypes.data, n, byte_quota, out.ctypes.data, out.shape[1],
+                                        sizes.ctypes.data, rcs.ctypes.data)
+        if rc != 0:
+            raise IcerHipError(f"icerx_encode_host rc={rc}: {self.lib.icerx_last_error().decode()}")
+
     def coefficients(self, frame: int = 0, channel: int = 0) -> np.ndarray:
         dst = np.zeros((self.h, self.w), dtype=np.uint16)
         rc = self.lib.icerx_get_coefficients(self.handle, frame, channel, dst.ctypes.data)
@@ -270,7 +283,28 @@ class Encoder:
             raise IcerHipError(f"icerx_timing_read rc={rc}")
         return {n: ms[i] for i, n in enumerate(STAGE_NAMES)}, int(calls.value)
 
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        self.lib.icerx_encoder_stats(self.handle, out)
+        return {"unit_timeouts": out[0], "fallback_batches": out[1], "slot_retries": out[2], "coder_mode": out[3]}
+
     def info(self):
         u, b, s = C.c_uint32(), C.c_uint32(), C.c_uint64()
         self.lib.icerx_info(self.handle, C.byref(u), C.byref(b), C.byref(s))
         return {"units_per_frame": u.value, "slot_bits_per_pixel": b.value, "slot_bytes_per_frame": s.value}
+
+
+def process_stats():
+    """unit time-outs / batches re-coded by the barrier-only coder / slot re-runs, summed over every encoder of the process"""
+    out = (C.c_uint64 * 4)()
+    load_library().icerx_process_stats(out)
+    return {"unit_timeouts": out[0], "fallback_batches": out[1], "slot_retries": out[2]}
+
+
+def pin_host(arr) -> bool:
+    """page-lock a numpy array (icerx_pin_host); returns False if the runtime refuses"""
+    return load_library().icerx_pin_host(arr.ctypes.data, arr.nbytes) == 0
+
+
+def unpin_host(arr) -> None:
+    load_library().icerx_unpin_host(arr.ctypes.data)

@@ -21,11 +21,17 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _tuning_flags():
+    """experiments only: ICER_WG_WAVES=<n> builds the workgroup coder with n wavefronts per coding unit (default 16)"""
+    w = os.environ.get("ICER_WG_WAVES")
+    return [f"-DICER_WG_WAVES={int(w)}"] if w else []
+
+
 def build_profiling_library(verbose: bool = False) -> str:
     """Separate build with per-phase s_memtime counters (-DICER_PHASE_TIMERS) for tools/phase_profile.py."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = os.path.join(PKG, "libicer_hip_prof.so")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DICER_PHASE_TIMERS", "-o", out] + \
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DICER_PHASE_TIMERS", "-o", out] + _tuning_flags() + \
         [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
@@ -38,7 +44,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wall",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + _tuning_flags() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

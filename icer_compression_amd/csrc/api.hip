@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
@@ -21,6 +22,7 @@ using namespace icer;
 namespace {
 
 thread_local std::string g_last_error;
+static std::atomic<uint64_t> g_stats[3];      // unit time-outs, fallback batches, slot re-runs (icerx_process_stats)
 CoderTables g_tables;
 bool g_tables_ready = false;
 std::recursive_mutex g_mutex;
@@ -34,6 +36,16 @@ void set_error(const char *fmt, ...)
     va_end(ap);
     g_last_error = buf;
     fprintf(stderr, "icer_hip: %s\n", buf);
+}
+
+// polite spin (the wait for a batch is tens of milliseconds; see encode_device_impl)
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
 }
 
 #define HIP_TRY(expr)                                                                         \
@@ -74,7 +86,12 @@ struct icerx_encoder {
     size_t slot_quota = (size_t)-1;     // quota the current slot table was built for
     unsigned bits_per_pixel = 3;        // slot bound; doubled on overflow
     bool units_uploaded = false;
-    bool coder_wg = true;               // coding units by code_units_wg_kernel (barrier-only windows); ICER_HIP_CODER=pipe: the eight-wave pipeline
+    // Which kernel codes the units.  0 (default): the eight-wave pipeline (code_units_kernel) for large quotas, the
+    // workgroup-window coder (code_units_wg_kernel: barriers only, runs of blank chunks in closed form) in progressive
+    // mode; 1 / 2: always the pipeline / always the window coder (ICER_HIP_CODER=pipe|wg, tests and measurements).
+    int coder_mode = 0;
+    bool wg_once = false;               // the next enqueue uses the window coder whatever the mode (after a unit time-out)
+    uint64_t n_timeouts = 0, n_fallbacks = 0, n_slot_retries = 0;   // icerx_encoder_stats
 
     DevBuf<int16_t> coef, tmp;
     DevBuf<unsigned long long> sums;
@@ -176,29 +193,19 @@ int accumulate_timing(icerx_encoder *e)
     return 0;
 }
 
-// enqueue the whole pipeline once; returns 0 or ICER_FATAL_ERROR
-int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
-            unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
+// The forward DWT of a batch: one fused tile pass per stage.  Stage 0 reads the caller's frames; every stage writes
+// HL/LH/HH to their final place in `coef` (as the coder's sign-magnitude words when `sm` != 0) and its LL band to a
+// compact side buffer in `tmp` that the next stage reads (the last stage writes LL into `coef`), so no workgroup reads
+// what another one of the same stage writes.  *cw, *ch: in the frame size, out the LL size.
+void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStream_t st, int sm, int *dwt_ovf, size_t *cw_io, size_t *ch_io)
 {
-    const size_t W = e->w, H = e->h, plane = W * H;
-    const int C = e->channels, P = n_frames * C;
-    const uint32_t n_units = (uint32_t)e->plan.units.size();
-    int *dwt_ovf = e->flags.p, *mean_ovf = e->flags.p + (size_t)e->max_frames * C;
-    int *skip = mean_ovf + (size_t)e->max_frames * C, *bound_ovf = skip + e->max_frames;
-    const FilterTaps ft = filter_taps(e->filt);
-
-    HIP_TRY(hipMemsetAsync(e->flags.p, 0, e->flags.n * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(e->sums.p, 0, (size_t)P * sizeof(unsigned long long), st));
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
-
-    // ---- DWT: one fused tile pass per stage.  Stage 0 reads the caller's frames; every stage writes HL/LH/HH
-    // to their final place in `coef` and its LL band to a compact side buffer in `tmp` that the next stage
-    // reads (the last stage writes LL into `coef`), so no workgroup reads what another one of the same
-    // stage writes.
-    size_t cw = W, ch = H, ll_off = 0;
+    const size_t W = e->w, plane = W * e->h;
+    const int P = n_frames * e->channels;
+    size_t cw = *cw_io, ch = *ch_io, ll_off = 0;
     DwtStageArgs da;
-    da.f = ft;
+    da.f = filter_taps(e->filt);
     da.lim = e->sample_bits == 8 ? 127 : 32767;
+    da.sm = sm;
     da.coef = e->coef.p; da.coef_stride = (uint32_t)W;
     da.src = reinterpret_cast<const int16_t *>(d_frames); da.src_stride = (uint32_t)W;
     size_t src_plane = plane;
@@ -215,6 +222,24 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         cw = nlw;
         ch = nlh;
     }
+    *cw_io = cw; *ch_io = ch;
+}
+
+// enqueue the whole pipeline once; returns 0 or ICER_FATAL_ERROR
+int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
+            unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
+{
+    const size_t W = e->w, H = e->h, plane = W * H;
+    const int C = e->channels, P = n_frames * C;
+    const uint32_t n_units = (uint32_t)e->plan.units.size();
+    int *dwt_ovf = e->flags.p, *mean_ovf = e->flags.p + (size_t)e->max_frames * C;
+    int *skip = mean_ovf + (size_t)e->max_frames * C, *bound_ovf = skip + e->max_frames;
+    HIP_TRY(hipMemsetAsync(e->flags.p, 0, e->flags.n * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(e->sums.p, 0, (size_t)P * sizeof(unsigned long long), st));
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
+
+    size_t cw = W, ch = H;
+    launch_dwt(e, d_frames, n_frames, st, e->sample_bits, dwt_ovf, &cw, &ch);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 
     // ---- LL mean, frame status, sign-magnitude
@@ -226,7 +251,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     hipLaunchKernelGGL(ll_mean_kernel, dim3((P + 63) / 64), dim3(64), 0, st, e->sums.p, (uint32_t)P, llw * llh,
                        e->means.p, mean_ovf, e->sample_bits);
     hipLaunchKernelGGL(frame_status_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, dwt_ovf, mean_ovf, C, n_frames, skip);
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, P), dim3(256), 0, st,
+    hipLaunchKernelGGL(finalize_ll_kernel, dim3((llw + 63u) / 64u, (llh + 3u) / 4u, P), dim3(256), 0, st,
                        reinterpret_cast<uint16_t *>(e->coef.p), plane, (uint32_t)W, llw, llh, e->means.p, skip, C, e->sample_bits);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
 
@@ -237,13 +262,14 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
-    if (e->coder_wg) {
+    const bool use_wg = e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive);
+    if (use_wg) {
         uint32_t max_chunks = 1;
         for (const UnitDesc &u : e->plan.units) max_chunks = std::max(max_chunks, (u.w * u.h + 63u) / 64u);
         hipLaunchKernelGGL(chunk_sig_kernel, dim3((max_chunks + 63u) / 64u, n_units, n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, skip, e->sig.p, e->plan.sig_bytes);
     }
-    if (e->coder_wg)
+    if (use_wg)
         hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
@@ -313,7 +339,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const int rc = build_plan(&e->plan, w, h, channels, stages, segments, sample_bits);
     if (rc != kOk) { delete e; return rc; }
     // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
-    if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_wg = strcmp(cd, "pipe") != 0;
+    if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -321,13 +347,15 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
 
     int count = 0;
     hipError_t he = hipGetDeviceCount(&count);
-    if (he != hipSuccess || count <= 0 || device >= count) {
+    if (he != hipSuccess || count <= 0 || device < 0 || device >= count) {
         set_error("no usable HIP device (hipGetDeviceCount: %s, count=%d, requested=%d); this library has no CPU path",
                   hipGetErrorString(he), count, device);
         delete e;
         return ICER_FATAL_ERROR;
     }
-    HIP_TRY(hipSetDevice(device));
+    // (a failing HIP call below must not leak the object and what it has allocated so far)
+#define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); icerx_encoder_destroy(e); return ICER_FATAL_ERROR; } } while (0)
+    CREATE_TRY(hipSetDevice(device));
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
@@ -337,16 +365,17 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         icerx_encoder_destroy(e);
         return ICER_FATAL_ERROR;
     }
-    HIP_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
     // the workgroup coder's LDS block is above the 64 KiB a kernel gets without asking
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)));
 #ifdef ICER_PHASE_TIMERS
     if (e->prof.ensure(kProfWords)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
-    HIP_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
 #endif
-    for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
-    HIP_TRY(hipHostMalloc((void **)&e->h_flag, sizeof(int), hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+    for (auto &ev : e->ev) CREATE_TRY(hipEventCreate(&ev));
+    CREATE_TRY(hipHostMalloc((void **)&e->h_flag, sizeof(int), hipHostMallocDefault));
+    CREATE_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
+#undef CREATE_TRY
     *out = e;
     return 0;
 }
@@ -405,7 +434,7 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
     hipStream_t st = (hipStream_t)stream;
     if (accumulate_timing(e)) return ICER_FATAL_ERROR;
     int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * e->channels + e->max_frames;
-    bool timed_out_once = false;
+    e->wg_once = false;
     for (;;) {
         if (upload_units(e, byte_quota, st)) return ICER_FATAL_ERROR;
         if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
@@ -425,21 +454,29 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
             const hipError_t q = hipEventQuery(e->done);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return ICER_FATAL_ERROR; }
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         const int ovf = *e->h_flag;
         if (!ovf) break;
         if (ovf & 2) {
-            // A wave of some coding unit waited longer than its spin bound (seconds) and gave the unit up; the frame's
-            // return code is ICER_FATAL_ERROR.  Seen once in ~60 000 randomised encodes and not reproducible on the same
-            // input, so the batch is simply run again, once, before the error is passed on.
+            // A wave of some coding unit of the eight-wave pipeline waited longer than its spin bound (seconds) and gave
+            // the unit up (seen once in ~60 000 randomised encodes in round 1, never reproduced).  The batch is coded again
+            // by the workgroup-window coder, which has no wave-to-wave hand-offs to wait for (barriers only) and produces
+            // the same streams: the caller gets its result, the event is counted (icerx_encoder_stats) and reported.
             report_timeouts(e, n_frames);
-            if (timed_out_once) break;
-            timed_out_once = true;
-            fprintf(stderr, "libicer_hip: a coding unit timed out; re-running the batch once\n");
+            e->n_timeouts++; g_stats[0]++;
+            if (e->wg_once) {                      // (can not happen: the window coder never reports a time-out)
+                e->wg_once = false;
+                set_error("a coding unit timed out in the workgroup-window coder");
+                return ICER_FATAL_ERROR;
+            }
+            e->n_fallbacks++; g_stats[1]++;
+            e->wg_once = true;
+            fprintf(stderr, "libicer_hip: a coding unit timed out; coding the batch again with the barrier-only coder\n");
             e->ev_pending = false;
             continue;
         }
+        e->n_slot_retries++; g_stats[2]++;
         if (e->bits_per_pixel >= 24) {
             set_error("coding-unit slot overflow at the theoretical bound");
             return ICER_FATAL_ERROR;
@@ -449,6 +486,7 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
         e->bits_per_pixel = e->bits_per_pixel * 2 > 24 ? 24 : e->bits_per_pixel * 2;
         e->units_uploaded = false;
     }
+    e->wg_once = false;
     return 0;
 }
 
@@ -517,6 +555,12 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
     HIP_TRY(hipSetDevice(e->device));
     const size_t plane = e->w * e->h, P = (size_t)n_frames * e->channels;
     if (upload_units(e, byte_quota, nullptr)) return ICER_FATAL_ERROR;
+    // a frame's stream can be as long as the quota (or everything the slots can hold): the caller's rows must hold it
+    if (n_frames > 1 && out_stride < (byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes)) {
+        set_error("icerx_encode_host: out_stride %zu smaller than the largest possible stream (%zu bytes)", out_stride,
+                  byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes);
+        return ICER_INVALID_INPUT;
+    }
     if (e->in.ensure((size_t)e->max_frames * e->channels * plane)) return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpy(e->in.p, frames, P * plane * 2, hipMemcpyHostToDevice));
     for (;;) {   // the device stride depends on the slot bound, which a retry may enlarge
@@ -530,10 +574,29 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
             HIP_TRY(hipMemcpy(sizes, e->sizes.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(rcs, e->rcs.p, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
             for (int f = 0; f < n_frames; f++)
-                if (sizes[f]) HIP_TRY(hipMemcpy(out + (size_t)f * out_stride, e->out.p + (size_t)f * (ds + 4), sizes[f], hipMemcpyDeviceToHost));
+                if (sizes[f]) {
+                    if (sizes[f] > out_stride && n_frames > 1) { set_error("icerx_encode_host: stream of frame %d (%llu bytes) longer than out_stride", f, (unsigned long long)sizes[f]); return ICER_INVALID_INPUT; }
+                    HIP_TRY(hipMemcpy(out + (size_t)f * out_stride, e->out.p + (size_t)f * (ds + 4), sizes[f], hipMemcpyDeviceToHost));
+                }
             break;
         }
     }
+    return 0;
+}
+
+// Page-lock a caller buffer (frames in, streams out) so that the host-buffer entry points move it at PCIe speed by DMA
+// instead of through the runtime's staging copies (hipHostRegister / hipHostUnregister behind a C ABI: a C caller need
+// not link the HIP runtime).  The caller unpins before it frees the memory.
+int icerx_pin_host(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return ICER_INVALID_INPUT;
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+int icerx_unpin_host(void *ptr)
+{
+    if (!ptr) return ICER_INVALID_INPUT;
+    HIP_TRY(hipHostUnregister(ptr));
     return 0;
 }
 
@@ -561,6 +624,21 @@ int icerx_timing_read(icerx_encoder *e, double ms[ICERX_NUM_STAGES], uint64_t *c
     for (int i = 0; i < ICERX_NUM_STAGES; i++) ms[i] = e->ms[i];
     *calls = e->timed_calls;
     if (reset) { for (auto &m : e->ms) m = 0; e->timed_calls = 0; }
+    return 0;
+}
+
+// the same counters summed over every encoder of the process (the lib_icer-shaped entry points use an internal one)
+int icerx_process_stats(uint64_t out[4])
+{
+    if (!out) return ICER_INVALID_INPUT;
+    out[0] = g_stats[0]; out[1] = g_stats[1]; out[2] = g_stats[2]; out[3] = 0;
+    return 0;
+}
+
+int icerx_encoder_stats(icerx_encoder *e, uint64_t out[4])
+{
+    if (!e || !out) return ICER_INVALID_INPUT;
+    out[0] = e->n_timeouts; out[1] = e->n_fallbacks; out[2] = e->n_slot_retries; out[3] = (uint64_t)e->coder_mode;
     return 0;
 }
 
@@ -681,6 +759,13 @@ static int compress_planes(void *const planes[], int channels, size_t w, size_t 
         HIP_TRY(hipMemcpy(fl.data(), e->flags.p, sizeof(int) * channels, hipMemcpyDeviceToHost));
         int last = channels - 1;
         for (int c = 0; c < channels; c++) if (fl[c]) { last = c; break; }
+        // (the detail bands are normally stored as sign-magnitude words: transform once more, plain)
+        {
+            size_t cw2 = w, ch2 = h;
+            int *scratch_flags = e->flags.p;
+            launch_dwt(e, reinterpret_cast<const uint16_t *>(e->in.p), 1, nullptr, 0, scratch_flags, &cw2, &ch2);
+            HIP_TRY(hipDeviceSynchronize());
+        }
         for (int c = 0; c <= last; c++)
             HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
         return rc;

@@ -149,6 +149,11 @@ struct WaveLds {                // per-wave LDS: the chunk's summaries and scrat
     int32_t bslot[17];          // ring slot (allocation count) of each bin's open word at chunk start, -1 if none
     uint16_t sumE[17];          // per bin: 255 untouched, 254 closed, else the chunk-relative slot of the word it leaves open
     uint8_t fe[20];             // per bin: position of its first end event in the chunk (255: none)
+    // bins 8..16, by bin - 8: the bin's events at even / odd positions (bit = lane), its one-events likewise; event count
+    uint64_t gmask[9][4];
+    uint8_t gn[12];
+    uint8_t onez[128];          // position of a Golomb bin's one-event -> zeros of that bin before it
+    uint8_t srank[128];         // position of a word start -> number of word starts before it in the chunk
     uint32_t nst;               // words the chunk opens
     uint32_t segtot;            // drain: code bits of this wave's 64 ring words
 };
@@ -308,6 +313,8 @@ ICER_DEV uint32_t pick_bin(const uint32_t *binlut, uint32_t zero, uint32_t total
     }
 
 ICER_DEV uint64_t below64(uint32_t x) { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); }
+// this lane's bit of a mask that differs from lane to lane (no 64-bit shift by a variable)
+ICER_DEV uint32_t own_bit(uint64_t A, int lane) { return ((lane < 32 ? (uint32_t)A : (uint32_t)(A >> 32)) >> (lane & 31)) & 1u; }
 // events of the set strictly before position pos (A1: even positions 2 * lane, A2: odd positions 2 * lane + 1)
 ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
 {
@@ -316,7 +323,7 @@ ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
 // the same for this lane's own events (position 2 * lane + slot): two v_mbcnt pairs instead of 64-bit shifts
 ICER_DEV uint32_t cnt_lt_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
 {
-    return (uint32_t)(mbcnt64(A1, lane) + mbcnt64(A2, lane)) + (slot ? (uint32_t)((A1 >> lane) & 1ull) : 0u);
+    return (uint32_t)(mbcnt64(A1, lane) + mbcnt64(A2, lane)) + (slot ? own_bit(A1, lane) : 0u);
 }
 // latest position <= pos in the set, -1 if none
 ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
@@ -331,6 +338,30 @@ ICER_DEV uint32_t first_pos(uint64_t A1, uint64_t A2)
 {
     const uint32_t k1 = A1 ? 2u * (uint32_t)ffs64(A1) : 255u, k2 = A2 ? 2u * (uint32_t)ffs64(A2) + 1u : 255u;
     return k1 < k2 ? k1 : k2;
+}
+
+// The same questions about THIS lane's own events (position 2 * lane + slot) of masks that differ from lane to lane
+// (vector registers): lane-relative masks from 32-bit operations, no 64-bit shifts by a variable.
+ICER_DEV uint64_t lanes_below(int lane)         // bits of the lanes below this one
+{
+    const uint32_t lo = lane < 32 ? (1u << (lane & 31)) - 1u : ~0u, hi = lane < 32 ? 0u : (1u << (lane & 31)) - 1u;
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+// latest position < (2 * lane + slot) in the set, -1 if none
+ICER_DEV int last_lt_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
+{
+    const uint64_t lt = lanes_below(lane);
+    const uint64_t c1 = A1 & (slot ? (lt << 1) | 1ull : lt), c2 = A2 & lt;
+    const int k1 = c1 ? 2 * (63 - clz64(c1)) : -1, k2 = c2 ? 2 * (63 - clz64(c2)) + 1 : -1;
+    return k1 > k2 ? k1 : k2;
+}
+// latest position <= (2 * lane + slot) in the set, -1 if none
+ICER_DEV int last_le_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
+{
+    const uint64_t lt = lanes_below(lane), le = (lt << 1) | 1ull;
+    const uint64_t c1 = A1 & le, c2 = A2 & (slot ? le : lt);
+    const int k1 = c1 ? 2 * (63 - clz64(c1)) : -1, k2 = c2 ? 2 * (63 - clz64(c2)) + 1 : -1;
+    return k1 > k2 ? k1 : k2;
 }
 
 // bits [start, start + 6) of a bit string stored with an offset of 8 (rank r lives at bit r + 8, so that
@@ -503,7 +534,7 @@ struct Wave {
     LANEVAR(uint32_t, cb); LANEVAR(uint32_t, ce);       // candidate lanes: their bin and the (compact) node they assume
     LANEVAR(uint32_t, slot);                            // lane b: ring slot of bin b's open word at chunk start / after it
     LANEVAR(uint32_t, slot0);                           // lane b: ring slot of bin b's open word before the pending chunks, ~0 if none
-    LANEVAR(uint32_t, dw);                              // drain: this lane's ring word between the two halves of a round
+    LANEVAR(uint32_t, dw); LANEVAR(uint32_t, doff);     // drain: this lane's two ring words and their bit offsets between the two halves of a round
     MergeChunk c;
     uint32_t blank, has_v2v;
     // uniform (the same value in every wave)
@@ -622,12 +653,6 @@ ICER_DEV void phase_a(Shared &s, const UnitArgs &a, Wave &R, uint32_t w, uint32_
         LV(cNW) = (hN && hW) ? LV(R.nNW) : 0u; LV(cNE) = (hN && hE) ? LV(R.nNE) : 0u;
         LV(cSW) = (hS && hW) ? LV(R.nSW) : 0u; LV(cSE) = (hS && hE) ? LV(R.nSE) : 0u;
     }
-    // this wave's chunk of the next window is fetched while this one is processed
-    {
-        const uint32_t jn = j + kWgWaves;
-        if (jn * 64u < npix && !table_says_blank(a, jn)) fetch_window(a, R, jn);
-    }
-
     // ---- context formation (C1-C6) ------------------------------------------------------------
     if (!tskip) FOR_LANES
     {
@@ -962,6 +987,9 @@ ICER_DEV void phase_c(Shared &s, Wave &R, uint32_t w)
                     const uint32_t all = (uint32_t)(popc64(m1) + popc64(m2));
                     const int lo1 = last_le(m1 & O1, m2 & O2, 127u);
                     q.sumC[lane] = lo1 < 0 ? all : (0x8000u | (all - cnt_lt(m1, m2, (uint32_t)lo1 + 1u)));
+                    // (kept for the records, phase E)
+                    q.gmask[lane - 8][0] = m1; q.gmask[lane - 8][1] = m2; q.gmask[lane - 8][2] = m1 & O1; q.gmask[lane - 8][3] = m2 & O2;
+                    q.gn[lane - 8] = (uint8_t)all;
                 }
             }
         }
@@ -1133,34 +1161,43 @@ ICER_DEV void phase_de(Shared &s, Wave &R, uint32_t w, uint32_t wbase)
         } else {
             const uint64_t G1 = BALLOT((LV(c.ev1) & 0x98u) >= 0x88u), G2 = BALLOT((LV(c.ev2) & 0x98u) >= 0x88u);
             if (G1 | G2) {
-                const uint64_t K0 = BALLOT(LV(c.ev1) & 1u), K1 = BALLOT(LV(c.ev1) & 2u), K2 = BALLOT(LV(c.ev1) & 4u), K3 = BALLOT((LV(c.ev1) & 31u) == 16u);
-                const uint64_t J0 = BALLOT(LV(c.ev2) & 1u), J1 = BALLOT(LV(c.ev2) & 2u), J2 = BALLOT(LV(c.ev2) & 4u), J3 = BALLOT((LV(c.ev2) & 31u) == 16u);
-                const uint64_t O1 = G1 & BALLOT(LV(c.ev1) & 0x20u), O2 = G2 & BALLOT(LV(c.ev2) & 0x20u);       // one-events
-                // key of a bin: bin - 8 = 0..8, i.e. the low three bits of the bin number and "bin == 16"
-                LANEVAR(uint64_t, ma1); LANEVAR(uint64_t, mb1); LANEVAR(uint64_t, ma2); LANEVAR(uint64_t, mb2);   // events of this lane's bins
-#define ICER_GOLOMB_LANE(EV, SLOT, KA, FL, WD, MA, MB)                                                        \
+                // The events of a lane's bin (and the one-events among them) come from the masks phase C left in LDS;
+                // everything an event needs to know about ITS OWN position is a lane-masked count of such a mask.
+                // Zeros since the bin's previous one-event: that event's lane publishes the zeros before IT (onez).
+                LANEVAR(uint32_t, zb1); LANEVAR(uint32_t, zb2);
+                FOR_LANES
+                {
+                    LV(ka1) = ~0u; LV(ka2) = ~0u; LV(zb1) = 0; LV(zb2) = 0;
+                    if ((LV(c.ev1) & 0x98u) >= 0x88u) {
+                        const uint64_t *g = q.gmask[(LV(c.ev1) & 31u) - 8u];
+                        LV(zb1) = cnt_lt_own(g[0] & ~g[2], g[1] & ~g[3], lane, 0u);
+                        if (LV(c.ev1) & 0x20u) q.onez[2 * lane] = (uint8_t)LV(zb1);
+                    }
+                    if ((LV(c.ev2) & 0x98u) >= 0x88u) {
+                        const uint64_t *g = q.gmask[(LV(c.ev2) & 31u) - 8u];
+                        LV(zb2) = cnt_lt_own(g[0] & ~g[2], g[1] & ~g[3], lane, 1u);
+                        if (LV(c.ev2) & 0x20u) q.onez[2 * lane + 1] = (uint8_t)LV(zb2);
+                    }
+                }
+                WAVE_SYNC();
+#define ICER_GOLOMB_LANE(EV, SLOT, ZB, KA, FL, WD)                                                              \
                 if (((EV) & 0x98u) >= 0x88u) {                                                                \
-                    const uint32_t b_ = (EV) & 31u, key_ = (b_ & 7u) | (b_ == 16u ? 8u : 0u);                  \
-                    const uint64_t m1_ = ICER_MATCH4(key_, G1, K0, K1, K2, K3), m2_ = ICER_MATCH4(key_, G2, J0, J1, J2, J3); \
-                    MA = m1_; MB = m2_;                                                                         \
-                    const uint64_t Z1 = m1_ & ~O1, Z2 = m2_ & ~O2;                                              \
-                    const uint32_t pos_ = 2u * (uint32_t)lane + (SLOT);                                         \
-                    const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                      \
-                    const int lo_ = last_lt(m1_ & O1, m2_ & O2, pos_);                                          \
-                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : q.gk[b_] + zb_;         \
+                    const uint32_t b_ = (EV) & 31u;                                                            \
+                    const uint64_t *g_ = q.gmask[b_ - 8u];                                                     \
+                    const int lo_ = last_lt_own(g_[2], g_[3], lane, (SLOT));                                   \
+                    const uint32_t z_ = lo_ >= 0 ? (ZB) - (uint32_t)q.onez[lo_] : q.gk[b_] + (ZB);              \
                     const uint32_t m = s.tab.gm[b_], inv = s.tab.ginv[b_];                                      \
                     const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
                     const uint32_t bit_ = ((EV) >> 5) & 1u;                                                     \
                     FL = (kb_ == 0u ? 1u : 0u) | ((bit_ || kb_ + 1u == m) ? 2u : 0u);                           \
-                    WD = bit_ ? wg_golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);               \
-                    const uint32_t before_ = cnt_lt_own(m1_, m2_, lane, (SLOT));                                \
-                    if (before_ + 1u == (uint32_t)(popc64(m1_) + popc64(m2_))) KA = (FL & 2u) ? 0u : kb_ + 1u;  \
+                    WD = bit_ ? wg_golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);            \
+                    const uint32_t before_ = cnt_lt_own(g_[0], g_[1], lane, (SLOT));                            \
+                    if (before_ + 1u == (uint32_t)q.gn[b_ - 8u]) KA = (FL & 2u) ? 0u : kb_ + 1u;                \
                 }
                 FOR_LANES
                 {
-                    LV(ma1) = 0; LV(mb1) = 0; LV(ma2) = 0; LV(mb2) = 0; LV(ka1) = ~0u; LV(ka2) = ~0u;
-                    ICER_GOLOMB_LANE(LV(c.ev1), 0u, LV(ka1), LV(c.fl1), LV(c.wd1), LV(ma1), LV(mb1))
-                    ICER_GOLOMB_LANE(LV(c.ev2), 1u, LV(ka2), LV(c.fl2), LV(c.wd2), LV(ma2), LV(mb2))
+                    ICER_GOLOMB_LANE(LV(c.ev1), 0u, LV(zb1), LV(ka1), LV(c.fl1), LV(c.wd1))
+                    ICER_GOLOMB_LANE(LV(c.ev2), 1u, LV(zb2), LV(ka2), LV(c.fl2), LV(c.wd2))
                 }
 #undef ICER_GOLOMB_LANE
                 // word starts of the Golomb bins; an end event's word began at its bin's latest start, and so did the
@@ -1170,12 +1207,14 @@ ICER_DEV void phase_de(Shared &s, Wave &R, uint32_t w, uint32_t wbase)
                 FOR_LANES
                 {
                     if ((LV(c.ev1) & 0x98u) >= 0x88u && ((LV(c.fl1) & 2u) || LV(ka1) != ~0u)) {
-                        const int sp = last_le(SB1 & LV(ma1), SB2 & LV(mb1), 2u * (uint32_t)lane);
+                        const uint64_t *g = q.gmask[(LV(c.ev1) & 31u) - 8u];
+                        const int sp = last_le_own(SB1 & g[0], SB2 & g[1], lane, 0u);
                         if (LV(c.fl1) & 2u) LV(c.sp1) = sp < 0 ? 255u : (uint32_t)sp;
                         if (LV(ka1) != ~0u) q.binst[LV(c.ev1) & 31u] = st_pack(LV(ka1) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka1), 0u);
                     }
                     if ((LV(c.ev2) & 0x98u) >= 0x88u && ((LV(c.fl2) & 2u) || LV(ka2) != ~0u)) {
-                        const int sp = last_le(SB1 & LV(ma2), SB2 & LV(mb2), 2u * (uint32_t)lane + 1u);
+                        const uint64_t *g = q.gmask[(LV(c.ev2) & 31u) - 8u];
+                        const int sp = last_le_own(SB1 & g[0], SB2 & g[1], lane, 1u);
                         if (LV(c.fl2) & 2u) LV(c.sp2) = sp < 0 ? 255u : (uint32_t)sp;
                         if (LV(ka2) != ~0u) q.binst[LV(c.ev2) & 31u] = st_pack(LV(ka2) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka2), 0u);
                     }
@@ -1186,13 +1225,21 @@ ICER_DEV void phase_de(Shared &s, Wave &R, uint32_t w, uint32_t wbase)
     WAVE_SYNC();
     c.S1 = BALLOT(LV(c.fl1) & 1u);
     c.S2 = BALLOT(LV(c.fl2) & 1u);
+    // a word's ring slot = allocation count before the chunk + the number of word starts before its first event
+    // (E2): every start event publishes that rank for the end events and the bins' open words
+    FOR_LANES
+    {
+        if (LV(c.fl1) & 1u) q.srank[2 * lane] = (uint8_t)cnt_lt_own(c.S1, c.S2, lane, 0u);
+        if (LV(c.fl2) & 1u) q.srank[2 * lane + 1] = (uint8_t)cnt_lt_own(c.S1, c.S2, lane, 1u);
+    }
+    WAVE_SYNC();
     // the chunk's ring summary: words opened; per bin closed / the chunk-relative slot of the word left open
     FOR_LANES
     {
         LV(c.st) = lane < 17 ? q.binst[lane] : 255u;
         if (lane < 17) {
             const uint32_t op = LV(c.st) & 255u;
-            q.sumE[lane] = (uint16_t)(op < 128u ? cnt_lt(c.S1, c.S2, op) : op);
+            q.sumE[lane] = (uint16_t)(op < 128u ? (uint32_t)q.srank[op] : op);
         }
         if (lane == 0) q.nst = (uint32_t)(popc64(c.S1) + popc64(c.S2));
     }
@@ -1303,19 +1350,20 @@ ICER_DEV void commit_bins(Shared &s, MergeChunk &c, uint32_t tail)
 
 // ring stores for the chunk's events at positions [lo, hi): the finished words of the code words that end there (slot of a word = tail0 + number of word starts before its first event, E2).
 // `bslot` = the bins' open slots at chunk start.
-ICER_DEV void commit_range(Shared &s, MergeChunk &c, const int32_t *bslot, uint32_t tail0, uint32_t lo, uint32_t hi)
+ICER_DEV void commit_range(Shared &s, MergeChunk &c, const int32_t *bslot, uint32_t tail0, uint32_t lo, uint32_t hi, const uint8_t *srank)
 {
     DECL_LANE;
     const uint64_t S1 = c.S1, S2 = c.S2;
+    // `srank`: the start ranks phase E published (null: the start flags have changed since, count them)
     FOR_LANES
     {
         const uint32_t p1 = 2u * (uint32_t)lane, p2 = p1 + 1u;
         if ((LV(c.fl1) & 2u) && p1 >= lo && p1 < hi) {
-            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)bslot[LV(c.ev1) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp1)));
+            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)bslot[LV(c.ev1) & 31u] : tail0 + (srank ? (uint32_t)srank[LV(c.sp1) & 127u] : cnt_lt(S1, S2, LV(c.sp1)));
             WRING_ST(slot, LV(c.wd1));
         }
         if ((LV(c.fl2) & 2u) && p2 >= lo && p2 < hi) {
-            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)bslot[LV(c.ev2) & 31u] : (tail0 + cnt_lt(S1, S2, LV(c.sp2)));
+            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)bslot[LV(c.ev2) & 31u] : tail0 + (srank ? (uint32_t)srank[LV(c.sp2) & 127u] : cnt_lt(S1, S2, LV(c.sp2)));
             WRING_ST(slot, LV(c.wd2));
         }
     }
@@ -1350,7 +1398,7 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
         const uint64_t h1 = BALLOT((LV(c.fl1) & 1u) && cnt_lt_own(S1, S2, lane, 0u) == t);
         const uint64_t h2 = BALLOT((LV(c.fl2) & 1u) && cnt_lt_own(S1, S2, lane, 1u) == t);
         const uint32_t P = h1 ? 2u * (uint32_t)ffs64(h1) : 2u * (uint32_t)ffs64(h2) + 1u;
-        commit_range(s, c, s.bin_slot, tail0, base, P);
+        commit_range(s, c, s.bin_slot, tail0, base, P, nullptr);
         const uint32_t alloc = tail0 + t;
         wave_drain(s, alloc);
         if (alloc - s.popped == (uint32_t)kRingWords) {
@@ -1433,7 +1481,7 @@ ICER_DEV void exact_chunk(Shared &s, MergeChunk &c, uint32_t tail0)
         }
         base = P;
     }
-    commit_range(s, c, s.bin_slot, tail0, base, 128u);
+    commit_range(s, c, s.bin_slot, tail0, base, 128u, nullptr);
     commit_bins(s, c, tail0);
     WAVE_SYNC();
 }
@@ -1458,7 +1506,7 @@ ICER_DEV void phase_f_commit(Shared &s, Wave &R, uint32_t w, uint32_t wbase, uin
     const uint32_t wL = R.wL;
     phase_f_scan(s, R, w, wbase, wL);
     if (w >= wbase && w < wL) {
-        commit_range(s, R.c, s.wl[w].bslot, R.tailw, 0u, 128u);
+        commit_range(s, R.c, s.wl[w].bslot, R.tailw, 0u, 128u, s.wl[w].srank);
         if (w + 1u == wL) {
             // the last committed chunk leaves the coder state (the next chunk's start state)
             const MergeChunk &c = R.c;
@@ -1466,7 +1514,7 @@ ICER_DEV void phase_f_commit(Shared &s, Wave &R, uint32_t w, uint32_t wbase, uin
             {
                 if (lane >= 1 && lane < kNumBins) {
                     const uint32_t op = LV(c.st) & 255u;
-                    s.bin_slot[lane] = op == 254u ? -1 : op < 128u ? (int32_t)(R.tailw + cnt_lt(c.S1, c.S2, op)) : (int32_t)LV(R.slot);
+                    s.bin_slot[lane] = op == 254u ? -1 : op < 128u ? (int32_t)(R.tailw + (uint32_t)s.wl[w].sumE[lane]) : (int32_t)LV(R.slot);
                     s.bin_state[lane] = LV(c.st);
                 }
             }
@@ -1671,6 +1719,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
             }
             const uint32_t wL = WG_UNIFORM(wL);
             // ---- drain: everything before the oldest open word is finished ------------------------------------
+            // (two ring words per lane: 128 * kWgWaves words per round, so that one round is almost always enough)
             for (;;) {
                 WG_EACH_WAVE
                     WG_TICK(0)
@@ -1680,15 +1729,37 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     uint32_t head = R.tail;
                     for (uint32_t b = 1; b < 17; b++) { const uint32_t v = READLANE(bs, b); if (v != ~0u && (int32_t)(v - head) < 0) head = v; }
                     uint32_t n = head - R.popped;
-                    if (n > 64u * kWgWaves) n = 64u * kWgWaves;
+                    if (n > 128u * kWgWaves) n = 128u * kWgWaves;
                     R.nflush = n;
-                    // this wave's 64 ring words: lengths, their sum
-                    LANEVAR(uint32_t, wd);
-                    FOR_LANES { LV(wd) = (w * 64u + (uint32_t)lane) < n ? WRING_LD(R.popped + w * 64u + (uint32_t)lane) : 0u; WG_ASSERT((w * 64u + (uint32_t)lane) >= n || (LV(wd) & kWordDone)); }
-                    const uint64_t L0 = BALLOT(LV(wd) & (1u << 11)), L1 = BALLOT(LV(wd) & (2u << 11)), L2 = BALLOT(LV(wd) & (4u << 11)), L3 = BALLOT(LV(wd) & (8u << 11));
-                    FOR_LANES { if (lane == 0) s.wl[w].segtot = (uint32_t)(popc64(L0) + 2 * popc64(L1) + 4 * popc64(L2) + 8 * popc64(L3)); }
-                    // (kept for the second half)
-                    FOR_LANES { LV(R.dw) = LV(wd); }
+                    // this wave's 128 ring words: lengths, their sum
+                    LANEVAR(uint32_t, wa); LANEVAR(uint32_t, wb);
+                    FOR_LANES
+                    {
+                        const uint32_t ia = w * 128u + (uint32_t)lane, ib = ia + 64u;
+                        LV(wa) = ia < n ? WRING_LD(R.popped + ia) : 0u;
+                        LV(wb) = ib < n ? WRING_LD(R.popped + ib) : 0u;
+                        WG_ASSERT(ia >= n || (LV(wa) & kWordDone));
+                        WG_ASSERT(ib >= n || (LV(wb) & kWordDone));
+                    }
+                    const uint64_t L0 = BALLOT(LV(wa) & (1u << 11)), L1 = BALLOT(LV(wa) & (2u << 11)), L2 = BALLOT(LV(wa) & (4u << 11)), L3 = BALLOT(LV(wa) & (8u << 11));
+                    const uint64_t M0 = BALLOT(LV(wb) & (1u << 11)), M1 = BALLOT(LV(wb) & (2u << 11)), M2 = BALLOT(LV(wb) & (4u << 11)), M3 = BALLOT(LV(wb) & (8u << 11));
+                    const uint32_t suma = (uint32_t)(popc64(L0) + 2 * popc64(L1) + 4 * popc64(L2) + 8 * popc64(L3));
+                    const uint32_t sumb = (uint32_t)(popc64(M0) + 2 * popc64(M1) + 4 * popc64(M2) + 8 * popc64(M3));
+                    FOR_LANES { if (lane == 0) s.wl[w].segtot = suma + sumb; }
+                    // (kept for the second half: the words, and each one's bit offset inside this wave's 128)
+                    FOR_LANES
+                    {
+                        const uint32_t offa = (uint32_t)(mbcnt64(L0, lane) + 2 * mbcnt64(L1, lane) + 4 * mbcnt64(L2, lane) + 8 * mbcnt64(L3, lane));
+                        const uint32_t offb = suma + (uint32_t)(mbcnt64(M0, lane) + 2 * mbcnt64(M1, lane) + 4 * mbcnt64(M2, lane) + 8 * mbcnt64(M3, lane));
+                        LV(R.dw) = LV(wa) | (LV(wb) << 16);
+                        LV(R.doff) = offa | (offb << 16);
+                    }
+                    // this wave's chunk of the next window is fetched now: the loads are in flight during the drain, and
+                    // their registers are free while the records are worked out (phases D to F)
+                    if (wL == nwin) {
+                        const uint32_t jn = j0 + kWgWaves + w;
+                        if (jn < nchunks && R.pf != jn && !table_says_blank(a, jn)) fetch_window(a, R, jn);
+                    }
                     WG_TICK(7)
                 WG_BARRIER
                 store_pending = false;
@@ -1698,26 +1769,31 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                     WG_TICK(0)
                     uint32_t before = 0, total = 0;
                     for (uint32_t v = 0; v < kWgWaves; v++) { const uint32_t tsum = s.wl[v].segtot; if (v < w) before += tsum; total += tsum; }
-                    LANEVAR(uint32_t, wd);
-                    FOR_LANES { LV(wd) = LV(R.dw); if ((w * 64u + (uint32_t)lane) < n) WRING_ST(R.popped + w * 64u + (uint32_t)lane, 0u); }
-                    const uint64_t L0 = BALLOT(LV(wd) & (1u << 11)), L1 = BALLOT(LV(wd) & (2u << 11)), L2 = BALLOT(LV(wd) & (4u << 11)), L3 = BALLOT(LV(wd) & (8u << 11));
                     FOR_LANES
                     {
-                        const uint32_t len = (LV(wd) >> 11) & 15u;
-                        if (len) {
-                            const uint32_t off = (uint32_t)(mbcnt64(L0, lane) + 2 * mbcnt64(L1, lane) + 4 * mbcnt64(L2, lane) + 8 * mbcnt64(L3, lane));
-                            const uint32_t p = R.bitpos + before + off, wi = (p >> 5) & (kStageWords - 1), sh = p & 31u;
-                            const uint32_t code = LV(wd) & 0x3FFu;
-                            LDS_OR(s.stage[wi], code << sh);
-                            if (sh + len > 32u) LDS_OR(s.stage[(wi + 1) & (kStageWords - 1)], code >> (32u - sh));
+                        const uint32_t ia = w * 128u + (uint32_t)lane, ib = ia + 64u;
+                        if (ia < n) WRING_ST(R.popped + ia, 0u);               // popped: the slots are free again
+                        if (ib < n) WRING_ST(R.popped + ib, 0u);
+#define ICER_PACK_WORD(WD, OFF)                                                                            \
+                        {                                                                                  \
+                            const uint32_t wd_ = (WD), len_ = (wd_ >> 11) & 15u;                           \
+                            if (len_) {                                                                    \
+                                const uint32_t p_ = R.bitpos + before + (OFF), wi_ = (p_ >> 5) & (kStageWords - 1), sh_ = p_ & 31u; \
+                                const uint32_t code_ = wd_ & 0x3FFu;                                       \
+                                LDS_OR(s.stage[wi_], code_ << sh_);                                        \
+                                if (sh_ + len_ > 32u) LDS_OR(s.stage[(wi_ + 1) & (kStageWords - 1)], code_ >> (32u - sh_)); \
+                            }                                                                              \
                         }
+                        ICER_PACK_WORD(LV(R.dw) & 0xFFFFu, LV(R.doff) & 0xFFFFu)
+                        ICER_PACK_WORD(LV(R.dw) >> 16, LV(R.doff) >> 16)
+#undef ICER_PACK_WORD
                     }
                     R.bitpos += total;
                     R.popped += n;
                     WG_TICK(8)
                 WG_BARRIER
                 store_pending = true;
-                if (n < 64u * kWgWaves) break;
+                if (n < 128u * kWgWaves) break;
             }
             if (wL < nwin) {
                 // ---- the chunk in which a word start may find the ring full: its wave alone -------------------

@@ -13,6 +13,13 @@
 #define ICER_LAUNCH(kernel, grid, block, shmem, ...) kernel<<<(grid), (block), (shmem)>>>(__VA_ARGS__)
 #define ICER_LAUNCH_WAVE(kernel, grid, shmem, ...) kernel<<<(grid), 64, (shmem)>>>(__VA_ARGS__)
 #define ICER_DYNAMIC_LDS(T, name) extern __shared__ T name[]
+// the decoder tables of a workgroup: a copy in LDS (every decision looks them up; from global memory each look-up is a
+// chain of dependent loads)
+#define ICER_LDS_TABLES(name, src)                                                                                   \
+    __shared__ DecoderTables name;                                                                                   \
+    for (uint32_t k_ = threadIdx.x; k_ < sizeof(DecoderTables) / 4u; k_ += blockDim.x)                               \
+        reinterpret_cast<uint32_t *>(&name)[k_] = reinterpret_cast<const uint32_t *>(src)[k_];                       \
+    __syncthreads()
 #endif
 
 #include <algorithm>
@@ -91,6 +98,7 @@ decode_chains_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int cha
                      const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes, int sign_bit)
 {
     ICER_DYNAMIC_LDS(uint8_t, state);                     // plane_block_bytes(64): the threads' per-bin arrays
+    ICER_LDS_TABLES(lt, tables);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ChainDesc c = chains[i];
@@ -98,7 +106,7 @@ decode_chains_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int cha
     PlaneDecoder job;
     plane_attach_columns(job, state, 64u, threadIdx.x);
     decode_chain(job, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband, data + f.stream_off,
-                 f.stream_len, *tables, nplanes, sign_bit);
+                 f.stream_len, lt, nplanes, sign_bit);
 }
 
 // the same with one wavefront per chain and one lane per packet (decoder_wave.hpp); dynamic LDS = the row ring
@@ -109,11 +117,12 @@ decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t frame_stride, in
                           int sign_bit, uint32_t pitch)
 {
     ICER_DYNAMIC_LDS(uint16_t, ring);                     // the row ring, then the lanes' per-bin arrays
+    ICER_LDS_TABLES(lt, tables);
     const ChainDesc c = chains[blockIdx.x];
     const FrameInfo f = frames[c.frame];
     uint8_t *state = reinterpret_cast<uint8_t *>(ring + (size_t)kRingRows * pitch);
     decode_chain_wave(ring, pitch, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
-                      data + f.stream_off, f.stream_len, *tables, nplanes, sign_bit, nullptr, state);
+                      data + f.stream_off, f.stream_len, lt, nplanes, sign_bit, nullptr, state);
 }
 
 // sign-magnitude words -> int16, LL mean back in (grid.y = frame * channels + channel)

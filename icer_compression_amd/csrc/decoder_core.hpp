@@ -33,13 +33,14 @@ constexpr int kDecoderOutOfData = -7;      // ICER_DECODER_OUT_OF_DATA, icer.h:1
 constexpr int kDecodedInvalidData = -8;    // ICER_DECODED_INVALID_DATA, icer.h:101
 constexpr uint32_t kNoPacket = 0xFFFFFFFFu;
 
-// tables of the entropy decoder (built on the host from the coder's tables, ~0.7 KiB)
+// tables of the entropy decoder (built on the host from the coder's tables, ~1.7 KiB; the decode kernels keep a copy in LDS)
 struct DecoderTables {
     // bins 1..7: [bin][code word value] -> code bits | pattern bits << 4 | reversed source pattern << 8 (0 = no entry):
     // the inverse of CoderTables::v2v (icer_init.c:38-120; reversed so that the pattern pops in input order)
     uint16_t dec[8][32];
     uint16_t gm[17], gl[17], gi[17];       // Golomb parameters of bins 8..16
     uint32_t cut[16];                      // probability cut-offs x65536 between the bins (icer_config.c:69-87)
+    uint32_t binlut[257];                  // CoderTables::binlut: the bin of floor(zero * 65536 / total) by one look-up
 };
 
 inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
@@ -56,6 +57,7 @@ inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
         }
     for (int b = 0; b < 17; b++) { d->gm[b] = t.gm[b]; d->gl[b] = t.gl[b]; d->gi[b] = t.gi[b]; }
     for (int k = 0; k < 16; k++) d->cut[k] = t.cut[k];
+    for (int k = 0; k <= 256; k++) d->binlut[k] = t.binlut[k];
 }
 
 // one chain = one segment of one subband of one channel
@@ -148,17 +150,25 @@ ICER_HD uint32_t reverse_low_bits(uint32_t v, uint32_t n)            // icer_rev
     for (uint32_t k = 0; k < n; k++) { r = (r << 1) | (v & 1u); v >>= 1; }
     return r & 0xFFFFu;
 }
-// icer_compute_bin, icer_util.c:48-56: the highest bin whose cut-off the probability of a zero reaches (the cut-offs
-// ascend, so a binary search finds it)
+// icer_compute_bin, icer_util.c:48-56: the highest bin whose cut-off the probability of a zero reaches.
+// zero * 65536 >= total * cut  <=>  floor(zero * 65536 / total) >= cut, so one exact division (total <= 500: a float
+// reciprocal estimate is within 1 of the quotient, then corrected) and one table look-up replace the search over the
+// 16 cut-offs (the same scheme as the encoder's pick_bin; tests/test_tables.py and the decoder tests pin it).
 ICER_HD int pick_bin_plain(const DecoderTables &t, uint32_t zero, uint32_t total)
 {
-    const uint32_t lhs = zero * 65536u;
-    int b = 0;
-    for (int step = 16; step >= 1; step >>= 1) {
-        const int nb = b + step;
-        if (nb <= 16 && lhs >= total * t.cut[nb - 1]) b = nb;
-    }
-    return b;
+    const uint32_t a = zero << 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)total));
+#else
+    uint32_t q = (uint32_t)((float)a * (1.0f / (float)total));
+#endif
+    int32_t rem = (int32_t)a - (int32_t)(q * total);
+    if (rem < 0) { q--; rem += (int32_t)total; }
+    if (rem < 0) { q--; rem += (int32_t)total; }
+    if (rem >= (int32_t)total) { q++; rem -= (int32_t)total; }
+    if (rem >= (int32_t)total) q++;
+    const uint32_t e = t.binlut[q >> 8];
+    return (int)((e & 255u) + (q >= (e >> 8) ? 1u : 0u));
 }
 
 // icer_decode_bit, icer_decoding.c:108-194

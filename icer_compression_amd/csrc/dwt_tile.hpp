@@ -8,7 +8,8 @@
 //   rows    every window row is lifted: low[k], high[k] for the tile's KX pair columns (dwt_pair on the LDS row);
 //   columns the KX low columns and KX high columns are lifted along the window rows for the tile's KY pair rows,
 //           giving LL/LH (from the low columns) and HL/HH (from the high columns);
-//   store   HL, LH, HH go straight to their final place in the coefficient plane, LL to the buffer the next stage
+//   store   HL, LH, HH go straight to their final place in the coefficient plane -- as the sign-magnitude words the
+//           coder reads (icer_to_sign_magnitude_int16 fused into the store) --, LL to the buffer the next stage
 //           reads (so no stage reads what another workgroup of the same stage writes).
 // HBM traffic per stage: the region once in (+ halo), once out; the row-pass intermediate never leaves LDS.
 // The phase bodies are plain per-thread functions so the tests-only CPU build (tests/emu) can run them in a loop.
@@ -38,7 +39,27 @@ struct DwtStageArgs {
     uint32_t ll_stride;
     FilterTaps f;
     int32_t lim;                        // largest storable sample: 32767, or 127 for the uint8 twins
+    int sm;                             // detail bands are stored as sign-magnitude words (what the coder reads): 16 = int16
+                                        // (icer_to_sign_magnitude_int16, icer_wavelet.c:871-877), 8 = the int8 word of the uint8
+                                        // twins widened to s|0..0|mmmmmmm (icer_wavelet.c:852-858), 0 = plain two's complement
 };
+
+// two's complement -> the coder's sign-magnitude word (fused into the store of HL / LH / HH: these bands are final
+// when a stage writes them; LL still loses its mean first, finalize_ll_kernel)
+DWT_HD int16_t to_coder_word(int16_t v, int sm)
+{
+    if (sm == 16) {
+        const uint16_t mask = (uint16_t)(v >> 15);
+        return (int16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
+    }
+    if (sm == 8) {
+        const int8_t v8 = (int8_t)v;
+        const uint8_t m8 = (uint8_t)(v8 >> 7);
+        const uint8_t w8 = (uint8_t)((((uint8_t)v8 + m8) ^ m8) | ((uint8_t)v8 & 0x80u));
+        return (int16_t)(uint16_t)(((w8 & 0x80u) << 8) | (w8 & 0x7Fu));
+    }
+    return v;
+}
 
 // window origin of the tile (tx, ty) in region coordinates (may be negative: clamped on load)
 DWT_HD int tile_x0(int tx) { return 2 * tx * kTileKX - 4; }
@@ -90,10 +111,10 @@ DWT_HD bool dwt_tile_cols(DwtTileShared &sh, const DwtStageArgs &a, int tx, int 
         ovf |= p.overflow;
         if (!which) {                                           // low column: LL (top) and LH (below)
             a.ll[(size_t)ky * a.ll_stride + kx] = p.low;
-            if (p.has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + kx] = p.high;
+            if (p.has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + kx] = to_coder_word(p.high, a.sm);
         } else {                                                // high column: HL (right) and HH (diagonal)
-            a.coef[(size_t)ky * a.coef_stride + nlw + kx] = p.low;
-            if (p.has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + nlw + kx] = p.high;
+            a.coef[(size_t)ky * a.coef_stride + nlw + kx] = to_coder_word(p.low, a.sm);
+            if (p.has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + nlw + kx] = to_coder_word(p.high, a.sm);
         }
     }
     return ovf;

@@ -2,7 +2,7 @@
 //
 //   dwt_tile_kernel                     one stage of the 2-D lifting transform, fused LDS tile pass (a-1..a-4)
 //   ll_sum_kernel / ll_mean_kernel      LL mean (a-5)
-//   finalize_kernel                     LL mean removal + sign-magnitude (a-5, a-6)
+//   finalize_ll_kernel                  LL mean removal + sign-magnitude of LL (a-5, a-6; the detail bands: at the DWT store)
 //   code_units_kernel                   context modeller + entropy coder + framing (a-9..a-15)
 //   scan_kernel / gather_kernel         quota cut + final stream order (a-16, a-17)
 // HBM layout: planes are row-major int16/uint16 with row stride = image width; plane p of a batch
@@ -69,29 +69,20 @@ __global__ void ll_mean_kernel(const unsigned long long *__restrict__ sums, uint
     mean_ovf[p] = m > (sample_bits == 8 ? 127 : 32767) ? 1 : 0;
 }
 
-// LL -= mean (int16 wrap), then two's complement -> sign-magnitude over the whole plane
-// (icer_compress.c:304-313, icer_wavelet.c:871-877).  grid = (ceil(w/256), h, planes)
-// uint8 twins (icer_compress.c:40-51, icer_wavelet.c:852-858): the subtraction wraps at 8 bits and the int8
-// sign-magnitude word s|mmmmmmm (-128 -> sign, magnitude 0) is widened to the coder's s|0..0|mmmmmmm.
+// LL -= mean (int16 wrap), then two's complement -> sign-magnitude, over the LL rectangle only: the detail bands were
+// stored as sign-magnitude words by the DWT (dwt_tile.hpp).  (icer_compress.c:304-313, icer_wavelet.c:871-877;
+// uint8 twins icer_compress.c:40-51, icer_wavelet.c:852-858: the subtraction wraps at 8 bits.)
+// grid = (ceil(llw/64), ceil(llh/4), planes), block = 256.  An aborted frame keeps its raw LL band.
 __global__ void __launch_bounds__(256)
-finalize_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t llw, uint32_t llh,
-                const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels, int sample_bits)
+finalize_ll_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32_t llw, uint32_t llh,
+                   const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels, int sample_bits)
 {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= w) return;
-    if (frame_skip[blockIdx.z / channels]) return;     // aborted frame: keep the raw transform output
+    const uint32_t c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= llw || r >= llh) return;
+    if (frame_skip[blockIdx.z / channels]) return;
     uint16_t *q = coef + blockIdx.z * plane + (size_t)r * w + c;
-    int16_t v = (int16_t)*q;
-    if (r < llh && c < llw) v = (int16_t)(v - (int16_t)means[blockIdx.z]);
-    if (sample_bits == 8) {
-        const int8_t v8 = (int8_t)v;
-        const uint8_t m8 = (uint8_t)(v8 >> 7);
-        const uint8_t sm = (uint8_t)((((uint8_t)v8 + m8) ^ m8) | ((uint8_t)v8 & 0x80u));
-        *q = (uint16_t)(((sm & 0x80u) << 8) | (sm & 0x7Fu));
-        return;
-    }
-    const uint16_t mask = (uint16_t)(v >> 15);
-    *q = (uint16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
+    const int16_t v = (int16_t)((int16_t)*q - (int16_t)means[blockIdx.z]);
+    *q = (uint16_t)to_coder_word(v, sample_bits);
 }
 
 // ------------------------------------------------------------------------------------------ coder

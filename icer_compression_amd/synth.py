@@ -85,3 +85,27 @@ def gray_frame_u8(w: int, h: int, seed: int = 12345, mode: int = 1) -> np.ndarra
 def color_frame_yuv_u8(w: int, h: int, seed: int = 12345):
     """Y, U, V planes of color_frame_yuv >> 2 as uint8."""
     return tuple((p >> 2).astype(np.uint8) for p in color_frame_yuv(w, h, seed))
+
+
+def gray_frames_torch(n: int, w: int, h: int, seed: int, device, mode: int = 1):
+    """gray_batch(n, w, h, seed, mode) built on `device` with torch (bench.py: the large batch configurations would take
+    minutes to generate on the host): the same LCG by jump-ahead in wrapping 64-bit integer arithmetic, the same float64
+    ramp.  Returns an (n, h, w) int16 tensor (8-bit content, as the uint16 API takes it).  tests/test_synth.py checks it
+    against the numpy generator."""
+    import torch
+    npix = w * h
+    m32 = 0xFFFFFFFF
+    a_pow = torch.full((npix,), int(LCG_A), dtype=torch.int64, device=device)
+    a_pow = torch.cumprod(a_pow, 0) & m32                     # a^k mod 2^32, k = 1..npix (int64 wraps mod 2^64: consistent)
+    ones = torch.ones(1, dtype=torch.int64, device=device)
+    geo = torch.cumsum(torch.cat([ones, a_pow[:-1]]), 0) & m32  # sum_{j<k} a^j mod 2^32
+    x = torch.arange(w, dtype=torch.float64, device=device) / w - 0.5
+    y = torch.arange(h, dtype=torch.float64, device=device) / h - 0.5
+    ramp = ((128.0 + 60.0 * x[None, :]) + 50.0 * y[:, None]).to(torch.int64)
+    out = torch.empty((n, h, w), dtype=torch.int16, device=device)
+    for k in range(n):
+        state = (a_pow * ((seed + k) & m32) + int(LCG_C) * geo) & m32
+        r = (state >> 8).reshape(h, w)
+        v = (r & 255) if mode == 0 else ramp + (r % 17) - 8
+        out[k] = torch.clamp(v, 0, 255).to(torch.int16)
+    return out

@@ -150,6 +150,12 @@ int icerx_encode_device_s8(icerx_encoder *enc, const uint8_t *d_planes, int n_fr
 int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, size_t byte_quota,
                       uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs);
 
+/* Optional: page-lock a caller buffer that icerx_encode_host / the lib_icer-shaped entry points read frames from or
+ * write streams to, so that it crosses PCIe by DMA at link speed (otherwise the runtime stages pageable memory through
+ * its own pinned buffers, about 4x slower).  Unpin before freeing the memory.  Returns 0 or ICER_FATAL_ERROR. */
+int icerx_pin_host(void *ptr, size_t bytes);
+int icerx_unpin_host(void *ptr);
+
 /* Copy the sign-magnitude coefficient plane of (frame, channel) of the last encode to host
  * memory (what the reference leaves in the caller's image buffer). */
 int icerx_get_coefficients(icerx_encoder *enc, int frame, int channel, uint16_t *dst);
@@ -164,6 +170,14 @@ int icerx_timing_read(icerx_encoder *enc, double ms[ICERX_NUM_STAGES], uint64_t 
 
 /* Number of coding units per frame and the bits-per-pixel slot bound currently in use. */
 int icerx_info(icerx_encoder *enc, uint32_t *units_per_frame, uint32_t *slot_bits_per_pixel, uint64_t *slot_bytes_per_frame);
+
+/* Event counters of an encoder since its creation: out[0] = coding units that gave up waiting for a hand-off of the
+ * eight-wave pipeline (bounded spins; expected 0), out[1] = batches coded again by the barrier-only workgroup coder
+ * because of that (the caller still gets its result), out[2] = batches re-run with larger per-unit slots,
+ * out[3] = coder selection in force (0 automatic, 1 pipeline only, 2 workgroup coder only; env ICER_HIP_CODER=pipe|wg). */
+int icerx_encoder_stats(icerx_encoder *enc, uint64_t out[4]);
+/* out[0..2] summed over all encoders of the process, including the one behind the lib_icer-shaped entry points */
+int icerx_process_stats(uint64_t out[4]);
 
 const char *icerx_last_error(void);
 

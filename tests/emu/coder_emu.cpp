@@ -5,6 +5,7 @@
 #define ICER_WAVE_EMU 1
 #include "../../icer_compression_amd/csrc/assemble_core.hpp"
 #include "../../icer_compression_amd/csrc/coder_core.hpp"
+#include "coder_emu_drivers.hpp"
 #include "../../icer_compression_amd/csrc/coder_wg.hpp"
 #include "../../icer_compression_amd/csrc/dwt_core.hpp"
 #include "../../icer_compression_amd/csrc/dwt_tile.hpp"
@@ -80,9 +81,10 @@ extern "C" long emu_code_unit_random(const uint16_t *seg, size_t w, size_t h, si
 
 // forward DWT with the structure of the product: one fused LDS-tile pass per stage (csrc/dwt_tile.hpp), the LL
 // band handed from stage to stage through a side buffer, the three detail bands written in place
-static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim);
-extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt) { return emu_dwt_lim(img, w, h, stages, filt, 32767); }
-static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim)
+static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim, int sm);
+extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt) { return emu_dwt_lim(img, w, h, stages, filt, 32767, 0); }
+// sm: how the detail bands are stored (DwtStageArgs::sm; 0 = plain two's complement, what oracle.dwt returns)
+static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim, int sm)
 {
     if (dim_low(w, stages) < 3 || dim_low(h, stages) < 3) return kTooManyStages;
     std::vector<int16_t> src((int16_t *)img, (int16_t *)img + w * h), tmp(w * h);
@@ -90,6 +92,7 @@ static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, 
     static DwtTileShared sh;
     DwtStageArgs a;
     a.lim = lim;
+    a.sm = sm;
     a.f = filter_taps(filt);
     a.coef = coef; a.coef_stride = (uint32_t)w;
     a.src = src.data(); a.src_stride = (uint32_t)w;
@@ -135,7 +138,7 @@ extern "C" int emu_compress_bits(uint16_t *const planes[], int channels, size_t 
     int rc = build_plan(&plan, w, h, channels, stages, segments, sample_bits);
     if (rc) return rc;
     for (int c = 0; c < channels; c++)
-        if ((rc = emu_dwt_lim(planes[c], w, h, stages, filt, sample_bits == 8 ? 127 : 32767)) != kOk) return rc;
+        if ((rc = emu_dwt_lim(planes[c], w, h, stages, filt, sample_bits == 8 ? 127 : 32767, sample_bits)) != kOk) return rc;
     const size_t llw = dim_low(w, stages), llh = dim_low(h, stages);
     uint16_t means[3];
     for (int c = 0; c < channels; c++) {
@@ -147,19 +150,10 @@ extern "C" int emu_compress_bits(uint16_t *const planes[], int channels, size_t 
     for (int c = 0; c < channels; c++)
         if (means[c] > (sample_bits == 8 ? 127 : 32767)) return kIntegerOverflow;
     for (int c = 0; c < channels; c++)
-        for (size_t r = 0; r < h; r++)
-            for (size_t x = 0; x < w; x++) {   // finalize_kernel
-                int16_t v = (int16_t)planes[c][r * w + x];
-                if (r < llh && x < llw) v = (int16_t)(v - (int16_t)means[c]);
-                if (sample_bits == 8) {
-                    const int8_t v8 = (int8_t)v;
-                    const uint8_t m8 = (uint8_t)(v8 >> 7);
-                    const uint8_t sm = (uint8_t)((((uint8_t)v8 + m8) ^ m8) | ((uint8_t)v8 & 0x80u));
-                    planes[c][r * w + x] = (uint16_t)(((sm & 0x80u) << 8) | (sm & 0x7Fu));
-                    continue;
-                }
-                const uint16_t mask = (uint16_t)(v >> 15);
-                planes[c][r * w + x] = (uint16_t)((((uint16_t)v + mask) ^ mask) | ((uint16_t)v & 0x8000u));
+        for (size_t r = 0; r < llh; r++)
+            for (size_t x = 0; x < llw; x++) {   // finalize_ll_kernel (the detail bands: sign-magnitude words since the DWT store)
+                const int16_t v = (int16_t)((int16_t)planes[c][r * w + x] - (int16_t)means[c]);
+                planes[c][r * w + x] = (uint16_t)to_coder_word(v, sample_bits);
             }
 
     assign_slots(&plan, quota, bits_per_pixel);

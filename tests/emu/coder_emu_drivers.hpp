@@ -1,0 +1,112 @@
+// coder_emu_drivers.hpp -- TESTS ONLY.  Drivers that run the eight wave roles of csrc/coder_core.hpp on the CPU: one
+// thread per wave with real waits (ICER_WAVE_THREADS, tests/emu/threads_main.cpp), all waves interleaved on one thread
+// as far ahead as the protocol allows (code_unit_emu), and under a random scheduler (code_unit_emu_random).  Included
+// after coder_core.hpp by the test translation units; nothing here is part of the product library.
+#pragma once
+#include "../../icer_compression_amd/csrc/coder_core.hpp"
+
+namespace icer {
+
+#if defined(ICER_WAVE_EMU) && defined(ICER_WAVE_THREADS)
+// tests only: one CPU thread per wave, the roles started exactly like code_units_kernel starts them
+static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
+{
+    unit_state_init(s);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    s.nchunks = nchunks;
+    uint32_t bits = kUnitTooBig;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    std::thread t[8];
+    t[0] = std::thread([&] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks); });
+    t[1] = std::thread([&] { CountWave cs; count_wave_run(s, a, cs, 0, nchunks); });
+    t[2] = std::thread([&] { compact_wave_run(s, a, 0, nchunks); });
+    t[3] = std::thread([&] { WalkWave ww; walk_wave_init(s, ww); walk_wave_run(s, a, ww, nchunks, ~0u); });
+    t[4] = std::thread([&] { GolombWave gw; golomb_wave_init(gw); golomb_wave_run(s, a, gw, nchunks, ~0u); });
+    t[5] = std::thread([&] { RecordsWave rw; records_wave_run(s, a, rw, ~0u); });
+    t[6] = std::thread([&] { drain_wave_run(s, a, ~0u); });
+    t[7] = std::thread([&] { bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig; });
+    for (auto &th : t) th.join();
+    if (__atomic_load_n(&s.abort, __ATOMIC_RELAXED) == 2u) bits = kUnitFailed;
+    return bits;
+}
+#elif defined(ICER_WAVE_EMU)
+// tests only: the seven waves interleaved on one CPU thread.  Each wave runs as far ahead as the queues and
+// the speculation rule allow, so slot reuse and the discard/reload protocol are exercised, not just the
+// lock-step order.
+static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
+{
+    unit_state_init(s);
+    PixelWave pw;
+    CountWave cs;
+    WalkWave ww;
+    GolombWave gw;
+    RecordsWave rw;
+    walk_wave_init(s, ww);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    golomb_wave_init(gw);
+    uint32_t jp = 0, ja = 0, jc = 0, jb = 0;
+    while (jb < nchunks) {
+        while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; }
+        while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; }
+        while (jc < ja) { compact_wave_run(s, a, jc, jc + 1); jc++; }
+        // both speculating waves run as far ahead as events allow (and roll back when told to)
+        walk_wave_run(s, a, ww, nchunks, kQueueDepth);
+        golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
+        records_wave_run(s, a, rw, kQueueDepth);
+        if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+        jb++;
+        drain_wave_run(s, a, jb & 1u);              // the drain lags behind the merge wave on purpose
+        if (s.abort) return kUnitTooBig;
+    }
+    return merge_wave_finish(s, a);
+}
+
+// tests only: the same eight waves under a RANDOM scheduler -- at every step one wave is picked at random and runs one
+// chunk if its inputs are there (exactly the conditions the GPU waits for), so waves lag and lead each other in ways
+// the deterministic order above never produces.  A state in which no wave can move is a protocol deadlock: reported as
+// kUnitFailed.
+static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, uint32_t seed)
+{
+    unit_state_init(s);
+    PixelWave pw;
+    CountWave cs;
+    WalkWave ww;
+    GolombWave gw;
+    RecordsWave rw;
+    walk_wave_init(s, ww);
+    golomb_wave_init(gw);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    uint32_t jp = 0, ja = 0, jc = 0, jb = 0, idle = 0;
+    uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+    while (jb < nchunks) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        const uint32_t pick = (uint32_t)(rng >> 33) % 8u;
+        bool moved = false;
+        switch (pick) {
+        case 0: if (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; moved = true; } break;
+        case 1: if (ja < s.p_done && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; moved = true; } break;
+        case 2: if (jc < s.a_done) { compact_wave_run(s, a, jc, jc + 1); jc++; moved = true; } break;
+        case 3: moved = walk_wave_run(s, a, ww, nchunks, 1u) != 0; break;
+        case 4: moved = golomb_wave_run(s, a, gw, nchunks, 1u) != 0; break;
+        case 5: { const uint32_t before = rw.next, g = rw.gen; records_wave_run(s, a, rw, 1u); moved = rw.next != before || rw.gen != g; } break;
+        case 6: {
+            const RecSlot &rq = s.rq[jb % kQueueDepth];
+            const uint32_t tag = chunk_tag(jb, s.exact_seq);
+            if (rq.gtag == tag && rq.rtag == tag) {
+                if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+                jb++;
+                moved = true;
+            }
+        } break;
+        default: { const uint32_t before = s.popped; drain_wave_run(s, a, 1u); moved = s.popped != before; } break;
+        }
+        if (s.abort) return kUnitTooBig;
+        idle = moved ? 0u : idle + 1u;
+        if (idle > 100000u) return kUnitFailed;
+    }
+    return merge_wave_finish(s, a);
+}
+#endif
+
+
+}  // namespace icer

@@ -56,3 +56,4 @@ static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *
     ICER_MOCK_GRID(grid, block, shmem, for (unsigned tx_ = 0; tx_ < b_.x; tx_++) { threadIdx = dim3(tx_); kernel(__VA_ARGS__); })
 #define ICER_LAUNCH_WAVE(kernel, grid, shmem, ...) ICER_MOCK_GRID(grid, 64, shmem, threadIdx = dim3(0); kernel(__VA_ARGS__);)
 #define ICER_DYNAMIC_LDS(T, name) T *name = (T *)g_mock_lds
+#define ICER_LDS_TABLES(name, src) const DecoderTables &name = *(src)

@@ -19,6 +19,7 @@
 #define ICER_WAVE_EMU
 #define ICER_WAVE_THREADS
 #include "../../icer_compression_amd/csrc/coder_core.hpp"
+#include "coder_emu_drivers.hpp"
 
 using namespace icer;
 

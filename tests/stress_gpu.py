@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity stress on a GPU (not collected by pytest): random geometries, filters, segment counts,
 quotas and content, HIP path through the C ABI vs the oracle.  Meant to shake out rare cross-wave races.
-   python tests/stress_gpu.py [seconds] [seed]
+   python tests/stress_gpu.py [seconds] [seed]          (ICER_HIP_CODER=pipe|wg pins the coding-unit kernel)
+Fails on any mismatch and on any coding-unit time-out (icerx_process_stats), even though a time-out no longer fails the
+call.  tests/test_gpu_stress.py runs a bounded slice of it under pytest -m gpu.
 With ICER_STRESS_DECODE=1 every stream the encoder produced is also decoded by libicer_hip_dec.so (both decode kernels)
 and compared with the decoder oracle."""
 import os
@@ -80,8 +82,10 @@ def main():
             bad += 1
             print("MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), color=bool(color), u8=bool(u8)),
                   "rc", a[0], b[0], "len", len(a[1]), len(b[1]), api.load_library().icerx_last_error() if a[0] == -10 else "", flush=True)
-    print(f"stress: {n} cases, {bad} mismatches, {time.time() - t0:.1f} s")
-    sys.exit(1 if bad else 0)
+    st = api.process_stats()
+    print(f"stress: {n} cases, {bad} mismatches, {time.time() - t0:.1f} s, coder={os.environ.get('ICER_HIP_CODER', 'auto')}, "
+          f"unit time-outs {st['unit_timeouts']}, batches re-coded by the barrier-only coder {st['fallback_batches']}, slot re-runs {st['slot_retries']}")
+    sys.exit(1 if bad or st["unit_timeouts"] else 0)
 
 
 if __name__ == "__main__":

@@ -60,3 +60,31 @@ def test_shard_range_properties():
                 covered += list(range(lo, hi))
                 assert 0 <= hi - lo <= -(-n // world)
             assert covered == list(range(n))
+
+
+def test_batch_configurations_cover_every_frame_once_and_have_goldens():
+    """bench.py's frame -> rank map for the two 8-GPU batch configurations of BASELINE.json: with 8 ranks every frame of
+    the batch is encoded exactly once, and every frame has a reference golden (tests/golden/batch_golden.json, which
+    agrees with the single-frame goldens of tests/golden/golden.json)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "tests", "golden", "batch_golden.json")) as fh:
+        bg = json.load(fh)
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as fh:
+        g = json.load(fh)
+    assert tuple(bg["C4"]["frames"][0]) == (g["C4_2048_frame0"]["size"], g["C4_2048_frame0"]["crc32"])
+    assert tuple(bg["C4"]["frames"][1]) == (g["C4_2048_frame1"]["size"], g["C4_2048_frame1"]["crc32"])
+    assert tuple(bg["C5"]["frames"][0]) == (g["C5_8192_frame0"]["size"], g["C5_8192_frame0"]["crc32"])
+    for name in ("C4", "C5"):
+        c = bench.CONFIGS[name]
+        assert c["per_gpu"] * 8 == c["total"] == len(bg[name]["frames"])
+        seen = []
+        for rank in range(8):
+            gold = bench.frame_goldens(name, rank)
+            assert len(gold) == c["per_gpu"]
+            lo = rank * c["per_gpu"]
+            assert gold == [tuple(f) for f in bg[name]["frames"][lo: lo + c["per_gpu"]]]
+            seen += list(range(lo, lo + c["per_gpu"]))
+        assert seen == list(range(c["total"]))
+    assert bench.frame_goldens("C2", 5) == [(g["C2_4096_gray_5st_10seg"]["size"], g["C2_4096_gray_5st_10seg"]["crc32"])]

@@ -112,7 +112,7 @@ static enum icer_filter_types parse_filter(const char *s)
         const char *p = strchr(names, s[0] >= 'a' && s[0] <= 'z' ? s[0] - 32 : s[0]);
         if (p) return (enum icer_filter_types)(p - names);
     }
-    fprintf(stderr, "Invalid filter type: %s. Using default filter A.\n", s);
+    fprintf(stderr, "unknown wavelet filter '%s' (one of A B C D E F Q); falling back to A\n", s);
     return ICER_FILTER_A;
 }
 
@@ -120,13 +120,13 @@ static void usage(const char *prog)
 {
     printf("usage: %s compress <input> <output> [options]\n\n", prog);
     printf("options:\n");
-    printf("  -s, --stages <n>      Number of wavelet decomposition stages (default: 4)\n");
-    printf("  -f, --filter <type>   Filter type: A, B, C, D, E, F, Q (default: A)\n");
-    printf("  -g, --segments <n>    Number of error containment segments (default: 6)\n");
-    printf("  -c, --color           Use color mode (YUV)\n");
-    printf("  -G, --grayscale       Use grayscale mode\n");
-    printf("  -t, --size <size>     Target compressed size in bytes (default: lossless)\n");
-    printf("      --help            Show this help message\n\n");
+    printf("  -s, --stages <n>      DWT decomposition levels, 1..6 [4]\n");
+    printf("  -f, --filter <type>   lifting filter: A B C D E F Q [A]\n");
+    printf("  -g, --segments <n>    error-containment segments per subband, 1..32 [6]\n");
+    printf("  -c, --color           encode three planes (Y, Cb, Cr)\n");
+    printf("  -G, --grayscale       encode one luminance plane\n");
+    printf("  -t, --size <bytes>    byte quota of the stream [0 = lossless: one byte per sample]\n");
+    printf("      --help            this text\n\n");
     printf("input: binary PGM/PPM (maxval 255) or uncompressed 8/24/32-bit BMP.  Encoding runs on the GPU (libicer_hip.so);\n");
     printf("decompress is not part of this library, use the reference's icer_util for it.\n");
 }
@@ -142,28 +142,28 @@ int main(int argc, char **argv)
     int c;
     while ((c = getopt_long(argc, argv, "s:f:g:t:cG", lo, NULL)) != -1) {
         switch (c) {
-        case 's': stages = atoi(optarg); if (stages < 1 || stages > 6) { fprintf(stderr, "Error: Stages must be between 1 and 6\n"); return 1; } break;
+        case 's': stages = atoi(optarg); if (stages < 1 || stages > 6) { fprintf(stderr, "%s: --stages takes 1..6\n", argv[0]); return 1; } break;
         case 'f': filt = parse_filter(optarg); break;
-        case 'g': segments = atoi(optarg); if (segments < 1 || segments > 32) { fprintf(stderr, "Error: Segments must be between 1 and 32\n"); return 1; } break;
-        case 't': target = atoi(optarg); if (target < 0) { fprintf(stderr, "Error: Target size must be non-negative (0 = lossless)\n"); return 1; } break;
+        case 'g': segments = atoi(optarg); if (segments < 1 || segments > 32) { fprintf(stderr, "%s: --segments takes 1..32\n", argv[0]); return 1; } break;
+        case 't': target = atoi(optarg); if (target < 0) { fprintf(stderr, "%s: --size takes a byte count >= 0 (0 = lossless)\n", argv[0]); return 1; } break;
         case 'c': force_color = 1; break;
         case 'G': force_gray = 1; break;
         case 'h': usage(argv[0]); return 0;
         default: return 1;
         }
     }
-    if (force_color && force_gray) { fprintf(stderr, "Error: Cannot specify both --color and --grayscale\n"); return 1; }
-    if (optind + 2 >= argc) { fprintf(stderr, "Error: Missing required arguments\n"); usage(argv[0]); return 1; }
+    if (force_color && force_gray) { fprintf(stderr, "%s: --color and --grayscale exclude each other\n", argv[0]); return 1; }
+    if (optind + 2 >= argc) { fprintf(stderr, "%s: expected <operation> <input> <output>\n", argv[0]); usage(argv[0]); return 1; }
     const char *op = argv[optind], *in = argv[optind + 1], *out = argv[optind + 2];
-    if (strcmp(op, "decompress") == 0) { fprintf(stderr, "Error: decompress is not provided by libicer_hip (encoder only); use the reference's icer_util\n"); return 2; }
-    if (strcmp(op, "compress") != 0) { fprintf(stderr, "Error: Operation must be 'compress'\n"); return 1; }
-    if (icer_init() != ICER_RESULT_OK) { fprintf(stderr, "Error: Failed to initialize ICER library\n"); return 1; }
+    if (strcmp(op, "decompress") == 0) { fprintf(stderr, "%s: 'decompress' is not part of this tool (see libicer_hip_dec.so / the reference's icer_util)\n", argv[0]); return 2; }
+    if (strcmp(op, "compress") != 0) { fprintf(stderr, "%s: the only operation is 'compress'\n", argv[0]); return 1; }
+    if (icer_init() != ICER_RESULT_OK) { fprintf(stderr, "%s: icer_init failed\n", argv[0]); return 1; }
 
     image_t im = {0, 0, 0, NULL};
-    if (load_image(in, &im)) { fprintf(stderr, "Error: Could not load image %s\n", in); return 1; }
-    printf("Loaded image: %s (%dx%d, %d channels)\n", in, im.w, im.h, im.channels);
+    if (load_image(in, &im)) { fprintf(stderr, "%s: cannot read %s (binary PGM/PPM or uncompressed BMP expected)\n", argv[0], in); return 1; }
+    printf("input %s: %d x %d, %d channel(s)\n", in, im.w, im.h, im.channels);
     const int use_color = force_color ? 1 : force_gray ? 0 : im.channels == 3;
-    printf("Compression mode: %s\n", use_color ? "Color (YUV)" : "Grayscale");
+    printf("planes: %s\n", use_color ? "Y Cb Cr" : "gray");
 
     const size_t n = (size_t)im.w * im.h;
     uint16_t *pl[3] = {NULL, NULL, NULL};
@@ -187,9 +187,9 @@ int main(int argc, char **argv)
     uint8_t *stream = (uint8_t *)malloc((size_t)buffer_size);
     icer_output_data_buf_typedef od;
     icer_init_output_struct(&od, stream, (size_t)buffer_size, (size_t)quota);
-    printf("Starting compression...\nParameters: stages=%d, filter=%d, segments=%d", stages, (int)filt, segments);
-    if (target > 0) printf(", target_size=%.2fKB\n", target / 1024.0);
-    else printf(", mode=lossless, quota=%.2fKB\n", quota / 1024.0);
+    printf("encoding on the GPU: %d stages, filter %d, %d segments", stages, (int)filt, segments);
+    if (target > 0) printf(", byte quota %.2f KiB\n", target / 1024.0);
+    else printf(", lossless (quota %.2f KiB)\n", quota / 1024.0);
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -197,15 +197,15 @@ int main(int argc, char **argv)
                              : icer_compress_image_uint16(pl[0], (size_t)im.w, (size_t)im.h, (uint8_t)stages, filt, (uint8_t)segments, &od);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (rc != ICER_RESULT_OK && rc != ICER_BYTE_QUOTA_EXCEEDED) {
-        fprintf(stderr, "Error: Compression failed with code %d (%s)\n", rc, icerx_last_error());
+        fprintf(stderr, "encode failed: status %d (%s)\n", rc, icerx_last_error());
         return 1;
     }
-    printf("Compression completed in %.3f seconds\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
-    printf("Compressed size: %zu bytes (%.1f%% of original)\n", od.size_used, 100.0 * (double)od.size_used / (double)(n * (use_color ? 3 : 1)));
+    printf("encode call took %.3f s\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    printf("stream: %zu bytes, %.1f %% of the samples' size\n", od.size_used, 100.0 * (double)od.size_used / (double)(n * (use_color ? 3 : 1)));
     FILE *f = fopen(out, "wb");
-    if (!f || fwrite(od.rearrange_start, 1, od.size_used, f) != od.size_used) { fprintf(stderr, "Error: Could not write output file %s\n", out); return 1; }
+    if (!f || fwrite(od.rearrange_start, 1, od.size_used, f) != od.size_used) { fprintf(stderr, "cannot write %s\n", out); return 1; }
     fclose(f);
-    printf("Compressed image saved to: %s (%zu bytes)\n", out, od.size_used);
+    printf("wrote %s (%zu bytes)\n", out, od.size_used);
     for (int k = 0; k < 3; k++) free(pl[k]);
     free(im.px);
     free(stream);

@@ -11,7 +11,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-B="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --batched-probe 0"
+B="python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --batched-probe 0 --no-traffic --no-batch-configs"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o r -- $B > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o r -- $B > /dev/null 2> "$out/pmc_fetch.err"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o r -- $B > /dev/null 2> "$out/pmc_write.err"

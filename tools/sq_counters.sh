@@ -8,8 +8,8 @@ out=$root/gpurun_out/sq_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 C="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAVES"
-timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$out/single" -o r -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batched-probe 0 > /dev/null 2> "$out/single.err"
-timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$out/batch8" -o r -- python $root/bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline --batched-probe 0 > /dev/null 2> "$out/batch8.err"
+timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$out/single" -o r -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batched-probe 0 --no-traffic --no-batch-configs > /dev/null 2> "$out/single.err"
+timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$out/batch8" -o r -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --batched-probe 0 --no-traffic --no-batch-configs > /dev/null 2> "$out/batch8.err"
 cd "$root"
 python - "$tag" "$out" <<'PY'
 import json, sqlite3, sys
