@@ -101,6 +101,8 @@ def source_digest():
     hsh = hashlib.sha256()
     csrc = os.path.join(ROOT, "icer_compression_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
+        if not os.path.isfile(os.path.join(csrc, f)):
+            continue
         with open(os.path.join(csrc, f), "rb") as fh:
             hsh.update(f.encode() + b"\0" + fh.read())
     return hsh.hexdigest()[:16]

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
@@ -581,6 +582,51 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
             break;
         }
     }
+    return 0;
+}
+
+// ---- a batch over the GPUs of the node (SURVEY 8b "our additions", 8e) ---------------------------------------------
+int icerx_device_count(void)
+{
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+// Frames are independent and a frame's transform needs the whole frame, so the batch is cut into contiguous blocks
+// of frames, one per device (earlier devices take the larger blocks, icer_compression_amd/shard.py has the same rule);
+// one host thread and one icerx_encoder per device, no communication between them.  Every frame's bytes, length and
+// return code equal a per-frame call of icer_compress_image_uint16.
+int icerx_compress_batch_uint16(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
+                                int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,
+                                int n_gpus)
+{
+    if (!frames || !out || !sizes || !rcs || n_frames < 1 || n_gpus < 0) { set_error("icerx_compress_batch_uint16: invalid arguments"); return ICER_INVALID_INPUT; }
+    const int have = icerx_device_count();
+    if (have <= 0) { set_error("no usable HIP device; this library has no CPU path"); return ICER_FATAL_ERROR; }
+    int g = n_gpus == 0 || n_gpus > have ? have : n_gpus;
+    if (g > n_frames) g = n_frames;
+    std::vector<int> rc((size_t)g, 0);
+    std::vector<std::string> err((size_t)g);
+    std::vector<std::thread> th;
+    const size_t frame_elems = w * h * (size_t)channels;
+    for (int d = 0; d < g; d++) {
+        const int base = n_frames / g, extra = n_frames % g;
+        const int lo = d * base + (d < extra ? d : extra), cnt = base + (d < extra ? 1 : 0);
+        th.emplace_back([=, &rc, &err] {
+            icerx_encoder *e = nullptr;
+            int r = icerx_encoder_create(&e, d, w, h, channels, stages, filt, segments, cnt);
+            if (r == 0) {
+                r = icerx_encode_host(e, frames + (size_t)lo * frame_elems, cnt, byte_quota, out + (size_t)lo * out_stride, out_stride,
+                                      sizes + lo, rcs + lo);
+                icerx_encoder_destroy(e);
+            }
+            if (r) err[(size_t)d] = icerx_last_error();          // (thread-local in the worker)
+            rc[(size_t)d] = r;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int d = 0; d < g; d++)
+        if (rc[(size_t)d]) { set_error("device %d: %s", d, err[(size_t)d].c_str()); return rc[(size_t)d]; }
     return 0;
 }
 

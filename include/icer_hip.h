@@ -150,6 +150,16 @@ int icerx_encode_device_s8(icerx_encoder *enc, const uint8_t *d_planes, int n_fr
 int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, size_t byte_quota,
                       uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs);
 
+/* A batch of frames of one geometry from host memory over the GPUs of the node (BASELINE configs 4 and 5): contiguous
+ * blocks of frames per device, one host thread and one encoder per device, no communication between devices.
+ * frames: n_frames x channels planes of w*h uint16; out: n_frames rows of out_stride bytes (out_stride >= byte_quota);
+ * n_gpus: devices to use (0 = all present; clamped to the number present and to n_frames).  sizes / rcs per frame equal
+ * a per-frame call of icer_compress_image_[yuv_]uint16 (reference: icer.h:440-444).  Returns 0, or the first device's error. */
+int icerx_device_count(void);
+int icerx_compress_batch_uint16(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
+                                int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,
+                                int n_gpus);
+
 /* Optional: page-lock a caller buffer that icerx_encode_host / the lib_icer-shaped entry points read frames from or
  * write streams to, so that it crosses PCIe by DMA at link speed (otherwise the runtime stages pageable memory through
  * its own pinned buffers, about 4x slower).  Unpin before freeing the memory.  Returns 0 or ICER_FATAL_ERROR. */

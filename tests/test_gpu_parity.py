@@ -121,6 +121,35 @@ def test_plain_c_program_links_and_matches(oracle, tmp_path):
         assert np.array_equal(np.fromfile(tmp_path / "coef.raw", "<u2").reshape(len(planes), h, w), np.stack(left))
 
 
+def test_batch_over_devices_and_two_threads_from_c(oracle, tmp_path):
+    """icerx_compress_batch_uint16 (a batch over the node's GPUs, one host thread + encoder per device) and two
+    icerx_encoders driven from two pthreads at once (two devices when there are two) from plain C
+    (tests/c_abi/batch_devices.c): all ways give the oracle's per-frame streams."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "batch_devices")
+    libdir = os.path.join(root, "icer_compression_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-pthread", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "batch_devices.c"),
+                           "-L", libdir, "-licer_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    n, w, h, st, f, sg = 5, 200, 144, 3, 0, 6
+    q = 2 * w * h
+    frames = synth.gray_batch(n, w, h, 31, 1)
+    frames.astype("<u2").tofile(tmp_path / "in.raw")
+    r = subprocess.run([exe, str(tmp_path / "in.raw"), str(n), str(w), str(h), str(st), str(f), str(sg), str(q), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and f"ok frames={n}" in r.stdout, r.stdout + r.stderr
+    blob = (tmp_path / "out.bin").read_bytes()
+    off = 0
+    for k in range(n):
+        size, rc = struct.unpack_from("<Qi", blob, off)
+        off += 12
+        want = oracle.compress([frames[k]], st, f, sg, q)
+        assert (rc, blob[off: off + size]) == (want[0], want[1]), k
+        off += size
+
+
 def test_frontend_fusion_u8_and_rgb8(oracle):
     """next-3: 8-bit gray widening and packed RGB888 -> YCbCr on the device give the same streams as the
     reference callers' host-side conversion followed by the uint16 encoders."""
