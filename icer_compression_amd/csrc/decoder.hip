@@ -2,7 +2,7 @@
 // a BATCH of streams (the lib_icer-shaped entry points are batches of one):
 //   streams -> device | header candidates (one thread per byte offset, grid.y = stream) | payload CRCs (one thread per
 //   candidate) | host: per stream the packet walk, table and chains (decoder_plan.hpp) | decode kernel over the
-//   chains of all streams (one thread per chain, or one wavefront per chain with ICER_DEC_WAVE=1) | sign-magnitude
+//   chains of all streams (one wavefront per chain; one thread per chain with ICER_DEC_WAVE=0) | sign-magnitude
 //   removal + LL mean | inverse DWT, one level at a time, one thread per line, all frames of a geometry per launch
 //   | clamp, narrow, copy back.
 // First version: correctness before speed; every loop is bounded by the stream / image size and no
@@ -306,7 +306,9 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         for (const ChainDesc &c : chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
         const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t) + plane_block_bytes(kStateColumns);
         const char *mode = getenv("ICER_DEC_WAVE");
-        if (mode && mode[0] == '1' && ring_bytes <= 65536u) {
+        // the wavefront-per-chain kernel unless ICER_DEC_WAVE=0 asks for the thread-per-chain one (tests) or the segment
+        // rows do not fit the LDS ring
+        if (!(mode && mode[0] == '0') && ring_bytes <= 65536u) {
             ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nc, ring_bytes, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
                              d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit, pitch);
         } else {

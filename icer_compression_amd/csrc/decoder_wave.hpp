@@ -3,8 +3,9 @@
 // source runs in the CPU lane-loop build (tests/emu/decoder_emu.cpp) where its ring / retire / roll-back logic is
 // checked against the decoder oracle.
 //
-// STATUS: second decode kernel, checked on the CPU build and in a first short run on an MI355X (bit-exact, 11 Mpix/s on
-// the 4096 x 4096 headline frame); not yet profiled.  decoder.hip uses it when ICER_DEC_WAVE=1 and the segment rows fit the LDS ring.
+// STATUS: the default decode kernel (decoder.hip uses it whenever the segment rows fit the LDS ring; ICER_DEC_WAVE=0
+// selects the thread-per-chain kernel).  Bit-exact on the CPU build and on an MI355X (tests/test_gpu_decoder.py);
+// 1.28 s for the 160 chains of the 4096 x 4096 headline frame (profiles/r02_decoder_v1_rocprof.md), DESIGN.md 6b.
 //
 // Lane j < planes decodes plane planes-1-j.  All lanes are in one wavefront, so there are no waits: every iteration a
 // lane either decodes its next sample or sits out (its upper neighbour is not far enough ahead, or the ring has no room).

@@ -1,8 +1,9 @@
 """Host-side mirror of the reference's DECODING interface over the C ABI of libicer_hip_dec.so
 (include/icer_hip_dec.h).
 
-STATUS: the device code behind it is checked against the decoder oracle in its CPU builds (tests/test_emu_decoder.py) and
-has had a first short hardware run (bit-exact); the wider GPU tests (tests/test_gpu_decoder.py) are opt-in.
+STATUS: the device code behind it is checked against the decoder oracle in its CPU builds (tests/test_emu_decoder.py) and,
+on an MI355X, by tests/test_gpu_decoder.py (gray / YUV, 16 / 8 bit, damaged streams, golden digests, the batch object;
+all in the default `pytest -m gpu` run).
 
 The reference's callers do (example/src/example_decode.c, example/src/icer_util.c `decompress`)
     icer_get_image_dimensions(stream, len, &w, &h);  buf = malloc(w * h * 2);

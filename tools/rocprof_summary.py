@@ -17,7 +17,7 @@ import sys
 
 
 def short(name: str) -> str:
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
     return n.split("::")[-1] if "::" in n else n
 
 
