@@ -22,9 +22,14 @@ def _stale() -> bool:
 
 
 def _tuning_flags():
-    """experiments only: ICER_WG_WAVES=<n> builds the workgroup coder with n wavefronts per coding unit (default 16)"""
-    w = os.environ.get("ICER_WG_WAVES")
-    return [f"-DICER_WG_WAVES={int(w)}"] if w else []
+    """experiments only: ICER_WG_WAVES=<n> builds the workgroup coder with n wavefronts per coding unit (default 16),
+    ICER_QUEUE_DEPTH=<n> the pipeline with queues of n chunks between its waves (default 4)"""
+    flags = []
+    for name in ("ICER_WG_WAVES", "ICER_QUEUE_DEPTH"):
+        v = os.environ.get(name)
+        if v:
+            flags.append(f"-D{name}={int(v)}")
+    return flags
 
 
 def build_profiling_library(verbose: bool = False) -> str:

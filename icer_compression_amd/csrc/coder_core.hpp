@@ -163,7 +163,11 @@ constexpr uint32_t kUnitFailed = 0xFFFFFFFEu;    // internal error (a bounded sp
 constexpr uint32_t kFailMagic = 0x1CEBAD00u;     // first word of the diagnostic record a failed unit leaves in its payload slot
 constexpr uint32_t kFailWords = 16;
 constexpr uint32_t kSpinLimit = 1u << 25;
-constexpr uint32_t kQueueDepth = 4;         // chunks in flight between the waves of a unit
+#ifndef ICER_QUEUE_DEPTH
+#define ICER_QUEUE_DEPTH 8
+#endif
+constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between the waves of a unit (8: 48 KiB of LDS per
+                                                     // workgroup, three per CU; measured 2-3 % faster than 4 on every configuration, gpurun_out/r02n)
 constexpr int kUnitWaves = 8;               // pixel, count, compaction, walker, golomb, merge, records, drain
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
 constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits + 16;     // + HW_ID of each wave of workgroup 0
@@ -222,6 +226,7 @@ struct CoderShared {
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
     uint8_t ctx_tab[48];            // pixel wave: context table of the unit's subband (see pixel_wave_run)
+    uint8_t srank[128];             // merge wave: position of a word start -> number of word starts before it in the chunk (merge_commit)
     uint32_t gk[kNumBins];          // golomb wave: zero-run length of each Golomb bin's open word as of its last chunk (0 = none)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
     uint32_t alloc;             // words allocated so far          (merge wave)
@@ -435,6 +440,14 @@ ICER_DEV bool flush_stage(CoderShared &s, const UnitArgs &a, bool final_partial)
 }
 
 ICER_DEV uint64_t below64(uint32_t x) { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); }
+// The same questions about THIS lane's own events (position 2 * lane + slot) of masks that differ from lane to lane
+// (vector registers): lane-relative masks from 32-bit operations, no 64-bit shift by a variable.
+ICER_DEV uint32_t own_bit(uint64_t A, int lane) { return ((lane < 32 ? (uint32_t)A : (uint32_t)(A >> 32)) >> (lane & 31)) & 1u; }
+ICER_DEV uint64_t lanes_below(int lane)         // bits of the lanes below this one
+{
+    const uint32_t lo = lane < 32 ? (1u << (lane & 31)) - 1u : ~0u, hi = lane < 32 ? 0u : (1u << (lane & 31)) - 1u;
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
 // events of the set strictly before position pos
 ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
 {
@@ -443,7 +456,7 @@ ICER_DEV uint32_t cnt_lt(uint64_t A1, uint64_t A2, uint32_t pos)
 // the same for this lane's own events (position 2 * lane + slot): two v_mbcnt pairs instead of 64-bit shifts
 ICER_DEV uint32_t cnt_lt_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
 {
-    return (uint32_t)(mbcnt64(A1, lane) + mbcnt64(A2, lane)) + (slot ? (uint32_t)((A1 >> lane) & 1ull) : 0u);
+    return (uint32_t)(mbcnt64(A1, lane) + mbcnt64(A2, lane)) + (slot ? own_bit(A1, lane) : 0u);
 }
 // latest position <= pos in the set, -1 if none
 ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
@@ -453,6 +466,21 @@ ICER_DEV int last_le(uint64_t A1, uint64_t A2, uint32_t pos)
     return k1 > k2 ? k1 : k2;
 }
 ICER_DEV int last_lt(uint64_t A1, uint64_t A2, uint32_t pos) { return pos == 0u ? -1 : last_le(A1, A2, pos - 1u); }
+// latest position < (2 * lane + slot) / <= (2 * lane + slot) in the set, -1 if none
+ICER_DEV int last_lt_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
+{
+    const uint64_t lt = lanes_below(lane);
+    const uint64_t c1 = A1 & (slot ? (lt << 1) | 1ull : lt), c2 = A2 & lt;
+    const int k1 = c1 ? 2 * (63 - clz64(c1)) : -1, k2 = c2 ? 2 * (63 - clz64(c2)) + 1 : -1;
+    return k1 > k2 ? k1 : k2;
+}
+ICER_DEV int last_le_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
+{
+    const uint64_t lt = lanes_below(lane), le = (lt << 1) | 1ull;
+    const uint64_t c1 = A1 & le, c2 = A2 & (slot ? le : lt);
+    const int k1 = c1 ? 2 * (63 - clz64(c1)) : -1, k2 = c2 ? 2 * (63 - clz64(c2)) + 1 : -1;
+    return k1 > k2 ? k1 : k2;
+}
 
 // drain finished words from the head of the ring, 64 per round: lengths -> prefix sum -> bit offsets,
 // code bits OR-ed into the LDS bit stage (icer_popbuf_while_avail, icer_encoding.c:114-139)
@@ -1194,9 +1222,8 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                     const uint64_t m1_ = ICER_MATCH(key_, G1, K0, K1, K2, K3), m2_ = ICER_MATCH(key_, G2, J0, J1, J2, J3); \
                     MA = m1_; MB = m2_;                                                                         \
                     const uint64_t Z1 = m1_ & ~O1, Z2 = m2_ & ~O2;                                              \
-                    const uint32_t pos_ = 2u * (uint32_t)lane + (SLOT);                                         \
                     const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                      \
-                    const int lo_ = last_lt(m1_ & O1, m2_ & O2, pos_);                                          \
+                    const int lo_ = last_lt_own(m1_ & O1, m2_ & O2, lane, (SLOT));                               \
                     const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : s.gk[b_] + zb_;         \
                     const uint32_t m = s.tab.gm[b_], inv = s.tab.ginv[b_];                                      \
                     const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
@@ -1220,7 +1247,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                 FOR_LANES
                 {
                     if ((LV(ev1) & 0x98u) >= 0x88u && ((LV(fl1) & 2u) || LV(ka1) != ~0u)) {
-                        const int sp = last_le(SB1 & LV(ma1), SB2 & LV(mb1), 2u * (uint32_t)lane);
+                        const int sp = last_le_own(SB1 & LV(ma1), SB2 & LV(mb1), lane, 0u);
                         if (LV(fl1) & 2u) LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
                         if (LV(ka1) != ~0u) {
                             const uint32_t b = LV(ev1) & 31u;
@@ -1229,7 +1256,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                         }
                     }
                     if ((LV(ev2) & 0x98u) >= 0x88u && ((LV(fl2) & 2u) || LV(ka2) != ~0u)) {
-                        const int sp = last_le(SB1 & LV(ma2), SB2 & LV(mb2), 2u * (uint32_t)lane + 1u);
+                        const int sp = last_le_own(SB1 & LV(ma2), SB2 & LV(mb2), lane, 1u);
                         if (LV(fl2) & 2u) LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
                         if (LV(ka2) != ~0u) {
                             const uint32_t b = LV(ev2) & 31u;
@@ -1336,28 +1363,49 @@ ICER_DEV void commit_bins(CoderShared &s, MergeChunk &c, uint32_t tail)
 
 // fast path: ring slots in allocation order = order of the words' first events (E2), finished words into
 // their slots, bin states as of this (now retired) chunk.  `tail` = allocation count before the chunk.
+// A word's slot is tail + (word starts before its first event): every start event knows that rank from two lane-masked
+// counts and leaves it in LDS (srank) for the event that ends the word and for the bin's state -- no 64-bit mask shifted
+// by another lane's position anywhere.
 ICER_DEV void merge_commit(CoderShared &s, MergeChunk &c, uint32_t tail)
 {
     DECL_LANE;
     const uint64_t S1 = c.S1, S2 = c.S2;
     FOR_LANES
     {
-        if (LV(c.fl1) & 1u) RING_ST((tail + cnt_lt_own(S1, S2, lane, 0u)) & (kRingWords - 1), LV(c.ev1));
-        if (LV(c.fl2) & 1u) RING_ST((tail + cnt_lt_own(S1, S2, lane, 1u)) & (kRingWords - 1), LV(c.ev2));
+        if (LV(c.fl1) & 1u) {
+            const uint32_t r = cnt_lt_own(S1, S2, lane, 0u);
+            s.srank[2 * lane] = (uint8_t)r;
+            RING_ST((tail + r) & (kRingWords - 1), LV(c.ev1));
+        }
+        if (LV(c.fl2) & 1u) {
+            const uint32_t r = cnt_lt_own(S1, S2, lane, 1u);
+            s.srank[2 * lane + 1] = (uint8_t)r;
+            RING_ST((tail + r) & (kRingWords - 1), LV(c.ev2));
+        }
     }
+    WAVE_SYNC();
     FOR_LANES
     {
         if (LV(c.fl1) & 2u) {
-            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1)] : (tail + cnt_lt(S1, S2, LV(c.sp1)));
+            const uint32_t slot = LV(c.sp1) == 255u ? (uint32_t)s.bin_slot[LV(c.ev1)] : tail + (uint32_t)s.srank[LV(c.sp1) & 127u];
             RING_ST(slot & (kRingWords - 1), LV(c.wd1));
         }
         if (LV(c.fl2) & 2u) {
-            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2)] : (tail + cnt_lt(S1, S2, LV(c.sp2)));
+            const uint32_t slot = LV(c.sp2) == 255u ? (uint32_t)s.bin_slot[LV(c.ev2)] : tail + (uint32_t)s.srank[LV(c.sp2) & 127u];
             RING_ST(slot & (kRingWords - 1), LV(c.wd2));
         }
     }
     WAVE_SYNC();
-    commit_bins(s, c, tail);
+    // the bins' open words and coder state after the chunk (as commit_bins, ranks from srank)
+    FOR_LANES
+    {
+        if (lane >= 1 && lane < kNumBins) {
+            const uint32_t op = LV(c.st) & 255u;
+            if (op == 254u) s.bin_slot[lane] = -1;
+            else if (op < 128u) s.bin_slot[lane] = (int32_t)((tail + (uint32_t)s.srank[op]) & (kRingWords - 1));
+            s.bin_state[lane] = LV(c.st);
+        }
+    }
 }
 
 // ring stores for the chunk's events at positions [lo, hi): open markers of the words that start there, finished

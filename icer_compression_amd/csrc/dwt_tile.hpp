@@ -4,15 +4,19 @@
 // 1-D lifting over every row of the current LL region and then over every column (stride W, cache hostile).
 // Here a workgroup owns a tile of kTileKX x kTileKY output *pairs*:
 //   load    the (2*KY+8) x (2*KX+8) input window (tile + the 4/3-sample halo the filters reach) into LDS with
-//           coalesced row reads;
-//   rows    every window row is lifted: low[k], high[k] for the tile's KX pair columns (dwt_pair on the LDS row);
-//   columns the KX low columns and KX high columns are lifted along the window rows for the tile's KY pair rows,
+//           coalesced row reads, two samples (one 32-bit word) per lane where the rows are word-aligned;
+//   rows    every window row is lifted in two steps: first the pair averages (lows) and pair differences of the whole
+//           row -- each computed ONCE and left in LDS --, then the highs of the tile's KX pair columns from them
+//           (a high needs the four lows around it and two differences: dwt_core.hpp's rule, with the lows shared
+//           instead of recomputed by each of the four pairs that need them);
+//   columns the same two steps down the KX low columns and KX high columns for the tile's KY pair rows,
 //           giving LL/LH (from the low columns) and HL/HH (from the high columns);
 //   store   HL, LH, HH go straight to their final place in the coefficient plane -- as the sign-magnitude words the
 //           coder reads (icer_to_sign_magnitude_int16 fused into the store) --, LL to the buffer the next stage
 //           reads (so no stage reads what another workgroup of the same stage writes).
 // HBM traffic per stage: the region once in (+ halo), once out; the row-pass intermediate never leaves LDS.
-// The phase bodies are plain per-thread functions so the tests-only CPU build (tests/emu) can run them in a loop.
+// The phase bodies are plain per-thread functions so the tests-only CPU build (tests/emu) can run them in a loop;
+// tests/test_emu_pipeline.py::test_dwt_core holds them to the oracle for every filter, odd sizes and int16 overflow.
 #pragma once
 #include "dwt_core.hpp"
 #include "icer_tables.hpp"
@@ -21,11 +25,16 @@ namespace icer {
 
 constexpr int kTileKX = 64, kTileKY = 16;                    // output pairs per tile
 constexpr int kWinW = 2 * kTileKX + 8, kWinH = 2 * kTileKY + 8;
+constexpr int kWinPX = kWinW / 2, kWinPY = kWinH / 2;        // pairs per window row / column (the window starts 2 pairs before the tile)
 constexpr int kTileThreads = 256;
 
 struct DwtTileShared {
-    int16_t win[kWinH][kWinW];          // input window
-    int16_t lo[kWinH][kTileKX];         // row pass: lows / highs of the tile's pair columns, per window row
+    union {
+        int16_t win[kWinH][kWinW];          // input window (dead once the row lows / differences exist)
+        struct { int16_t lo[2][kWinPY][kTileKX], di[2][kWinPY][kTileKX]; } col;   // column step 1: [low / high column set]
+    };
+    int16_t rlo[kWinH][kWinPX], rdi[kWinH][kWinPX];   // row step 1: lows and differences of every pair of every window row
+    int16_t lo[kWinH][kTileKX];             // row pass result: lows / highs of the tile's pair columns, per window row
     int16_t hi[kWinH][kTileKX];
 };
 
@@ -65,56 +74,149 @@ DWT_HD int16_t to_coder_word(int16_t v, int sm)
 DWT_HD int tile_x0(int tx) { return 2 * tx * kTileKX - 4; }
 DWT_HD int tile_y0(int ty) { return 2 * ty * kTileKY - 4; }
 
-// phase 1, thread t: load window elements t, t + T, ... (out-of-region elements are never read later)
+// phase 1, thread t: load window sample pairs t, t + T, ... (out-of-region elements read as 0 and are never used)
 DWT_HD void dwt_tile_load(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
 {
     const int x0 = tile_x0(tx), y0 = tile_y0(ty);
-    for (int i = t; i < kWinH * kWinW; i += kTileThreads) {
-        const int r = i / kWinW, c = i - r * kWinW;
-        const int gx = x0 + c, gy = y0 + r;
-        sh.win[r][c] = (gx >= 0 && gx < a.cw && gy >= 0 && gy < a.ch) ? a.src[(size_t)gy * a.src_stride + gx] : (int16_t)0;
+    // a pair of samples is one aligned 32-bit word when the rows start word-aligned (x0 is even)
+    const bool words = ((a.src_stride & 1u) == 0u) && ((reinterpret_cast<uintptr_t>(a.src) & 3u) == 0u);
+    for (int i = t; i < kWinH * kWinPX; i += kTileThreads) {
+        const int r = i / kWinPX, p = i - r * kWinPX;
+        const int gx = x0 + 2 * p, gy = y0 + r;
+        int16_t v0 = 0, v1 = 0;
+        if (gy >= 0 && gy < a.ch && gx + 1 >= 0 && gx < a.cw) {
+            const int16_t *q = a.src + (size_t)gy * a.src_stride + gx;
+            if (words && gx >= 0 && gx + 1 < a.cw) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(q);
+                v0 = (int16_t)(w & 0xFFFFu); v1 = (int16_t)(w >> 16);
+            } else {
+                if (gx >= 0) v0 = q[0];
+                if (gx + 1 < a.cw) v1 = q[1];
+            }
+        }
+        sh.win[r][2 * p] = v0; sh.win[r][2 * p + 1] = v1;
     }
 }
 
-// phase 2, thread t: row lifting of window rows; returns true on int16 overflow
-DWT_HD bool dwt_tile_rows(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+// One line of `n` samples, step 1 for pair index k (0 <= k < ceil(n/2)): its low (pair average, or the odd tail sample)
+// and, for k < floor(n/2), its difference; exactly the values the reference forms for that pair (icer_wavelet.c:410-428).  Returns the overflow flag.
+DWT_HD bool dwt_pair_step1(int32_t a, int32_t b, int n, int k, int32_t lim, int16_t *low, int16_t *dif)
 {
-    const int x0 = tile_x0(tx), y0 = tile_y0(ty);
+    const int nh = n >> 1;
+    bool ovf = false;
+    if (k < nh) {
+        const int32_t v = (a + b) >> 1, d = a - b;
+        ovf = v < -lim - 1 || v > lim || d < -lim - 1 || d > lim;
+        *low = (int16_t)v; *dif = (int16_t)d;
+    } else { *low = (int16_t)a; *dif = 0; }                 // (odd n, k == nh: the tail sample is a low)
+    return ovf;
+}
+
+// Step 2: the high of pair k from the line's lows and differences (dwt_core.hpp's boundary rules and quirk W3).
+// LO(j) / DI(j): low / difference of pair j, called with 0 <= j < ceil(n/2) only.
+template <class Lo, class Di>
+DWT_HD bool dwt_pair_step2(const Lo &LO, const Di &DI, int n, int k, int am1, int a0, int a1, int be, int32_t lim, int16_t *high)
+{
+    const int nl = (n + 1) >> 1, nh = n >> 1;
+    const bool odd = (n & 1) != 0;
+    const auto clampi = [nl](int j) { return j < 0 ? 0 : (j > nl - 1 ? nl - 1 : j); };
+    const int32_t l0 = LO(clampi(k - 2)), l1 = LO(clampi(k - 1)), l2 = LO(k), l3 = LO(clampi(k + 1));
+    const int32_t r_km1 = (int16_t)(l0 - l1), r_k = (int16_t)(l1 - l2), r_kp1 = (int16_t)(l2 - l3);
+    const int32_t dk = DI(k);
+    const int32_t dn = (k + 1 < nh) ? (int32_t)DI(k + 1) : 0;
+    int32_t sub;
+    if (k == 0) sub = r_kp1 >> 2;
+    else if (k == 1 && am1 != 0) {
+        const int32_t x = (odd && nl == 3) ? 0 : dk;            // QUIRK W3
+        sub = (2 * r_k + 3 * r_kp1 - 2 * x + 4) >> 3;
+    } else if (!odd && k == nh - 1) sub = r_k >> 2;
+    else {
+        const int32_t rm = (k >= 2) ? r_km1 : 1;                // r[0] reads as 1 (times alpha_-1 == 0)
+        sub = (am1 * rm + a0 * r_k + a1 * r_kp1 - be * dn + 8) >> 4;
+    }
+    const int32_t h = dk - sub;
+    *high = (int16_t)h;
+    return h < -lim - 1 || h > lim;
+}
+
+// phase 2a, thread t: lows and differences of every pair of every window row; returns true on int16 overflow
+DWT_HD bool dwt_tile_rows_step1(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+{
+    const int y0 = tile_y0(ty);
     const int nl = (a.cw + 1) >> 1;
+    bool ovf = false;
+    for (int i = t; i < kWinH * kWinPX; i += kTileThreads) {
+        const int r = i / kWinPX, p = i - r * kWinPX;
+        const int gy = y0 + r, k = tx * kTileKX - 2 + p;
+        if (gy < 0 || gy >= a.ch || k < 0 || k >= nl) continue;
+        ovf |= dwt_pair_step1(sh.win[r][2 * p], sh.win[r][2 * p + 1], a.cw, k, a.lim, &sh.rlo[r][p], &sh.rdi[r][p]);
+    }
+    return ovf;
+}
+
+// phase 2b, thread t: row highs of the tile's pair columns (and a copy of their lows)
+DWT_HD bool dwt_tile_rows_step2(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+{
+    const int y0 = tile_y0(ty);
+    const int nl = (a.cw + 1) >> 1, nh = a.cw >> 1;
+    const int kbase = tx * kTileKX - 2;
     bool ovf = false;
     for (int i = t; i < kWinH * kTileKX; i += kTileThreads) {
         const int r = i / kTileKX, kk = i - r * kTileKX;
         const int gy = y0 + r, k = tx * kTileKX + kk;
         if (gy < 0 || gy >= a.ch || k >= nl) continue;
-        const int16_t *row = sh.win[r];
-        const DwtPair p = dwt_pair([row, x0](int x) { return row[x - x0]; }, a.cw, k, a.f.am1, a.f.a0, a.f.a1, a.f.be, a.lim);
-        sh.lo[r][kk] = p.low;
-        sh.hi[r][kk] = p.has_high ? p.high : (int16_t)0;
-        ovf |= p.overflow;
+        const int16_t *rl = sh.rlo[r], *rd = sh.rdi[r];
+        sh.lo[r][kk] = rl[k - kbase];
+        int16_t h = 0;
+        if (k < nh)
+            ovf |= dwt_pair_step2([rl, kbase](int j) { return (int32_t)rl[j - kbase]; }, [rd, kbase](int j) { return (int32_t)rd[j - kbase]; },
+                                  a.cw, k, a.f.am1, a.f.a0, a.f.a1, a.f.be, a.lim, &h);
+        sh.hi[r][kk] = h;
     }
     return ovf;
 }
 
-// phase 3, thread t: column lifting + stores; returns true on int16 overflow
-DWT_HD bool dwt_tile_cols(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+// phase 3a, thread t: lows and differences down the tile's low columns (which = 0) and high columns (1) -- into the
+// LDS block the input window lived in
+DWT_HD bool dwt_tile_cols_step1(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
 {
-    const int y0 = tile_y0(ty);
     const int nlw = (a.cw + 1) >> 1, nhw = a.cw >> 1, nlh = (a.ch + 1) >> 1;
+    bool ovf = false;
+    for (int i = t; i < 2 * kWinPY * kTileKX; i += kTileThreads) {
+        const int kk = i % kTileKX, q = (i / kTileKX) % kWinPY, which = i / (kTileKX * kWinPY);
+        const int kx = tx * kTileKX + kk, ky = ty * kTileKY - 2 + q;
+        if (ky < 0 || ky >= nlh || kx >= (which ? nhw : nlw)) continue;
+        const int16_t(*col)[kTileKX] = which ? sh.hi : sh.lo;
+        ovf |= dwt_pair_step1(col[2 * q][kk], col[2 * q + 1][kk], a.ch, ky, a.lim, &sh.col.lo[which][q][kk], &sh.col.di[which][q][kk]);
+    }
+    return ovf;
+}
+
+// phase 3b, thread t: column highs + stores; returns true on int16 overflow
+DWT_HD bool dwt_tile_cols_step2(DwtTileShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+{
+    const int nlw = (a.cw + 1) >> 1, nhw = a.cw >> 1, nlh = (a.ch + 1) >> 1, nhh = a.ch >> 1;
+    const int qbase = ty * kTileKY - 2;
     bool ovf = false;
     for (int i = t; i < 2 * kTileKX * kTileKY; i += kTileThreads) {
         // consecutive threads -> consecutive pair columns (coalesced stores); low columns first, then high columns
         const int kk = i % kTileKX, which = (i / kTileKX) & 1, jj = i / (2 * kTileKX);
         const int kx = tx * kTileKX + kk, ky = ty * kTileKY + jj;
         if (ky >= nlh || kx >= (which ? nhw : nlw)) continue;
-        const int16_t(*col)[kTileKX] = which ? sh.hi : sh.lo;
-        const DwtPair p = dwt_pair([col, kk, y0](int y) { return col[y - y0][kk]; }, a.ch, ky, a.f.am1, a.f.a0, a.f.a1, a.f.be, a.lim);
-        ovf |= p.overflow;
+        const int16_t(*cl)[kTileKX] = sh.col.lo[which];
+        const int16_t(*cd)[kTileKX] = sh.col.di[which];
+        const int16_t low = cl[ky - qbase][kk];
+        int16_t high = 0;
+        const bool has_high = ky < nhh;
+        if (has_high)
+            ovf |= dwt_pair_step2([cl, kk, qbase](int j) { return (int32_t)cl[j - qbase][kk]; }, [cd, kk, qbase](int j) { return (int32_t)cd[j - qbase][kk]; },
+                                  a.ch, ky, a.f.am1, a.f.a0, a.f.a1, a.f.be, a.lim, &high);
         if (!which) {                                           // low column: LL (top) and LH (below)
-            a.ll[(size_t)ky * a.ll_stride + kx] = p.low;
-            if (p.has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + kx] = to_coder_word(p.high, a.sm);
+            a.ll[(size_t)ky * a.ll_stride + kx] = low;
+            if (has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + kx] = to_coder_word(high, a.sm);
         } else {                                                // high column: HL (right) and HH (diagonal)
-            a.coef[(size_t)ky * a.coef_stride + nlw + kx] = to_coder_word(p.low, a.sm);
-            if (p.has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + nlw + kx] = to_coder_word(p.high, a.sm);
+            a.coef[(size_t)ky * a.coef_stride + nlw + kx] = to_coder_word(low, a.sm);
+            if (has_high) a.coef[(size_t)(nlh + ky) * a.coef_stride + nlw + kx] = to_coder_word(high, a.sm);
         }
     }
     return ovf;

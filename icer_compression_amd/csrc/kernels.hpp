@@ -33,9 +33,13 @@ dwt_tile_kernel(DwtStageArgs a, size_t src_plane, size_t coef_plane, size_t ll_p
     const int tx = blockIdx.x, ty = blockIdx.y, t = threadIdx.x;
     dwt_tile_load(sh, a, tx, ty, t);
     __syncthreads();
-    bool o = dwt_tile_rows(sh, a, tx, ty, t);
+    bool o = dwt_tile_rows_step1(sh, a, tx, ty, t);
     __syncthreads();
-    o |= dwt_tile_cols(sh, a, tx, ty, t);
+    o |= dwt_tile_rows_step2(sh, a, tx, ty, t);
+    __syncthreads();
+    o |= dwt_tile_cols_step1(sh, a, tx, ty, t);
+    __syncthreads();
+    o |= dwt_tile_cols_step2(sh, a, tx, ty, t);
     if (o) atomicOr(&ovf[blockIdx.z], 1);
 }
 

@@ -107,8 +107,10 @@ static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, 
             for (int tx = 0; tx < (nlw + kTileKX - 1) / kTileKX; tx++) {
                 memset(&sh, 0x5A, sizeof sh);
                 for (int t = 0; t < kTileThreads; t++) dwt_tile_load(sh, a, tx, ty, t);
-                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_rows(sh, a, tx, ty, t);
-                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_cols(sh, a, tx, ty, t);
+                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_rows_step1(sh, a, tx, ty, t);
+                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_rows_step2(sh, a, tx, ty, t);
+                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_cols_step1(sh, a, tx, ty, t);
+                for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_cols_step2(sh, a, tx, ty, t);
             }
         a.src = a.ll; a.src_stride = a.ll_stride;
         off += (size_t)nlw * nlh;
