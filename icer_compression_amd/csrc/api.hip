@@ -92,6 +92,8 @@ struct icerx_encoder {
     // mode; 1 / 2: always the pipeline / always the window coder (ICER_HIP_CODER=pipe|wg, tests and measurements).
     int coder_mode = 0;
     bool wg_once = false;               // the next enqueue uses the window coder whatever the mode (after a unit time-out)
+    int pipe_waves = 0;                 // 0: shape of the pipeline's workgroups chosen per launch; 8 / 12: pinned (ICER_HIP_PIPE_WAVES)
+    int n_cus = 256;                    // compute units of the device
     uint64_t n_timeouts = 0, n_fallbacks = 0, n_slot_retries = 0;   // icerx_encoder_stats
 
     DevBuf<int16_t> coef, tmp;
@@ -276,11 +278,22 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
                            e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
                            e->sig.p, e->plan.sig_bytes);
-    else
-    hipLaunchKernelGGL(code_units_kernel, dim3(n_units, n_frames), dim3(64 * kUnitWaves), 0, st,
-                       reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                       progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                       e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+    else {
+        // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
+        // largest units, which the large shape (two pixel waves, golomb state wave + two workers, ring wave) shortens; a batch wants
+        // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|12 pins one (measurements).
+        const bool large = e->pipe_waves ? e->pipe_waves == kUnitWavesLarge : n_frames == 1;
+        if (large)
+            hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units, n_frames), dim3(64 * kUnitWavesLarge), 0, st,
+                               reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                               progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+        else
+            hipLaunchKernelGGL(code_units_kernel<kUnitWavesSmall>, dim3(n_units, n_frames), dim3(64 * kUnitWavesSmall), 0, st,
+                               reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                               progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+    }
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
@@ -340,6 +353,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const int rc = build_plan(&e->plan, w, h, channels, stages, segments, sample_bits);
     if (rc != kOk) { delete e; return rc; }
     // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
+    if (const char *pw = getenv("ICER_HIP_PIPE_WAVES")) { const int v = atoi(pw); if (v == kUnitWavesSmall || v == kUnitWavesLarge) e->pipe_waves = v; }
     if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
@@ -354,6 +368,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         delete e;
         return ICER_FATAL_ERROR;
     }
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
     // (a failing HIP call below must not leak the object and what it has allocated so far)
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); icerx_encoder_destroy(e); return ICER_FATAL_ERROR; } } while (0)
     CREATE_TRY(hipSetDevice(device));
@@ -715,7 +730,7 @@ int icerx_prof_trace(icerx_encoder *e, uint64_t *out, int n_blocks)
     uint64_t hw[16];
     HIP_TRY(hipMemcpy(hw, e->prof.p + 9 * 32 + 4 * kTraceUnits, sizeof hw, hipMemcpyDeviceToHost));
     fprintf(stderr, "workgroup 0, wave -> SIMD:");
-    for (int w = 0; w < kUnitWaves; w++) fprintf(stderr, " %d->%d", w, (int)((hw[w] >> 4) & 3));
+    for (int w = 0; w < kUnitWavesLarge; w++) fprintf(stderr, " %d->%d", w, (int)((hw[w] >> 4) & 3));
     fprintf(stderr, "\n");
     return n_blocks;
 }

@@ -168,7 +168,16 @@ constexpr uint32_t kSpinLimit = 1u << 25;
 #endif
 constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between the waves of a unit (8: 48 KiB of LDS per
                                                      // workgroup, three per CU; measured 2-3 % faster than 4 on every configuration, gpurun_out/r02n)
-constexpr int kUnitWaves = 8;               // pixel, count, compaction, walker, golomb, merge, records, drain
+// The pixel stage keeps no state from chunk to chunk, so several wavefronts can share it: wave k of `npw` takes the
+// chunks j with j % npw == k.  The Golomb stage (bins 0, 8..16) is split the same way: what carries over from chunk to
+// chunk is only the zero-run length of every bin, and that follows from the chunk's events by a few counts
+// (golomb_state_run, one wave); the per-event work is then free of state and shared by `ngw` worker waves.
+// Two shapes of a workgroup are built (code_units_kernel<...>): 8 waves -- one pixel wave, one golomb wave that keeps the
+// run lengths itself; three workgroups per CU, for batches (more waves per unit cost a batch a quarter of its throughput,
+// gpurun_out/r02r) -- and 12 waves -- two pixel waves, golomb state wave + two workers, a ring wave that does the merge
+// wave's ring stores; two workgroups per CU, a shorter chain per chunk, for a launch that cannot fill the chip anyway (a single frame).
+constexpr uint32_t kMaxPixelWaves = 2, kMaxGolombWorkers = 2;
+constexpr int kUnitWavesSmall = 8, kUnitWavesLarge = 12;
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
 constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits + 16;     // + HW_ID of each wave of workgroup 0
 
@@ -214,6 +223,17 @@ struct WalkSlot {               // walker wave -> records wave (bins 1..7)
     uint32_t tag;               // as RecSlot::gtag
 };
 
+struct RunSlot {                // golomb state wave -> golomb workers: the bins' zero-run lengths at the start of the chunk
+    uint32_t tag;               // chunk_tag(chunk, generation)
+    uint32_t gk[kNumBins];
+};
+
+struct HeadSlot {               // merge wave -> ring wave (large shape): what the ring stores of a chunk need besides its records
+    uint32_t tail;              // allocation count before the chunk
+    uint32_t skip;              // the merge wave has stored the chunk itself (exact path)
+    int32_t bslot[kNumBins];    // the bins' open slots at the start of the chunk (words carried in end there)
+};
+
 struct CoderShared {
     uint32_t stage[kStageWords];
     uint16_t ring[kRingWords];
@@ -223,9 +243,12 @@ struct CoderShared {
     EventSlot eq[kQueueDepth];
     WalkSlot wq[kQueueDepth];
     RecSlot rq[kQueueDepth];
+    RunSlot kq[kQueueDepth];
+    HeadSlot hq[kQueueDepth];
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
     uint8_t ctx_tab[48];            // pixel wave: context table of the unit's subband (see pixel_wave_run)
+    uint8_t srank2[128];            // ring wave: the same for its stores (ring_wave_run)
     uint8_t srank[128];             // merge wave: position of a word start -> number of word starts before it in the chunk (merge_commit)
     uint32_t gk[kNumBins];          // golomb wave: zero-run length of each Golomb bin's open word as of its last chunk (0 = none)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
@@ -237,7 +260,10 @@ struct CoderShared {
     uint32_t hold_seq, hold_ack, drain_exit;
     uint32_t nchunks;           // chunks of the unit
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
-    uint32_t p_done, a_done, c_done, b_done, abort;
+    uint32_t p_done[4];         // per pixel wave: 1 + the last chunk it has handed over
+    uint32_t a_done, c_done, b_done, abort;
+    uint32_t head_tail;         // large shape: the merge wave's allocation count (alloc lags behind it by what the ring wave has not stored yet)
+    uint32_t h_done, w_done;    // large shape: chunks decided by the merge wave / chunks whose ring stores are done (ring wave)
     uint32_t abort_site;        // who set abort = 2: source line | wave << 16 (GPU build; diagnostics only)
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
     // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
@@ -549,7 +575,7 @@ struct PixelWave {                // next chunk's 3x3 coefficient window, one pi
 };
 
 // fetch the 3x3 windows of the 64 pixels starting at BASE; (cw.row, cw.col) = raster coordinates of pixel
-// BASE + lane, advanced by 64 pixels per chunk without a division when the segment is at least 64 wide
+// BASE + lane, advanced to this wave's next chunk without a division when the segment is wide enough
 #define ICER_FETCH_WINDOW(BASE)                                                                        \
     FOR_LANES                                                                                          \
     {                                                                                                  \
@@ -568,40 +594,51 @@ struct PixelWave {                // next chunk's 3x3 coefficient window, one pi
         LV(cw.nC) = vC_; LV(cw.nW) = vW_; LV(cw.nE) = vE_; LV(cw.nN) = vN_; LV(cw.nS) = vS_;             \
         LV(cw.nNW) = vNW_; LV(cw.nNE) = vNE_; LV(cw.nSW) = vSW_; LV(cw.nSE) = vSE_;                     \
         LV(cw.has) = (hasW_ ? 1u : 0u) | (hasE_ ? 2u : 0u) | (hasN_ ? 4u : 0u) | (hasS_ ? 8u : 0u);     \
-        /* advance to the same lane of the next chunk */                                               \
-        if (a.w >= 64u) {                                                                              \
-            uint32_t nc_ = LV(cw.col) + 64u;                                                           \
+        /* advance to the same lane of this wave's next chunk (npw chunks further on) */               \
+        if (a.w >= 64u * npw) {                                                                        \
+            uint32_t nc_ = LV(cw.col) + 64u * npw;                                                     \
             if (nc_ >= a.w) { nc_ -= a.w; LV(cw.row)++; }                                              \
             LV(cw.col) = nc_;                                                                          \
         } else {                                                                                       \
-            const uint32_t np_ = (BASE) + 64u + (uint32_t)lane;                                        \
+            const uint32_t np_ = (BASE) + 64u * npw + (uint32_t)lane;                                  \
             LV(cw.row) = np_ / a.w;                                                                    \
             LV(cw.col) = np_ - LV(cw.row) * a.w;                                                       \
         }                                                                                              \
     }
 
-// chunks [j0, j1) of the unit; the first call must start at chunk 0
-ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1)
+// context of a not-yet-significant pixel by neighbour counts (icer_config.c:26-67) for the unit's subband: HH indexed
+// (h + v) * 5 + d, the other subbands (h * 3 + v) * 5 + d with h, v <= 2, d <= 4.  One wave, before the pixel waves start.
+ICER_DEV void pixel_tables_init(CoderShared &s, const UnitArgs &a)
+{
+    DECL_LANE;
+    const bool is_hh = a.subband == kHH;
+    FOR_LANES
+    {
+        if (lane < 45) s.ctx_tab[lane] = (uint8_t)(is_hh ? ctx_hh((uint32_t)lane / 5u, (uint32_t)lane % 5u)
+                                                        : ctx_plain((uint32_t)lane / 15u, ((uint32_t)lane / 5u) % 3u, (uint32_t)lane % 5u));
+    }
+    WAVE_SYNC();
+}
+
+// pixel wave k of npw: its chunks (j % npw == k) among [j0, j1); its first call must include its first chunk, k
+ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
     const uint32_t npix = a.w * a.h;
     const uint32_t lsb = (uint32_t)a.lsb;
     const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
-    if (j0 == 0 && npix) {
+    const uint32_t jfirst = j0 + (k + npw - j0 % npw) % npw;                        // first chunk >= j0 of this wave
+    if (jfirst == k && k * 64u < npix) {
         FOR_LANES
         {
-            LV(cw.row) = (uint32_t)lane / a.w; LV(cw.col) = (uint32_t)lane - LV(cw.row) * a.w;
-            // context of a not-yet-significant pixel by neighbour counts (icer_config.c:26-67): HH indexed
-            // (h + v) * 5 + d, the other subbands (h * 3 + v) * 5 + d with h, v <= 2, d <= 4
-            if (lane < 45) s.ctx_tab[lane] = (uint8_t)(is_hh ? ctx_hh((uint32_t)lane / 5u, (uint32_t)lane % 5u)
-                                                            : ctx_plain((uint32_t)lane / 15u, ((uint32_t)lane / 5u) % 3u, (uint32_t)lane % 5u));
+            const uint32_t np = k * 64u + (uint32_t)lane;
+            LV(cw.row) = np / a.w; LV(cw.col) = np - LV(cw.row) * a.w;
         }
-        WAVE_SYNC();
-        ICER_FETCH_WINDOW(0u)
+        ICER_FETCH_WINDOW(k * 64u)
     }
 
-    for (uint32_t j = j0; j < j1; j++) {
+    for (uint32_t j = jfirst; j < j1; j += npw) {
         const uint32_t base = j * 64u;
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
@@ -616,8 +653,8 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             LV(cNW) = (hN && hW) ? LV(cw.nNW) : 0u; LV(cNE) = (hN && hE) ? LV(cw.nNE) : 0u;
             LV(cSW) = (hS && hW) ? LV(cw.nSW) : 0u; LV(cSE) = (hS && hE) ? LV(cw.nSE) : 0u;
         }
-        // the next chunk's window is fetched while this one is processed (the LDS-only fences never drain vmcnt)
-        if (base + 64u < npix) ICER_FETCH_WINDOW(base + 64u)
+        // this wave's next chunk's window is fetched while this one is processed (the LDS-only fences never drain vmcnt)
+        if (base + 64u * npw < npix) ICER_FETCH_WINDOW(base + 64u * npw)
 
         // ---- context formation (C1-C6) ------------------------------------------------------------
         FOR_LANES
@@ -723,7 +760,7 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             if (lane < 17) o.cn[lane] = (uint16_t)LV(cnw);
             if (lane == 17) o.cn[17] = blank ? 1u : 0u;            // handed on to the golomb wave (EventSlot::blank)
         }
-        ICER_PUBLISH(s.p_done, j + 1u)
+        ICER_PUBLISH(s.p_done[k], j + 1u)
     }
     ICER_TIMERS_STORE(a.timers)
 }
@@ -736,7 +773,7 @@ struct CountWave {              // lane c: adaptive counts of context c (icer_co
     LANEVAR(uint32_t, ctot);
 };
 
-ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1)
+ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1, uint32_t npw)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -747,7 +784,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         LV(ctot) = j0 == 0 ? 4u : LV(cs.ctot);
     }
     for (uint32_t j = j0; j < j1; j++) {
-        ICER_WAIT_CNT(s.p_done, pd_, pd_ > j, ab_, 1)
+        ICER_WAIT_CNT(s.p_done[j % npw], pd_, pd_ > j, ab_, 1)
         if (ab_) break;
         ICER_TICK(2)
         const PixelSlot &in = s.pq[j % kQueueDepth];
@@ -768,7 +805,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         }
 
 #ifdef ICER_WAVE_THREADS
-        assert(ICER_LOAD_CNT(s.p_done) <= j + kQueueDepth);      // (test build) the pixel wave has not recycled this slot
+        assert(ICER_LOAD_CNT(s.p_done[j % npw]) <= j + kQueueDepth);      // (test build) the pixel wave has not recycled this slot
 #endif
         // ---- adaptive counts per event (C5) --------------------------------------------------------------
         // counts an event sees = its context's counts at chunk start + the ranks the pixel wave prepared; lane c
@@ -1105,7 +1142,7 @@ ICER_DEV uint32_t walk_wave_run(CoderShared &s, const UnitArgs &a, WalkWave &ww,
 // ==========================================================================================
 // golomb wave (bins 0 and 8..16)
 // ==========================================================================================
-struct GolombWave {             // (the bins' zero-run lengths live in CoderShared::gk)
+struct GolombWave {             // golomb state wave and golomb workers (the state wave keeps the bins' zero-run lengths in CoderShared::gk)
     uint32_t next, gen;         // as WalkWave
 };
 
@@ -1115,11 +1152,13 @@ ICER_DEV void golomb_wave_init(GolombWave &gw)
     gw.gen = 0;
 }
 
-// same speculation / roll-back scheme as walk_wave_run
-ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw, uint32_t nchunks, uint32_t max_chunks)
+// The zero-run length of every Golomb bin at the start of every chunk: lane b = bin b.  After a chunk it is
+// (run before + the bin's events) mod m if the bin had no one-event in the chunk, else (its zero events after its last
+// one-event) mod m -- a word ends at a one-event or when the run reaches m (icer_encoding.c:62-80).
+// Same speculation / roll-back scheme as walk_wave_run.
+ICER_DEV uint32_t golomb_state_run(CoderShared &s, const UnitArgs &a, GolombWave &gw, uint32_t nchunks, uint32_t max_chunks)
 {
     DECL_LANE;
-    ICER_TIMERS_DECL
     ICER_IDLE_DECL
     (void)a;
     uint32_t done = 0;
@@ -1143,7 +1182,88 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
         }
         if (done >= max_chunks) break;
         ICER_ACQUIRE()
+        // (slot j % depth is free: the count wave is at most `depth` chunks ahead of the merge wave's retire count, and a
+        // chunk is only retired after its worker has handed it over)
+        const EventSlot &q = s.eq[j % kQueueDepth];
+        RunSlot &o = s.kq[j % kQueueDepth];
+        LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2); LANEVAR(uint32_t, run);
+        FOR_LANES
+        {
+            LV(ev1) = q.ev1[lane];
+            LV(ev2) = q.ev2[lane];
+            LV(run) = lane < kNumBins ? s.gk[lane] : 0u;
+            if (lane < kNumBins) o.gk[lane] = LV(run);
+        }
+        const uint64_t G1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), G2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u);
+        if (G1 | G2) {
+#define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
+            ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+            const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u);
+            const uint64_t J0 = BALLOT(LV(ev2) & 1u), J1 = BALLOT(LV(ev2) & 2u), J2 = BALLOT(LV(ev2) & 4u), J3 = BALLOT((LV(ev2) & 31u) == 16u);
+            const uint64_t O1 = G1 & BALLOT(LV(ev1) & 0x20u), O2 = G2 & BALLOT(LV(ev2) & 0x20u);       // one-events
+            FOR_LANES
+            {
+                if (lane >= 8 && lane <= 16) {
+                    const uint32_t key = ((uint32_t)lane & 7u) | (lane == 16 ? 8u : 0u);
+                    const uint64_t m1 = ICER_MATCH(key, G1, K0, K1, K2, K3), m2 = ICER_MATCH(key, G2, J0, J1, J2, J3);
+                    const uint32_t all = (uint32_t)(popc64(m1) + popc64(m2));
+                    if (all) {
+                        const int lo1 = last_le(m1 & O1, m2 & O2, 127u);
+                        uint32_t z = lo1 < 0 ? LV(run) + all : all - cnt_lt(m1, m2, (uint32_t)lo1 + 1u);
+                        z -= ((z * s.tab.ginv[lane]) >> 20) * s.tab.gm[lane];
+                        s.gk[lane] = z;
+                    }
+                }
+            }
+#undef ICER_MATCH
+        }
+        ICER_PUBLISH(o.tag, chunk_tag(j, gw.gen))
+        gw.next = j + 1u;
+        done++;
+        ICER_IDLE_RESET
+    }
+    return done;
+}
+
+// Golomb worker k of ngw: the chunks j with j % ngw == k, each from the run lengths the state wave
+// left for it (RunSlot); keeps no state of its own.  Same speculation / roll-back scheme as walk_wave_run.
+ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave &gw, uint32_t nchunks, uint32_t max_chunks, uint32_t k, uint32_t ngw)
+{
+    DECL_LANE;
+    ICER_TIMERS_DECL
+    ICER_IDLE_DECL
+    (void)a;
+    uint32_t done = 0;
+    // ngw == 0: no state wave -- this wave is the whole Golomb stage (the small shape of the workgroup): it takes the run
+    // lengths from CoderShared::gk and leaves the new ones there itself
+    const bool fused = ngw == 0u;
+    const uint32_t step = fused ? 1u : ngw;
+    if (!fused && gw.next % ngw != k) gw.next = k;              // (first call)
+    for (;;) {
+        const uint32_t ab_ = ICER_LOAD_CNT(s.abort), seq = ICER_LOAD_CNT(s.exact_seq), ad_ = ICER_LOAD_CNT(s.a_done);
+        if (ab_) break;
+        if (seq != gw.gen) {
+            ICER_ACQUIRE()
+            gw.gen = seq;
+            const uint32_t first = s.last_exact + 1u;
+            gw.next = fused ? first : first + (k + ngw - first % ngw) % ngw;
+            if (fused) {
+                FOR_LANES
+                {
+                    if (lane >= 8 && lane <= 16) s.gk[lane] = st_acc(s.bin_state[lane]);
+                }
+            }
+        }
+        const uint32_t j = gw.next;
+        if (j >= nchunks || (fused ? ad_ <= j : ICER_LOAD_CNT(s.kq[j % kQueueDepth].tag) != chunk_tag(j, gw.gen))) {
+            if (ICER_LOAD_CNT(s.b_done) >= nchunks || done >= max_chunks) break;
+            ICER_IDLE()
+            continue;
+        }
+        if (done >= max_chunks) break;
+        ICER_ACQUIRE()
         ICER_TICK(10)
+        struct { const uint32_t *gk; } runs_in = {fused ? s.gk : s.kq[j % kQueueDepth].gk};
         const EventSlot &q = s.eq[j % kQueueDepth];
         RecSlot &o = s.rq[j % kQueueDepth];
         LANEVAR(uint32_t, ev1); LANEVAR(uint32_t, ev2);
@@ -1156,7 +1276,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             LV(ev2) = q.ev2[lane];
             LV(fl1) = 0; LV(fl2) = 0; LV(wd1) = 0; LV(wd2) = 0; LV(sp1) = 255; LV(sp2) = 255;
             // a bin without events in this chunk keeps its run length and its open word (open_pos 255)
-            if (lane == 0 || (lane >= 8 && lane <= 16)) o.binst[lane] = st_pack(255u, s.gk[lane], 0u);
+            if (lane == 0 || (lane >= 8 && lane <= 16)) o.binst[lane] = st_pack(255u, runs_in.gk[lane], 0u);
             // bin 0 (uncoded): every event is a complete one-bit word (E3)
             if ((LV(ev1) & 0x9Fu) == 0x80u) { LV(fl1) = 3; LV(wd1) = kWordDone | (1u << 11) | ((LV(ev1) >> 5) & 1u); LV(sp1) = 2u * (uint32_t)lane; }
             if ((LV(ev2) & 0x9Fu) == 0x80u) { LV(fl2) = 3; LV(wd2) = kWordDone | (1u << 11) | ((LV(ev2) >> 5) & 1u); LV(sp2) = 2u * (uint32_t)lane + 1u; }
@@ -1189,7 +1309,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             {
                 const uint32_t b = LV(ev1) & 31u, m = s.tab.gm[b], inv = s.tab.ginv[b];
                 const uint32_t r = (uint32_t)lane >= c ? (uint32_t)lane - c : (uint32_t)lane;      // rank inside the run
-                const uint32_t z = s.gk[b] + r;
+                const uint32_t z = runs_in.gk[b] + r;
                 const uint32_t kb = z - ((z * inv) >> 20) * m;
                 const uint32_t ends = kb + 1u == m ? 1u : 0u;
                 const uint32_t first = kb <= r ? 2u * ((uint32_t)lane - kb) : 255u;               // first event of the word this event is in
@@ -1204,7 +1324,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             {
                 if (LV(ka1) != ~0u) {
                     const uint32_t b = LV(ev1) & 31u;
-                    s.gk[b] = LV(ka1);
+                    if (fused) s.gk[b] = LV(ka1);
                     o.binst[b] = st_pack(LV(ka1) ? LV(ka2) : 254u, LV(ka1), 0u);
                 }
             }
@@ -1224,7 +1344,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                     const uint64_t Z1 = m1_ & ~O1, Z2 = m2_ & ~O2;                                              \
                     const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                      \
                     const int lo_ = last_lt_own(m1_ & O1, m2_ & O2, lane, (SLOT));                               \
-                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : s.gk[b_] + zb_;         \
+                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : runs_in.gk[b_] + zb_;   \
                     const uint32_t m = s.tab.gm[b_], inv = s.tab.ginv[b_];                                      \
                     const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
                     const uint32_t bit_ = ((EV) >> 5) & 1u;                                                     \
@@ -1251,7 +1371,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                         if (LV(fl1) & 2u) LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
                         if (LV(ka1) != ~0u) {
                             const uint32_t b = LV(ev1) & 31u;
-                            s.gk[b] = LV(ka1);
+                            if (fused) s.gk[b] = LV(ka1);
                             o.binst[b] = st_pack(LV(ka1) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka1), 0u);
                         }
                     }
@@ -1260,7 +1380,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
                         if (LV(fl2) & 2u) LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
                         if (LV(ka2) != ~0u) {
                             const uint32_t b = LV(ev2) & 31u;
-                            s.gk[b] = LV(ka2);
+                            if (fused) s.gk[b] = LV(ka2);
                             o.binst[b] = st_pack(LV(ka2) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka2), 0u);
                         }
                     }
@@ -1281,7 +1401,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             }
         }
         ICER_PUBLISH(o.gtag, chunk_tag(j, gw.gen))
-        gw.next = j + 1u;
+        gw.next = j + step;
         done++;
         ICER_IDLE_RESET
         ICER_TICK(12)
@@ -1697,11 +1817,14 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
 #define ICER_DRAIN_RELEASE(S) { ICER_PUBLISH((S).hold_seq, ((S).hold_seq | 1u) + 1u) }
 
 // chunks [j0, j1); returns false when the unit was abandoned (payload slot too small)
-ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
+// `split` (the large shape of the workgroup): the ring stores of a chunk on the fast path -- most of this wave's time per
+// chunk -- are left to the ring wave (ring_wave_run); this wave keeps what is sequential: the allocation count, the bins'
+// open slots and states, the forced-flush test, the exact path.
+ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1, bool split = false)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
-    uint32_t tail = s.alloc;                                // allocation count (this wave owns it)
+    uint32_t tail = split ? s.head_tail : s.alloc;          // allocation count (this wave owns it)
     uint32_t gen = s.exact_seq;                             // generation (this wave bumps it)
     for (uint32_t j = j0; j < j1; j++) {
         MergeChunk c;
@@ -1716,6 +1839,10 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         bool held = false, fast = true;
         ICER_COUNT(31)
         if (tail - popped_seen + nstarts > (uint32_t)kRingWords) {
+            if (split) {                                     // the ring must hold every word allocated so far
+                ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.w_done) == j || ICER_LOAD_CNT(s.abort))
+                if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+            }
             ICER_DRAIN_HOLD(s, a)
             if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             held = true;
@@ -1723,6 +1850,23 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             wave_drain(s, tail, 2u);
             fast = tail - s.popped + nstarts <= (uint32_t)kRingWords;
             ICER_COUNT(30)
+        }
+        if (fast && split && !held) {
+            HeadSlot &hs = s.hq[j % kQueueDepth];
+            FOR_LANES
+            {
+                if (lane < kNumBins) hs.bslot[lane] = s.bin_slot[lane];
+                if (lane == 0) { hs.tail = tail; hs.skip = 0u; }
+            }
+            WAVE_SYNC();
+            commit_bins(s, c, tail);
+            tail += nstarts;
+            ICER_EMU_COUNT(0);
+            ICER_TICK(14)
+            FOR_LANES { if (lane == 0) s.head_tail = tail; }
+            ICER_PUBLISH(s.h_done, j + 1u)
+            ICER_TICK(17)
+            continue;
         }
         if (fast) {
             merge_commit(s, c, tail);
@@ -1759,6 +1903,10 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             ICER_PUBLISH(s.alloc, tail)
             ICER_DRAIN_RELEASE(s)
             ICER_PUBLISH(s.b_done, j + 1u)
+            if (split) {
+                FOR_LANES { if (lane == 0) { s.hq[j % kQueueDepth].skip = 1u; s.head_tail = tail; } }
+                ICER_PUBLISH(s.h_done, j + 1u)
+            }
         } else {
 #ifdef ICER_WAVE_THREADS
             {   // (test build) nobody recycled the chunk's slots before it was retired
@@ -1776,11 +1924,82 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
     return true;
 }
 
-// end of unit: park the drain wave for good, force-complete whatever is still open (C8,
-// icer_context_modeller.c:452-455); returns the payload length in bits, or kUnitTooBig
-ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a)
+// ==========================================================================================
+// ring wave (large shape of the workgroup)
+// ==========================================================================================
+// The ring stores of the chunks the merge wave has decided on its fast path: open markers of the words that start in the
+// chunk, finished words of the ones that end there, exactly as merge_commit does them -- from the chunk's records, the
+// allocation count before the chunk and the bins' open slots at its start (HeadSlot).  Then the chunk is retired: the new
+// words become visible to the drain wave (alloc) and the chunk's queue slots are free (b_done).
+struct RingWave { uint32_t next = 0; };
+
+ICER_DEV void ring_wave_run(CoderShared &s, const UnitArgs &a, RingWave &rw, uint32_t nchunks, uint32_t max_steps)
 {
     DECL_LANE;
+    ICER_IDLE_DECL
+    (void)a;
+    for (uint32_t step = 0; rw.next < nchunks;) {
+        if (ICER_LOAD_CNT(s.abort)) break;
+        const uint32_t j = rw.next;
+        if (ICER_LOAD_CNT(s.h_done) <= j || step >= max_steps) {
+            if (step >= max_steps) break;
+            ICER_IDLE()
+            continue;
+        }
+        ICER_ACQUIRE()
+        const HeadSlot &hs = s.hq[j % kQueueDepth];
+        if (!hs.skip) {
+            const RecSlot &rq = s.rq[j % kQueueDepth];
+            const uint32_t tail = hs.tail;
+            LANEVAR(uint32_t, r1); LANEVAR(uint32_t, r2);
+            FOR_LANES { LV(r1) = rq.rec[2 * lane]; LV(r2) = rq.rec[2 * lane + 1]; }
+            const uint64_t S1 = BALLOT(LV(r1) & 1u), S2 = BALLOT(LV(r2) & 1u);
+            FOR_LANES
+            {
+                if (LV(r1) & 1u) {
+                    const uint32_t r = cnt_lt_own(S1, S2, lane, 0u);
+                    s.srank2[2 * lane] = (uint8_t)r;
+                    RING_ST((tail + r) & (kRingWords - 1), (LV(r1) >> 2) & 31u);
+                }
+                if (LV(r2) & 1u) {
+                    const uint32_t r = cnt_lt_own(S1, S2, lane, 1u);
+                    s.srank2[2 * lane + 1] = (uint8_t)r;
+                    RING_ST((tail + r) & (kRingWords - 1), (LV(r2) >> 2) & 31u);
+                }
+            }
+            WAVE_SYNC();
+            FOR_LANES
+            {
+                if (LV(r1) & 2u) {
+                    const uint32_t sp = (LV(r1) >> 8) & 255u;
+                    const uint32_t slot = sp == 255u ? (uint32_t)hs.bslot[(LV(r1) >> 2) & 31u] : tail + (uint32_t)s.srank2[sp & 127u];
+                    RING_ST(slot & (kRingWords - 1), LV(r1) >> 16);
+                }
+                if (LV(r2) & 2u) {
+                    const uint32_t sp = (LV(r2) >> 8) & 255u;
+                    const uint32_t slot = sp == 255u ? (uint32_t)hs.bslot[(LV(r2) >> 2) & 31u] : tail + (uint32_t)s.srank2[sp & 127u];
+                    RING_ST(slot & (kRingWords - 1), LV(r2) >> 16);
+                }
+            }
+            const uint32_t tail_after = tail + (uint32_t)(popc64(S1) + popc64(S2));
+            ICER_PUBLISH2(s.alloc, tail_after, s.b_done, j + 1u)
+        }
+        ICER_PUBLISH(s.w_done, j + 1u)
+        rw.next = j + 1u;
+        step++;
+        ICER_IDLE_RESET
+    }
+}
+
+// end of unit: park the drain wave for good, force-complete whatever is still open (C8,
+// icer_context_modeller.c:452-455); returns the payload length in bits, or kUnitTooBig
+ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a, bool split = false, uint32_t nchunks = 0)
+{
+    DECL_LANE;
+    if (split) {                                             // every chunk's words must be in the ring
+        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.w_done) >= nchunks || ICER_LOAD_CNT(s.abort))
+        if (ICER_LOAD_CNT(s.abort)) return kUnitTooBig;
+    }
     ICER_PUBLISH(s.drain_exit, 1u)
     ICER_DRAIN_HOLD(s, a)
     if (ICER_LOAD_CNT(s.abort)) return kUnitTooBig;
@@ -1806,8 +2025,8 @@ ICER_DEV void unit_state_init(CoderShared &s)
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.gk[lane] = 0; }
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
-            s.p_done = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
-            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; }
+            s.p_done[0] = s.p_done[1] = s.p_done[2] = s.p_done[3] = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.h_done = 0; s.w_done = 0; s.head_tail = 0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
+            for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; s.kq[i].tag = 0; }
         }
     }
     WAVE_SYNC();

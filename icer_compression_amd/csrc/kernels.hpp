@@ -90,9 +90,13 @@ finalize_ll_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32
 }
 
 // ------------------------------------------------------------------------------------------ coder
-// One workgroup of eight wavefronts = one coding unit of one frame: pixel, count, compaction, walker, golomb, merge, records and
-// drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  grid = (units, frames), block = 512.
-__global__ void __launch_bounds__(64 * kUnitWaves)
+// One workgroup = one coding unit of one frame: pixel, count, compaction, walker, golomb state + workers, merge, records and
+// drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  WAVES = 8: one pixel wave, one golomb wave
+// (three workgroups per CU: batches); WAVES = 12: two pixel waves, golomb state wave + two workers, ring wave (two per
+// CU, a shorter chain per chunk: single frames).
+// grid = (units, frames), block = 64 * WAVES.
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
@@ -145,16 +149,21 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     {   // tables -> LDS
         const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
-        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * kUnitWaves) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * WAVES) dst[i] = src[i];
     }
     // Role of each wavefront.  Waves w and w + 4 of a workgroup share a SIMD (observed placement, used for speed
     // only): the count wave, which issues the most vector instructions per chunk, gets a SIMD to itself and the
     // other issue-heavy roles are paired with latency-bound ones.
+    // (wave 8: the second pixel wave -- on the SIMD of the walker, the lightest role)
     constexpr uint32_t kWalker = 0, kPixel = 1, kGolomb = 2, kMerge = 3, kCompact = 4, kCount = 5, kRecords = 6, kDrain = 7;
+    // large shape only: golomb state wave, second pixel wave, second golomb worker, ring wave
+    constexpr uint32_t kGolombState = 8, kPixel2 = 9, kGolomb2 = 10, kRing = 11;
+    static_assert(WAVES == kUnitWavesSmall || WAVES == kUnitWavesLarge, "two shapes of a workgroup");
+    constexpr bool large = WAVES == kUnitWavesLarge;
+    constexpr uint32_t npw = large ? 2u : 1u, ngw = large ? 2u : 0u;   // (0: no golomb state wave)
     if (wave == 0) unit_state_init(s);
     if (threadIdx.x == 64) s.nchunks = (u.w * u.h + 63u) / 64u;
     if (wave == kMerge) build_crc_table(s);
-    __syncthreads();
 
     uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
     UnitArgs a;
@@ -170,21 +179,30 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     // profiling build: per-wave cycle counters of the level-1 (largest) units, one row per bit plane
     a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
+    if (wave == kCount) pixel_tables_init(s, a);
+    __syncthreads();
 
-    if (wave == kPixel) {
+    if (wave == kPixel || wave == kPixel2) {
         PixelWave pw;
-        pixel_wave_run(s, a, pw, 0, nchunks);
+        pixel_wave_run(s, a, pw, 0, nchunks, wave == kPixel ? 0u : 1u, npw);
     } else if (wave == kCount) {
         CountWave cs;
-        count_wave_run(s, a, cs, 0, nchunks);
+        count_wave_run(s, a, cs, 0, nchunks, npw);
     } else if (wave == kWalker) {
         WalkWave ww;
         walk_wave_init(s, ww);
         walk_wave_run(s, a, ww, nchunks, ~0u);
-    } else if (wave == kGolomb) {
+    } else if (wave == kGolomb || wave == kGolomb2) {
         GolombWave gw;
         golomb_wave_init(gw);
-        golomb_wave_run(s, a, gw, nchunks, ~0u);
+        golomb_wave_run(s, a, gw, nchunks, ~0u, wave == kGolomb ? 0u : 1u, ngw);
+    } else if (wave == kGolombState) {
+        GolombWave gw;
+        golomb_wave_init(gw);
+        golomb_state_run(s, a, gw, nchunks, ~0u);
+    } else if (wave == kRing) {
+        RingWave gwr;
+        ring_wave_run(s, a, gwr, nchunks, ~0u);
     } else if (wave == kRecords) {
         RecordsWave rw;
         records_wave_run(s, a, rw, ~0u);
@@ -193,13 +211,13 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     } else if (wave == kCompact) {
         compact_wave_run(s, a, 0, nchunks);
     } else {
-        uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
+        uint32_t bits = merge_wave_run(s, a, 0, nchunks, large) ? merge_wave_finish(s, a, large, nchunks) : kUnitTooBig;
         if (s.abort == 2u) {                          // a bounded spin expired: internal error, never a silent hang
             bits = kUnitFailed;
             // leave the unit's hand-off counters where its payload would have been (api.hip prints them)
             if ((threadIdx.x & 63) == 0 && u.cap_words >= kFailWords) {
                 uint32_t *dbg = slot_words + kHeaderBytes / 4;
-                dbg[0] = kFailMagic; dbg[1] = s.abort_site; dbg[2] = nchunks; dbg[3] = s.p_done; dbg[4] = s.a_done;
+                dbg[0] = kFailMagic; dbg[1] = s.abort_site; dbg[2] = nchunks; dbg[3] = s.p_done[0]; dbg[4] = s.a_done;
                 dbg[5] = s.c_done; dbg[6] = s.b_done; dbg[7] = s.alloc; dbg[8] = s.popped; dbg[9] = s.hold_seq;
                 dbg[10] = s.hold_ack; dbg[11] = s.exact_seq; dbg[12] = s.last_exact; dbg[13] = s.bitpos;
                 dbg[14] = s.flushed_words; dbg[15] = s.drain_exit;

@@ -7,6 +7,11 @@
 
 namespace icer {
 
+// the shape of the emulated workgroup: pixel waves (1 or 2) and golomb workers (0 = one golomb wave without a state wave,
+// 2 = state wave + two workers), as code_units_kernel<8> / <11>
+static uint32_t g_emu_npw = 2, g_emu_ngw = 2;
+static bool g_emu_split = true;                  // the merge wave leaves its ring stores to a ring wave (large shape)
+
 #if defined(ICER_WAVE_EMU) && defined(ICER_WAVE_THREADS)
 // tests only: one CPU thread per wave, the roles started exactly like code_units_kernel starts them
 static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
@@ -16,16 +21,25 @@ static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
     s.nchunks = nchunks;
     uint32_t bits = kUnitTooBig;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    std::thread t[8];
-    t[0] = std::thread([&] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks); });
-    t[1] = std::thread([&] { CountWave cs; count_wave_run(s, a, cs, 0, nchunks); });
+    pixel_tables_init(s, a);
+    std::thread t[8], tp[4];
+    for (uint32_t k = 1; k < g_emu_npw; k++) tp[k] = std::thread([&s, &a, nchunks, k] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks, k, g_emu_npw); });
+    t[0] = std::thread([&] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks, 0, g_emu_npw); });
+    t[1] = std::thread([&] { CountWave cs; count_wave_run(s, a, cs, 0, nchunks, g_emu_npw); });
     t[2] = std::thread([&] { compact_wave_run(s, a, 0, nchunks); });
     t[3] = std::thread([&] { WalkWave ww; walk_wave_init(s, ww); walk_wave_run(s, a, ww, nchunks, ~0u); });
-    t[4] = std::thread([&] { GolombWave gw; golomb_wave_init(gw); golomb_wave_run(s, a, gw, nchunks, ~0u); });
+    t[4] = std::thread([&] { GolombWave gw; golomb_wave_init(gw); if (g_emu_ngw) golomb_state_run(s, a, gw, nchunks, ~0u); else golomb_wave_run(s, a, gw, nchunks, ~0u, 0, 0); });
+    std::thread tg[4];
+    for (uint32_t k = 0; k < g_emu_ngw; k++) tg[k] = std::thread([&s, &a, nchunks, k] { GolombWave gw; golomb_wave_init(gw); golomb_wave_run(s, a, gw, nchunks, ~0u, k, g_emu_ngw); });
     t[5] = std::thread([&] { RecordsWave rw; records_wave_run(s, a, rw, ~0u); });
     t[6] = std::thread([&] { drain_wave_run(s, a, ~0u); });
-    t[7] = std::thread([&] { bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig; });
+    t[7] = std::thread([&] { bits = merge_wave_run(s, a, 0, nchunks, g_emu_split) ? merge_wave_finish(s, a, g_emu_split, nchunks) : kUnitTooBig; });
+    std::thread tr;
+    if (g_emu_split) tr = std::thread([&] { RingWave rwr; ring_wave_run(s, a, rwr, nchunks, ~0u); });
     for (auto &th : t) th.join();
+    for (uint32_t k = 1; k < g_emu_npw; k++) tp[k].join();
+    for (uint32_t k = 0; k < g_emu_ngw; k++) tg[k].join();
+    if (tr.joinable()) tr.join();
     if (__atomic_load_n(&s.abort, __ATOMIC_RELAXED) == 2u) bits = kUnitFailed;
     return bits;
 }
@@ -36,29 +50,36 @@ static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
 static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
 {
     unit_state_init(s);
-    PixelWave pw;
+    pixel_tables_init(s, a);
+    PixelWave pw[4];
     CountWave cs;
     WalkWave ww;
-    GolombWave gw;
+    GolombWave gs, gw[4];
     RecordsWave rw;
+    RingWave rwr;
     walk_wave_init(s, ww);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
-    golomb_wave_init(gw);
+    golomb_wave_init(gs);
+    for (auto &g : gw) golomb_wave_init(g);
     uint32_t jp = 0, ja = 0, jc = 0, jb = 0;
     while (jb < nchunks) {
-        while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; }
-        while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; }
+        while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw[jp % g_emu_npw], jp, jp + 1, jp % g_emu_npw, g_emu_npw); jp++; }
+        while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1, g_emu_npw); ja++; }
         while (jc < ja) { compact_wave_run(s, a, jc, jc + 1); jc++; }
         // both speculating waves run as far ahead as events allow (and roll back when told to)
         walk_wave_run(s, a, ww, nchunks, kQueueDepth);
-        golomb_wave_run(s, a, gw, nchunks, kQueueDepth);
+        if (g_emu_ngw) golomb_state_run(s, a, gs, nchunks, kQueueDepth); else golomb_wave_run(s, a, gs, nchunks, kQueueDepth, 0, 0);
+        for (uint32_t k = 0; k < g_emu_ngw; k++) golomb_wave_run(s, a, gw[k], nchunks, kQueueDepth, k, g_emu_ngw);
         records_wave_run(s, a, rw, kQueueDepth);
-        if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+        if (!merge_wave_run(s, a, jb, jb + 1, g_emu_split)) return kUnitTooBig;
         jb++;
+        // (the ring wave lags now and then -- but never when the ring is so full that the merge wave might have to wait for
+        // it, which this single-threaded driver cannot do: at most 3 chunks of at most 128 words on top of half a ring)
+        if (g_emu_split && (jb % 3u != 1u || jb == nchunks || s.alloc - s.popped >= 1024u)) ring_wave_run(s, a, rwr, nchunks, ~0u);
         drain_wave_run(s, a, jb & 1u);              // the drain lags behind the merge wave on purpose
         if (s.abort) return kUnitTooBig;
     }
-    return merge_wave_finish(s, a);
+    return merge_wave_finish(s, a, g_emu_split, nchunks);
 }
 
 // tests only: the same eight waves under a RANDOM scheduler -- at every step one wave is picked at random and runs one
@@ -68,43 +89,59 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
 static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, uint32_t seed)
 {
     unit_state_init(s);
-    PixelWave pw;
+    pixel_tables_init(s, a);
+    PixelWave pw[4];
     CountWave cs;
     WalkWave ww;
-    GolombWave gw;
+    GolombWave gs, gw[4];
     RecordsWave rw;
+    RingWave rwr;
     walk_wave_init(s, ww);
-    golomb_wave_init(gw);
+    golomb_wave_init(gs);
+    for (auto &g : gw) golomb_wave_init(g);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
-    uint32_t jp = 0, ja = 0, jc = 0, jb = 0, idle = 0;
+    uint32_t jpw[4] = {0, 1, 2, 3};                  // next chunk of every pixel wave
+    (void)jpw;
+    uint32_t ja = 0, jc = 0, jb = 0, idle = 0;
     uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
     while (jb < nchunks) {
         rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-        const uint32_t pick = (uint32_t)(rng >> 33) % 8u;
+        const uint32_t pick = (uint32_t)(rng >> 33) % 16u;
         bool moved = false;
         switch (pick) {
-        case 0: if (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw, jp, jp + 1); jp++; moved = true; } break;
-        case 1: if (ja < s.p_done && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1); ja++; moved = true; } break;
+        case 0: case 8: case 9: case 10: {
+            const uint32_t k = pick == 0 ? 0u : pick - 7u;           // the pixel waves lag and lead each other too
+            if (k >= g_emu_npw) break;
+            uint32_t &jp = jpw[k];
+            if (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, pw[k], jp, jp + 1, k, g_emu_npw); jp += g_emu_npw; moved = true; }
+        } break;
+        case 1: if (ja < s.p_done[ja % g_emu_npw] && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1, g_emu_npw); ja++; moved = true; } break;
         case 2: if (jc < s.a_done) { compact_wave_run(s, a, jc, jc + 1); jc++; moved = true; } break;
         case 3: moved = walk_wave_run(s, a, ww, nchunks, 1u) != 0; break;
-        case 4: moved = golomb_wave_run(s, a, gw, nchunks, 1u) != 0; break;
+        case 4: moved = (g_emu_ngw ? golomb_state_run(s, a, gs, nchunks, 1u) : golomb_wave_run(s, a, gs, nchunks, 1u, 0, 0)) != 0; break;
+        case 11: case 12: { const uint32_t k = pick - 11u; if (k < g_emu_ngw) moved = golomb_wave_run(s, a, gw[k], nchunks, 1u, k, g_emu_ngw) != 0; } break;
         case 5: { const uint32_t before = rw.next, g = rw.gen; records_wave_run(s, a, rw, 1u); moved = rw.next != before || rw.gen != g; } break;
         case 6: {
             const RecSlot &rq = s.rq[jb % kQueueDepth];
             const uint32_t tag = chunk_tag(jb, s.exact_seq);
             if (rq.gtag == tag && rq.rtag == tag) {
-                if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
+                // (the emulated merge wave cannot wait: a chunk that needs the ring complete first is tried again later)
+                if (g_emu_split && s.w_done != jb && (s.alloc - s.popped >= 1024u || jb - s.w_done > 3u)) break;
+                if (!merge_wave_run(s, a, jb, jb + 1, g_emu_split)) return kUnitTooBig;
                 jb++;
                 moved = true;
             }
         } break;
-        default: { const uint32_t before = s.popped; drain_wave_run(s, a, 1u); moved = s.popped != before; } break;
+        case 13: case 14: { if (g_emu_split) { const uint32_t before = rwr.next; ring_wave_run(s, a, rwr, nchunks, 1u); moved = rwr.next != before; } } break;
+        case 7: case 15: { const uint32_t before = s.popped; drain_wave_run(s, a, 1u); moved = s.popped != before; } break;
+        default: break;
         }
         if (s.abort) return kUnitTooBig;
         idle = moved ? 0u : idle + 1u;
         if (idle > 100000u) return kUnitFailed;
     }
-    return merge_wave_finish(s, a);
+    if (g_emu_split) ring_wave_run(s, a, rwr, nchunks, ~0u);
+    return merge_wave_finish(s, a, g_emu_split, nchunks);
 }
 #endif
 
