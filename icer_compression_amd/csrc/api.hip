@@ -92,7 +92,7 @@ struct icerx_encoder {
     // mode; 1 / 2: always the pipeline / always the window coder (ICER_HIP_CODER=pipe|wg, tests and measurements).
     int coder_mode = 0;
     bool wg_once = false;               // the next enqueue uses the window coder whatever the mode (after a unit time-out)
-    int pipe_waves = 0;                 // 0: shape of the pipeline's workgroups chosen per launch; 8 / 12: pinned (ICER_HIP_PIPE_WAVES)
+    int pipe_waves = 0;                 // 0: shape of the pipeline's workgroups chosen per launch; 8 / 11: pinned (ICER_HIP_PIPE_WAVES)
     int n_cus = 256;                    // compute units of the device
     uint64_t n_timeouts = 0, n_fallbacks = 0, n_slot_retries = 0;   // icerx_encoder_stats
 
@@ -280,8 +280,8 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                            e->sig.p, e->plan.sig_bytes);
     else {
         // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
-        // largest units, which the large shape (two pixel waves, golomb state wave + two workers, ring wave) shortens; a batch wants
-        // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|12 pins one (measurements).
+        // largest units, which the large shape (two pixel waves, golomb state wave + two workers) shortens; a batch wants
+        // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|11 pins one (measurements).
         const bool large = e->pipe_waves ? e->pipe_waves == kUnitWavesLarge : n_frames == 1;
         if (large)
             hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units, n_frames), dim3(64 * kUnitWavesLarge), 0, st,

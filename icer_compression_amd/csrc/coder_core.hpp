@@ -174,10 +174,10 @@ constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between
 // (golomb_state_run, one wave); the per-event work is then free of state and shared by `ngw` worker waves.
 // Two shapes of a workgroup are built (code_units_kernel<...>): 8 waves -- one pixel wave, one golomb wave that keeps the
 // run lengths itself; three workgroups per CU, for batches (more waves per unit cost a batch a quarter of its throughput,
-// gpurun_out/r02r) -- and 12 waves -- two pixel waves, golomb state wave + two workers, a ring wave that does the merge
-// wave's ring stores; two workgroups per CU, a shorter chain per chunk, for a launch that cannot fill the chip anyway (a single frame).
+// gpurun_out/r02r) -- and 11 waves -- two pixel waves, golomb state wave + two workers; two workgroups per CU, a shorter
+// chain per chunk, for a launch that cannot fill the chip anyway (a single frame).
 constexpr uint32_t kMaxPixelWaves = 2, kMaxGolombWorkers = 2;
-constexpr int kUnitWavesSmall = 8, kUnitWavesLarge = 12;
+constexpr int kUnitWavesSmall = 8, kUnitWavesLarge = 11;
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
 constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits + 16;     // + HW_ID of each wave of workgroup 0
 
@@ -228,12 +228,6 @@ struct RunSlot {                // golomb state wave -> golomb workers: the bins
     uint32_t gk[kNumBins];
 };
 
-struct HeadSlot {               // merge wave -> ring wave (large shape): what the ring stores of a chunk need besides its records
-    uint32_t tail;              // allocation count before the chunk
-    uint32_t skip;              // the merge wave has stored the chunk itself (exact path)
-    int32_t bslot[kNumBins];    // the bins' open slots at the start of the chunk (words carried in end there)
-};
-
 struct CoderShared {
     uint32_t stage[kStageWords];
     uint16_t ring[kRingWords];
@@ -244,11 +238,9 @@ struct CoderShared {
     WalkSlot wq[kQueueDepth];
     RecSlot rq[kQueueDepth];
     RunSlot kq[kQueueDepth];
-    HeadSlot hq[kQueueDepth];
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
     uint8_t ctx_tab[48];            // pixel wave: context table of the unit's subband (see pixel_wave_run)
-    uint8_t srank2[128];            // ring wave: the same for its stores (ring_wave_run)
     uint8_t srank[128];             // merge wave: position of a word start -> number of word starts before it in the chunk (merge_commit)
     uint32_t gk[kNumBins];          // golomb wave: zero-run length of each Golomb bin's open word as of its last chunk (0 = none)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
@@ -262,8 +254,6 @@ struct CoderShared {
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
     uint32_t p_done[4];         // per pixel wave: 1 + the last chunk it has handed over
     uint32_t a_done, c_done, b_done, abort;
-    uint32_t head_tail;         // large shape: the merge wave's allocation count (alloc lags behind it by what the ring wave has not stored yet)
-    uint32_t h_done, w_done;    // large shape: chunks decided by the merge wave / chunks whose ring stores are done (ring wave)
     uint32_t abort_site;        // who set abort = 2: source line | wave << 16 (GPU build; diagnostics only)
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
     // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
@@ -1817,14 +1807,11 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
 #define ICER_DRAIN_RELEASE(S) { ICER_PUBLISH((S).hold_seq, ((S).hold_seq | 1u) + 1u) }
 
 // chunks [j0, j1); returns false when the unit was abandoned (payload slot too small)
-// `split` (the large shape of the workgroup): the ring stores of a chunk on the fast path -- most of this wave's time per
-// chunk -- are left to the ring wave (ring_wave_run); this wave keeps what is sequential: the allocation count, the bins'
-// open slots and states, the forced-flush test, the exact path.
-ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1, bool split = false)
+ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
-    uint32_t tail = split ? s.head_tail : s.alloc;          // allocation count (this wave owns it)
+    uint32_t tail = s.alloc;                                // allocation count (this wave owns it)
     uint32_t gen = s.exact_seq;                             // generation (this wave bumps it)
     for (uint32_t j = j0; j < j1; j++) {
         MergeChunk c;
@@ -1839,10 +1826,6 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         bool held = false, fast = true;
         ICER_COUNT(31)
         if (tail - popped_seen + nstarts > (uint32_t)kRingWords) {
-            if (split) {                                     // the ring must hold every word allocated so far
-                ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.w_done) == j || ICER_LOAD_CNT(s.abort))
-                if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
-            }
             ICER_DRAIN_HOLD(s, a)
             if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
             held = true;
@@ -1850,23 +1833,6 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             wave_drain(s, tail, 2u);
             fast = tail - s.popped + nstarts <= (uint32_t)kRingWords;
             ICER_COUNT(30)
-        }
-        if (fast && split && !held) {
-            HeadSlot &hs = s.hq[j % kQueueDepth];
-            FOR_LANES
-            {
-                if (lane < kNumBins) hs.bslot[lane] = s.bin_slot[lane];
-                if (lane == 0) { hs.tail = tail; hs.skip = 0u; }
-            }
-            WAVE_SYNC();
-            commit_bins(s, c, tail);
-            tail += nstarts;
-            ICER_EMU_COUNT(0);
-            ICER_TICK(14)
-            FOR_LANES { if (lane == 0) s.head_tail = tail; }
-            ICER_PUBLISH(s.h_done, j + 1u)
-            ICER_TICK(17)
-            continue;
         }
         if (fast) {
             merge_commit(s, c, tail);
@@ -1903,10 +1869,6 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             ICER_PUBLISH(s.alloc, tail)
             ICER_DRAIN_RELEASE(s)
             ICER_PUBLISH(s.b_done, j + 1u)
-            if (split) {
-                FOR_LANES { if (lane == 0) { s.hq[j % kQueueDepth].skip = 1u; s.head_tail = tail; } }
-                ICER_PUBLISH(s.h_done, j + 1u)
-            }
         } else {
 #ifdef ICER_WAVE_THREADS
             {   // (test build) nobody recycled the chunk's slots before it was retired
@@ -1924,82 +1886,11 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
     return true;
 }
 
-// ==========================================================================================
-// ring wave (large shape of the workgroup)
-// ==========================================================================================
-// The ring stores of the chunks the merge wave has decided on its fast path: open markers of the words that start in the
-// chunk, finished words of the ones that end there, exactly as merge_commit does them -- from the chunk's records, the
-// allocation count before the chunk and the bins' open slots at its start (HeadSlot).  Then the chunk is retired: the new
-// words become visible to the drain wave (alloc) and the chunk's queue slots are free (b_done).
-struct RingWave { uint32_t next = 0; };
-
-ICER_DEV void ring_wave_run(CoderShared &s, const UnitArgs &a, RingWave &rw, uint32_t nchunks, uint32_t max_steps)
-{
-    DECL_LANE;
-    ICER_IDLE_DECL
-    (void)a;
-    for (uint32_t step = 0; rw.next < nchunks;) {
-        if (ICER_LOAD_CNT(s.abort)) break;
-        const uint32_t j = rw.next;
-        if (ICER_LOAD_CNT(s.h_done) <= j || step >= max_steps) {
-            if (step >= max_steps) break;
-            ICER_IDLE()
-            continue;
-        }
-        ICER_ACQUIRE()
-        const HeadSlot &hs = s.hq[j % kQueueDepth];
-        if (!hs.skip) {
-            const RecSlot &rq = s.rq[j % kQueueDepth];
-            const uint32_t tail = hs.tail;
-            LANEVAR(uint32_t, r1); LANEVAR(uint32_t, r2);
-            FOR_LANES { LV(r1) = rq.rec[2 * lane]; LV(r2) = rq.rec[2 * lane + 1]; }
-            const uint64_t S1 = BALLOT(LV(r1) & 1u), S2 = BALLOT(LV(r2) & 1u);
-            FOR_LANES
-            {
-                if (LV(r1) & 1u) {
-                    const uint32_t r = cnt_lt_own(S1, S2, lane, 0u);
-                    s.srank2[2 * lane] = (uint8_t)r;
-                    RING_ST((tail + r) & (kRingWords - 1), (LV(r1) >> 2) & 31u);
-                }
-                if (LV(r2) & 1u) {
-                    const uint32_t r = cnt_lt_own(S1, S2, lane, 1u);
-                    s.srank2[2 * lane + 1] = (uint8_t)r;
-                    RING_ST((tail + r) & (kRingWords - 1), (LV(r2) >> 2) & 31u);
-                }
-            }
-            WAVE_SYNC();
-            FOR_LANES
-            {
-                if (LV(r1) & 2u) {
-                    const uint32_t sp = (LV(r1) >> 8) & 255u;
-                    const uint32_t slot = sp == 255u ? (uint32_t)hs.bslot[(LV(r1) >> 2) & 31u] : tail + (uint32_t)s.srank2[sp & 127u];
-                    RING_ST(slot & (kRingWords - 1), LV(r1) >> 16);
-                }
-                if (LV(r2) & 2u) {
-                    const uint32_t sp = (LV(r2) >> 8) & 255u;
-                    const uint32_t slot = sp == 255u ? (uint32_t)hs.bslot[(LV(r2) >> 2) & 31u] : tail + (uint32_t)s.srank2[sp & 127u];
-                    RING_ST(slot & (kRingWords - 1), LV(r2) >> 16);
-                }
-            }
-            const uint32_t tail_after = tail + (uint32_t)(popc64(S1) + popc64(S2));
-            ICER_PUBLISH2(s.alloc, tail_after, s.b_done, j + 1u)
-        }
-        ICER_PUBLISH(s.w_done, j + 1u)
-        rw.next = j + 1u;
-        step++;
-        ICER_IDLE_RESET
-    }
-}
-
 // end of unit: park the drain wave for good, force-complete whatever is still open (C8,
 // icer_context_modeller.c:452-455); returns the payload length in bits, or kUnitTooBig
-ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a, bool split = false, uint32_t nchunks = 0)
+ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a)
 {
     DECL_LANE;
-    if (split) {                                             // every chunk's words must be in the ring
-        ICER_WAIT_UNTIL(ICER_LOAD_CNT(s.w_done) >= nchunks || ICER_LOAD_CNT(s.abort))
-        if (ICER_LOAD_CNT(s.abort)) return kUnitTooBig;
-    }
     ICER_PUBLISH(s.drain_exit, 1u)
     ICER_DRAIN_HOLD(s, a)
     if (ICER_LOAD_CNT(s.abort)) return kUnitTooBig;
@@ -2025,7 +1916,7 @@ ICER_DEV void unit_state_init(CoderShared &s)
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.gk[lane] = 0; }
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
-            s.p_done[0] = s.p_done[1] = s.p_done[2] = s.p_done[3] = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.h_done = 0; s.w_done = 0; s.head_tail = 0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
+            s.p_done[0] = s.p_done[1] = s.p_done[2] = s.p_done[3] = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
             for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; s.kq[i].tag = 0; }
         }
     }

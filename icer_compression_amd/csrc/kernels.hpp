@@ -92,8 +92,8 @@ finalize_ll_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32
 // ------------------------------------------------------------------------------------------ coder
 // One workgroup = one coding unit of one frame: pixel, count, compaction, walker, golomb state + workers, merge, records and
 // drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  WAVES = 8: one pixel wave, one golomb wave
-// (three workgroups per CU: batches); WAVES = 12: two pixel waves, golomb state wave + two workers, ring wave (two per
-// CU, a shorter chain per chunk: single frames).
+// (three workgroups per CU: batches); WAVES = 11: two pixel waves, golomb state wave + two workers (two per CU, a
+// shorter chain per chunk: single frames).
 // grid = (units, frames), block = 64 * WAVES.
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
@@ -156,8 +156,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     // other issue-heavy roles are paired with latency-bound ones.
     // (wave 8: the second pixel wave -- on the SIMD of the walker, the lightest role)
     constexpr uint32_t kWalker = 0, kPixel = 1, kGolomb = 2, kMerge = 3, kCompact = 4, kCount = 5, kRecords = 6, kDrain = 7;
-    // large shape only: golomb state wave, second pixel wave, second golomb worker, ring wave
-    constexpr uint32_t kGolombState = 8, kPixel2 = 9, kGolomb2 = 10, kRing = 11;
+    // large shape only: golomb state wave, second pixel wave, second golomb worker
+    constexpr uint32_t kGolombState = 8, kPixel2 = 9, kGolomb2 = 10;
     static_assert(WAVES == kUnitWavesSmall || WAVES == kUnitWavesLarge, "two shapes of a workgroup");
     constexpr bool large = WAVES == kUnitWavesLarge;
     constexpr uint32_t npw = large ? 2u : 1u, ngw = large ? 2u : 0u;   // (0: no golomb state wave)
@@ -200,9 +200,6 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         GolombWave gw;
         golomb_wave_init(gw);
         golomb_state_run(s, a, gw, nchunks, ~0u);
-    } else if (wave == kRing) {
-        RingWave gwr;
-        ring_wave_run(s, a, gwr, nchunks, ~0u);
     } else if (wave == kRecords) {
         RecordsWave rw;
         records_wave_run(s, a, rw, ~0u);
@@ -211,7 +208,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     } else if (wave == kCompact) {
         compact_wave_run(s, a, 0, nchunks);
     } else {
-        uint32_t bits = merge_wave_run(s, a, 0, nchunks, large) ? merge_wave_finish(s, a, large, nchunks) : kUnitTooBig;
+        uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (s.abort == 2u) {                          // a bounded spin expired: internal error, never a silent hang
             bits = kUnitFailed;
             // leave the unit's hand-off counters where its payload would have been (api.hip prints them)

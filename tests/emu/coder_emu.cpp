@@ -23,7 +23,7 @@ static int g_use_wg = 0;
 static wg::Shared g_wsh;
 extern "C" void emu_set_coder(int use_wg, unsigned order) { g_use_wg = use_wg; wg::g_wg_order = order; wg::g_wg_order_state = order; }
 // shape of the emulated pipeline workgroup: pixel waves, golomb workers (1 or 2 each)
-extern "C" void emu_set_shape(unsigned npw, unsigned ngw, int split) { g_emu_npw = npw; g_emu_ngw = ngw; g_emu_split = split != 0; }
+extern "C" void emu_set_shape(unsigned npw, unsigned ngw) { g_emu_npw = npw; g_emu_ngw = ngw; }
 extern "C" int emu_wg_assert_line(void) { const int l = wg::g_wg_assert_line; wg::g_wg_assert_line = 0; return l; }
 static uint32_t wg_unit(const UnitArgs &a0)
 {

@@ -10,7 +10,6 @@ namespace icer {
 // the shape of the emulated workgroup: pixel waves (1 or 2) and golomb workers (0 = one golomb wave without a state wave,
 // 2 = state wave + two workers), as code_units_kernel<8> / <11>
 static uint32_t g_emu_npw = 2, g_emu_ngw = 2;
-static bool g_emu_split = true;                  // the merge wave leaves its ring stores to a ring wave (large shape)
 
 #if defined(ICER_WAVE_EMU) && defined(ICER_WAVE_THREADS)
 // tests only: one CPU thread per wave, the roles started exactly like code_units_kernel starts them
@@ -33,13 +32,10 @@ static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
     for (uint32_t k = 0; k < g_emu_ngw; k++) tg[k] = std::thread([&s, &a, nchunks, k] { GolombWave gw; golomb_wave_init(gw); golomb_wave_run(s, a, gw, nchunks, ~0u, k, g_emu_ngw); });
     t[5] = std::thread([&] { RecordsWave rw; records_wave_run(s, a, rw, ~0u); });
     t[6] = std::thread([&] { drain_wave_run(s, a, ~0u); });
-    t[7] = std::thread([&] { bits = merge_wave_run(s, a, 0, nchunks, g_emu_split) ? merge_wave_finish(s, a, g_emu_split, nchunks) : kUnitTooBig; });
-    std::thread tr;
-    if (g_emu_split) tr = std::thread([&] { RingWave rwr; ring_wave_run(s, a, rwr, nchunks, ~0u); });
+    t[7] = std::thread([&] { bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig; });
     for (auto &th : t) th.join();
     for (uint32_t k = 1; k < g_emu_npw; k++) tp[k].join();
     for (uint32_t k = 0; k < g_emu_ngw; k++) tg[k].join();
-    if (tr.joinable()) tr.join();
     if (__atomic_load_n(&s.abort, __ATOMIC_RELAXED) == 2u) bits = kUnitFailed;
     return bits;
 }
@@ -56,7 +52,6 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
     WalkWave ww;
     GolombWave gs, gw[4];
     RecordsWave rw;
-    RingWave rwr;
     walk_wave_init(s, ww);
     const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
     golomb_wave_init(gs);
@@ -71,15 +66,12 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
         if (g_emu_ngw) golomb_state_run(s, a, gs, nchunks, kQueueDepth); else golomb_wave_run(s, a, gs, nchunks, kQueueDepth, 0, 0);
         for (uint32_t k = 0; k < g_emu_ngw; k++) golomb_wave_run(s, a, gw[k], nchunks, kQueueDepth, k, g_emu_ngw);
         records_wave_run(s, a, rw, kQueueDepth);
-        if (!merge_wave_run(s, a, jb, jb + 1, g_emu_split)) return kUnitTooBig;
+        if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
         jb++;
-        // (the ring wave lags now and then -- but never when the ring is so full that the merge wave might have to wait for
-        // it, which this single-threaded driver cannot do: at most 3 chunks of at most 128 words on top of half a ring)
-        if (g_emu_split && (jb % 3u != 1u || jb == nchunks || s.alloc - s.popped >= 1024u)) ring_wave_run(s, a, rwr, nchunks, ~0u);
         drain_wave_run(s, a, jb & 1u);              // the drain lags behind the merge wave on purpose
         if (s.abort) return kUnitTooBig;
     }
-    return merge_wave_finish(s, a, g_emu_split, nchunks);
+    return merge_wave_finish(s, a);
 }
 
 // tests only: the same eight waves under a RANDOM scheduler -- at every step one wave is picked at random and runs one
@@ -95,7 +87,6 @@ static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, u
     WalkWave ww;
     GolombWave gs, gw[4];
     RecordsWave rw;
-    RingWave rwr;
     walk_wave_init(s, ww);
     golomb_wave_init(gs);
     for (auto &g : gw) golomb_wave_init(g);
@@ -125,14 +116,11 @@ static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, u
             const RecSlot &rq = s.rq[jb % kQueueDepth];
             const uint32_t tag = chunk_tag(jb, s.exact_seq);
             if (rq.gtag == tag && rq.rtag == tag) {
-                // (the emulated merge wave cannot wait: a chunk that needs the ring complete first is tried again later)
-                if (g_emu_split && s.w_done != jb && (s.alloc - s.popped >= 1024u || jb - s.w_done > 3u)) break;
-                if (!merge_wave_run(s, a, jb, jb + 1, g_emu_split)) return kUnitTooBig;
+                if (!merge_wave_run(s, a, jb, jb + 1)) return kUnitTooBig;
                 jb++;
                 moved = true;
             }
         } break;
-        case 13: case 14: { if (g_emu_split) { const uint32_t before = rwr.next; ring_wave_run(s, a, rwr, nchunks, 1u); moved = rwr.next != before; } } break;
         case 7: case 15: { const uint32_t before = s.popped; drain_wave_run(s, a, 1u); moved = s.popped != before; } break;
         default: break;
         }
@@ -140,8 +128,7 @@ static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, u
         idle = moved ? 0u : idle + 1u;
         if (idle > 100000u) return kUnitFailed;
     }
-    if (g_emu_split) ring_wave_run(s, a, rwr, nchunks, ~0u);
-    return merge_wave_finish(s, a, g_emu_split, nchunks);
+    return merge_wave_finish(s, a);
 }
 #endif
 

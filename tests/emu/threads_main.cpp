@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     const size_t w = (size_t)atol(argv[2]), h = (size_t)atol(argv[3]);
     const int sb = atoi(argv[4]), lsb = atoi(argv[5]), reps = atoi(argv[6]);
     const int stop_us = argc > 7 ? atoi(argv[7]) : 0, cap_div = argc > 8 ? atoi(argv[8]) : 1;
-    if (const char *sh = getenv("ICER_EMU_SHAPE")) { const bool small = atoi(sh) == 1; g_emu_npw = small ? 1u : 2u; g_emu_ngw = small ? 0u : 2u; g_emu_split = !small; }   // workgroup shape: 1 = 8 waves, 2 = 12
+    if (const char *sh = getenv("ICER_EMU_SHAPE")) { const bool small = atoi(sh) == 1; g_emu_npw = small ? 1u : 2u; g_emu_ngw = small ? 0u : 2u; }   // workgroup shape: 1 = 8 waves, 2 = 11
     std::mt19937 rng(12345);
     std::vector<uint16_t> plane(w * h);
     FILE *f = fopen(argv[1], "rb");

@@ -7,14 +7,14 @@ import pytest
 from icer_compression_amd import synth
 
 
-@pytest.fixture(params=[1, 2], ids=["8-waves", "12-waves"], autouse=True)
+@pytest.fixture(params=[1, 2], ids=["8-waves", "11-waves"], autouse=True)
 def pipeline_shape(request, emu, monkeypatch):
-    """both shapes of the pipeline's workgroup (code_units_kernel<8>: one pixel wave, one golomb wave; <12>: two pixel waves,
-    golomb state wave + two workers, ring wave)"""
-    emu.lib.emu_set_shape(request.param, 0 if request.param == 1 else 2, 0 if request.param == 1 else 1)
+    """both shapes of the pipeline's workgroup (code_units_kernel<8>: one pixel wave, one golomb wave; <11>: two pixel waves,
+    golomb state wave + two workers)"""
+    emu.lib.emu_set_shape(request.param, 0 if request.param == 1 else 2)
     monkeypatch.setenv("ICER_EMU_SHAPE", str(request.param))
     yield request.param
-    emu.lib.emu_set_shape(2, 2, 1)
+    emu.lib.emu_set_shape(2, 2)
 
 
 def test_dwt_core(emu, oracle):
