@@ -344,8 +344,8 @@ def main():
         k_ms = stage_ms["code_units"] / max(calls, 1)
         alg_bytes = float(B * W * H * 2 + h_sizes_sum)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        kernel = {0: "code_units_kernel (eight-wave pipeline; code_units_wg_kernel in progressive mode)", 1: "code_units_kernel",
-                  2: "code_units_wg_kernel"}[stats["coder_mode"]]
+        pipe = "code_units_kernel<11> (wave pipeline, 11-wave workgroups)" if B == 1 else "code_units_kernel<8> (wave pipeline, 8-wave workgroups)"
+        kernel = {0: pipe + "; code_units_wg_kernel in progressive mode", 1: pipe, 2: "code_units_wg_kernel"}[stats["coder_mode"]]
         line = {
             "metric": "Mpixels/s encode (bit-exact), 4096x4096 gray", "value": round(value, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),

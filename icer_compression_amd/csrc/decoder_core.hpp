@@ -108,6 +108,11 @@ ICER_HD void entropy_fill(EntropyDecoder &d)               // afterwards the win
 {
     while (d.win_bits < 32u) {
         uint32_t v = 0;
+        const uint32_t at = d.base + d.win_next;
+        if (at + 4u <= d.stream_len) {                       // (the usual case: four bytes inside the stream, one after the other)
+            const uint8_t *q = d.stream + at;
+            v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        } else
         for (uint32_t i = 0; i < 4u; i++) v |= entropy_byte(d, d.win_next + i) << (8u * i);
         d.win_next += 4u;
         d.win |= (uint64_t)v << d.win_bits;
@@ -146,9 +151,13 @@ ICER_HD int entropy_read(EntropyDecoder &d, uint32_t nb, bool consume)
 }
 ICER_HD uint32_t reverse_low_bits(uint32_t v, uint32_t n)            // icer_reverse_bits, icer.h:601-610 (16-bit)
 {
+#if defined(__clang__)
+    return n ? (__builtin_bitreverse32(v) >> (32u - n)) & 0xFFFFu : 0u;
+#else
     uint32_t r = 0;
     for (uint32_t k = 0; k < n; k++) { r = (r << 1) | (v & 1u); v >>= 1; }
     return r & 0xFFFFu;
+#endif
 }
 // icer_compute_bin, icer_util.c:48-56: the highest bin whose cut-off the probability of a zero reaches.
 // zero * 65536 >= total * cut  <=>  floor(zero * 65536 / total) >= cut, so one exact division (total <= 500: a float
@@ -339,8 +348,7 @@ ICER_HD void plane_step_img(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
     const uint32_t left = p.left;
     const uint32_t cur = img.at(r, c);
     const uint32_t m = cur & mask;
-    int msb = 0;
-    for (uint32_t v = m | 1u; v > 1u; v >>= 1) msb++;
+    const int msb = 31 - __builtin_clz(m | 1u);
     int cat = msb < lsb ? 0 : msb - lsb;
     if (cat > 3) cat = 3;
     uint32_t bit, val;

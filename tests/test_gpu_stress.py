@@ -1,6 +1,6 @@
 """A bounded slice of tests/stress_gpu.py in the GPU gate: randomised geometries / filters / quotas / content through the C
-ABI against the oracle, once per coding-unit kernel (the eight-wave pipeline and the barrier-only workgroup coder) and
-once with the automatic choice.  Fails on a mismatch and on any coding-unit time-out (icerx_process_stats)."""
+ABI against the oracle, once per coding-unit kernel (the wave pipeline in both workgroup shapes, the barrier-only workgroup coder)
+and once with the automatic choice.  Fails on a mismatch and on any coding-unit time-out (icerx_process_stats)."""
 import os
 import subprocess
 import sys
@@ -12,11 +12,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("coder,seconds,seed", [("pipe", 18, 101), ("wg", 18, 202), ("auto", 12, 303)])
+@pytest.mark.parametrize("coder,seconds,seed", [("pipe8", 12, 101), ("pipe11", 12, 111), ("wg", 14, 202), ("auto", 10, 303)])
 def test_randomised_encodes(coder, seconds, seed):
+    """pipe8 / pipe11: the wave pipeline with its workgroup shape pinned (8 waves: batches, 11 waves: single frames --
+    the drop-in entry points would always pick 11); wg: the barrier-only workgroup coder; auto: the library's own choice"""
     env = dict(os.environ, ICER_STRESS_BIG="0.08")
     env.pop("ICER_HIP_CODER", None)
-    if coder != "auto":
+    env.pop("ICER_HIP_PIPE_WAVES", None)
+    if coder.startswith("pipe"):
+        env["ICER_HIP_CODER"] = "pipe"
+        env["ICER_HIP_PIPE_WAVES"] = coder[4:]
+    elif coder != "auto":
         env["ICER_HIP_CODER"] = coder
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stress_gpu.py"), str(seconds), str(seed)], env=env,
                        capture_output=True, text=True, timeout=170)
