@@ -182,7 +182,7 @@ def measure_traffic(args):
             d = os.path.join(td, tag)
             try:
                 subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100)
                 db = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
                 cur = sqlite3.connect(db[0]).cursor()
                 q = ("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%code_units%' "
