@@ -108,7 +108,7 @@ constexpr uint32_t kWgWaves = ICER_WG_WAVES;
 static_assert(kWgWaves * 128u <= (uint32_t)kRingWords, "a window must not be able to open more words than the ring holds (E5 test)");
 constexpr uint32_t kPhysRing = 2u * kRingWords;     // physical ring entries: ring occupancy + one window of new words
 constexpr uint32_t kStageWords = 2048;              // LDS bit stage (circular, 32-bit words): one full drain of the physical ring
-constexpr uint32_t kBlankRunMin = 2, kBlankRunMax = 32;   // blank chunks coded in closed form at a time (blank_run)
+constexpr uint32_t kBlankRunMin = 2, kBlankRunMax = 64;   // blank chunks coded in closed form at a time (blank_run)
 constexpr uint32_t kUnitTooBig = 0xFFFFFFFFu;
 constexpr uint32_t kUnitStopped = 0xFFFFFFFDu;      // progressive mode: the quota cut lies before this unit
 
@@ -1541,48 +1541,76 @@ ICER_DEV bool blank_run_ok(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
     return R.tail + nev / 5u + 2u - R.popped <= (uint32_t)kRingWords;      // (5 = the smallest Golomb parameter)
 }
 
+// ceil(num / den) for 0 < num < 2^25, 144 <= den < 2^16 (one float reciprocal, corrected: no integer division)
+ICER_DEV uint32_t ceil_div_small(uint32_t num, uint32_t den)
+{
+#ifdef ICER_WAVE_EMU
+    uint32_t q = (uint32_t)((float)num * (1.0f / (float)den));
+#else
+    uint32_t q = (uint32_t)((float)num * __builtin_amdgcn_rcpf((float)den));
+#endif
+    int32_t rem = (int32_t)num - (int32_t)(q * den);            // the estimate is within 2 of the quotient
+    if (rem < 0) { q--; rem += (int32_t)den; }
+    if (rem < 0) { q--; rem += (int32_t)den; }
+    if (rem >= (int32_t)den) { q++; rem -= (int32_t)den; }
+    if (rem >= (int32_t)den) { q++; rem -= (int32_t)den; }
+    return q + (rem ? 1u : 0u);
+}
+
 // One wave; the others wait at the barrier that follows.  Leaves the counts in the OTHER copy (the caller flips `par`)
-// and the allocation count in Shared::run_tail[par].
+// and the allocation count in Shared::run_tail[par].  Lane b keeps bin b's run length, open slot and Golomb parameters in
+// registers for the whole run (read by readlane with the wave-uniform bin number): the loop over the segments touches LDS
+// only to store finished words.
 ICER_DEV void blank_run(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
 {
     DECL_LANE;
     uint32_t z = s.czer[par][0], t = s.ctot[par][0], tail = R.tail;
     const uint32_t one_word = kWordDone | (1u << 11) | 1u;
+    LANEVAR(uint32_t, run); LANEVAR(uint32_t, slot); LANEVAR(uint32_t, gm); LANEVAR(uint32_t, ginv); LANEVAR(uint32_t, cutv);
+    FOR_LANES
+    {
+        const bool gb = lane >= 8 && lane < kNumBins;
+        LV(run) = gb ? st_acc(s.bin_state[lane]) : 0u;
+        LV(slot) = gb ? (uint32_t)s.bin_slot[lane] : ~0u;
+        LV(gm) = gb ? (uint32_t)s.tab.gm[lane] : 1u;
+        LV(ginv) = gb ? s.tab.ginv[lane] : 0u;
+        LV(cutv) = lane < 16 ? s.tab.cut[lane] : 0u;            // the cut-off above bin `lane`
+    }
+    uint32_t touched = 0;                                       // bins whose state changed
     while (nev) {
         const uint32_t b = pick_bin(s.tab.binlut, z, t);
         WG_ASSERT(b >= 8u && z >= (t >> 1));
         uint32_t n = kRescaleCap - t;                 // events up to and including the one that triggers the rescale
         if (b < 16u) {
             // first event that sees the next bin: (z + i) * 65536 >= (t + i) * cut
-            const uint32_t cut = s.tab.cut[b], num = t * cut - (z << 16), den = 65536u - cut;
-            const uint32_t nb = (num + den - 1u) / den;
+            const uint32_t cut = READLANE(cutv, b);
+            const uint32_t nb = ceil_div_small(t * cut - (z << 16), 65536u - cut);
             n = nb < n ? nb : n;
         }
         n = nev < n ? nev : n;
-        const uint32_t m = s.tab.gm[b], inv = s.tab.ginv[b];
-        uint32_t k = st_acc(s.bin_state[b]);
-        int32_t slot = s.bin_slot[b];
-        WAVE_SYNC();
+        const uint32_t m = READLANE(gm, b), inv = READLANE(ginv, b);
+        uint32_t k = READLANE(run, b);
+        uint32_t sl = READLANE(slot, b);
         uint32_t left = n;
-        if (slot < 0) { slot = (int32_t)tail++; k = 0; }                     // a word starts at the segment's first event
+        if ((int32_t)sl < 0) { sl = tail++; k = 0; }                             // a word starts at the segment's first event
         if (left >= m - k) {
             left -= m - k;                                                   // the open word is filled up ...
             const uint32_t q = (left * inv) >> 20;                           // ... then q whole words, each started by the next event
             left -= q * m;
             FOR_LANES
             {
-                if (lane == 0) WRING_ST((uint32_t)slot, one_word);
+                if (lane == 0) WRING_ST(sl, one_word);
                 for (uint32_t i = (uint32_t)lane; i < q; i += 64u) WRING_ST(tail + i, one_word);
             }
             tail += q;
-            if (left) { slot = (int32_t)tail++; k = left; }
-            else { slot = -1; k = 0; }
+            if (left) { sl = tail++; k = left; }
+            else { sl = ~0u; k = 0; }
         } else k += left;
         FOR_LANES
         {
-            if (lane == 0) { s.bin_state[b] = st_pack(0u, k, 0u); s.bin_slot[b] = slot; }
+            if ((uint32_t)lane == b) { LV(run) = k; LV(slot) = sl; }
         }
-        WAVE_SYNC();
+        touched |= 1u << b;
         z += n; t += n;
         if (t >= kRescaleCap) { t = kRescaleCap / 2; if (z > kRescaleCap / 2) z >>= 1; }     // QUIRK C5
         nev -= n;
@@ -1591,6 +1619,7 @@ ICER_DEV void blank_run(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
     // blank_run_ok on this one) and this run's copy of the allocation count
     FOR_LANES
     {
+        if (lane < 32 && ((touched >> lane) & 1u)) { s.bin_state[lane] = st_pack(0u, LV(run), 0u); s.bin_slot[lane] = (int32_t)LV(slot); }
         if (lane < 17) { s.czer[par ^ 1u][lane] = lane ? s.czer[par][lane] : z; s.ctot[par ^ 1u][lane] = lane ? s.ctot[par][lane] : t; }
         if (lane == 0) s.run_tail[par] = tail;
     }
@@ -1819,6 +1848,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                 WG_BARRIER
                 if (s.stop == 2u) return kUnitTooBig;
                 WG_EACH_WAVE
+                    (void)w;
                     R.tail = s.alloc; R.popped = s.popped; R.bitpos = s.bitpos; R.flushed_words = s.flushed_words;
                 WG_BARRIER
             }

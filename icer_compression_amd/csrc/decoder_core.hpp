@@ -41,7 +41,12 @@ struct DecoderTables {
     uint16_t gm[17], gl[17], gi[17];       // Golomb parameters of bins 8..16
     uint32_t cut[16];                      // probability cut-offs x65536 between the bins (icer_config.c:69-87)
     uint32_t binlut[257];                  // CoderTables::binlut: the bin of floor(zero * 65536 / total) by one look-up
+    // bins 1..7: [bin - 1][the next 10 bits of the payload] -> what the code-word search of icer_decode_bit (:154-172) arrives
+    // at: bits consumed | pattern bits << 4 | reversed pattern << 8; 0 = ten bits without a match (nothing consumed, no bit
+    // pending); kLutInvalid = the search runs into a value >= 32 first (ICER_DECODED_INVALID_DATA)
+    uint16_t v2vlut[7][1024];
 };
+constexpr uint16_t kLutInvalid = 0xFFFFu;
 
 inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
 {
@@ -58,6 +63,17 @@ inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
     for (int b = 0; b < 17; b++) { d->gm[b] = t.gm[b]; d->gl[b] = t.gl[b]; d->gi[b] = t.gi[b]; }
     for (int k = 0; k < 16; k++) d->cut[k] = t.cut[k];
     for (int k = 0; k <= 256; k++) d->binlut[k] = t.binlut[k];
+    for (int b = 1; b <= 7; b++)
+        for (uint32_t x = 0; x < 1024u; x++) {
+            uint16_t r = 0;
+            for (uint32_t nb = 1; nb <= 10u; nb++) {
+                const uint32_t code = x & ((1u << nb) - 1u);
+                if (code >= 32u) { r = kLutInvalid; break; }
+                const uint32_t e = d->dec[b][code];
+                if ((e & 15u) == nb) { r = (uint16_t)(nb | (e & 0xFFF0u)); break; }
+            }
+            d->v2vlut[b - 1][x] = r;
+        }
 }
 
 // one chain = one segment of one subband of one channel
@@ -81,6 +97,7 @@ struct EntropyDecoder {
     uint64_t win;               // (packets of >= 8 bits) the next win_bits bits of the payload, from `pos` on
     uint32_t win_bits;
     uint32_t win_next;          // next payload byte to load into the window
+    uint32_t ahead;             // (entropy_decode_fast) the four bytes at win_next, loaded one refill early
     // per-bin state, entry b at [b * ss]: in the thread's own memory (ss = 1) or a column of an LDS block (plane_attach_*)
     int16_t *n;                 // bits pending per bin, served from the top
     uint8_t *bits;              // bins 0..7: the pending pattern (bit k = k-th from the bottom); bins 8..16: bottom bit
@@ -251,34 +268,131 @@ ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *
     return kOk;
 }
 
+// ---- the same for packets of >= kFastPacketBits bits, where none of the reference's length tests can fire (they compare
+// at most 11 with the packet's length): the code word of bins 1..7 by ONE look-up of the next ten bits (v2vlut), the
+// window refilled from a word that was loaded a refill earlier (its latency is off the decoding chain), and no loop -- the
+// lanes of a wavefront that decode side by side stay together.  State and results are those of entropy_decode.
+constexpr uint32_t kFastPacketBits = 16;
+// Four payload bytes from byte i on, bytes behind the stream reading as zero -- as ONE unconditional load (from a clamped
+// address; needs stream_len >= 4, which a packet of kFastPacketBits bits implies) whose result is only touched when the
+// window takes it in, a refill later (entropy_ahead): no branch and no wait at the load.
+ICER_HD uint32_t entropy_load4(const EntropyDecoder &d, uint32_t i)
+{
+    const uint32_t at = d.base + i, last = d.stream_len - 4u, from = at < last ? at : last;
+    uint32_t v;
+    memcpy(&v, d.stream + from, 4);
+    return v;
+}
+ICER_HD uint32_t entropy_ahead(const EntropyDecoder &d)         // the bytes at win_next, from the word loaded for them
+{
+    const uint32_t at = d.base + d.win_next, last = d.stream_len - 4u, skip = at < last ? 0u : at - last;
+    return skip >= 4u ? 0u : d.ahead >> (8u * skip);
+}
+ICER_HD void entropy_fast_begin(EntropyDecoder &d) { d.ahead = entropy_load4(d, 0); }      // after entropy_init
+ICER_HD int entropy_decode_fast(EntropyDecoder &d, const DecoderTables &t, uint32_t *bit, uint32_t zero, uint32_t total)
+{
+    const bool inv = zero < (total >> 1);
+    if (inv) zero = total - zero;
+    const int bin = pick_bin_plain(t, zero, total);
+    const uint32_t at = (uint32_t)bin * d.ss;
+    int n = d.n[at];
+    uint32_t pat = d.bits[at];
+    const uint32_t last_word = d.index[at];
+    if ((n <= 0) | (d.words - last_word >= (uint32_t)kRingWords)) {
+        if (d.win_bits < 32u) {
+            d.win |= (uint64_t)entropy_ahead(d) << d.win_bits;
+            d.win_bits += 32u;
+            d.win_next += 4u;
+            d.ahead = entropy_load4(d, d.win_next);
+        }
+        const uint32_t x = (uint32_t)d.win & 0x7FFu;
+        uint32_t len;
+        if (bin >= 8) {
+            const uint32_t m = t.gm[bin], l = t.gl[bin], gi = t.gi[bin];
+            const uint32_t k0 = reverse_low_bits(x & ((1u << l) - 1u), l);
+            const uint32_t k1 = (reverse_low_bits(x & ((2u << l) - 1u), l + 1u) - gi) & 0xFFFFu;
+            const bool full = (x & 1u) != 0, shortw = k0 < gi;
+            const uint32_t k = shortw ? k0 : k1;
+            len = full ? 1u : (shortw ? l : l + 1u);
+            pat = full ? 0u : 1u;
+            n = full ? (int)m : (int)(1u + k > 32767u ? 32767u : 1u + k);
+        } else if (bin >= 1) {
+            const uint32_t e = t.v2vlut[bin - 1][x & 1023u];
+            if (e == kLutInvalid) return kDecodedInvalidData;
+            len = e & 15u; n = (int)((e >> 4) & 15u); pat = e >> 8;
+        } else { len = 1u; n = 1; pat = x & 1u; }
+        d.win >>= len; d.win_bits -= len;
+        d.words++;
+        d.index[at] = d.words;
+        d.bits[at] = (uint8_t)pat;
+    }
+    uint32_t b = 0;
+    if (n > 0) b = bin >= 8 ? (n == 1 ? pat : 0u) : (pat >> (n - 1)) & 1u;
+    d.n[at] = (int16_t)(n - 1);
+    *bit = inv ? (b ^ 1u) : b;
+    return kOk;
+}
+
 // ------------------------------------------------------------------------------------------ bit-plane decoder
 // context tables (icer_config.c:26-67)
-ICER_HD int dec_ctx_plain(int h, int v, int d)
+constexpr ICER_HD int dec_ctx_plain(int h, int v, int d)
 {
     if (h == 2) return 8;
     if (h == 1) return v == 0 ? (d == 0 ? 5 : d == 1 ? 6 : 7) : 7;
     if (v == 0) return d > 2 ? 2 : d;
     return v == 1 ? 3 : 4;
 }
-ICER_HD int dec_ctx_hh(int hv, int d)
+constexpr ICER_HD int dec_ctx_hh(int hv, int d)
 {
     if (d >= 3) return 8;
-    const int k = hv > 2 ? 2 : hv;
-    if (d == 0) return k;
-    if (d == 1) return 3 + k;
+    if (d == 0) return hv > 2 ? 2 : hv;
+    if (d == 1) return 3 + (hv > 2 ? 2 : hv);
     return hv == 0 ? 6 : 7;
 }
-ICER_HD int dec_sign_ctx(int sh, int sv)      // icer_sign_context_table
+constexpr ICER_HD int dec_sign_ctx(int sh, int sv)      // icer_sign_context_table
 {
     if (sh == 2) return sv == 2 ? 12 : 13;
     if (sv == 2) return 15;
     return ((sh < 2) == (sv < 2)) ? 14 : 16;
 }
-ICER_HD int dec_sign_pred(int sh, int sv)     // icer_sign_prediction_table
+constexpr ICER_HD int dec_sign_pred(int sh, int sv)     // icer_sign_prediction_table
 {
     if (sh < 2) return 1;
     if (sh == 2) return sv > 2 ? 1 : 0;
     return 0;
+}
+// the same tables as nibbles of 64-bit constants (made from the functions above at compile time), for code that must not
+// branch: entry i of table word(s) K is (K[i / 16] >> 4 * (i % 16)) & 15
+constexpr uint64_t dec_pack_plain(int word)
+{
+    uint64_t k = 0;
+    for (int i = word * 16; i < word * 16 + 16 && i < 45; i++) k |= (uint64_t)dec_ctx_plain(i / 15, (i / 5) % 3, i % 5) << (4 * (i % 16));
+    return k;
+}
+constexpr uint64_t dec_pack_hh(int word)
+{
+    uint64_t k = 0;
+    for (int i = word * 16; i < word * 16 + 16 && i < 25; i++) k |= (uint64_t)dec_ctx_hh(i / 5, i % 5) << (4 * (i % 16));
+    return k;
+}
+constexpr uint64_t dec_pack_sign()          // per (sh, sv): sign context - 12, predicted sign << 3
+{
+    uint64_t k = 0;
+    for (int i = 0; i < 9; i++) k |= (uint64_t)((dec_sign_ctx(i / 3, i % 3) - 12) | (dec_sign_pred(i / 3, i % 3) << 3)) << (4 * i);
+    return k;
+}
+ICER_HD uint32_t dec_ctx_plain_packed(uint32_t h, uint32_t v, uint32_t d)      // h, v <= 2, d <= 4
+{
+    constexpr uint64_t k0 = dec_pack_plain(0), k1 = dec_pack_plain(1), k2 = dec_pack_plain(2);
+    const uint32_t i = h * 15u + v * 5u + d;
+    const uint64_t k = i < 16u ? k0 : i < 32u ? k1 : k2;
+    return (uint32_t)(k >> (4u * (i & 15u))) & 15u;
+}
+ICER_HD uint32_t dec_ctx_hh_packed(uint32_t hv, uint32_t d)                   // hv, d <= 4
+{
+    constexpr uint64_t k0 = dec_pack_hh(0), k1 = dec_pack_hh(1);
+    const uint32_t i = hv * 5u + d;
+    return (uint32_t)((i < 16u ? k0 : k1) >> (4u * (i & 15u))) & 15u;
 }
 ICER_HD void dec_model_update(uint16_t &zero, uint16_t &total, bool was_zero)
 {
@@ -301,6 +415,12 @@ struct PlaneDecoder {
     uint32_t done;              // samples finished (= r * w + c)
     int lsb;
     int status;                 // 1 = running, 0 = finished (kOk), < 0 = failed with that code, 2 = not started
+    // (plane_decision) a sample that became significant and whose sign is the next decision: its word, sign context and
+    // predicted sign
+    uint32_t pend, pval, psctx, ppred;
+    // (plane_decision) the neighbourhood slides along the row in registers: the words above-left / above / below-left /
+    // below / at the next sample, and where the three rows start in the image
+    uint32_t nul, nu0, ndl, nd0, ncur, ou, oc, od;
 };
 
 // where a plane job keeps its per-bin / per-context arrays: its own memory ...
@@ -332,7 +452,7 @@ ICER_HD void plane_attach_columns(PlaneDecoder &p, uint8_t *block, uint32_t colu
 ICER_HD void plane_begin(PlaneDecoder &p, int lsb, int sign_bit, uint32_t w, uint32_t h)
 {
     for (uint32_t k = 0; k < (uint32_t)kNumContexts; k++) { p.zero[k * p.d.ss] = 2; p.total[k * p.d.ss] = 4; }
-    p.r = 0; p.c = 0; p.left = 0; p.done = 0; p.lsb = lsb;
+    p.r = 0; p.c = 0; p.left = 0; p.done = 0; p.lsb = lsb; p.pend = 0; p.pval = 0; p.psctx = 0; p.ppred = 0;
     p.status = (lsb + 1 >= sign_bit + 1) ? kBitplaneOutOfRange : ((w == 0 || h == 0) ? kOk : 1);
 }
 
@@ -398,11 +518,96 @@ ICER_HD void plane_step_img(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
     else { p.c = 0; p.left = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
 }
 
+// ---- one DECISION per call instead of one sample: the sign of a sample that just became significant is left for the
+// next call.  Lanes of a wavefront that decode planes side by side (decoder_wave.hpp) then run the same instructions call
+// after call -- one context, one entropy_decode_fast, one model update -- instead of taking turns through the branches
+// of plane_step_img; everything a sample reads is loaded up front (clamped addresses, masked by validity) and the
+// context is selected without branches.  Packets shorter than kFastPacketBits take plane_step_img.
+template <class Img>
+ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, int subband, int sign_bit, const DecoderTables &t)
+{
+    if (p.d.total_bits < kFastPacketBits) { plane_step_img(p, img, w, h, subband, sign_bit, t); return; }
+    const int lsb = p.lsb;
+    const uint32_t mask = (1u << sign_bit) - 1u;
+    const uint32_t r = p.r, c = p.c;
+    uint32_t cur = p.pval, ctx = p.psctx, sctx = p.psctx, pred = p.ppred;
+    int cat = 0;
+    const bool magnitude = p.pend == 0;
+    if (magnitude) {
+        const bool up = r > 0, dn = r + 1 < h, hr = c + 1 < w;
+        if (c == 0) {                              // a new row: where its three rows lie, and their first column
+            p.ou = img.row_at(up ? r - 1u : r); p.oc = img.row_at(r); p.od = img.row_at(dn ? r + 1u : r);
+            p.nul = 0; p.ndl = 0;
+            p.nu0 = up ? img.at_row(p.ou, 0) : 0u; p.ncur = img.at_row(p.oc, 0); p.nd0 = dn ? img.at_row(p.od, 0) : 0u;
+        }
+        // three new words per sample (the column to the right); nothing that is read here can still change in the bits
+        // this plane looks at: the planes above are past it, the planes below only add lower bits -- and signs of
+        // samples that are insignificant from this plane up, which are not looked at
+        const uint32_t cr = hr ? c + 1u : c;
+        const uint32_t ur0 = img.at_row(p.ou, cr), right0 = img.at_row(p.oc, cr), dr0 = img.at_row(p.od, cr);
+        const uint32_t ur = (up && hr) ? ur0 : 0u, right = hr ? right0 : 0u, dr = (dn && hr) ? dr0 : 0u;
+        const uint32_t left = p.left, u0 = p.nu0, d0 = p.nd0, ul = p.nul, dl = p.ndl;
+        cur = p.ncur;
+        p.nul = u0; p.nu0 = ur; p.ndl = d0; p.nd0 = dr; p.ncur = right;
+        const uint32_t m = cur & mask;
+        const int msb = 31 - __builtin_clz(m | 1u);
+        cat = msb < lsb ? 0 : msb - lsb;
+        if (cat > 3) cat = 3;
+        // significance at this plane (visited) / the plane above (not yet visited), icer_context_modeller.c:509-521
+        const uint32_t s_l = ((left & mask) >> lsb) != 0, s_r = ((right & mask) >> (lsb + 1)) != 0;
+        const uint32_t s_u = ((u0 & mask) >> lsb) != 0, s_d = ((d0 & mask) >> (lsb + 1)) != 0;
+        int hh = (int)(s_l + s_r), vv = (int)(s_u + s_d);
+        const int dd = (int)((((ul & mask) >> lsb) != 0) + (((ur & mask) >> lsb) != 0) +
+                             (((dl & mask) >> (lsb + 1)) != 0) + (((dr & mask) >> (lsb + 1)) != 0));
+        // sign context: only negative significant neighbours count (QUIRK C6)
+        int sh = 2 - (int)(s_l & (left >> sign_bit) & 1u) - (int)(s_r & (right >> sign_bit) & 1u);
+        int sv = 2 - (int)(s_u & (u0 >> sign_bit) & 1u) - (int)(s_d & (d0 >> sign_bit) & 1u);
+        const int any_hv = hh + vv;
+        if (subband == kHL) { int x = hh; hh = vv; vv = x; x = sh; sh = sv; sv = x; }
+        const uint32_t c0 = subband == kHH ? dec_ctx_hh_packed((uint32_t)any_hv, (uint32_t)dd) : dec_ctx_plain_packed((uint32_t)hh, (uint32_t)vv, (uint32_t)dd);
+        ctx = cat == 0 ? c0 : cat == 1 ? (any_hv == 0 ? 9u : 10u) : 11u;
+        constexpr uint64_t ksign = dec_pack_sign();
+        const uint32_t se = (uint32_t)(ksign >> (4u * (uint32_t)(sh * 3 + sv))) & 15u;
+        sctx = 12u + (se & 7u);
+        pred = se >> 3;
+    }
+    const bool modelled = !(magnitude && cat == 3);
+    const uint32_t zi = ctx * p.d.ss;
+    uint16_t zero = 1, total = 2;
+    if (modelled) { zero = p.zero[zi]; total = p.total[zi]; }
+    uint32_t bit;
+    const int res = entropy_decode_fast(p.d, t, &bit, zero, total);
+    if (res != kOk) {
+        if (!magnitude) img.put_row(p.oc, c, cur);       // (the magnitude bit of the sample stays, as in plane_step_img)
+        p.status = res;
+        return;
+    }
+    if (modelled) {
+        dec_model_update(zero, total, bit == 0);
+        p.zero[zi] = zero; p.total[zi] = total;
+    }
+    uint32_t val;
+    if (magnitude) {
+        val = cur | (bit << lsb);
+        if (cat == 0 && bit) { p.pend = 1; p.pval = val; p.psctx = sctx; p.ppred = pred; return; }
+    } else {
+        val = cur | (((bit ^ pred) & 1u) << sign_bit);
+        p.pend = 0;
+    }
+    img.put_row(p.oc, c, val);
+    p.done++;
+    if (c + 1 < w) { p.c = c + 1; p.left = val; }
+    else { p.c = 0; p.left = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
+}
+
 // the segment in place, in the channel plane
 struct GlobalImage {
     uint16_t *seg; size_t stride;
     ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return seg[(size_t)r * stride + c]; }
     ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { seg[(size_t)r * stride + c] = (uint16_t)v; }
+    ICER_HD uint32_t row_at(uint32_t r) const { return (uint32_t)(r * stride); }
+    ICER_HD uint32_t at_row(uint32_t row, uint32_t c) const { return seg[(size_t)row + c]; }
+    ICER_HD void put_row(uint32_t row, uint32_t c, uint32_t v) { seg[(size_t)row + c] = (uint16_t)v; }
 };
 ICER_HD void plane_step(PlaneDecoder &p, uint16_t *seg, uint32_t w, uint32_t h, size_t stride, int subband, int sign_bit,
                         const DecoderTables &t)

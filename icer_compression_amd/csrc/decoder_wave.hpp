@@ -28,13 +28,16 @@
 namespace icer {
 
 constexpr uint32_t kRingRows = 16;          // >= kPlanes + 3; power of two
-constexpr uint32_t kBurst = 8;              // samples a plane may take per look at its neighbours
+constexpr uint32_t kBurst = 16;             // samples a plane may take per look at its neighbours
 constexpr uint32_t kStateColumns = 16;      // >= kPlanes: lanes that keep their per-bin arrays in the LDS state block
 
 struct RingImage {
     uint16_t *ring; uint32_t pitch;
     ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return ring[(r & (kRingRows - 1u)) * pitch + c]; }
     ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { ring[(r & (kRingRows - 1u)) * pitch + c] = (uint16_t)v; }
+    ICER_HD uint32_t row_at(uint32_t r) const { return (r & (kRingRows - 1u)) * pitch; }
+    ICER_HD uint32_t at_row(uint32_t row, uint32_t c) const { return ring[row + c]; }
+    ICER_HD void put_row(uint32_t row, uint32_t c, uint32_t v) { ring[row + c] = (uint16_t)v; }
 };
 
 // `ring`: kRingRows * pitch words of LDS (pitch >= c.w); `plane`: the channel plane (zero where not yet decoded);
@@ -62,69 +65,71 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
             const uint32_t at = c.pkt[lsb];
             entropy_init(LV(pd).d, stream, stream_len, at + (uint32_t)kHeaderBytes, packet_bits(stream, at));
             plane_begin(LV(pd), lsb, sign_bit, w, h);
+            if (LV(pd).d.total_bits >= kFastPacketBits) entropy_fast_begin(LV(pd).d);
         }
     }
     uint32_t retired = 0;                                    // rows written back so far (wave-uniform)
     for (;;) {
         WAVE_SYNC();
-        // where every plane stands at the start of the iteration
-        LANEVAR(uint32_t, st); LANEVAR(uint32_t, dn); LANEVAR(uint32_t, row);
+        // where every plane stands at the start of the iteration; its upper neighbour's state comes from the lane below
+        LANEVAR(uint32_t, st); LANEVAR(uint32_t, dn); LANEVAR(uint32_t, up_lane);
         FOR_LANES
         {
-            LV(st) = (uint32_t)LV(pd).status; LV(dn) = LV(pd).done; LV(row) = LV(pd).r;
+            LV(st) = (uint32_t)LV(pd).status; LV(dn) = LV(pd).done; LV(up_lane) = lane > 0 ? (uint32_t)lane - 1u : 0u;
         }
-        uint32_t st_u[kPlanes], dn_u[kPlanes], row_u[kPlanes];
-        for (int j = 0; j < nrun; j++) { st_u[j] = READLANE(st, j); dn_u[j] = READLANE(dn, j); row_u[j] = READLANE(row, j); }
-        // a plane under a failed or cancelled one never runs (again): cancel it, top-down
-        for (int j = 1; j < nrun; j++) {
-            const int above = (int)st_u[j - 1];
-            if (st_u[j] == 1u && (above < 0 || above == 2)) st_u[j] = 2u;
+        // a plane under a failed or cancelled one never runs (again).  (A finished plane has only finished planes above it.)
+        const uint64_t dead = BALLOT(lane < nrun && ((int)LV(st) < 0 || LV(st) == 2u));
+        FOR_LANES
+        {
+            if (lane < nrun && LV(st) == 1u && (dead & ((1ull << lane) - 1ull)) != 0ull) { LV(st) = 2u; LV(pd).status = 2; }
         }
+        LANEVAR(uint32_t, ast); LANEVAR(uint32_t, adn);
+        WAVE_GATHER(ast, st, up_lane);
+        WAVE_GATHER(adn, dn, up_lane);
         // how many samples each plane may take before the next look (kBurst at most): its upper neighbour has to stay
         // w + 2 samples ahead of the last one -- plane_needs(), rounded up -- and the row below must have its ring slot
-        LANEVAR(uint32_t, grant);
+        LANEVAR(uint32_t, grant); LANEVAR(uint32_t, low);
         FOR_LANES
         {
             uint32_t g = 0;
-            if (lane < nrun) {
-                uint32_t mine = 0;
-                int above_status = kOk;
-                uint32_t above_done = 0;
-                for (int j = 0; j < nrun; j++)              // (uniform arrays are not indexed by the lane number)
-                    if (lane == j) {
-                        mine = st_u[j];
-                        if (j > 0) { above_status = (int)st_u[j - 1]; above_done = dn_u[j - 1]; }
-                    }
-                if (LV(pd).status == 1 && mine == 2u) LV(pd).status = 2;
-                if (LV(pd).status == 1) {
-                    g = kBurst;
-                    if (above_status == 1) {
-                        const uint32_t need = LV(pd).done + w + 2u;          // for the first sample of the burst
-                        g = above_done >= need ? (above_done - need + 1u < kBurst ? above_done - need + 1u : kBurst) : 0u;
-                    } else if (above_status != kOk) g = 0;
-                    const uint32_t room_end = (retired + kRingRows - 1u) * w;       // samples of rows whose row below has a slot
-                    const uint32_t room = room_end > LV(pd).done ? room_end - LV(pd).done : 0u;
-                    if (room < g) g = room;
-                }
+            const bool running = lane < nrun && LV(st) == 1u;
+            if (running) {
+                const int above_status = lane > 0 ? (int)LV(ast) : kOk;
+                g = kBurst;
+                if (above_status == 1) {
+                    const uint32_t need = LV(dn) + w + 2u;                        // for the first sample of the burst
+                    g = LV(adn) >= need ? (LV(adn) - need + 1u < kBurst ? LV(adn) - need + 1u : kBurst) : 0u;
+                } else if (above_status != kOk) g = 0;
+                const uint32_t room_end = (retired + kRingRows - 1u) * w;       // samples of rows whose row below has a slot
+                const uint32_t room = room_end > LV(dn) ? room_end - LV(dn) : 0u;
+                if (room < g) g = room;
             }
             LV(grant) = g;
+            LV(low) = LV(pd).r;
         }
         const uint64_t G = BALLOT(LV(grant) != 0u);
-        // rows below `limit` are dead: a running plane in row r still reads row r - 1
+        // rows below `limit` are dead: a running plane in row r still reads row r - 1; the lowest running plane is the
+        // one furthest behind
+        const uint64_t running_now = BALLOT(lane < nrun && LV(st) == 1u);
         uint32_t limit = h;
-        for (int j = 0; j < nrun; j++)
-            if (st_u[j] == 1u) { const uint32_t l = row_u[j] > 0u ? row_u[j] - 1u : 0u; if (l < limit) limit = l; }
+        if (running_now) { const uint32_t rr = READLANE(low, 63 - clz64(running_now)); limit = rr > 0u ? rr - 1u : 0u; }
         const bool retire = retired < limit;
         if (G == 0ull && !retire) break;
         uint32_t steps = 0;
-        for (uint32_t k = 0; k < kBurst; k++) {
-            const uint64_t A = BALLOT(k < LV(grant) && LV(pd).status == 1);
+        // a burst: up to `grant` samples per plane, one decision (a magnitude bit or a sign) per round
+        LANEVAR(uint32_t, stop_at);
+        FOR_LANES
+        {
+            LV(stop_at) = LV(pd).done + LV(grant);
+        }
+        for (uint32_t k = 0; k < 2u * kBurst; k++) {
+            const uint64_t A = BALLOT(LV(pd).done < LV(stop_at) && LV(pd).status == 1);
             if (A == 0ull) break;
             FOR_LANES
             {
-                if (k < LV(grant) && LV(pd).status == 1) {
+                if (LV(pd).done < LV(stop_at) && LV(pd).status == 1) {
                     RingImage img{ring, pitch};
-                    plane_step_img(LV(pd), img, w, h, subband, sign_bit, t);
+                    plane_decision(LV(pd), img, w, h, subband, sign_bit, t);
                 }
             }
             WAVE_SYNC();

@@ -13,7 +13,7 @@ from icer_compression_amd import api, build, synth  # noqa: E402
 
 NAMES = ["pixel wave: context+loads", "pixel wave: wait (queue full)",
          "count wave: wait (pixels)", "count wave: counts", "count wave: fold+bin", "count wave: wait (queue full)",
-         "walk wave: wait (events/verdict)", "walk wave: compaction", "walk wave: walk", "walk wave: records",
+         "walk wave: wait (events/verdict)", "walk wave: walks (two halves)", "walk wave: join + results", "walk wave: (unused)",
          "golomb wave: wait (events/verdict)", "golomb wave: bins 0, 8-16", "golomb wave: hand-over",
          "merge wave: wait (events)", "merge wave: walker reads + ring slots", "merge wave: drain", "merge wave: exact path",
          "merge wave: retire", "merge wave: event reads + wait golomb", "merge wave: golomb reads + wait walker",
