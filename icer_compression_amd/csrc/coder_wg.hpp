@@ -1529,16 +1529,20 @@ ICER_DEV void phase_f_commit(Shared &s, Wave &R, uint32_t w, uint32_t wbase, uin
 // counts alone -- the estimate zero / total only rises from event to event, except for a slight drop where the counts are
 // halved (at most one bin down) --, so the events fall into a few SEGMENTS of one Golomb bin each, ending where the
 // estimate crosses the bin's upper cut-off or the counts are rescaled; and n zero events of a Golomb bin with parameter
-// m just fill up words of m zeros (code word "1", icer_encoding.c:68-72).  blank_run_ok: the closed form applies -- the
+// m just fill up words of m zeros (code word "1", icer_encoding.c:68-72).  blank_run_chunks: how many of the nb chunks the closed form may take (0: it does not apply) -- the
 // estimate is not folded, every bin on the way is a Golomb bin, and no word start can find the ring full whatever the
 // segments turn out to be (an upper bound of the words they open; also keeps the physical ring from overflowing, since
 // nothing is popped here).  Every wave evaluates it (wave-uniform, same answer).
-ICER_DEV bool blank_run_ok(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
+ICER_DEV uint32_t blank_run_chunks(Shared &s, const Wave &R, uint32_t par, uint32_t nb)
 {
     const uint32_t z = s.czer[par][0], t = s.ctot[par][0];
-    if (z < (t >> 1)) return false;
-    if (pick_bin(s.tab.binlut, z, t) < 9u) return false;
-    return R.tail + nev / 5u + 2u - R.popped <= (uint32_t)kRingWords;      // (5 = the smallest Golomb parameter)
+    if (z < (t >> 1)) return 0u;
+    if (pick_bin(s.tab.binlut, z, t) < 9u) return 0u;
+    // words the run may open: events / 5 + 2 (5 = the smallest Golomb parameter); as many chunks as that leaves room for
+    const uint32_t used = R.tail - R.popped + 2u;
+    if (used >= (uint32_t)kRingWords) return 0u;
+    const uint32_t fit = ((uint32_t)kRingWords - used) * 5u / 64u;
+    return nb < fit ? nb : fit;
 }
 
 // ceil(num / den) for 0 < num < 2^25, 144 <= den < 2^16 (one float reciprocal, corrected: no integer division)
@@ -1616,7 +1620,7 @@ ICER_DEV void blank_run(Shared &s, const Wave &R, uint32_t par, uint32_t nev)
         nev -= n;
     }
     // results go where nobody is reading: the other copy of the counts (a slower wave may still be evaluating
-    // blank_run_ok on this one) and this run's copy of the allocation count
+    // blank_run_chunks on this one) and this run's copy of the allocation count
     FOR_LANES
     {
         if (lane < 32 && ((touched >> lane) & 1u)) { s.bin_state[lane] = st_pack(0u, LV(run), 0u); s.bin_slot[lane] = (int32_t)LV(slot); }
@@ -1670,7 +1674,8 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
             bool ok = false;
             WG_EACH_WAVE
                 (void)w;
-                ok = nb >= kBlankRunMin && blank_run_ok(s, R, par, nb * 64u);
+                if (nb >= kBlankRunMin) nb = blank_run_chunks(s, R, par, nb);
+                ok = nb >= kBlankRunMin;
             WG_BARRIER_NONE
             if (ok) {
                 WG_EACH_WAVE

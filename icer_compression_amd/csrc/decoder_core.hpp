@@ -41,12 +41,14 @@ struct DecoderTables {
     uint16_t gm[17], gl[17], gi[17];       // Golomb parameters of bins 8..16
     uint32_t cut[16];                      // probability cut-offs x65536 between the bins (icer_config.c:69-87)
     uint32_t binlut[257];                  // CoderTables::binlut: the bin of floor(zero * 65536 / total) by one look-up
-    // bins 1..7: [bin - 1][the next 10 bits of the payload] -> what the code-word search of icer_decode_bit (:154-172) arrives
-    // at: bits consumed | pattern bits << 4 | reversed pattern << 8; 0 = ten bits without a match (nothing consumed, no bit
-    // pending); kLutInvalid = the search runs into a value >= 32 first (ICER_DECODED_INVALID_DATA)
-    uint16_t v2vlut[7][1024];
+    // bins 1..7: [bin - 1][the next 5 bits of the payload] -> what the code-word search of icer_decode_bit (:154-172) arrives
+    // at: bits consumed | pattern bits << 4 | reversed pattern << 8.  The reference's codes are complete prefix codes of at
+    // most 5 bits, so the search never runs on to its other exits (ten bits without a match; a value >= 32:
+    // ICER_DECODED_INVALID_DATA) -- build_decoder_tables checks that on all 1024 ten-bit inputs and clears `lut_ok`
+    // otherwise, which sends every packet through the general routine.
+    uint16_t v2vlut[7][32];
+    uint32_t lut_ok;
 };
-constexpr uint16_t kLutInvalid = 0xFFFFu;
 
 inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
 {
@@ -63,16 +65,18 @@ inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
     for (int b = 0; b < 17; b++) { d->gm[b] = t.gm[b]; d->gl[b] = t.gl[b]; d->gi[b] = t.gi[b]; }
     for (int k = 0; k < 16; k++) d->cut[k] = t.cut[k];
     for (int k = 0; k <= 256; k++) d->binlut[k] = t.binlut[k];
+    d->lut_ok = 1;
     for (int b = 1; b <= 7; b++)
         for (uint32_t x = 0; x < 1024u; x++) {
-            uint16_t r = 0;
+            uint32_t r = 0xFFFFFFFFu;                               // (no match in ten bits / invalid: not representable)
             for (uint32_t nb = 1; nb <= 10u; nb++) {
                 const uint32_t code = x & ((1u << nb) - 1u);
-                if (code >= 32u) { r = kLutInvalid; break; }
+                if (code >= 32u) break;
                 const uint32_t e = d->dec[b][code];
-                if ((e & 15u) == nb) { r = (uint16_t)(nb | (e & 0xFFF0u)); break; }
+                if ((e & 15u) == nb) { r = nb | (e & 0xFFF0u); break; }
             }
-            d->v2vlut[b - 1][x] = r;
+            if (x < 32u) d->v2vlut[b - 1][x] = (uint16_t)r;
+            if (r == 0xFFFFFFFFu || (r & 15u) > 5u || r != d->v2vlut[b - 1][x & 31u]) d->lut_ok = 0;
         }
 }
 
@@ -269,7 +273,7 @@ ICER_HD int entropy_decode(EntropyDecoder &d, const DecoderTables &t, uint32_t *
 }
 
 // ---- the same for packets of >= kFastPacketBits bits, where none of the reference's length tests can fire (they compare
-// at most 11 with the packet's length): the code word of bins 1..7 by ONE look-up of the next ten bits (v2vlut), the
+// at most 11 with the packet's length): the code word of bins 1..7 by ONE look-up of the next five bits (v2vlut), the
 // window refilled from a word that was loaded a refill earlier (its latency is off the decoding chain), and no loop -- the
 // lanes of a wavefront that decode side by side stay together.  State and results are those of entropy_decode.
 constexpr uint32_t kFastPacketBits = 16;
@@ -317,8 +321,7 @@ ICER_HD int entropy_decode_fast(EntropyDecoder &d, const DecoderTables &t, uint3
             pat = full ? 0u : 1u;
             n = full ? (int)m : (int)(1u + k > 32767u ? 32767u : 1u + k);
         } else if (bin >= 1) {
-            const uint32_t e = t.v2vlut[bin - 1][x & 1023u];
-            if (e == kLutInvalid) return kDecodedInvalidData;
+            const uint32_t e = t.v2vlut[bin - 1][x & 31u];
             len = e & 15u; n = (int)((e >> 4) & 15u); pat = e >> 8;
         } else { len = 1u; n = 1; pat = x & 1u; }
         d.win >>= len; d.win_bits -= len;
@@ -526,7 +529,7 @@ ICER_HD void plane_step_img(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
 template <class Img>
 ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, int subband, int sign_bit, const DecoderTables &t)
 {
-    if (p.d.total_bits < kFastPacketBits) { plane_step_img(p, img, w, h, subband, sign_bit, t); return; }
+    if (p.d.total_bits < kFastPacketBits || !t.lut_ok) { plane_step_img(p, img, w, h, subband, sign_bit, t); return; }
     const int lsb = p.lsb;
     const uint32_t mask = (1u << sign_bit) - 1u;
     const uint32_t r = p.r, c = p.c;

@@ -65,7 +65,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
             const uint32_t at = c.pkt[lsb];
             entropy_init(LV(pd).d, stream, stream_len, at + (uint32_t)kHeaderBytes, packet_bits(stream, at));
             plane_begin(LV(pd), lsb, sign_bit, w, h);
-            if (LV(pd).d.total_bits >= kFastPacketBits) entropy_fast_begin(LV(pd).d);
+            if (LV(pd).d.total_bits >= kFastPacketBits && t.lut_ok) entropy_fast_begin(LV(pd).d);
         }
     }
     uint32_t retired = 0;                                    // rows written back so far (wave-uniform)

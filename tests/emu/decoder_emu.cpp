@@ -62,6 +62,15 @@ static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDes
 // mode 1 / 2: decode chains with the lock-step schedule (planes top-down / bottom-up inside an iteration); mode 3: the
 // wave kernel of decoder_wave.hpp (LDS row ring).  stats: iterations, samples decoded, roll-backs, chains with rows left
 extern "C" void emu_decoder_mode(int lockstep) { g_lockstep = lockstep; g_stats[0] = g_stats[1] = g_stats[2] = g_stats[3] = 0; }
+// 1: the code-word table of entropy_decode_fast covers the code (so mode 3 really runs plane_decision's fast path)
+extern "C" int emu_decoder_lut_ok(void)
+{
+    CoderTables ct;
+    build_coder_tables(&ct);
+    static DecoderTables dt;
+    build_decoder_tables(&dt, ct);
+    return (int)dt.lut_ok;
+}
 extern "C" void emu_decoder_stats(unsigned long long *out) { for (int i = 0; i < 4; i++) out[i] = g_stats[i]; }
 
 // planes[c]: >= bufsize uint16 words; for sample_bits = 8 the low byte of each word is the uint8 result.

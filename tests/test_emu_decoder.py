@@ -64,6 +64,11 @@ def kernel(request, emu):
     emu.lib.emu_decoder_mode(0)
 
 
+def test_fast_code_word_table_covers_the_code(emu):
+    """the 5-bit look-up of entropy_decode_fast stands for the reference's search on all 1024 ten-bit inputs of every bin"""
+    assert emu.lib.emu_decoder_lut_ok() == 1
+
+
 def test_device_decoder_matches_the_oracle_on_random_streams(emu, orc, kernel):
     rng = np.random.default_rng(424242 + kernel)
     done, rcs = 0, set()

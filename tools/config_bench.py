@@ -50,6 +50,9 @@ def run(name, w, h, channels, stages, segments, quota, frames, golden_first=None
 
 
 if __name__ == "__main__":
+    if "--c2" in sys.argv:                      # (measurements of launch variants: the single-frame case only)
+        run("C2 4096^2 gray 5st 10seg lossless", 4096, 4096, 1, 5, 10, 2 * 4096 * 4096, 1, "C2_4096_gray_5st_10seg", steps=10)
+        sys.exit(0)
     run("C2 4096^2 gray 5st 10seg lossless", 4096, 4096, 1, 5, 10, 2 * 4096 * 4096, 1, "C2_4096_gray_5st_10seg")
     run("C3 4096^2 YUV 5st 10seg quota 70000", 4096, 4096, 3, 5, 10, 70000, 1, "C3_4096_yuv_quota70000")
     run("C4 2048^2 gray 4st 16seg, 32 of 256 frames", 2048, 2048, 1, 4, 16, 2 * 2048 * 2048, 32, "C4_2048_frame0")
