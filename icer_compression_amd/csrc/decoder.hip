@@ -114,15 +114,15 @@ __global__ void __launch_bounds__(64)
 decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels,
                           const ChainDesc *__restrict__ chains, const uint8_t *__restrict__ data,
                           const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes,
-                          int sign_bit, uint32_t pitch)
+                          int sign_bit)
 {
-    ICER_DYNAMIC_LDS(uint16_t, ring);                     // the row ring, then the lanes' per-bin arrays
+    ICER_DYNAMIC_LDS(uint8_t, lds);                       // the lanes' per-bin arrays, then the chain's row ring
     ICER_LDS_TABLES(lt, tables);
     const ChainDesc c = chains[blockIdx.x];
     const FrameInfo f = frames[c.frame];
-    uint8_t *state = reinterpret_cast<uint8_t *>(ring + (size_t)kRingRows * pitch);
-    decode_chain_wave(ring, pitch, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
-                      data + f.stream_off, f.stream_len, lt, nplanes, sign_bit, nullptr, state);
+    uint16_t *ring = reinterpret_cast<uint16_t *>(lds + ((plane_block_bytes(kStateColumns) + 15u) & ~(size_t)15));
+    decode_chain_wave(ring, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
+                      data + f.stream_off, f.stream_len, lt, nplanes, sign_bit, nullptr, lds);
 }
 
 // sign-magnitude words -> int16, LL mean back in (grid.y = frame * channels + channel)
@@ -301,16 +301,16 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         const uint32_t nc = (uint32_t)chains.size();
         HIP_TRY(ensure(d->chains, sizeof(ChainDesc) * nc));
         HIP_TRY(hipMemcpy(d->chains.p, chains.data(), sizeof(ChainDesc) * nc, hipMemcpyHostToDevice));
-        // ICER_DEC_WAVE=1: the planes of a segment side by side (one wavefront per chain), if its rows fit the LDS ring
-        uint32_t pitch = 2;
-        for (const ChainDesc &c : chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
-        const size_t ring_bytes = (size_t)kRingRows * pitch * sizeof(uint16_t) + plane_block_bytes(kStateColumns);
+        // the planes of a segment side by side (one wavefront per chain) if the chain's row ring fits LDS
+        size_t ring_elems = 2;
+        for (const ChainDesc &c : chains) ring_elems = std::max(ring_elems, ring_elems_for(c.w, nplanes));
+        const size_t ring_bytes = ring_elems * sizeof(uint16_t) + ((plane_block_bytes(kStateColumns) + 15u) & ~(size_t)15);
         const char *mode = getenv("ICER_DEC_WAVE");
         // the wavefront-per-chain kernel unless ICER_DEC_WAVE=0 asks for the thread-per-chain one (tests) or the segment
         // rows do not fit the LDS ring
         if (!(mode && mode[0] == '0') && ring_bytes <= 65536u) {
             ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nc, ring_bytes, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
-                             d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit, pitch);
+                             d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
         } else {
             ICER_LAUNCH(decode_chains_kernel, (nc + 63u) / 64u, 64, plane_block_bytes(64u), d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
                         nc, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);

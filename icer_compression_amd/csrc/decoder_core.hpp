@@ -421,9 +421,9 @@ struct PlaneDecoder {
     // (plane_decision) a sample that became significant and whose sign is the next decision: its word, sign context and
     // predicted sign
     uint32_t pend, pval, psctx, ppred;
-    // (plane_decision) the neighbourhood slides along the row in registers: the words above-left / above / below-left /
-    // below / at the next sample, and where the three rows start in the image
-    uint32_t nul, nu0, ndl, nd0, ncur, ou, oc, od;
+    // (plane_decision) the neighbourhood slides along the row in registers: significant / negative flags of the words
+    // around the next sample, that sample's word, and where the three rows start in the image
+    uint32_t nf, ncur, ou, oc, od;
 };
 
 // where a plane job keeps its per-bin / per-context arrays: its own memory ...
@@ -538,10 +538,20 @@ ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
     const bool magnitude = p.pend == 0;
     if (magnitude) {
         const bool up = r > 0, dn = r + 1 < h, hr = c + 1 < w;
+        const int lsb1 = lsb + 1;
+        // what the context needs of a neighbour: is it significant (at this plane if already visited, else at the plane
+        // above), and if so is it negative -- two flags, taken once when the word enters the neighbourhood
+        const auto flags_of = [mask, sign_bit](uint32_t v, int plane) {
+            const uint32_t sg = ((v & mask) >> plane) != 0u ? 1u : 0u;
+            return sg | ((sg & (v >> sign_bit)) << 8);
+        };
         if (c == 0) {                              // a new row: where its three rows lie, and their first column
-            p.ou = img.row_at(up ? r - 1u : r); p.oc = img.row_at(r); p.od = img.row_at(dn ? r + 1u : r);
-            p.nul = 0; p.ndl = 0;
-            p.nu0 = up ? img.at_row(p.ou, 0) : 0u; p.ncur = img.at_row(p.oc, 0); p.nd0 = dn ? img.at_row(p.od, 0) : 0u;
+            // (row r - 1 and row r are where the last row had its rows r and r + 1)
+            if (r == 0) { p.oc = img.row_at(0); p.ou = p.oc; } else { p.ou = p.oc; p.oc = p.od; }
+            p.od = dn ? img.row_after(p.oc) : p.oc;
+            const uint32_t u0 = up ? img.at_row(p.ou, 0) : 0u, d0 = dn ? img.at_row(p.od, 0) : 0u;
+            p.ncur = img.at_row(p.oc, 0);
+            p.nf = (flags_of(u0, lsb) << 1) | (flags_of(d0, lsb1) << 4);
         }
         // three new words per sample (the column to the right); nothing that is read here can still change in the bits
         // this plane looks at: the planes above are past it, the planes below only add lower bits -- and signs of
@@ -549,28 +559,26 @@ ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
         const uint32_t cr = hr ? c + 1u : c;
         const uint32_t ur0 = img.at_row(p.ou, cr), right0 = img.at_row(p.oc, cr), dr0 = img.at_row(p.od, cr);
         const uint32_t ur = (up && hr) ? ur0 : 0u, right = hr ? right0 : 0u, dr = (dn && hr) ? dr0 : 0u;
-        const uint32_t left = p.left, u0 = p.nu0, d0 = p.nd0, ul = p.nul, dl = p.ndl;
+        // flag bits: 0..2 above-left / above / above-right, 3..5 the same below, 6 left, 7 right; + 8: negative
+        const uint32_t f = p.nf | (flags_of(ur, lsb) << 2) | (flags_of(dr, lsb1) << 5) | (flags_of(right, lsb1) << 7);
         cur = p.ncur;
-        p.nul = u0; p.nu0 = ur; p.ndl = d0; p.nd0 = dr; p.ncur = right;
+        p.nf = (f >> 1) & 0x1B1Bu;                 // the window moves on: above -> above-left, above-right -> above, ...
+        p.ncur = right;
         const uint32_t m = cur & mask;
         const int msb = 31 - __builtin_clz(m | 1u);
         cat = msb < lsb ? 0 : msb - lsb;
         if (cat > 3) cat = 3;
-        // significance at this plane (visited) / the plane above (not yet visited), icer_context_modeller.c:509-521
-        const uint32_t s_l = ((left & mask) >> lsb) != 0, s_r = ((right & mask) >> (lsb + 1)) != 0;
-        const uint32_t s_u = ((u0 & mask) >> lsb) != 0, s_d = ((d0 & mask) >> (lsb + 1)) != 0;
-        int hh = (int)(s_l + s_r), vv = (int)(s_u + s_d);
-        const int dd = (int)((((ul & mask) >> lsb) != 0) + (((ur & mask) >> lsb) != 0) +
-                             (((dl & mask) >> (lsb + 1)) != 0) + (((dr & mask) >> (lsb + 1)) != 0));
+        // significance at this plane (visited) / the plane above (not yet visited), icer_context_modeller.c:509-521;
         // sign context: only negative significant neighbours count (QUIRK C6)
-        int sh = 2 - (int)(s_l & (left >> sign_bit) & 1u) - (int)(s_r & (right >> sign_bit) & 1u);
-        int sv = 2 - (int)(s_u & (u0 >> sign_bit) & 1u) - (int)(s_d & (d0 >> sign_bit) & 1u);
-        const int any_hv = hh + vv;
-        if (subband == kHL) { int x = hh; hh = vv; vv = x; x = sh; sh = sv; sv = x; }
-        const uint32_t c0 = subband == kHH ? dec_ctx_hh_packed((uint32_t)any_hv, (uint32_t)dd) : dec_ctx_plain_packed((uint32_t)hh, (uint32_t)vv, (uint32_t)dd);
-        ctx = cat == 0 ? c0 : cat == 1 ? (any_hv == 0 ? 9u : 10u) : 11u;
+        uint32_t hh = (uint32_t)__builtin_popcount(f & 0x00C0u), vv = (uint32_t)__builtin_popcount(f & 0x0012u);
+        const uint32_t dd = (uint32_t)__builtin_popcount(f & 0x002Du);
+        uint32_t sh = 2u - (uint32_t)__builtin_popcount(f & 0xC000u), sv = 2u - (uint32_t)__builtin_popcount(f & 0x1200u);
+        const bool any_hv = (f & 0x00D2u) != 0u;
+        if (subband == kHL) { uint32_t x = hh; hh = vv; vv = x; x = sh; sh = sv; sv = x; }
+        const uint32_t c0 = subband == kHH ? dec_ctx_hh_packed(hh + vv, dd) : dec_ctx_plain_packed(hh, vv, dd);
+        ctx = cat == 0 ? c0 : cat == 1 ? (any_hv ? 10u : 9u) : 11u;
         constexpr uint64_t ksign = dec_pack_sign();
-        const uint32_t se = (uint32_t)(ksign >> (4u * (uint32_t)(sh * 3 + sv))) & 15u;
+        const uint32_t se = (uint32_t)(ksign >> (4u * (sh * 3u + sv))) & 15u;
         sctx = 12u + (se & 7u);
         pred = se >> 3;
     }
@@ -599,8 +607,11 @@ ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
     }
     img.put_row(p.oc, c, val);
     p.done++;
-    if (c + 1 < w) { p.c = c + 1; p.left = val; }
-    else { p.c = 0; p.left = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
+    if (c + 1 < w) {
+        p.c = c + 1;
+        const uint32_t sg = ((val & mask) >> lsb) != 0u ? 1u : 0u;             // this sample is the next one's left neighbour
+        p.nf |= (sg << 6) | ((sg & (val >> sign_bit)) << 14);
+    } else { p.c = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
 }
 
 // the segment in place, in the channel plane
@@ -609,6 +620,7 @@ struct GlobalImage {
     ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return seg[(size_t)r * stride + c]; }
     ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { seg[(size_t)r * stride + c] = (uint16_t)v; }
     ICER_HD uint32_t row_at(uint32_t r) const { return (uint32_t)(r * stride); }
+    ICER_HD uint32_t row_after(uint32_t row) const { return row + (uint32_t)stride; }
     ICER_HD uint32_t at_row(uint32_t row, uint32_t c) const { return seg[(size_t)row + c]; }
     ICER_HD void put_row(uint32_t row, uint32_t c, uint32_t v) { seg[(size_t)row + c] = (uint16_t)v; }
 };

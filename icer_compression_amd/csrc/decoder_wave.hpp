@@ -9,10 +9,10 @@
 //
 // Lane j < planes decodes plane planes-1-j.  All lanes are in one wavefront, so there are no waits: every iteration a
 // lane either decodes its next sample or sits out (its upper neighbour is not far enough ahead, or the ring has no room).
-// The samples live in a ring of kRingRows rows: the most advanced plane reads row r + 1, the least advanced row r - 1,
+// The samples live in a ring of rows (ring_rows_for): the most advanced plane reads row r + 1, the least advanced row r - 1,
 // and consecutive planes are about one row apart, so the live rows (planes + 2 of them) fit the ring; a row that no
 // running plane can still touch is written back to the channel plane by the whole wave and its slot is zeroed for the row
-// kRingRows further down.
+// `rows` further down.
 #pragma once
 #include "wave.hpp"
 
@@ -27,28 +27,40 @@
 
 namespace icer {
 
-constexpr uint32_t kRingRows = 16;          // >= kPlanes + 3; power of two
+// Rows of a chain's ring.  The live rows are planes + 2 (the lowest plane still reads its row - 1, the highest its row
+// + 1, consecutive planes are a row and two samples apart); the schedule cannot lock up -- every plane waiting for the one
+// above and the top one for a ring slot -- when (rows - planes - 2) * w >= 2 * (planes - 1), and one row more keeps the
+// top plane from waiting on every retired row.  Every row costs LDS, which decides how many chains a compute unit holds.
+ICER_HD uint32_t ring_rows_for(uint32_t w, int planes)
+{
+    const uint32_t p = (uint32_t)planes, ww = w ? w : 1u;
+    return p + 3u + (2u * (p - 1u) + ww - 1u) / ww;
+}
+ICER_HD uint32_t ring_pitch_for(uint32_t w) { return w < 2u ? 2u : (w + 1u) & ~1u; }          // (even, >= w)
+ICER_HD size_t ring_elems_for(uint32_t w, int planes) { return (size_t)ring_rows_for(w, planes) * ring_pitch_for(w); }
 constexpr uint32_t kBurst = 16;             // samples a plane may take per look at its neighbours
 constexpr uint32_t kStateColumns = 16;      // >= kPlanes: lanes that keep their per-bin arrays in the LDS state block
 
 struct RingImage {
-    uint16_t *ring; uint32_t pitch;
-    ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return ring[(r & (kRingRows - 1u)) * pitch + c]; }
-    ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { ring[(r & (kRingRows - 1u)) * pitch + c] = (uint16_t)v; }
-    ICER_HD uint32_t row_at(uint32_t r) const { return (r & (kRingRows - 1u)) * pitch; }
+    uint16_t *ring; uint32_t pitch, rows;
+    ICER_HD uint32_t at(uint32_t r, uint32_t c) const { return ring[(r % rows) * pitch + c]; }
+    ICER_HD void put(uint32_t r, uint32_t c, uint32_t v) { ring[(r % rows) * pitch + c] = (uint16_t)v; }
+    ICER_HD uint32_t row_at(uint32_t r) const { return (r % rows) * pitch; }
+    ICER_HD uint32_t row_after(uint32_t row) const { return row + pitch == rows * pitch ? 0u : row + pitch; }
     ICER_HD uint32_t at_row(uint32_t row, uint32_t c) const { return ring[row + c]; }
     ICER_HD void put_row(uint32_t row, uint32_t c, uint32_t v) { ring[row + c] = (uint16_t)v; }
 };
 
-// `ring`: kRingRows * pitch words of LDS (pitch >= c.w); `plane`: the channel plane (zero where not yet decoded);
+// `ring`: ring_elems_for(c.w, planes) words of LDS; `plane`: the channel plane (zero where not yet decoded);
 // `state_block`: plane_block_bytes(kStateColumns) bytes of LDS for the lanes' per-bin arrays.
 // stats (tests): [0] iterations, [1] samples decoded, [2] roll-backs, [3] chains that ended with rows not retired.
-ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane, size_t stride, const ChainDesc &c,
+ICER_DEV void decode_chain_wave(uint16_t *ring, uint16_t *plane, size_t stride, const ChainDesc &c,
                                 int subband, const uint8_t *stream, uint32_t stream_len, const DecoderTables &t,
                                 int planes, int sign_bit, unsigned long long *stats, uint8_t *state_block)
 {
     DECL_LANE;
     const uint32_t w = c.w, h = c.h;
+    const uint32_t pitch = ring_pitch_for(w), rows = ring_rows_for(w, planes);
     uint16_t *seg = plane + c.first;
     // planes that can run: from the top down to the first missing packet (icer_partition.c:431)
     int nrun = 0;
@@ -58,7 +70,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
     {
         // (lanes that run no plane share a column they never touch)
         plane_attach_columns(LV(pd), state_block, kStateColumns, (uint32_t)lane & (kStateColumns - 1u));
-        for (uint32_t i = (uint32_t)lane; i < kRingRows * pitch; i += 64) ring[i] = 0;
+        for (uint32_t i = (uint32_t)lane; i < rows * pitch; i += 64) ring[i] = 0;
         LV(pd).status = 2; LV(pd).done = 0; LV(pd).r = 0; LV(pd).c = 0; LV(pd).lsb = 0;
         if (lane < nrun) {
             const int lsb = planes - 1 - lane;
@@ -68,7 +80,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
             if (LV(pd).d.total_bits >= kFastPacketBits && t.lut_ok) entropy_fast_begin(LV(pd).d);
         }
     }
-    uint32_t retired = 0;                                    // rows written back so far (wave-uniform)
+    uint32_t retired = 0, retire_at = 0;                     // rows written back so far, and the ring slot of the next one (wave-uniform)
     for (;;) {
         WAVE_SYNC();
         // where every plane stands at the start of the iteration; its upper neighbour's state comes from the lane below
@@ -100,7 +112,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
                     const uint32_t need = LV(dn) + w + 2u;                        // for the first sample of the burst
                     g = LV(adn) >= need ? (LV(adn) - need + 1u < kBurst ? LV(adn) - need + 1u : kBurst) : 0u;
                 } else if (above_status != kOk) g = 0;
-                const uint32_t room_end = (retired + kRingRows - 1u) * w;       // samples of rows whose row below has a slot
+                const uint32_t room_end = (retired + rows - 1u) * w;       // samples of rows whose row below has a slot
                 const uint32_t room = room_end > LV(dn) ? room_end - LV(dn) : 0u;
                 if (room < g) g = room;
             }
@@ -128,7 +140,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
             FOR_LANES
             {
                 if (LV(pd).done < LV(stop_at) && LV(pd).status == 1) {
-                    RingImage img{ring, pitch};
+                    RingImage img{ring, pitch, rows};
                     plane_decision(LV(pd), img, w, h, subband, sign_bit, t);
                 }
             }
@@ -137,12 +149,13 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint32_t pitch, uint16_t *plane,
         }
         // (rows that became dead before this burst; at most as many as the burst can open up again)
         for (uint32_t k = 0; k < kBurst / 4u + 1u && retired < limit; k++) {
-            uint16_t *slot = ring + (retired & (kRingRows - 1u)) * pitch;
+            uint16_t *slot = ring + retire_at;
             FOR_LANES
             {
                 for (uint32_t x = (uint32_t)lane; x < w; x += 64) { seg[(size_t)retired * stride + x] = slot[x]; slot[x] = 0; }
             }
             retired++;
+            retire_at = retire_at + pitch == rows * pitch ? 0u : retire_at + pitch;
         }
         WAVE_SYNC();
         if (stats) { stats[0]++; stats[1] += (unsigned long long)steps; }

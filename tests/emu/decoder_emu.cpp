@@ -98,12 +98,12 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     build_decoder_tables(&dt, ct);
     const int nplanes = sample_bits == 8 ? kPlanes8 : kPlanes, sign_bit = sample_bits == 8 ? 7 : 15;
     // chain kernel: one thread per chain
-    uint32_t pitch = 2;
-    for (const ChainDesc &c : pl.chains) pitch = std::max<uint32_t>(pitch, (c.w + 1u) & ~1u);
-    std::vector<uint16_t> ring((size_t)kRingRows * pitch);
+    size_t ring_elems = 2;
+    for (const ChainDesc &c : pl.chains) ring_elems = std::max(ring_elems, ring_elems_for(c.w, nplanes));
+    std::vector<uint16_t> ring(ring_elems);
     std::vector<uint8_t> state(plane_block_bytes(kStateColumns));
     for (size_t i = 0; i < pl.chains.size(); i++) {
-        if (g_lockstep == 3) decode_chain_wave(ring.data(), pitch, planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats, state.data());
+        if (g_lockstep == 3) decode_chain_wave(ring.data(), planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats, state.data());
         else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
         else {
             PlaneDecoder job;

@@ -171,6 +171,25 @@ def test_planes_side_by_side_schedule(emu, orc, mode):
         emu.lib.emu_decoder_mode(0)
 
 
+def test_wave_kernel_on_very_narrow_segments(emu, orc):
+    """segments one to a few samples wide: the planes of a chain then lie many rows apart (each needs w + 2 samples of
+    lead), which is what sizes the row ring (ring_rows_for); too few rows and the side-by-side schedule would lock up"""
+    emu.lib.emu_decoder_mode(3)
+    try:
+        rng = np.random.default_rng(5150)
+        stats = (C.c_ulonglong * 4)()
+        for w, h, st, sg in ((6, 180, 1, 6), (9, 150, 2, 8), (7, 96, 1, 3), (12, 200, 2, 12), (17, 120, 3, 9), (24, 160, 3, 32),
+                             (6, 6, 1, 1), (200, 6, 1, 2), (40, 130, 4, 20)):
+            img = rng.integers(0, 256, (h, w)).astype(np.uint16)
+            rc, stream, _ = orc.compress([img], st, 0, sg, 4 * w * h + 40000)
+            assert stream
+            assert same(emu(stream, 1, st, 0, sg), orc.decompress(stream, 1, st, 0, sg)), (w, h, st, sg)
+        emu.lib.emu_decoder_stats(stats)
+        assert stats[3] == 0
+    finally:
+        emu.lib.emu_decoder_mode(0)
+
+
 def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
     """decoder.hip itself -- its C ABI, allocations, copies, launch geometries and clean-up -- compiled by g++ against
     tests/emu/hip_mock.h (device memory = poisoned host memory, a launch = a loop over the grid) and called through

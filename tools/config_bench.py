@@ -50,10 +50,14 @@ def run(name, w, h, channels, stages, segments, quota, frames, golden_first=None
 
 
 if __name__ == "__main__":
-    if "--c2" in sys.argv:                      # (measurements of launch variants: the single-frame case only)
-        run("C2 4096^2 gray 5st 10seg lossless", 4096, 4096, 1, 5, 10, 2 * 4096 * 4096, 1, "C2_4096_gray_5st_10seg", steps=10)
-        sys.exit(0)
-    run("C2 4096^2 gray 5st 10seg lossless", 4096, 4096, 1, 5, 10, 2 * 4096 * 4096, 1, "C2_4096_gray_5st_10seg")
-    run("C3 4096^2 YUV 5st 10seg quota 70000", 4096, 4096, 3, 5, 10, 70000, 1, "C3_4096_yuv_quota70000")
-    run("C4 2048^2 gray 4st 16seg, 32 of 256 frames", 2048, 2048, 1, 4, 16, 2 * 2048 * 2048, 32, "C4_2048_frame0")
-    run("C5 8192^2 gray 6st 32seg, 8 of 64 frames", 8192, 8192, 1, 6, 32, 2 * 8192 * 8192, 8, "C5_8192_frame0", steps=2)
+    only = None                                  # --only C2,C4: a subset (measurements of launch variants)
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    if not only or "C2" in only:
+        run("C2 4096^2 gray 5st 10seg lossless", 4096, 4096, 1, 5, 10, 2 * 4096 * 4096, 1, "C2_4096_gray_5st_10seg", steps=10 if only else 3)
+    if not only or "C3" in only:
+        run("C3 4096^2 YUV 5st 10seg quota 70000", 4096, 4096, 3, 5, 10, 70000, 1, "C3_4096_yuv_quota70000")
+    if not only or "C4" in only:
+        run("C4 2048^2 gray 4st 16seg, 32 of 256 frames", 2048, 2048, 1, 4, 16, 2 * 2048 * 2048, 32, "C4_2048_frame0")
+    if not only or "C5" in only:
+        run("C5 8192^2 gray 6st 32seg, 8 of 64 frames", 8192, 8192, 1, 6, 32, 2 * 8192 * 8192, 8, "C5_8192_frame0", steps=2)
