@@ -105,8 +105,6 @@ struct icerx_encoder {
     DevBuf<uint64_t> final_off;
     DevBuf<uint8_t> slots;
     DevBuf<uint8_t> sig;                // chunk tables (chunk_sig_kernel), max_frames * plan.sig_bytes
-    DevBuf<uint8_t> route;              // max_frames * units: the coder of each unit when both share a launch
-    int hybrid_percent = 0;             // > 0: units with at least this share of blank chunks go to the workgroup coder (ICER_HIP_HYBRID)
     DevBuf<CoderTables> tables;
     // host-API staging
     DevBuf<uint16_t> in;
@@ -268,22 +266,19 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
     const bool use_wg = e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive);
-    // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
-    // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
-    const bool hybrid = !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0;
-    if (use_wg || hybrid) {
+    if (use_wg) {
         uint32_t max_chunks = 1;
         for (const UnitDesc &u : e->plan.units) max_chunks = std::max(max_chunks, (u.w * u.h + 63u) / 64u);
         hipLaunchKernelGGL(chunk_sig_kernel, dim3((max_chunks + 63u) / 64u, n_units, n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, skip, e->sig.p, e->plan.sig_bytes);
     }
-    const uint8_t *route = nullptr;
-    if (hybrid) {
-        hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
-                           (uint32_t)e->hybrid_percent, 64u, e->route.p);
-        route = e->route.p;
-    }
-    if (!use_wg) {
+    if (use_wg)
+        hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
+                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
+                           e->sig.p, e->plan.sig_bytes);
+    else {
         // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
         // largest units, which the large shape (two pixel waves, golomb state wave + two workers) shortens; a batch wants
         // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|11 pins one (measurements).
@@ -292,19 +287,13 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
             hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units, n_frames), dim3(64 * kUnitWavesLarge), 0, st,
                                reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                                progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route);
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
         else
             hipLaunchKernelGGL(code_units_kernel<kUnitWavesSmall>, dim3(n_units, n_frames), dim3(64 * kUnitWavesSmall), 0, st,
                                reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                                progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route);
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
     }
-    if (use_wg || hybrid)
-        hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
-                           e->sig.p, e->plan.sig_bytes, route);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
@@ -366,7 +355,6 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
     if (const char *pw = getenv("ICER_HIP_PIPE_WAVES")) { const int v = atoi(pw); if (v == kUnitWavesSmall || v == kUnitWavesLarge) e->pipe_waves = v; }
     if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
-    if (const char *hy = getenv("ICER_HIP_HYBRID")) { const int v = atoi(hy); if (v >= 0 && v <= 100) e->hybrid_percent = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -387,7 +375,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
-        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -413,7 +401,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
-    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->route.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);

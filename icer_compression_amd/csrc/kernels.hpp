@@ -89,9 +89,6 @@ finalize_ll_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32
     *q = (uint16_t)to_coder_word(v, sample_bits);
 }
 
-// a launch shared by the two coders (route_units_kernel): which one takes a unit
-constexpr uint8_t kRoutePipeline = 0, kRouteWindows = 1;
-
 // ------------------------------------------------------------------------------------------ coder
 // One workgroup = one coding unit of one frame: pixel, count, compaction, walker, golomb state + workers, merge, records and
 // drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  WAVES = 8: one pixel wave, one golomb wave
@@ -105,12 +102,10 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                   size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route)
+                  uint32_t *__restrict__ done_bytes, uint64_t early_quota)
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
-    // (two coders share a launch: a unit belongs to the one route_units_kernel names -- 0 here)
-    if (route && route[(size_t)frame * n_units + (work_order ? work_order[blockIdx.x] : blockIdx.x)] != kRoutePipeline) return;
 #ifdef ICER_PHASE_TIMERS
     uint64_t *trace = (timers && frame == 0 && blockIdx.x < (uint32_t)kTraceUnits) ? timers + 9 * 32 + 4 * blockIdx.x : nullptr;
     if (trace && threadIdx.x == 0) {
@@ -275,29 +270,6 @@ chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w
     }
 }
 
-// Which coder takes a unit when both share a launch: the pipeline (code_units_kernel) is the faster one on dense bit planes,
-// the workgroup coder (code_units_wg_kernel) on planes that are mostly runs of blank chunks, which it closes in closed form
-// (wg::blank_run).  One workgroup per unit and frame counts the unit's blank chunks in the chunk table:
-// route = windows when at least `percent` % of the chunks are blank.  grid = (units, frames), block = 256.
-__global__ void __launch_bounds__(256)
-route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const uint8_t *__restrict__ sig, size_t sig_frame_stride,
-                   uint32_t percent, uint32_t min_chunks, uint8_t *__restrict__ route)
-{
-    const UnitDesc u = units[blockIdx.x];
-    const uint32_t frame = blockIdx.y, nfull = (u.w * u.h) / 64u, nchunks = (u.w * u.h + 63u) / 64u;
-    const uint8_t *t = sig + (size_t)frame * sig_frame_stride + u.sig_off;
-    uint32_t blank = 0;
-    for (uint32_t j = threadIdx.x; j < nfull; j += 256u) blank += (uint32_t)u.lsb >= (uint32_t)t[j] ? 1u : 0u;
-    __shared__ uint32_t total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    for (int o = 32; o > 0; o >>= 1) blank += (uint32_t)__shfl_xor((int)blank, o);
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&total, blank);
-    __syncthreads();
-    if (threadIdx.x == 0)
-        route[(size_t)frame * n_units + blockIdx.x] = (nchunks >= min_chunks && total * 100u >= percent * nchunks) ? kRouteWindows : kRoutePipeline;
-}
-
 // ------------------------------------------------------------------------------------------ coder (workgroup windows)
 // One workgroup of wg::kWgWaves wavefronts = one coding unit of one frame; the unit is coded in windows of kWgWaves
 // chunks of 64 pixels, one chunk per wave, the waves meeting at workgroup barriers only (coder_wg.hpp): no wave ever
@@ -310,13 +282,12 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
                      const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                      size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
                      uint32_t *__restrict__ done_bytes, uint64_t early_quota,
-                     const uint8_t *__restrict__ sig, size_t sig_frame_stride, const uint8_t *__restrict__ route)
+                     const uint8_t *__restrict__ sig, size_t sig_frame_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     wg::Shared &s = *reinterpret_cast<wg::Shared *>(wg_lds);
     const uint32_t frame = blockIdx.y;
     const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
-    if (route && route[(size_t)frame * n_units + ui] != kRouteWindows) return;
     const uint32_t wave = threadIdx.x >> 6;
     if (frame_skip[frame]) {                      // DWT / mean overflow: the reference emits nothing
         if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
