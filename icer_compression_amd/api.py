@@ -21,7 +21,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libicer_hip.so")
+# (ICER_HIP_LIB: another build of the same library, e.g. one made with different tuning flags -- measurements only)
+LIB_PATH = os.environ.get("ICER_HIP_LIB") or os.path.join(PKG, "libicer_hip.so")
 
 # enum icer_status (lib_icer/inc/icer.h:92-105)
 ICER_RESULT_OK = 0
