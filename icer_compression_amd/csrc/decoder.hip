@@ -120,7 +120,7 @@ decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t frame_stride, in
     ICER_LDS_TABLES(lt, tables);
     const ChainDesc c = chains[blockIdx.x];
     const FrameInfo f = frames[c.frame];
-    uint16_t *ring = reinterpret_cast<uint16_t *>(lds + ((plane_block_bytes(kStateColumns) + 15u) & ~(size_t)15));
+    uint16_t *ring = reinterpret_cast<uint16_t *>(lds + kStateBytes);
     decode_chain_wave(ring, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
                       data + f.stream_off, f.stream_len, lt, nplanes, sign_bit, nullptr, lds);
 }
@@ -304,7 +304,7 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         // the planes of a segment side by side (one wavefront per chain) if the chain's row ring fits LDS
         size_t ring_elems = 2;
         for (const ChainDesc &c : chains) ring_elems = std::max(ring_elems, ring_elems_for(c.w, nplanes));
-        const size_t ring_bytes = ring_elems * sizeof(uint16_t) + ((plane_block_bytes(kStateColumns) + 15u) & ~(size_t)15);
+        const size_t ring_bytes = ring_elems * sizeof(uint16_t) + kStateBytes;
         const char *mode = getenv("ICER_DEC_WAVE");
         // the wavefront-per-chain kernel unless ICER_DEC_WAVE=0 asks for the thread-per-chain one (tests) or the segment
         // rows do not fit the LDS ring

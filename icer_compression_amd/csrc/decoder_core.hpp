@@ -48,6 +48,7 @@ struct DecoderTables {
     // otherwise, which sends every packet through the general routine.
     uint16_t v2vlut[7][32];
     uint32_t lut_ok;
+    uint32_t gpk[17];                      // bins 8..16: gm | gl << 12 | gi << 16 (one look-up instead of three)
 };
 
 inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
@@ -65,7 +66,9 @@ inline void build_decoder_tables(DecoderTables *d, const CoderTables &t)
     for (int b = 0; b < 17; b++) { d->gm[b] = t.gm[b]; d->gl[b] = t.gl[b]; d->gi[b] = t.gi[b]; }
     for (int k = 0; k < 16; k++) d->cut[k] = t.cut[k];
     for (int k = 0; k <= 256; k++) d->binlut[k] = t.binlut[k];
+    for (int b = 0; b < 17; b++) d->gpk[b] = (uint32_t)d->gm[b] | ((uint32_t)d->gl[b] << 12) | ((uint32_t)d->gi[b] << 16);
     d->lut_ok = 1;
+    for (int b = 8; b < 17; b++) if (d->gm[b] >= 4096u || d->gl[b] >= 16u) d->lut_ok = 0;
     for (int b = 1; b <= 7; b++)
         for (uint32_t x = 0; x < 1024u; x++) {
             uint32_t r = 0xFFFFFFFFu;                               // (no match in ten bits / invalid: not representable)
@@ -107,6 +110,7 @@ struct EntropyDecoder {
     uint8_t *bits;              // bins 0..7: the pending pattern (bit k = k-th from the bottom); bins 8..16: bottom bit
     uint32_t *index;            // `words` when the bin's last code word was read
     uint32_t ss;
+    uint32_t *fst;              // (entropy_decode_fast; plane_attach_chunk) per bin: bits pending (int16) | pattern << 16, entry b at [b]
 };
 
 ICER_HD void entropy_init(EntropyDecoder &d, const uint8_t *stream, uint32_t stream_len, uint32_t base, uint32_t total_bits)
@@ -292,16 +296,19 @@ ICER_HD uint32_t entropy_ahead(const EntropyDecoder &d)         // the bytes at 
     const uint32_t at = d.base + d.win_next, last = d.stream_len - 4u, skip = at < last ? 0u : at - last;
     return skip >= 4u ? 0u : d.ahead >> (8u * skip);
 }
-ICER_HD void entropy_fast_begin(EntropyDecoder &d) { d.ahead = entropy_load4(d, 0); }      // after entropy_init
+ICER_HD void entropy_fast_begin(EntropyDecoder &d)                  // after entropy_init, storage from plane_attach_chunk
+{
+    d.ahead = entropy_load4(d, 0);
+    for (uint32_t b = 0; b < (uint32_t)kNumBins; b++) { d.fst[b] = 0; d.index[b] = 0; }
+}
 ICER_HD int entropy_decode_fast(EntropyDecoder &d, const DecoderTables &t, uint32_t *bit, uint32_t zero, uint32_t total)
 {
     const bool inv = zero < (total >> 1);
     if (inv) zero = total - zero;
     const int bin = pick_bin_plain(t, zero, total);
-    const uint32_t at = (uint32_t)bin * d.ss;
-    int n = d.n[at];
-    uint32_t pat = d.bits[at];
-    const uint32_t last_word = d.index[at];
+    const uint32_t st = d.fst[bin], last_word = d.index[bin];
+    int n = (int)(int16_t)(st & 0xFFFFu);
+    uint32_t pat = st >> 16;
     if ((n <= 0) | (d.words - last_word >= (uint32_t)kRingWords)) {
         if (d.win_bits < 32u) {
             d.win |= (uint64_t)entropy_ahead(d) << d.win_bits;
@@ -312,9 +319,15 @@ ICER_HD int entropy_decode_fast(EntropyDecoder &d, const DecoderTables &t, uint3
         const uint32_t x = (uint32_t)d.win & 0x7FFu;
         uint32_t len;
         if (bin >= 8) {
-            const uint32_t m = t.gm[bin], l = t.gl[bin], gi = t.gi[bin];
-            const uint32_t k0 = reverse_low_bits(x & ((1u << l) - 1u), l);
-            const uint32_t k1 = (reverse_low_bits(x & ((2u << l) - 1u), l + 1u) - gi) & 0xFFFFu;
+            const uint32_t g = t.gpk[bin], m = g & 0xFFFu, l = (g >> 12) & 15u, gi = g >> 16;
+#if defined(__clang__)
+            const uint32_t rx = __builtin_bitreverse32(x);                    // the low l / l + 1 bits, first bit on top
+#else
+            uint32_t rx = 0;
+            for (uint32_t k = 0; k < 32u; k++) rx |= ((x >> k) & 1u) << (31u - k);
+#endif
+            const uint32_t k0 = rx >> (32u - l);                              // (l >= 3)
+            const uint32_t k1 = ((rx >> (31u - l)) - gi) & 0xFFFFu;
             const bool full = (x & 1u) != 0, shortw = k0 < gi;
             const uint32_t k = shortw ? k0 : k1;
             len = full ? 1u : (shortw ? l : l + 1u);
@@ -326,12 +339,11 @@ ICER_HD int entropy_decode_fast(EntropyDecoder &d, const DecoderTables &t, uint3
         } else { len = 1u; n = 1; pat = x & 1u; }
         d.win >>= len; d.win_bits -= len;
         d.words++;
-        d.index[at] = d.words;
-        d.bits[at] = (uint8_t)pat;
+        d.index[bin] = d.words;
     }
     uint32_t b = 0;
     if (n > 0) b = bin >= 8 ? (n == 1 ? pat : 0u) : (pat >> (n - 1)) & 1u;
-    d.n[at] = (int16_t)(n - 1);
+    d.fst[bin] = ((uint32_t)(n - 1) & 0xFFFFu) | (pat << 16);
     *bit = inv ? (b ^ 1u) : b;
     return kOk;
 }
@@ -424,6 +436,7 @@ struct PlaneDecoder {
     // (plane_decision) the neighbourhood slides along the row in registers: significant / negative flags of the words
     // around the next sample, that sample's word, and where the three rows start in the image
     uint32_t nf, ncur, ou, oc, od;
+    uint32_t *fzt;              // (plane_decision; plane_attach_chunk) context k: zero | total << 16 at [k]
 };
 
 // where a plane job keeps its per-bin / per-context arrays: its own memory ...
@@ -449,6 +462,28 @@ ICER_HD void plane_attach_columns(PlaneDecoder &p, uint8_t *block, uint32_t colu
     p.total = reinterpret_cast<uint16_t *>(q) + col;   q += (size_t)columns * kNumContexts * 2u;
     p.d.bits = q + col;
     p.d.ss = columns;
+}
+
+// ... or a chunk of its own (kPlaneChunkBytes, 4-byte aligned; an odd number of words apart, so the same entry of
+// different lanes lies in different LDS banks) that holds either the arrays above or the packed ones of plane_decision /
+// entropy_decode_fast -- a plane uses one form from its first sample to its last.
+constexpr uint32_t kPlaneChunkBytes = 53u * 4u;
+ICER_HD void plane_attach_chunk(PlaneDecoder &p, uint8_t *chunk)
+{
+    p.d.index = reinterpret_cast<uint32_t *>(chunk);                         // 17 x 4 (both forms)
+    p.d.n = reinterpret_cast<int16_t *>(chunk + 68);                         // 17 x 2
+    p.zero = reinterpret_cast<uint16_t *>(chunk + 102);                      // 17 x 2
+    p.total = reinterpret_cast<uint16_t *>(chunk + 136);                     // 17 x 2
+    p.d.bits = chunk + 170;                                                  // 17
+    p.d.ss = 1;
+    p.d.fst = reinterpret_cast<uint32_t *>(chunk + 68);                      // 17 x 4 (packed form)
+    p.fzt = reinterpret_cast<uint32_t *>(chunk + 136);                       // 17 x 4
+}
+// after plane_begin, for a plane that takes plane_decision
+ICER_HD void plane_fast_begin(PlaneDecoder &p)
+{
+    entropy_fast_begin(p.d);
+    for (uint32_t k = 0; k < (uint32_t)kNumContexts; k++) p.fzt[k] = 2u | (4u << 16);
 }
 
 // (attach the storage, then entropy_init, then plane_begin)
@@ -583,9 +618,8 @@ ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
         pred = se >> 3;
     }
     const bool modelled = !(magnitude && cat == 3);
-    const uint32_t zi = ctx * p.d.ss;
     uint16_t zero = 1, total = 2;
-    if (modelled) { zero = p.zero[zi]; total = p.total[zi]; }
+    if (modelled) { const uint32_t zt = p.fzt[ctx]; zero = (uint16_t)(zt & 0xFFFFu); total = (uint16_t)(zt >> 16); }
     uint32_t bit;
     const int res = entropy_decode_fast(p.d, t, &bit, zero, total);
     if (res != kOk) {
@@ -595,7 +629,7 @@ ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
     }
     if (modelled) {
         dec_model_update(zero, total, bit == 0);
-        p.zero[zi] = zero; p.total[zi] = total;
+        p.fzt[ctx] = (uint32_t)zero | ((uint32_t)total << 16);
     }
     uint32_t val;
     if (magnitude) {

@@ -39,7 +39,9 @@ ICER_HD uint32_t ring_rows_for(uint32_t w, int planes)
 ICER_HD uint32_t ring_pitch_for(uint32_t w) { return w < 2u ? 2u : (w + 1u) & ~1u; }          // (even, >= w)
 ICER_HD size_t ring_elems_for(uint32_t w, int planes) { return (size_t)ring_rows_for(w, planes) * ring_pitch_for(w); }
 constexpr uint32_t kBurst = 16;             // samples a plane may take per look at its neighbours
-constexpr uint32_t kStateColumns = 16;      // >= kPlanes: lanes that keep their per-bin arrays in the LDS state block
+constexpr uint32_t kStateColumns = 10;      // kPlanes + 1: a chunk of per-bin / per-context arrays for every plane, one for the idle lanes
+static_assert(kStateColumns > (uint32_t)kPlanes, "a chunk per plane and one spare");
+constexpr size_t kStateBytes = ((size_t)kStateColumns * kPlaneChunkBytes + 15u) & ~(size_t)15;
 
 struct RingImage {
     uint16_t *ring; uint32_t pitch, rows;
@@ -52,7 +54,7 @@ struct RingImage {
 };
 
 // `ring`: ring_elems_for(c.w, planes) words of LDS; `plane`: the channel plane (zero where not yet decoded);
-// `state_block`: plane_block_bytes(kStateColumns) bytes of LDS for the lanes' per-bin arrays.
+// `state_block`: kStateBytes of LDS for the lanes' per-bin / per-context arrays.
 // stats (tests): [0] iterations, [1] samples decoded, [2] roll-backs, [3] chains that ended with rows not retired.
 ICER_DEV void decode_chain_wave(uint16_t *ring, uint16_t *plane, size_t stride, const ChainDesc &c,
                                 int subband, const uint8_t *stream, uint32_t stream_len, const DecoderTables &t,
@@ -69,7 +71,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint16_t *plane, size_t stride, 
     FOR_LANES
     {
         // (lanes that run no plane share a column they never touch)
-        plane_attach_columns(LV(pd), state_block, kStateColumns, (uint32_t)lane & (kStateColumns - 1u));
+        plane_attach_chunk(LV(pd), state_block + (size_t)(lane < nrun ? lane + 1 : 0) * kPlaneChunkBytes);
         for (uint32_t i = (uint32_t)lane; i < rows * pitch; i += 64) ring[i] = 0;
         LV(pd).status = 2; LV(pd).done = 0; LV(pd).r = 0; LV(pd).c = 0; LV(pd).lsb = 0;
         if (lane < nrun) {
@@ -77,7 +79,7 @@ ICER_DEV void decode_chain_wave(uint16_t *ring, uint16_t *plane, size_t stride, 
             const uint32_t at = c.pkt[lsb];
             entropy_init(LV(pd).d, stream, stream_len, at + (uint32_t)kHeaderBytes, packet_bits(stream, at));
             plane_begin(LV(pd), lsb, sign_bit, w, h);
-            if (LV(pd).d.total_bits >= kFastPacketBits && t.lut_ok) entropy_fast_begin(LV(pd).d);
+            if (LV(pd).d.total_bits >= kFastPacketBits && t.lut_ok) plane_fast_begin(LV(pd));
         }
     }
     uint32_t retired = 0, retire_at = 0;                     // rows written back so far, and the ring slot of the next one (wave-uniform)

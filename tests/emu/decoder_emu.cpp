@@ -101,7 +101,7 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     size_t ring_elems = 2;
     for (const ChainDesc &c : pl.chains) ring_elems = std::max(ring_elems, ring_elems_for(c.w, nplanes));
     std::vector<uint16_t> ring(ring_elems);
-    std::vector<uint8_t> state(plane_block_bytes(kStateColumns));
+    std::vector<uint8_t> state(kStateBytes);
     for (size_t i = 0; i < pl.chains.size(); i++) {
         if (g_lockstep == 3) decode_chain_wave(ring.data(), planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats, state.data());
         else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
