@@ -65,6 +65,19 @@ def test_random_streams(dec, orc, kernel):
     assert done > 80
 
 
+@pytest.mark.timeout(300)
+def test_very_narrow_segments(dec, orc, kernel):
+    """segments a few samples wide put the planes of a chain many rows apart: sizes the wave kernel's row ring
+    (ring_rows_for in decoder_wave.hpp); same cases as tests/test_emu_decoder.py::test_wave_kernel_on_very_narrow_segments"""
+    rng = np.random.default_rng(5150)
+    for w, h, st, sg in ((6, 180, 1, 6), (9, 150, 2, 8), (7, 96, 1, 3), (12, 200, 2, 12), (17, 120, 3, 9), (24, 160, 3, 32),
+                         (6, 6, 1, 1), (200, 6, 1, 2), (40, 130, 4, 20)):
+        img = rng.integers(0, 256, (h, w)).astype(np.uint16)
+        rc, stream, _ = orc.compress([img], st, 0, sg, 4 * w * h + 40000)
+        assert stream
+        assert same(dec.decompress(stream, 1, st, 0, sg, bufsize=w * h), orc.decompress(stream, 1, st, 0, sg, bufsize=w * h)), (w, h, st, sg)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("name", ["kat_512_m1", "kat_512_quota30000", "kat_odd_517x389_filtC", "kat_color_512_quota",
                                   "u8_512_gray", "u8_517x389_filtB_quota", "u8_512_yuv_4st", "C2_4096_gray_5st_10seg"])
