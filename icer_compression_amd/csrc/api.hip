@@ -105,6 +105,13 @@ struct icerx_encoder {
     DevBuf<uint64_t> final_off;
     DevBuf<uint8_t> slots;
     DevBuf<uint8_t> sig;                // chunk tables (chunk_sig_kernel), max_frames * plan.sig_bytes
+    DevBuf<uint32_t> sig_blocks;        // Plan::sig_blocks on the device
+    DevBuf<uint8_t> route;              // max_frames * units: the coder of each unit when both share a launch
+    DevBuf<uint32_t> route_list, route_ctl;   // the units of the workgroup coder (frame * units + unit), [length, cursor]
+    hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
+    hipEvent_t fork = nullptr, join = nullptr;
+    int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
+    int hybrid_frames = 2;              // ... in launches of at least this many frames (ICER_HIP_HYBRID_FRAMES): one frame alone is bound by its dense units
     DevBuf<CoderTables> tables;
     // host-API staging
     DevBuf<uint16_t> in;
@@ -175,6 +182,8 @@ int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
     if (e->units.ensure(n) || e->work_order.ensure(n) || e->final_order.ensure(n)) return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpyAsync(e->units.p, e->plan.units.data(), n * sizeof(UnitDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(e->work_order.p, e->plan.work_order.data(), n * 4, hipMemcpyHostToDevice, st));
+    if (e->sig_blocks.ensure(e->plan.sig_blocks.size() + 1)) return ICER_FATAL_ERROR;
+    HIP_TRY(hipMemcpyAsync(e->sig_blocks.p, e->plan.sig_blocks.data(), e->plan.sig_blocks.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(e->final_order.p, e->plan.final_order.data(), n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));       // the host vectors may change on the next re-plan
     e->slot_quota = quota;
@@ -266,19 +275,31 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
     const bool use_wg = e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive);
-    if (use_wg) {
-        uint32_t max_chunks = 1;
-        for (const UnitDesc &u : e->plan.units) max_chunks = std::max(max_chunks, (u.w * u.h + 63u) / 64u);
-        hipLaunchKernelGGL(chunk_sig_kernel, dim3((max_chunks + 63u) / 64u, n_units, n_frames), dim3(256), 0, st,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, skip, e->sig.p, e->plan.sig_bytes);
+    // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
+    // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
+    const bool hybrid = !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames >= e->hybrid_frames;
+    if (use_wg || hybrid) {
+        hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)e->plan.sig_blocks.size(), n_frames), dim3(256), 0, st,
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,
+                           e->plan.sig_bytes);
     }
-    if (use_wg)
-        hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
-                           e->sig.p, e->plan.sig_bytes);
-    else {
+    const uint8_t *route = nullptr;
+    if (hybrid) {
+        HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
+                           (uint32_t)e->hybrid_percent, 16u, e->route.p, e->route_list.p, e->route_ctl.p);
+        route = e->route.p;
+        // the workgroup coder takes its list on a second stream, beside the pipeline kernel (it is submitted first: its
+        // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
+        HIP_TRY(hipEventRecord(e->fork, st));
+        HIP_TRY(hipStreamWaitEvent(e->side_stream, e->fork, 0));
+        hipLaunchKernelGGL(code_units_wgs_list_kernel, dim3((unsigned)e->n_cus), dim3(64 * wgs::kWgWaves), sizeof(wgs::Shared), e->side_stream,
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,
+                           e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,
+                           e->plan.sig_bytes, e->route_list.p, e->route_ctl.p);
+        HIP_TRY(hipEventRecord(e->join, e->side_stream));
+    }
+    if (!use_wg) {
         // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
         // largest units, which the large shape (two pixel waves, golomb state wave + two workers) shortens; a batch wants
         // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|11 pins one (measurements).
@@ -287,13 +308,20 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
             hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units, n_frames), dim3(64 * kUnitWavesLarge), 0, st,
                                reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                                progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route);
         else
             hipLaunchKernelGGL(code_units_kernel<kUnitWavesSmall>, dim3(n_units, n_frames), dim3(64 * kUnitWavesSmall), 0, st,
                                reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                                progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull);
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route);
+        if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join, 0));
     }
+    if (use_wg)
+        hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
+                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
+                           e->sig.p, e->plan.sig_bytes);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
@@ -355,6 +383,8 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     // tuning knob: initial per-unit slot bound in bits per pixel (doubled automatically on overflow)
     if (const char *pw = getenv("ICER_HIP_PIPE_WAVES")) { const int v = atoi(pw); if (v == kUnitWavesSmall || v == kUnitWavesLarge) e->pipe_waves = v; }
     if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
+    if (const char *hy = getenv("ICER_HIP_HYBRID")) { const int v = atoi(hy); if (v >= 0 && v <= 100) e->hybrid_percent = v; }
+    if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -375,7 +405,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
-        e->done_bytes.ensure((size_t)max_frames * n_units) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure((size_t)max_frames * n_units) || e->route_ctl.ensure(2) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -384,6 +414,10 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     CREATE_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
     // the workgroup coder's LDS block is above the 64 KiB a kernel gets without asking
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wgs_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&e->join, hipEventDisableTiming));
 #ifdef ICER_PHASE_TIMERS
     if (e->prof.ensure(kProfWords)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
     CREATE_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
@@ -401,11 +435,14 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
-    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->sig_blocks.release(); e->route.release(); e->route_list.release(); e->route_ctl.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->done) (void)hipEventDestroy(e->done);
+    if (e->fork) (void)hipEventDestroy(e->fork);
+    if (e->join) (void)hipEventDestroy(e->join);
+    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     delete e;
 }

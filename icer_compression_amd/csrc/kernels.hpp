@@ -13,6 +13,7 @@
 #include "assemble_core.hpp"
 #include "coder_core.hpp"
 #include "coder_wg.hpp"
+#include "coder_wg_small.hpp"
 #include "dwt_core.hpp"
 #include "dwt_tile.hpp"
 #include "plan.hpp"
@@ -89,6 +90,9 @@ finalize_ll_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32
     *q = (uint16_t)to_coder_word(v, sample_bits);
 }
 
+// a launch shared by the two coders (route_units_kernel): which one takes a unit
+constexpr uint8_t kRoutePipeline = 0, kRouteWindows = 1;
+
 // ------------------------------------------------------------------------------------------ coder
 // One workgroup = one coding unit of one frame: pixel, count, compaction, walker, golomb state + workers, merge, records and
 // drain waves, a software pipeline over 64-pixel chunks (coder_core.hpp).  WAVES = 8: one pixel wave, one golomb wave
@@ -102,10 +106,12 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                   size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                  uint32_t *__restrict__ done_bytes, uint64_t early_quota)
+                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route)
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
+    // (two coders share a launch: a unit belongs to the one route_units_kernel names -- 0 here)
+    if (route && route[(size_t)frame * n_units + (work_order ? work_order[blockIdx.x] : blockIdx.x)] != kRoutePipeline) return;
 #ifdef ICER_PHASE_TIMERS
     uint64_t *trace = (timers && frame == 0 && blockIdx.x < (uint32_t)kTraceUnits) ? timers + 9 * 32 + 4 * blockIdx.x : nullptr;
     if (trace && threadIdx.x == 0) {
@@ -249,24 +255,53 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
 
 // ------------------------------------------------------------------------------------------ chunk tables
 // One byte per 64-pixel chunk of every (channel, level, subband, segment): the lowest bit plane from which the chunk
-// is blank (wg::chunk_blank_plane), for all bit planes of the family at once.  Launched over the units, of which the
-// plane-0 ones do the work: grid = (ceil(max chunks / 64), units, frames), block = 256 (16 chunks per wavefront).
+// is blank (wg::chunk_blank_plane), for all bit planes of the family at once.  Work list (Plan::sig_blocks): one entry per
+// family and block of 64 chunks; grid = (entries, frames), block = 256 (16 chunks per wavefront).
 __global__ void __launch_bounds__(256)
 chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, int channels,
-                 const UnitDesc *__restrict__ units, const int *__restrict__ frame_skip,
+                 const UnitDesc *__restrict__ units, const uint32_t *__restrict__ blocks, const int *__restrict__ frame_skip,
                  uint8_t *__restrict__ sig, size_t sig_frame_stride)
 {
-    const UnitDesc u = units[blockIdx.y];
-    const uint32_t frame = blockIdx.z, nchunks = (u.w * u.h + 63u) / 64u;
-    if (u.lsb != 0u || blockIdx.x * 64u >= nchunks || frame_skip[frame]) return;
+    const uint32_t entry = blocks[blockIdx.x];
+    const UnitDesc u = units[entry >> 12];
+    const uint32_t frame = blockIdx.y, nchunks = (u.w * u.h + 63u) / 64u, first = (entry & 4095u) * 64u;
+    if (frame_skip[frame]) return;
     const uint16_t *seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
     uint8_t *out = sig + (size_t)frame * sig_frame_stride + u.sig_off;
     const uint32_t wave = threadIdx.x >> 6;
     for (uint32_t i = 0; i < 16u; i++) {
-        const uint32_t j = blockIdx.x * 64u + wave * 16u + i;
+        const uint32_t j = first + wave * 16u + i;
         if (j >= nchunks) break;
         const uint32_t t = wg::chunk_blank_plane(seg, img_w, u.w, u.h, j);
         if ((threadIdx.x & 63u) == 0u) out[j] = (uint8_t)t;
+    }
+}
+
+// Which coder takes a unit when both share a launch: the pipeline (code_units_kernel) is the faster one on dense bit planes,
+// the workgroup coder (code_units_wg_kernel) on planes that are mostly runs of blank chunks, which it closes in closed form
+// (wg::blank_run).  One workgroup per unit and frame counts the unit's blank chunks in the chunk table:
+// route = windows when at least `percent` % of the chunks are blank; those units are also appended to a list
+// (list_ctl[0] = its length).  grid = (units, frames), block = 256.
+__global__ void __launch_bounds__(256)
+route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const uint8_t *__restrict__ sig, size_t sig_frame_stride,
+                   uint32_t percent, uint32_t min_chunks, uint8_t *__restrict__ route, uint32_t *__restrict__ list,
+                   uint32_t *__restrict__ list_ctl)
+{
+    const UnitDesc u = units[blockIdx.x];
+    const uint32_t frame = blockIdx.y, nfull = (u.w * u.h) / 64u, nchunks = (u.w * u.h + 63u) / 64u;
+    const uint8_t *t = sig + (size_t)frame * sig_frame_stride + u.sig_off;
+    uint32_t blank = 0;
+    for (uint32_t j = threadIdx.x; j < nfull; j += 256u) blank += (uint32_t)u.lsb >= (uint32_t)t[j] ? 1u : 0u;
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) blank += (uint32_t)__shfl_xor((int)blank, o);
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&total, blank);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool windows = nchunks >= min_chunks && total * 100u >= percent * nchunks;
+        route[(size_t)frame * n_units + blockIdx.x] = windows ? kRouteWindows : kRoutePipeline;
+        if (windows) list[atomicAdd(&list_ctl[0], 1u)] = frame * n_units + blockIdx.x;      // (code_units_wg_list_kernel)
     }
 }
 
@@ -275,19 +310,36 @@ chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w
 // chunks of 64 pixels, one chunk per wave, the waves meeting at workgroup barriers only (coder_wg.hpp): no wave ever
 // waits on a flag, so there is no hand-off that could stall.  grid = (units, frames), block = 64 * kWgWaves, LDS =
 // sizeof(wg::Shared) (dynamic: above the 64 KiB static limit).
-__global__ void __launch_bounds__(64 * wg::kWgWaves)
-code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
-                     const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
-                     const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
-                     const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
-                     size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                     uint32_t *__restrict__ done_bytes, uint64_t early_quota,
-                     const uint8_t *__restrict__ sig, size_t sig_frame_stride)
+struct WgLaunch {
+    const uint16_t *coef; size_t plane; uint32_t img_w, img_h; int channels;
+    const UnitDesc *units; uint32_t n_units; const uint16_t *means; const int *frame_skip; uint8_t *slots;
+    size_t slot_frame_stride; uint32_t *unit_bits; uint64_t *timers; uint32_t *done_bytes; uint64_t early_quota;
+    const uint8_t *sig; size_t sig_frame_stride;
+};
+// the two instances of the workgroup coder: icer::wg (16 wavefronts) and icer::wgs (2, coder_wg_small.hpp)
+struct WgFull {
+    using Shared = wg::Shared; using UnitArgs = wg::UnitArgs; using Wave = wg::Wave;
+    static constexpr uint32_t kWaves = wg::kWgWaves;
+    static __device__ __forceinline__ void init(Shared &s, const UnitArgs &a) { wg::unit_state_init(s, a); }
+    static __device__ __forceinline__ bool spent(const UnitArgs &a) { return wg::quota_already_spent(a); }
+    static __device__ __forceinline__ uint32_t code(Shared &s, const UnitArgs &a, Wave &r) { return wg::code_unit_wg(s, a, r); }
+};
+struct WgSmall {
+    using Shared = wgs::Shared; using UnitArgs = wgs::UnitArgs; using Wave = wgs::Wave;
+    static constexpr uint32_t kWaves = wgs::kWgWaves;
+    static __device__ __forceinline__ void init(Shared &s, const UnitArgs &a) { wgs::unit_state_init(s, a); }
+    static __device__ __forceinline__ bool spent(const UnitArgs &a) { return wgs::quota_already_spent(a); }
+    static __device__ __forceinline__ uint32_t code(Shared &s, const UnitArgs &a, Wave &r) { return wgs::code_unit_wg(s, a, r); }
+};
+
+// one coding unit of one frame by the calling workgroup; the tables and the CRC table are in `s` already
+template <class I>
+__device__ __forceinline__ void wg_code_one_unit(typename I::Shared &s, const WgLaunch &L, uint32_t frame, uint32_t ui)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
-    wg::Shared &s = *reinterpret_cast<wg::Shared *>(wg_lds);
-    const uint32_t frame = blockIdx.y;
-    const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
+    const uint16_t *coef = L.coef; const size_t plane = L.plane; const uint32_t img_w = L.img_w, img_h = L.img_h; const int channels = L.channels;
+    const UnitDesc *units = L.units; const uint32_t n_units = L.n_units; const uint16_t *means = L.means; const int *frame_skip = L.frame_skip;
+    uint8_t *slots = L.slots; const size_t slot_frame_stride = L.slot_frame_stride; uint32_t *unit_bits = L.unit_bits; uint64_t *timers = L.timers;
+    uint32_t *done_bytes = L.done_bytes; const uint64_t early_quota = L.early_quota; const uint8_t *sig = L.sig; const size_t sig_frame_stride = L.sig_frame_stride;
     const uint32_t wave = threadIdx.x >> 6;
     if (frame_skip[frame]) {                      // DWT / mean overflow: the reference emits nothing
         if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
@@ -295,7 +347,7 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
     }
     const UnitDesc u = units[ui];
     uint32_t *slot_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + u.slot_off);
-    wg::UnitArgs a;
+    typename I::UnitArgs a;
     a.seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
     a.stride = img_w;
     a.w = u.w; a.h = u.h;
@@ -308,24 +360,18 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
     // profiling build: per-phase cycle counters of the level-1 (largest) units, one row per bit plane
     a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
     a.sig = sig ? sig + (size_t)frame * sig_frame_stride + u.sig_off : nullptr;
-    {   // tables -> LDS
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
-        for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * wg::kWgWaves) dst[i] = src[i];
-    }
     if (wave == 0) {
-        wg::unit_state_init(s, a);
+        I::init(s, a);
         // progressive mode: a unit whose finished higher-priority predecessors have already used up the quota can not
         // be in the stream (quota_already_spent)
-        if (early_quota && wg::quota_already_spent(a) && threadIdx.x == 0) s.stop = 1u;
+        if (early_quota && I::spent(a) && threadIdx.x == 0) s.stop = 1u;
     }
-    if (wave == 1) build_crc_table(s);
     __syncthreads();
     uint32_t bits;
     if (s.stop) bits = wg::kUnitStopped;
     else {
-        wg::Wave regs;
-        bits = wg::code_unit_wg(s, a, regs);
+        typename I::Wave regs;
+        bits = I::code(s, a, regs);
     }
     const bool stopped = bits == wg::kUnitStopped;
     if (stopped) bits = 0;                        // the quota cut lies before this unit
@@ -351,6 +397,65 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
                 __hip_atomic_store(&done_bytes[(size_t)frame * n_units + ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
+}
+
+template <class I>
+__device__ __forceinline__ void wg_shared_tables(typename I::Shared &s, const CoderTables *__restrict__ tables)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
+    for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * I::kWaves) dst[i] = src[i];
+    if ((threadIdx.x >> 6) == 1) build_crc_table(s);
+}
+
+__global__ void __launch_bounds__(64 * wg::kWgWaves)
+code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
+                     const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
+                     const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
+                     const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
+                     size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
+                     uint32_t *__restrict__ done_bytes, uint64_t early_quota,
+                     const uint8_t *__restrict__ sig, size_t sig_frame_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
+    wg::Shared &s = *reinterpret_cast<wg::Shared *>(wg_lds);
+    const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
+    wg_shared_tables<WgFull>(s, tables);
+    const WgLaunch L{coef, plane, img_w, img_h, channels, units, n_units, means, frame_skip, slots, slot_frame_stride, unit_bits, timers,
+                     done_bytes, early_quota, sig, sig_frame_stride};
+    wg_code_one_unit<WgFull>(s, L, blockIdx.y, ui);
+}
+
+// The coder's small instance (icer::wgs: two wavefronts, 40 KiB of LDS) over a LIST of (frame, unit) pairs -- the units
+// route_units_kernel found to be all but blank -- by workgroups that stay: each takes the next entry until the list is
+// used up, so the tables and the CRC table are set up once per workgroup and not once per (quickly coded) unit.  The
+// kernel runs beside the pipeline kernel, whose workgroups leave room for it on every compute unit.
+// grid = a few workgroups per compute unit, block = 128, LDS = sizeof(wgs::Shared).
+__global__ void __launch_bounds__(64 * wgs::kWgWaves)
+code_units_wgs_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
+                           const UnitDesc *__restrict__ units, uint32_t n_units,
+                           const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
+                           const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
+                           size_t slot_frame_stride, uint32_t *__restrict__ unit_bits,
+                           const uint8_t *__restrict__ sig, size_t sig_frame_stride,
+                           const uint32_t *__restrict__ list, uint32_t *__restrict__ list_ctl)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
+    wgs::Shared &s = *reinterpret_cast<wgs::Shared *>(wg_lds);
+    __shared__ uint32_t next_entry;
+    wg_shared_tables<WgSmall>(s, tables);
+    const WgLaunch L{coef, plane, img_w, img_h, channels, units, n_units, means, frame_skip, slots, slot_frame_stride, unit_bits, nullptr,
+                     nullptr, 0ull, sig, sig_frame_stride};
+    const uint32_t count = list_ctl[0];                       // entries in the list (route_units_kernel is done)
+    for (;;) {
+        __syncthreads();                                      // (the last unit's reads of `s` and of next_entry are over)
+        if (threadIdx.x == 0) next_entry = atomicAdd(&list_ctl[1], 1u);
+        __syncthreads();
+        const uint32_t at = next_entry;
+        if (at >= count) break;
+        const uint32_t e = list[at];
+        wg_code_one_unit<WgSmall>(s, L, e / n_units, e % n_units);
     }
 }
 

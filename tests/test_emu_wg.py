@@ -14,15 +14,17 @@ from icer_compression_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def wg():
+@pytest.fixture(scope="module", params=[16, 2], ids=["16_waves", "2_waves"])
+def wg(request):
+    """the two instances the product builds: icer::wg (16 wavefronts per workgroup) and icer::wgs (2, coder_wg_small.hpp)"""
     src = os.path.join(ROOT, "tests", "emu", "wg_emu.cpp")
-    so = os.path.join(ROOT, "tests", "emu", "libwg_emu.so")
+    so = os.path.join(ROOT, "tests", "emu", f"libwg_emu_{request.param}.so")
     csrc = os.path.join(ROOT, "icer_compression_amd", "csrc")
     newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
     if not os.path.exists(so) or os.path.getmtime(so) < max(newest, os.path.getmtime(src)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", f"-DICER_WG_WAVES={request.param}", "-o", so, src])
     L = C.CDLL(so)
+    assert L.emu_wg_waves() == request.param
     u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
     L.emu_wg_code_unit.restype = C.c_long
     L.emu_wg_code_unit.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.c_int]
@@ -44,7 +46,7 @@ def wg():
         def stats(reset=True):
             buf = (C.c_ulonglong * 8)()
             L.emu_wg_stats(buf, 1 if reset else 0)
-            return dict(windows=buf[0], detailed=buf[1], exact_chunks=buf[2], forced_flushes=buf[3], blank_runs=buf[4])
+            return dict(windows=buf[0], detailed=buf[1], exact_chunks=buf[2], forced_flushes=buf[3], blank_runs=buf[4], steady_steps=buf[5])
     return Wg
 
 
@@ -123,6 +125,32 @@ def test_blank_runs_in_closed_form(wg, oracle):
                 wg.lib.emu_wg_use_table(1)
     st = wg.stats()
     assert st["blank_runs"] > 300 and st["forced_flushes"] > 0, st
+
+
+def test_blank_planes_in_steady_state(wg, oracle):
+    """all-blank stretches long enough for the counts of context 0 to reach their cycle (blank_run's steady-state step:
+    all remaining whole rescale cycles at once): empty planes of many sizes, planes that are busy first / in between /
+    at the end (the step starts from every state of the Golomb bins and open words), all subbands"""
+    rng = np.random.default_rng(2718)
+    wg.stats()
+    for trial in range(16):
+        w, h = int(rng.integers(100, 640)), int(rng.integers(100, 500))
+        plane = np.zeros((h, w), np.uint16)
+        kind = trial % 4
+        if kind == 1:                                   # busy first rows
+            k = int(rng.integers(1, 12))
+            plane[:k] = _sparse_plane(rng, w, k, 300, float(rng.choice([0.02, 0.3, 0.9])))
+        elif kind == 2:                                 # busy band in the middle
+            r0 = h // 2
+            plane[r0:r0 + 3] = _sparse_plane(rng, w, 3, 90, 0.5)
+        elif kind == 3:                                 # busy last rows and a lone pixel
+            plane[-2:] = _sparse_plane(rng, w, 2, 2000, 0.4)
+            plane[h // 3, w // 2] = 7
+        for sb, lsb in ((0, 0), (1, 3), (3, 8), (2, 6)):
+            want = oracle.code_unit(plane, 0, 0, w, h, sb, lsb)
+            assert wg.code_unit(plane, 0, 0, w, h, sb, lsb, order=trial) == want, (trial, w, h, sb, lsb)
+    st = wg.stats()
+    assert st["steady_steps"] > 100 and st["blank_runs"] > 50, st
 
 
 def test_slot_capacity_rule_and_stop(wg, oracle):

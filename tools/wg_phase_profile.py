@@ -39,6 +39,13 @@ def main():
         print(f"  {name:32s}" + "  ".join(f"{v:4.1f}" for v in row))
     print(f"  {'total per window':32s}" + "  ".join(f"{v:4.1f}" for v in tot))
     print(f"  {'per chunk':32s}" + "  ".join(f"{v / waves:4.2f}" for v in tot))
+    # totals of wave 0's clock per bit plane (all level-1 units of the plane together), for planes that are mostly blank runs
+    print("sum over the level-1 units of a plane, kcyc per wave (bucket / waves):")
+    for k, name in enumerate(NAMES):
+        if name is None:
+            continue
+        print(f"  {name:32s}" + "  ".join(f"{v / waves / 1e3:7.0f}" for v in t[:, k]))
+    print(f"  {'windows (general path)':32s}" + "  ".join(f"{v / waves:7.0f}" for v in t[:, 11]))
 
 
 if __name__ == "__main__":
