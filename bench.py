@@ -325,7 +325,9 @@ def main():
                     "value": round(pix / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_launch": round(t_el / nst * 1e3, 3), "launches": nst,
                     "n_gpus": world, "parity": ok, "frames_checked_per_rank": c["per_gpu"],
                     "parity_note": "every frame of every rank: rc, length and CRC-32 equal the reference CPU encoder's (tests/golden/batch_golden.json)",
-                    "bytes_out_rank0": out_bytes, "code_units_ms": round(st_ms["code_units"] / max(cl, 1), 3)}
+                    "bytes_out_rank0": out_bytes, "code_units_ms": round(st_ms["code_units"] / max(cl, 1), 3),
+                    "coder": "code_units_kernel<8> for the dense coding units; the all-but-blank ones (>= 95 % blank chunks, listed on the "
+                             "device by route_units_kernel) by code_units_wgs_list_kernel on a second stream beside it"}
                 if rank == 0 and world == 1:
                     ab = float(c["per_gpu"] * c["w"] * c["h"] * 2 + out_bytes)
                     kms = st_ms["code_units"] / max(cl, 1)
