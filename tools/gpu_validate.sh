@@ -17,7 +17,7 @@ python - "$DB" > $O/decode_rocprof.md 2>> $O/decprof_run.log <<'PY'
 import sqlite3, sys
 print("| kernel | calls | avg us | % of GPU time |\n|---|---|---|---|")
 for name, calls, avg, pct in sqlite3.connect(sys.argv[1]).cursor().execute("select name,total_calls,average,percentage from top_kernels"):
-    print(f"| {name.split('(')[0][-60:]} | {calls} | {avg:.1f} | {pct:.2f} |")
+    print(f"| {name.replace('(anonymous namespace)::', '').split('(')[0][-60:]} | {calls} | {avg:.1f} | {pct:.2f} |")
 PY
 timeout 150 python tests/stress_gpu_diff.py 120 777001 > $O/stress_diff.log 2>&1
 ICER_HIP_CODER=pipe ICER_STRESS_BIG=0.3 timeout 90 python tests/stress_gpu.py 60 777002 > $O/stress_pipe.log 2>&1
