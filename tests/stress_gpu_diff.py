@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """High-rate differential stress on a GPU (not collected by pytest): the two coding-unit kernels -- the wave pipeline
-(both workgroup shapes, alternating) and the barrier-only workgroup coder -- encode the same random batches (random geometry, filter, segment
+(both workgroup shapes and the batch default with the small workgroup coder beside it, taking turns) and the barrier-only workgroup coder -- encode the same random batches (random geometry, filter, segment
 count, quota class, content made on the device) and must produce the same return codes, lengths and bytes; a sample of
 the frames is also checked against the oracle.  No oracle call sits in the inner loop, so this runs thousands of
 encodes per second: it is the campaign that looks for the hand-off stall of the pipeline.
@@ -17,15 +17,21 @@ sys.path.insert(0, ROOT)
 
 
 def make_encoder(api, coder, *a, **k):
-    """coder: "wg", or "pipe8" / "pipe11" (the wave pipeline with its workgroup shape pinned)"""
-    os.environ["ICER_HIP_CODER"] = "pipe" if coder.startswith("pipe") else coder
-    if coder.startswith("pipe") and coder[4:]:
-        os.environ["ICER_HIP_PIPE_WAVES"] = coder[4:]
+    """coder: "wg", "pipe8" / "pipe11" (the wave pipeline with its workgroup shape pinned), or "auto": the library's own
+    choice for a batch -- the pipeline with the all-but-blank units routed to the small workgroup coder beside it (threshold
+    lowered to 80 % so that more units take that way), the workgroup coder in progressive mode"""
+    if coder == "auto":
+        os.environ["ICER_HIP_HYBRID"] = "80"
+        os.environ["ICER_HIP_HYBRID_FRAMES"] = "1"
+    else:
+        os.environ["ICER_HIP_CODER"] = "pipe" if coder.startswith("pipe") else coder
+        if coder.startswith("pipe") and coder[4:]:
+            os.environ["ICER_HIP_PIPE_WAVES"] = coder[4:]
     try:
         return api.Encoder(*a, **k)
     finally:
-        os.environ.pop("ICER_HIP_CODER", None)
-        os.environ.pop("ICER_HIP_PIPE_WAVES", None)
+        for v in ("ICER_HIP_CODER", "ICER_HIP_PIPE_WAVES", "ICER_HIP_HYBRID", "ICER_HIP_HYBRID_FRAMES"):
+            os.environ.pop(v, None)
 
 
 def main():
@@ -64,8 +70,9 @@ def main():
         frames = x.clamp_(0, 32767).to(torch.int16).contiguous()
         res = []
         try:
-            # the pipeline's two workgroup shapes take turns against the workgroup coder
-            for coder in ("pipe8" if cases % 2 == 0 else "pipe11", "wg"):
+            # the pipeline's two workgroup shapes and the batch default (both coders in one launch) take turns against the
+            # workgroup coder
+            for coder in (("pipe8", "pipe11", "auto")[cases % 3], "wg"):
                 enc = make_encoder(api, coder, w, h, ch, st, filt, sg, max_frames=n)
                 if enc.create_rc != 0:
                     res.append((enc.create_rc,))
