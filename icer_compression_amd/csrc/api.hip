@@ -111,6 +111,7 @@ struct icerx_encoder {
     hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
     hipEvent_t fork = nullptr, join = nullptr;
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
+    int hybrid_wgs = 1;                 // staying workgroups of the small coder per compute unit (ICER_HIP_HYBRID_WGS)
     int hybrid_frames = 2;              // ... in launches of at least this many frames (ICER_HIP_HYBRID_FRAMES): one frame alone is bound by its dense units
     DevBuf<CoderTables> tables;
     // host-API staging
@@ -293,7 +294,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
         HIP_TRY(hipEventRecord(e->fork, st));
         HIP_TRY(hipStreamWaitEvent(e->side_stream, e->fork, 0));
-        hipLaunchKernelGGL(code_units_wgs_list_kernel, dim3((unsigned)e->n_cus), dim3(64 * wgs::kWgWaves), sizeof(wgs::Shared), e->side_stream,
+        hipLaunchKernelGGL(code_units_wgs_list_kernel, dim3((unsigned)(e->n_cus * e->hybrid_wgs)), dim3(64 * wgs::kWgWaves), sizeof(wgs::Shared), e->side_stream,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,
                            e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,
                            e->plan.sig_bytes, e->route_list.p, e->route_ctl.p);
@@ -385,6 +386,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
     if (const char *hy = getenv("ICER_HIP_HYBRID")) { const int v = atoi(hy); if (v >= 0 && v <= 100) e->hybrid_percent = v; }
     if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
+    if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
