@@ -184,7 +184,11 @@ int icerx_info(icerx_encoder *enc, uint32_t *units_per_frame, uint32_t *slot_bit
 /* Event counters of an encoder since its creation: out[0] = coding units that gave up waiting for a hand-off of the
  * eight-wave pipeline (bounded spins; expected 0), out[1] = batches coded again by the barrier-only workgroup coder
  * because of that (the caller still gets its result), out[2] = batches re-run with larger per-unit slots,
- * out[3] = coder selection in force (0 automatic, 1 pipeline only, 2 workgroup coder only; env ICER_HIP_CODER=pipe|wg). */
+ * out[3] = coder selection in force (0 automatic, 1 pipeline only, 2 workgroup coder only; env ICER_HIP_CODER=pipe|wg).
+ * Automatic: the wave pipeline; the workgroup coder for byte quotas below half a byte per sample (progressive mode);
+ * in launches of two or more frames the coding units with >= 95 % blank chunks go to the workgroup coder's two-wave
+ * instance, which runs beside the pipeline kernel (env ICER_HIP_HYBRID=<percent, 0 = off>, ICER_HIP_HYBRID_FRAMES=<n>).
+ * None of this changes a byte of the streams. */
 int icerx_encoder_stats(icerx_encoder *enc, uint64_t out[4]);
 /* out[0..2] summed over all encoders of the process, including the one behind the lib_icer-shaped entry points */
 int icerx_process_stats(uint64_t out[4]);

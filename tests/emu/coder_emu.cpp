@@ -216,6 +216,23 @@ extern "C" int emu_plan_units(size_t w, size_t h, int channels, int stages, int 
     return n;
 }
 
+// the work list of chunk_sig_kernel: per entry unit index, block, the unit's chunk-table offset and chunk count, its plane
+extern "C" int emu_plan_sig_blocks(size_t w, size_t h, int channels, int stages, int segments, uint32_t *out /* n*5 */, int cap, size_t *sig_bytes)
+{
+    Plan plan;
+    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    if (rc) return rc;
+    *sig_bytes = plan.sig_bytes;
+    int n = (int)plan.sig_blocks.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const uint32_t e = plan.sig_blocks[i];
+        const UnitDesc &u = plan.units[e >> 12];
+        uint32_t *o = out + (size_t)i * 5;
+        o[0] = e >> 12; o[1] = e & 4095u; o[2] = u.sig_off; o[3] = (u.w * u.h + 63u) / 64u; o[4] = u.lsb;
+    }
+    return n;
+}
+
 // raw copy of the product's coder tables (csrc/icer_tables.hpp) for tests/test_tables.py
 extern "C" size_t emu_get_tables(void *dst, size_t cap)
 {

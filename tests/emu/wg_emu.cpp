@@ -17,6 +17,9 @@ static int g_no_table = 0;
 extern "C" void emu_wg_use_table(int on) { g_no_table = !on; }
 
 extern "C" int emu_wg_waves(void) { return (int)wg::kWgWaves; }
+// the exact small divisions of blank_run (float reciprocal + correction)
+extern "C" unsigned emu_wg_floor_div(unsigned num, unsigned den) { return wg::floor_div_small(num, den); }
+extern "C" unsigned emu_wg_ceil_div(unsigned num, unsigned den) { return wg::ceil_div_small(num, den); }
 // 0: the waves run every region in order, 1: backwards, >= 2: shuffled (seed)
 extern "C" void emu_wg_set_order(unsigned order) { wg::g_wg_order = order; wg::g_wg_order_state = order; }
 extern "C" void emu_wg_stats(unsigned long long *out, int reset) { for (int i = 0; i < 8; i++) { out[i] = wg::g_wg_stats[i]; if (reset) wg::g_wg_stats[i] = 0; } }

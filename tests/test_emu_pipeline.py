@@ -107,6 +107,32 @@ def test_planner_units_match_oracle_geometry(emu, oracle):
             assert int((block[:, 2].astype(np.int64) * block[:, 3]).sum()) == _subband_area(w, h, lv, sb)
 
 
+def test_chunk_table_work_list_covers_every_family_once(emu):
+    """Plan::sig_blocks (the grid of chunk_sig_kernel): every block of 64 chunks of every family (channel, level, subband,
+    segment) exactly once, through that family's plane-0 unit; the families' table areas tile the per-frame area"""
+    import ctypes as C
+    emu.lib.emu_plan_sig_blocks.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    for (w, h, ch, st, sg) in [(4096, 4096, 1, 5, 10), (2048, 2048, 1, 4, 16), (517, 389, 3, 4, 7), (100, 75, 1, 3, 32), (8192, 8192, 1, 6, 32)]:
+        buf = np.zeros((400000, 5), np.uint32)
+        sig_bytes = C.c_size_t(0)
+        n = emu.lib.emu_plan_sig_blocks(w, h, ch, st, sg, buf.ctypes.data, len(buf), C.byref(sig_bytes))
+        assert 0 < n <= len(buf)
+        e = buf[:n]
+        assert (e[:, 4] == 0).all()                                    # plane-0 units only
+        fams = {}
+        for unit, blk, off, nchunks, _ in e.tolist():
+            fams.setdefault((unit, off, nchunks), []).append(blk)
+        assert len(fams) == (3 * st + 1) * sg * ch
+        areas = []
+        for (unit, off, nchunks), blks in fams.items():
+            assert sorted(blks) == list(range((nchunks + 63) // 64))   # every block once
+            areas.append((off, nchunks))
+        areas.sort()
+        for (o0, n0), (o1, _) in zip(areas, areas[1:]):
+            assert o0 + n0 <= o1                                       # table areas do not overlap
+        assert areas[-1][0] + areas[-1][1] <= sig_bytes.value
+
+
 def _subband_area(w, h, lv, sb):
     low = lambda d, l: -(-d // (1 << l))
     high = lambda d, l: low(d, l - 1) // 2

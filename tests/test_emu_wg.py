@@ -55,6 +55,21 @@ def _sparse_plane(rng, w, h, amp, dens):
     return (mag | ((rng.integers(0, 2, (h, w)).astype(np.uint16) << 15) * (mag > 0))).astype(np.uint16)
 
 
+def test_small_divisions_are_exact(wg):
+    """floor_div_small / ceil_div_small (a float reciprocal estimate, corrected): the operand ranges blank_run uses"""
+    L = wg.lib
+    L.emu_wg_floor_div.restype = L.emu_wg_ceil_div.restype = C.c_uint
+    L.emu_wg_floor_div.argtypes = L.emu_wg_ceil_div.argtypes = [C.c_uint, C.c_uint]
+    rng = np.random.default_rng(99)
+    dens = [1, 2, 5, 6, 7, 11, 17, 31, 44, 70, 144, 200, 206, 250, 512, 979, 4096, 65535]
+    nums = [0, 1, 2, 199, 200, 201, 249, 250, 251, 511, 512, 513, 65535, 65536, 131071, (1 << 24) - 1] + [int(x) for x in rng.integers(0, 1 << 24, 300)]
+    for d in dens + [int(x) for x in rng.integers(1, 1 << 16, 60)]:
+        for n in nums:
+            assert L.emu_wg_floor_div(n, d) == n // d, (n, d)
+            if n and d >= 144:                                          # (ceil_div_small: 0 < num < 2^25, den >= 144)
+                assert L.emu_wg_ceil_div(n, d) == -(-n // d), (n, d)
+
+
 def test_units_small_and_degenerate(wg, oracle):
     img = synth.gray_frame(256, 192, 3, 0)
     coef = oracle.compress([img], 3, 0, 1, 1 << 22)[2][0]
