@@ -87,6 +87,7 @@ def load_library() -> C.CDLL:
     L.icerx_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.icerx_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.icerx_encoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.icerx_encoder_routing.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.icerx_process_stats.argtypes = [C.POINTER(C.c_uint64)]
     L.icerx_pin_host.argtypes = [C.c_void_p, C.c_size_t]
     L.icerx_unpin_host.argtypes = [C.c_void_p]
@@ -288,6 +289,12 @@ class Encoder:
         out = (C.c_uint64 * 4)()
         self.lib.icerx_encoder_stats(self.handle, out)
         return {"unit_timeouts": out[0], "fallback_batches": out[1], "slot_retries": out[2], "coder_mode": out[3]}
+
+    def routing(self):
+        """coding units that went to the small workgroup coder beside the pipeline kernel, and the calls that routed"""
+        out = (C.c_uint64 * 2)()
+        self.lib.icerx_encoder_routing(self.handle, out)
+        return {"routed_units": out[0], "routed_calls": out[1]}
 
     def info(self):
         u, b, s = C.c_uint32(), C.c_uint32(), C.c_uint64()

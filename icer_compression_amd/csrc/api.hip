@@ -95,6 +95,8 @@ struct icerx_encoder {
     int pipe_waves = 0;                 // 0: shape of the pipeline's workgroups chosen per launch; 8 / 11: pinned (ICER_HIP_PIPE_WAVES)
     int n_cus = 256;                    // compute units of the device
     uint64_t n_timeouts = 0, n_fallbacks = 0, n_slot_retries = 0;   // icerx_encoder_stats
+    uint64_t n_routed_units = 0, n_routed_launches = 0;             // icerx_encoder_routing
+    bool last_routed = false;           // the last enqueue used both coders
 
     DevBuf<int16_t> coef, tmp;
     DevBuf<unsigned long long> sums;
@@ -122,7 +124,7 @@ struct icerx_encoder {
     DevBuf<int32_t> rcs;
     DevBuf<uint64_t> prof;              // profiling build only (-DICER_PHASE_TIMERS): per-phase cycle sums
 
-    int *h_flag = nullptr;              // pinned host word: slot-bound overflow flag of the last batch
+    int *h_flag = nullptr;              // pinned host words: slot-bound overflow flag of the last batch, units on its route list
     hipEvent_t done = nullptr;          // end of the last batch on its stream
 
     bool timing = false;
@@ -285,6 +287,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                            e->plan.sig_bytes);
     }
     const uint8_t *route = nullptr;
+    e->last_routed = hybrid;
     if (hybrid) {
         HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
@@ -425,7 +428,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     CREATE_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
 #endif
     for (auto &ev : e->ev) CREATE_TRY(hipEventCreate(&ev));
-    CREATE_TRY(hipHostMalloc((void **)&e->h_flag, sizeof(int), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void **)&e->h_flag, 2 * sizeof(int), hipHostMallocDefault));
     CREATE_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
 #undef CREATE_TRY
     *out = e;
@@ -504,6 +507,7 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
         // instead of blocking in hipStreamSynchronize: an encode call is tens of milliseconds and the wake-up
         // latency of a blocking wait (measured: up to 3 ms per call on a busy host) would be charged to every frame.
         HIP_TRY(hipMemcpyAsync(e->h_flag, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (e->last_routed) HIP_TRY(hipMemcpyAsync(e->h_flag + 1, e->route_ctl.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(e->done, st));
         for (;;) {
             const hipError_t q = hipEventQuery(e->done);
@@ -512,7 +516,10 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
             cpu_relax();
         }
         const int ovf = *e->h_flag;
-        if (!ovf) break;
+        if (!ovf) {
+            if (e->last_routed) { e->n_routed_units += (uint64_t)(uint32_t)e->h_flag[1]; e->n_routed_launches++; }
+            break;
+        }
         if (ovf & 2) {
             // A wave of some coding unit of the eight-wave pipeline waited longer than its spin bound (seconds) and gave
             // the unit up (seen once in ~60 000 randomised encodes in round 1, never reproduced).  The batch is coded again
@@ -739,6 +746,13 @@ int icerx_encoder_stats(icerx_encoder *e, uint64_t out[4])
 {
     if (!e || !out) return ICER_INVALID_INPUT;
     out[0] = e->n_timeouts; out[1] = e->n_fallbacks; out[2] = e->n_slot_retries; out[3] = (uint64_t)e->coder_mode;
+    return 0;
+}
+
+int icerx_encoder_routing(icerx_encoder *e, uint64_t out[2])
+{
+    if (!e || !out) return ICER_INVALID_INPUT;
+    out[0] = e->n_routed_units; out[1] = e->n_routed_launches;
     return 0;
 }
 

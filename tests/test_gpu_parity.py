@@ -85,6 +85,26 @@ def test_batch_extension_equals_per_frame_calls(oracle):
     enc.close()
 
 
+def test_batch_routes_blank_units_to_the_small_coder(oracle):
+    """in a launch of several frames the all-but-blank coding units (the upper bit planes) are coded by the workgroup coder's
+    two-wave instance beside the pipeline kernel: the streams are the reference's, and the counters show
+    that the routing really took place -- and that a single frame goes through the pipeline alone"""
+    w, h, st, sg, n = 512, 384, 3, 8, 4
+    frames = synth.gray_batch(n, w, h, 7, 1)
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=n)
+    got = enc.encode_host(frames, 2 * w * h)
+    for k in range(n):
+        rc, stream, _ = oracle.compress([frames[k]], st, 0, sg, 2 * w * h)
+        assert got[k] == (rc, stream)
+    r = enc.routing()
+    units = enc.info()["units_per_frame"]
+    assert r["routed_calls"] == 1 and n * units // 10 < r["routed_units"] < n * units, (r, units)
+    assert enc.encode_host(frames[:1], 2 * w * h)[0] == got[0]
+    assert enc.routing() == r                                      # one frame: no routing
+    assert enc.stats()["unit_timeouts"] == 0
+    enc.close()
+
+
 def test_batch_color(oracle):
     w, h = 128, 128
     fr = np.stack([np.stack(synth.color_frame_yuv(w, h, 50 + k)) for k in range(3)])
