@@ -341,8 +341,9 @@ ICER_HD int entropy_decode_fast(EntropyDecoder &d, const DecoderTables &t, uint3
         d.words++;
         d.index[bin] = d.words;
     }
-    uint32_t b = 0;
-    if (n > 0) b = bin >= 8 ? (n == 1 ? pat : 0u) : (pat >> (n - 1)) & 1u;
+    // (selects, no branch: the shift count is masked so that it is defined for n <= 0 too, where a zero is served)
+    const uint32_t top = (pat >> ((uint32_t)(n - 1) & 31u)) & 1u;
+    const uint32_t b = n > 0 ? (bin >= 8 ? (n == 1 ? pat : 0u) : top) : 0u;
     d.fst[bin] = ((uint32_t)(n - 1) & 0xFFFFu) | (pat << 16);
     *bit = inv ? (b ^ 1u) : b;
     return kOk;
@@ -617,35 +618,26 @@ ICER_HD void plane_decision(PlaneDecoder &p, Img &img, uint32_t w, uint32_t h, i
         sctx = 12u + (se & 7u);
         pred = se >> 3;
     }
+    // (no branches around the model: an unmodelled decision -- category 3 -- reads and writes back context 11's counts)
     const bool modelled = !(magnitude && cat == 3);
-    uint16_t zero = 1, total = 2;
-    if (modelled) { const uint32_t zt = p.fzt[ctx]; zero = (uint16_t)(zt & 0xFFFFu); total = (uint16_t)(zt >> 16); }
+    const uint32_t zt = p.fzt[ctx];
+    uint16_t zero = modelled ? (uint16_t)(zt & 0xFFFFu) : (uint16_t)1, total = modelled ? (uint16_t)(zt >> 16) : (uint16_t)2;
     uint32_t bit;
-    const int res = entropy_decode_fast(p.d, t, &bit, zero, total);
-    if (res != kOk) {
-        if (!magnitude) img.put_row(p.oc, c, cur);       // (the magnitude bit of the sample stays, as in plane_step_img)
-        p.status = res;
-        return;
-    }
-    if (modelled) {
-        dec_model_update(zero, total, bit == 0);
-        p.fzt[ctx] = (uint32_t)zero | ((uint32_t)total << 16);
-    }
-    uint32_t val;
-    if (magnitude) {
-        val = cur | (bit << lsb);
-        if (cat == 0 && bit) { p.pend = 1; p.pval = val; p.psctx = sctx; p.ppred = pred; return; }
-    } else {
-        val = cur | (((bit ^ pred) & 1u) << sign_bit);
-        p.pend = 0;
-    }
+    (void)entropy_decode_fast(p.d, t, &bit, zero, total);          // (always kOk: packets of >= kFastPacketBits bits)
+    dec_model_update(zero, total, bit == 0);
+    p.fzt[ctx] = modelled ? ((uint32_t)zero | ((uint32_t)total << 16)) : zt;
+    const bool to_sign = magnitude && cat == 0 && bit != 0u;        // the sample became significant: its sign is the next decision
+    const uint32_t val = magnitude ? (cur | (bit << lsb)) : (cur | (((bit ^ pred) & 1u) << sign_bit));
+    p.pend = to_sign ? 1u : 0u; p.pval = val; p.psctx = sctx; p.ppred = pred;
+    if (to_sign) return;
     img.put_row(p.oc, c, val);
     p.done++;
-    if (c + 1 < w) {
-        p.c = c + 1;
-        const uint32_t sg = ((val & mask) >> lsb) != 0u ? 1u : 0u;             // this sample is the next one's left neighbour
-        p.nf |= (sg << 6) | ((sg & (val >> sign_bit)) << 14);
-    } else { p.c = 0; p.r = r + 1; if (r + 1 >= h) p.status = kOk; }
+    const bool more = c + 1 < w, last = !more && r + 1 >= h;
+    const uint32_t sg = ((val & mask) >> lsb) != 0u ? 1u : 0u;                 // this sample is the next one's left neighbour
+    p.nf |= (sg << 6) | ((sg & (val >> sign_bit)) << 14);                      // (a new row starts its flags afresh)
+    p.c = more ? c + 1u : 0u;
+    p.r = more ? r : r + 1u;
+    p.status = last ? kOk : p.status;
 }
 
 // the segment in place, in the channel plane
