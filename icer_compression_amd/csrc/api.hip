@@ -114,7 +114,7 @@ struct icerx_encoder {
     hipEvent_t fork = nullptr, join = nullptr;
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
     int hybrid_wgs = 1;                 // staying workgroups of the small coder per compute unit (ICER_HIP_HYBRID_WGS)
-    int hybrid_frames = 2;              // ... in launches of at least this many frames (ICER_HIP_HYBRID_FRAMES): one frame alone is bound by its dense units
+    int hybrid_frames = 2;              // ... in launches of at least this many planes (frames x channels; ICER_HIP_HYBRID_FRAMES): one gray frame alone is bound by its dense units
     DevBuf<CoderTables> tables;
     // host-API staging
     DevBuf<uint16_t> in;
@@ -280,7 +280,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     const bool use_wg = e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive);
     // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
     // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
-    const bool hybrid = !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames >= e->hybrid_frames;
+    const bool hybrid = !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames;
     if (use_wg || hybrid) {
         hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)e->plan.sig_blocks.size(), n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,

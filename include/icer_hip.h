@@ -186,12 +186,12 @@ int icerx_info(icerx_encoder *enc, uint32_t *units_per_frame, uint32_t *slot_bit
  * because of that (the caller still gets its result), out[2] = batches re-run with larger per-unit slots,
  * out[3] = coder selection in force (0 automatic, 1 pipeline only, 2 workgroup coder only; env ICER_HIP_CODER=pipe|wg).
  * Automatic: the wave pipeline; the workgroup coder for byte quotas below half a byte per sample (progressive mode);
- * in launches of two or more frames the coding units with >= 95 % blank chunks go to the workgroup coder's two-wave
+ * in launches of two or more planes (frames x channels) the coding units with >= 95 % blank chunks go to the workgroup coder's two-wave
  * instance, which runs beside the pipeline kernel (env ICER_HIP_HYBRID=<percent, 0 = off>, ICER_HIP_HYBRID_FRAMES=<n>).
  * None of this changes a byte of the streams. */
 int icerx_encoder_stats(icerx_encoder *enc, uint64_t out[4]);
 /* out[0] = coding units (summed over frames and calls) that went to the workgroup coder's two-wave instance beside the
- * pipeline kernel, out[1] = encode calls in which that routing was active (see above: launches of >= 2 frames). */
+ * pipeline kernel, out[1] = encode calls in which that routing was active (see above: launches of >= 2 planes). */
 int icerx_encoder_routing(icerx_encoder *enc, uint64_t out[2]);
 /* out[0..2] summed over all encoders of the process, including the one behind the lib_icer-shaped entry points */
 int icerx_process_stats(uint64_t out[4]);
