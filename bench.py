@@ -9,12 +9,22 @@ hot path (DWT -> LL mean -> sign-magnitude -> all coding units -> quota scan -> 
 batch (default: ONE frame, as the config says) whose input already sits in HBM; the final stream stays
 in HBM.  With --gpus N every rank encodes its own copy of the workload per step (frames are independent; no
 collective on the data path) -> weak scaling; value = all ranks' pixels / max-over-ranks time.  EVERY rank checks
-its streams against the reference goldens before anything is timed.
+its streams against the reference goldens before anything is timed AND again after the timed loop.
 
-The same line also carries, as secondary objects, the two batch configurations BASELINE.json names for 8 GPUs, run
-as this GPU's share of them: "C4" = 256 x 2048x2048 (32 frames per GPU, frames 32*rank ..), "C5" = 64 x 8192x8192
-(8 frames per GPU); every frame of every rank is checked against tests/golden/batch_golden.json (reference CPU
-encoder).  --config C4|C5 makes one of them the timed workload instead.
+Secondary objects of the same line (none of them is `value`):
+  batched        C2 geometry, 8 frames per launch
+  batch_configs  this GPU's share of the two batch configurations BASELINE.json names for 8 GPUs: "C4" = 256 x 2048x2048
+                 (32 frames per GPU, frames 32*rank ..), "C5" = 64 x 8192x8192 (8 per GPU); every frame of every rank is
+                 checked against tests/golden/batch_golden.json (reference CPU encoder)
+  batch_host     the same shares fed from (page-locked) HOST memory through icerx_compress_batch_uint16_devices: upload,
+                 kernels and download of the streams overlapped in sub-batches -- the one resource N GPUs of a node share
+  C3             BASELINE configs[2]: 4096x4096 YUV, byte quota 70 000 (progressive early stop)
+  decode         the C2 stream back through libicer_hip_dec.so, with the reference decoder on one core
+  host_buffers, cpu_baseline, cpu_all_cores, roofline.traffic / roofline.issue (child rocprofv3 passes)
+
+--config C4|C5 makes one of the batch configurations the timed workload; with --sweep it is run as every rank of an
+8-GPU job in turn on this one GPU (all 256 / 64 frames, each against its reference golden); with --scaling strong the
+whole batch is split over the ranks (N = 1: all of it on one GPU); --source host times the host-fed path instead.
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -43,7 +53,17 @@ CONFIGS = {
     "C5": dict(w=8192, h=8192, stages=6, segments=32, per_gpu=8, total=64, what="BASELINE configs[4]"),
 }
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-CUS, SIMDS_PER_CU = 256, 4      # MI355X; one wave64 VALU instruction occupies a SIMD for 4 cycles
+CUS, SIMDS_PER_CU = 256, 4
+CLOCK_HZ = 2.4e9
+# Issue cost of a wave64 instruction on one SIMD, MEASURED on this chip by tools/valu_rate_ubench.py
+# (profiles/r03_valu_rate_ubench.md): cycles a SIMD is occupied per wave-instruction of the class when enough waves are
+# resident to saturate it.  The coder's VALU mix is 32-bit integer ALU (v_and / v_lshl / v_cndmask / v_bfe / v_mbcnt / v_add).
+ISSUE_CYCLES = {"valu_int32": None, "source": "profiles/r03_valu_rate_ubench.md"}
+try:
+    with open(os.path.join(ROOT, "profiles", "r03_valu_rate_ubench.json")) as _fh:
+        ISSUE_CYCLES.update(json.load(_fh).get("bench_constants", {}))
+except Exception:                                                          # noqa: BLE001 -- not measured yet
+    pass
 
 
 def cpu_baseline(frame: np.ndarray, expect_crc: str, cfg):
@@ -108,8 +128,9 @@ def source_digest():
     return hsh.hexdigest()[:16]
 
 
-def frame_goldens(name, rank):
-    """(size, crc32) of the reference streams of this rank's frames of configuration `name`"""
+def frame_goldens(name, rank, first=None, count=None):
+    """(size, crc32) of the reference streams of this rank's frames of configuration `name` (weak scaling: frames
+    per_gpu * rank ..; `first` / `count` name another block of the batch)"""
     gdir = os.path.join(ROOT, "tests", "golden")
     if name == "C2":
         with open(os.path.join(gdir, "golden.json")) as fh:
@@ -118,34 +139,40 @@ def frame_goldens(name, rank):
     with open(os.path.join(gdir, "batch_golden.json")) as fh:
         fr = json.load(fh)[name]["frames"]
     c = CONFIGS[name]
-    lo = (rank * c["per_gpu"]) % c["total"]
-    return [tuple(fr[(lo + k) % c["total"]]) for k in range(c["per_gpu"])]
+    lo = (rank * c["per_gpu"]) % c["total"] if first is None else first
+    n = c["per_gpu"] if count is None else count
+    return [tuple(fr[(lo + k) % c["total"]]) for k in range(n)]
 
 
 class Workload:
-    """this rank's frames of one configuration, resident in HBM, with an encoder and output buffers"""
+    """a block of frames of one configuration, resident in HBM, with an encoder and output buffers; coded in launches of
+    at most `per_gpu` frames"""
 
-    def __init__(self, name, rank, dev, local_rank):
+    def __init__(self, name, rank, dev, local_rank, first=None, count=None):
         import torch
         from icer_compression_amd import api, synth
         self.name, self.cfg = name, CONFIGS[name]
         c = self.cfg
-        self.B, self.w, self.h = c["per_gpu"], c["w"], c["h"]
+        self.w, self.h = c["w"], c["h"]
         self.quota = 2 * self.w * self.h
         # frame k of the whole batch uses seed 12345 + k (SURVEY 8d); C2 is the one golden frame on every rank
-        first = 0 if name == "C2" else (rank * self.B) % c["total"]
-        self.frames = synth.gray_frames_torch(self.B, self.w, self.h, synth.DEFAULT_SEED + first, dev, 1)
+        self.first = (0 if name == "C2" else (rank * c["per_gpu"]) % c["total"]) if first is None else first
+        self.B = c["per_gpu"] if count is None else count
+        self.launch = min(self.B, c["per_gpu"])
+        self.frames = synth.gray_frames_torch(self.B, self.w, self.h, synth.DEFAULT_SEED + self.first, dev, 1)
         self.out = torch.empty((self.B, self.quota), dtype=torch.uint8, device=dev)
         self.sizes = torch.zeros(self.B, dtype=torch.int64, device=dev)
         self.rcs = torch.zeros(self.B, dtype=torch.int32, device=dev)
-        self.enc = api.Encoder(self.w, self.h, 1, c["stages"], FILT, c["segments"], max_frames=self.B, device=local_rank)
-        self.gold = frame_goldens(name, rank)
+        self.enc = api.Encoder(self.w, self.h, 1, c["stages"], FILT, c["segments"], max_frames=self.launch, device=local_rank)
+        self.gold = frame_goldens(name, rank, self.first, self.B)
 
     def step(self):
-        self.enc.encode_torch(self.frames, self.quota, self.out, self.sizes, self.rcs)
+        for lo in range(0, self.B, self.launch):
+            hi = min(lo + self.launch, self.B)
+            self.enc.encode_torch(self.frames[lo:hi], self.quota, self.out[lo:hi], self.sizes[lo:hi], self.rcs[lo:hi])
 
     def verify(self):
-        """every frame of this rank: return code, stream length and CRC-32 equal the reference's"""
+        """every frame of this block: return code, stream length and CRC-32 equal the reference's"""
         import torch
         torch.cuda.synchronize()
         sizes, rcs = self.sizes.cpu().numpy(), self.rcs.cpu().numpy()
@@ -156,7 +183,7 @@ class Workload:
             if ok:
                 ok = ("%08x" % zlib.crc32(self.out[k, :size].cpu().numpy().tobytes())) == crc
             if not ok:
-                bad.append(k)
+                bad.append(self.first + k)
         return bad, int(sizes.sum())
 
     def close(self):
@@ -164,34 +191,97 @@ class Workload:
         del self.frames, self.out
 
 
+class HostWorkload:
+    """the same block of frames in page-locked HOST memory, coded by icerx_compress_batch_uint16_devices on this rank's
+    device: copy-in, kernels and copy-out of sub-batches overlap on three streams (csrc/api.hip)"""
+
+    def __init__(self, name, rank, dev, local_rank, first=None, count=None):
+        import torch
+        from icer_compression_amd import api, synth
+        self.api = api
+        self.name, self.cfg = name, CONFIGS[name]
+        c = self.cfg
+        self.w, self.h, self.local_rank = c["w"], c["h"], local_rank
+        self.quota = 2 * self.w * self.h
+        self.first = (0 if name == "C2" else (rank * c["per_gpu"]) % c["total"]) if first is None else first
+        self.B = c["per_gpu"] if count is None else count
+        self.frames = np.empty((self.B, self.h, self.w), np.uint16)
+        for lo in range(0, self.B, 8):                                          # generated on the device, kept on the host
+            hi = min(lo + 8, self.B)
+            d = synth.gray_frames_torch(hi - lo, self.w, self.h, synth.DEFAULT_SEED + self.first + lo, dev, 1)
+            self.frames[lo:hi] = d.cpu().numpy().view(np.uint16)
+            del d
+        torch.cuda.empty_cache()
+        # rows of a lossless stream's worst case (bytes <= samples here: 8-bit content costs ~0.6 B per pixel)
+        self.stride = self.w * self.h
+        self.out = np.zeros((self.B, self.stride), np.uint8)
+        self.sizes, self.rcs = np.zeros(self.B, np.uint64), np.zeros(self.B, np.int32)
+        self.pinned = bool(api.pin_host(self.frames)) and bool(api.pin_host(self.out))
+        self.gold = frame_goldens(name, rank, self.first, self.B)
+        self.enc = None
+
+    def step(self):
+        c = self.cfg
+        rc = self.api.compress_batch(self.frames, c["stages"], FILT, c["segments"], self.quota, self.out, self.sizes, self.rcs, devices=[self.local_rank])
+        if rc != 0:
+            raise RuntimeError(f"icerx_compress_batch_uint16_devices rc={rc}: {self.api.load_library().icerx_last_error().decode()}")
+
+    def verify(self):
+        bad = []
+        for k in range(self.B):
+            size, crc = self.gold[k]
+            ok = int(self.rcs[k]) == 0 and int(self.sizes[k]) == size and ("%08x" % zlib.crc32(self.out[k, :size].tobytes())) == crc
+            if not ok:
+                bad.append(self.first + k)
+        return bad, int(self.sizes.sum())
+
+    def close(self):
+        if self.pinned:
+            self.api.unpin_host(self.frames); self.api.unpin_host(self.out)
+        self.api.load_library().icerx_batch_release()
+        del self.frames, self.out
+
+
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+              ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"]),
+              # hardware's own account of the waves' time (quad-cycles, MI355X_MICROARCH.md "rocprofv3 PMC slots"): no
+              # cycles-per-instruction assumption needed
+              ("sqw", ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INST_CYCLES_SALU"]),
+              ("lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]))
+
+
 def measure_traffic(args):
     """HBM traffic and issue counters of the dominant kernel, measured on THIS build in child runs under rocprofv3:
     --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, kernel trace only; gfx950 FETCH_SIZE counts half the bytes of a
-    streaming read, calibrated on finalize_kernel, see tools/rocprof_summary.py) and the SQ instruction counters."""
+    streaming read, calibrated on finalize_kernel, see tools/rocprof_summary.py) and the SQ counters.  A pass that fails
+    (a counter this rocprofv3 does not know) is reported and skipped; the others still count."""
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
     import sqlite3
     import tempfile
-    res = {}
+    res, failed = {}, []
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batched-probe", "0",
-             "--no-batch-configs", "--no-traffic", "--config", args.config]
+             "--no-batch-configs", "--no-traffic", "--no-extras", "--config", args.config]
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        for tag, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"])):
+        for tag, ctrs in PMC_PASSES:
             d = os.path.join(td, tag)
             try:
                 subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env,
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100)
                 db = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
                 cur = sqlite3.connect(db[0]).cursor()
-                q = ("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%code_units%' "
+                q = ("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%code_units_kernel%' "
                      "group by counter_name")
                 for n, v, _ in cur.execute(q):
                     res[n] = v
             except Exception as exc:                                   # noqa: BLE001 -- the bench line survives a failed pass
-                return None, f"rocprofv3 pass {tag} failed: {exc!r}"
-    return res, "measured in this run: rocprofv3 --kernel-trace --pmc passes on a child bench.py (3 steps)"
+                failed.append(f"{tag}: {exc!r}")
+    note = "measured in this run: rocprofv3 --kernel-trace --pmc passes on a child bench.py (3 steps)"
+    if failed:
+        note += "; failed passes: " + "; ".join(failed)
+    return res, note
 
 
 def run_timed(wl, steps, warmup, barrier, dev):
@@ -200,8 +290,9 @@ def run_timed(wl, steps, warmup, barrier, dev):
     for _ in range(warmup):
         wl.step()
     torch.cuda.synchronize(dev)
-    wl.enc.timing_enable(True)
-    wl.enc.timing_read(reset=True)
+    if wl.enc is not None:
+        wl.enc.timing_enable(True)
+        wl.enc.timing_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     step_ms = []
@@ -211,9 +302,112 @@ def run_timed(wl, steps, warmup, barrier, dev):
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
     barrier()
     elapsed = time.perf_counter() - t0
-    stage_ms, calls = wl.enc.timing_read(reset=True)
-    wl.enc.timing_enable(False)
+    stage_ms, calls = ({}, 0)
+    if wl.enc is not None:
+        stage_ms, calls = wl.enc.timing_read(reset=True)
+        wl.enc.timing_enable(False)
     return shard.max_over_ranks(elapsed, dev), step_ms, stage_ms, calls
+
+
+def c3_object(dev, local_rank, barrier, all_ranks_ok, world):
+    """BASELINE configs[2]: one 4096x4096 YUV frame, 5 stages, 10 segments, byte quota 70 000 (the stream keeps the
+    highest-priority packets up to the quota: icer_color.c:343-530), device-resident, against the reference golden"""
+    import torch
+    from icer_compression_amd import api, shard, synth
+    w = h = 4096
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as fh:
+        g = json.load(fh)["C3_4096_yuv_quota70000"]
+    planes = np.stack(synth.color_frame_yuv(w, h, synth.DEFAULT_SEED))[None]
+    d = torch.from_numpy(planes.view(np.int16)).to(dev)
+    out = torch.empty((1, g["quota"] + 64), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros(1, dtype=torch.int64, device=dev)
+    rcs = torch.zeros(1, dtype=torch.int32, device=dev)
+    enc = api.Encoder(w, h, 3, g["stages"], FILT, g["segments"], max_frames=1, device=local_rank)
+
+    def check():
+        torch.cuda.synchronize()
+        s = out[0, : int(sizes[0])].cpu().numpy().tobytes()
+        return int(rcs[0]) == g["rc"] and len(s) == g["size"] and "%08x" % zlib.crc32(s) == g["crc32"]
+    enc.encode_torch(d, g["quota"], out, sizes, rcs)
+    ok = check()
+    enc.timing_enable(True)
+    enc.timing_read(reset=True)
+    barrier()
+    t = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        enc.encode_torch(d, g["quota"], out, sizes, rcs)
+    barrier()
+    el = shard.max_over_ranks(time.perf_counter() - t, dev)
+    st, calls = enc.timing_read(reset=True)
+    ok = ok and check()
+    mode = enc.stats()["coder_mode"]
+    enc.close()
+    return {"workload": "BASELINE configs[2]: 1 x 4096x4096 YUV (3 planes, uint16 API), 5 stages, filter A, 10 segments, byte quota 70 000 "
+                        "(rc = ICER_BYTE_QUOTA_EXCEEDED, 69 982 bytes); input and stream resident in HBM",
+            "value": round(world * w * h * n / el / 1e6, 3), "unit": "Mpixels/s (pixels = W*H, not x channels)", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
+            "parity": all_ranks_ok(ok), "parity_note": "rc, length and CRC-32 equal the reference golden, before and after the timed loop",
+            "stage_ms_per_step": {k: round(v / max(calls, 1), 4) for k, v in st.items()},
+            "coder": "code_units_wg_kernel (progressive mode: units in priority order, early stop, blank runs in closed form)" if mode == 0 else f"coder_mode {mode}",
+            "roofline_frac": round((w * h * 2 * 3 + g["size"]) / (st["code_units"] / max(calls, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6) if st.get("code_units") else None}
+
+
+def decode_object(stream_dev, size, frame_dev, cfg, with_cpu):
+    """the C2 stream (already in HBM: the encoder's output) -> uint16 planes in HBM through
+    libicer_hip_dec.so (icerx_decode_device, whole call); 1 stream and 16 streams per call; every decoded frame equals
+    the encoder's input; the reference decoder (oracle/_ref) on one host core on the same stream beside it"""
+    import torch
+    from icer_compression_amd import decoder
+    W, H = cfg["w"], cfg["h"]
+    os.environ.setdefault("ICER_DEC_WAVE", "1")
+    dev = stream_dev.device
+
+    def run(n, reps):
+        d_data = stream_dev[:size].repeat(n).contiguous()
+        d_out = torch.zeros((n, H * W), dtype=torch.int16, device=dev)
+        dec = decoder.Decoder(1, cfg["stages"], FILT, cfg["segments"])
+        offs, lens = [k * size for k in range(n)], [size] * n
+        times = []
+        for _ in range(reps + 1):                                # (first call: allocations)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            rc2, rcs, _, _ = dec.decode_device(n, d_data.data_ptr(), offs, lens, d_out.data_ptr(), W * H)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t)
+        ok = rc2 == 0 and all(r == 0 for r in rcs) and all(bool(torch.equal(d_out[k].view(H, W), frame_dev)) for k in range(n))
+        dec.close()
+        return min(times[1:]), ok
+    t1, ok1 = run(1, 2)
+    tb, okb = run(16, 2)
+    alg = float(size + W * H * 2)
+    obj = {"metric": "Mpixels/s decode (bit-exact)", "workload": f"the stream of the timed workload ({size} bytes = the reference golden) resident in HBM -> uint16 planes "
+           "in HBM; icerx_decode_device, whole call incl. the packet walk", "value": round(W * H / t1 / 1e6, 2), "unit": "Mpixels/s",
+           "ms_per_frame": round(t1 * 1e3, 2), "parity": bool(ok1 and okb), "parity_note": "every decoded frame equals the encoder's input",
+           "streams_16_per_call": {"value": round(16 * W * H / tb / 1e6, 2), "ms_per_call": round(tb * 1e3, 2)},
+           "roofline_frac": round(alg / t1 / 1e9 / HBM_PEAK_GBPS, 7)}
+    if with_cpu:
+        try:
+            from oracle import binding
+            binding.build()
+            stream = stream_dev[:size].cpu().numpy().tobytes()
+            img = frame_dev.cpu().numpy().view(np.uint16)
+            if binding.have_reference():
+                ref, kind = binding.Reference(), "reference"
+                t = time.perf_counter()
+                out = ref.decompress(stream, 1, cfg["stages"], FILT, cfg["segments"])
+                dt = time.perf_counter() - t
+                good = out[0] == 0 and np.array_equal(np.asarray(out[1][0]).reshape(H, W), img)
+            else:
+                ref, kind = binding.Oracle(), "port"
+                t = time.perf_counter()
+                out = ref.decompress(stream, 1, cfg["stages"], FILT, cfg["segments"], bufsize=W * H)
+                dt = time.perf_counter() - t
+                good = out[0] == 0 and np.array_equal(np.asarray(out[3][0]).reshape(H, W), img)
+            obj["cpu_baseline"] = {"value": round(W * H / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+                                   "sample": f"the same stream, one full frame, {dt:.2f} s, decoded image equals the input: {bool(good)}"}
+        except Exception as exc:                                   # noqa: BLE001
+            obj["cpu_baseline"] = {"error": repr(exc)}
+    return obj
 
 
 def main():
@@ -222,9 +416,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=list(CONFIGS), default="C2", help="timed workload (default C2 = BASELINE configs[1])")
+    ap.add_argument("--sweep", action="store_true", help="with --config C4|C5 on one GPU: run the share of every rank of an 8-GPU job in turn "
+                    "(all 256 / 64 frames), every frame against its reference golden")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="strong (--config C4|C5): the WHOLE batch split over the ranks, "
+                    "N = 1 codes all of it; weak: every rank its 1/8 share")
+    ap.add_argument("--source", choices=["device", "host"], default="device", help="host: frames and streams in page-locked host memory, "
+                    "icerx_compress_batch_uint16_devices (PCIe overlapped with the kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-configs", action="store_true", help="skip the secondary C4 / C5 figures")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip C3, decode, batch_host and host_buffers (the child runs under rocprofv3)")
     ap.add_argument("--batched-probe", type=int, default=8,
                     help="also report C2 throughput with this many frames per launch (secondary figure, 0 = skip)")
     args = ap.parse_args()
@@ -263,8 +464,45 @@ def main():
         return bool(t.item())
 
     cfg = CONFIGS[args.config]
-    W, H, B = cfg["w"], cfg["h"], cfg["per_gpu"]
-    wl = Workload(args.config, rank, dev, local_rank)
+    W, H = cfg["w"], cfg["h"]
+    if args.scaling == "strong" and args.config == "C2":
+        raise SystemExit("--scaling strong needs a batch configuration (--config C4|C5): C2 is one frame")
+    if args.sweep and (args.config == "C2" or world != 1):
+        raise SystemExit("--sweep needs --config C4|C5 on one GPU")
+    WL = HostWorkload if args.source == "host" else Workload
+
+    # ---- sweep: this GPU plays every rank of the 8-GPU job in turn ----------------------------------------------------
+    if args.sweep:
+        shares = cfg["total"] // cfg["per_gpu"]
+        bad_all, ms_all, checked, bytes_all = [], [], 0, 0
+        for r in range(shares):
+            wl = WL(args.config, r, dev, local_rank)
+            wl.step()
+            bad, nbytes = wl.verify()
+            t_el, _, _, _ = run_timed(wl, 2, 0, barrier, dev)
+            bad2, _ = wl.verify()
+            bad_all += bad + [b for b in bad2 if b not in bad]
+            ms_all.append(round(t_el / 2 * 1e3, 3))
+            checked += wl.B
+            bytes_all += nbytes
+            wl.close()
+            del wl
+            torch.cuda.empty_cache()
+        tot_ms = sum(ms_all)
+        print(json.dumps({"sweep": args.config, "source": args.source, "workload": f"{cfg['what']}: all {cfg['total']} x {W}x{H} frames as {shares} launches of {cfg['per_gpu']} on ONE GPU",
+                          "frames_checked": checked, "frames_not_bit_exact": bad_all, "parity": not bad_all, "bytes_out": bytes_all,
+                          "parity_note": "every frame: rc, length and CRC-32 equal the reference CPU encoder's (tests/golden/batch_golden.json), after the first "
+                                         "encode and again after two timed ones", "ms_per_launch": ms_all,
+                          "value": round(cfg["total"] * W * H / (tot_ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "n_gpus": 1}), flush=True)
+        raise SystemExit(0 if not bad_all else 1)
+
+    # ---- the timed workload ----------------------------------------------------------------------------------------------
+    if args.scaling == "strong":
+        lo, hi = shard.shard_range(cfg["total"], rank, world)
+        wl = WL(args.config, rank, dev, local_rank, first=lo, count=hi - lo)
+    else:
+        wl = WL(args.config, rank, dev, local_rank)
+    B = wl.B
 
     # parity gate first (one extra untimed encode): EVERY rank checks EVERY one of its frames against the reference
     wl.step()
@@ -273,14 +511,21 @@ def main():
         raise SystemExit(f"rank {rank}: frames {bad} are not bit-exact with the reference golden; no number reported")
 
     elapsed_max, step_ms, stage_ms, calls = run_timed(wl, args.steps, args.warmup, barrier, dev)
+    # ... and again on what the LAST timed step left in the output buffers (the timed calls run with event timing on)
+    bad_after, _ = wl.verify()
+    parity_after = all_ranks_ok(not bad_after)
+    if not parity_after:
+        raise SystemExit(f"rank {rank}: frames {bad_after} differ from the reference golden after the timed loop; no number reported")
     h_sizes_sum = bytes_out
-    units_per_frame = wl.enc.info()["units_per_frame"]
-    stats = wl.enc.stats()
+    device_wl = args.source == "device"
+    units_per_frame = wl.enc.info()["units_per_frame"] if device_wl else None
+    stats = wl.enc.stats() if device_wl else api.process_stats()
+    launches_per_step = (B + wl.launch - 1) // wl.launch if device_wl else 1
 
     # secondary figure: the C2 geometry with several frames per launch; one frame alone cannot fill 256 CUs because its
     # largest coding units form a serial chain
     batched = None
-    if args.batched_probe > 1 and args.config == "C2":
+    if args.batched_probe > 1 and args.config == "C2" and device_wl:
         PB = args.batched_probe
         bf = synth.gray_frames_torch(1, W, H, synth.DEFAULT_SEED, dev, 1).repeat(PB, 1, 1).contiguous()
         bout = torch.empty((PB, wl.quota), dtype=torch.uint8, device=dev)
@@ -303,20 +548,22 @@ def main():
         benc.close()
         del bf, bout
 
-    # the batch configurations BASELINE.json names for 8 GPUs, as this GPU's share of them
-    batch_cfgs = {}
-    if not args.no_batch_configs:
-        have = os.path.exists(os.path.join(ROOT, "tests", "golden", "batch_golden.json"))
+    # the batch configurations BASELINE.json names for 8 GPUs, as this GPU's share of them: device-resident, and fed from
+    # page-locked host memory through the overlapped batch call
+    batch_cfgs, batch_host = {}, {}
+    have_bg = os.path.exists(os.path.join(ROOT, "tests", "golden", "batch_golden.json"))
+    if not args.no_batch_configs and have_bg:
         for name in ("C4", "C5"):
-            if name == args.config or not have:
+            if name == args.config:
                 continue
             try:
                 bw = Workload(name, rank, dev, local_rank)
                 bw.step()
                 badf, out_bytes = bw.verify()
-                ok = all_ranks_ok(not badf)
                 nst = 3
                 t_el, _, st_ms, cl = run_timed(bw, nst, 1, barrier, dev)
+                badf2, _ = bw.verify()
+                ok = all_ranks_ok(not badf and not badf2)
                 c = bw.cfg
                 pix = world * c["per_gpu"] * c["w"] * c["h"] * nst
                 batch_cfgs[name] = {
@@ -324,8 +571,9 @@ def main():
                                 f"{c['per_gpu']} frames per GPU per launch (frames {c['per_gpu']}*rank ..)",
                     "value": round(pix / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_launch": round(t_el / nst * 1e3, 3), "launches": nst,
                     "n_gpus": world, "parity": ok, "frames_checked_per_rank": c["per_gpu"],
-                    "parity_note": "every frame of every rank: rc, length and CRC-32 equal the reference CPU encoder's (tests/golden/batch_golden.json)",
-                    "bytes_out_rank0": out_bytes, "code_units_ms": round(st_ms["code_units"] / max(cl, 1), 3),
+                    "parity_note": "every frame of every rank: rc, length and CRC-32 equal the reference CPU encoder's (tests/golden/batch_golden.json), "
+                                   "before and after the timed launches",
+                    "bytes_out_rank0": out_bytes, "code_units_ms": round(st_ms["code_units"] / max(cl, 1), 3), "dwt_ms": round(st_ms["dwt"] / max(cl, 1), 3),
                     "coder": "code_units_kernel<8> for the dense coding units; the all-but-blank ones (>= 95 % blank chunks, listed on the "
                              "device by route_units_kernel) by code_units_wgs_list_kernel on a second stream beside it"}
                 if rank == 0 and world == 1:
@@ -337,52 +585,111 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 batch_cfgs[name] = {"error": repr(exc)}
+            if args.no_extras:
+                continue
+            try:
+                hw = HostWorkload(name, rank, dev, local_rank)
+                hw.step()
+                badh, _ = hw.verify()
+                nst = 3
+                t_el, _, _, _ = run_timed(hw, nst, 0, barrier, dev)
+                badh2, _ = hw.verify()
+                c = hw.cfg
+                pix = world * c["per_gpu"] * c["w"] * c["h"] * nst
+                val = pix / t_el / 1e6
+                batch_host[name] = {
+                    "workload": f"{c['what']}: this rank's {c['per_gpu']} frames in page-locked host memory -> streams in page-locked host memory; "
+                                "icerx_compress_batch_uint16_devices on this rank's GPU (upload, kernels, download of sub-batches on three streams)",
+                    "value": round(val, 3), "unit": "Mpixels/s", "ms_per_call": round(t_el / nst * 1e3, 3), "calls": nst, "n_gpus": world,
+                    "parity": all_ranks_ok(not badh and not badh2), "frames_checked_per_rank": c["per_gpu"], "pinned": hw.pinned,
+                    "pcie_bytes_per_call": int(c["per_gpu"] * c["w"] * c["h"] * 2 + hw.sizes.sum()),
+                    "vs_device_resident": round(val / batch_cfgs[name]["value"], 3) if "value" in batch_cfgs.get(name, {}) else None}
+                hw.close()
+                del hw
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                batch_host[name] = {"error": repr(exc)}
+
+    extras = {}
+    if not args.no_extras and args.config == "C2" and device_wl:
+        try:
+            extras["C3"] = c3_object(dev, local_rank, barrier, all_ranks_ok, world)
+        except Exception as exc:                                       # noqa: BLE001 -- secondary figure
+            extras["C3"] = {"error": repr(exc)}
+        if rank == 0:
+            try:
+                extras["decode"] = decode_object(wl.out[0], wl.gold[0][0], wl.frames[0], cfg, with_cpu=not args.no_cpu_baseline)
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                extras["decode"] = {"error": repr(exc)}
 
     if rank == 0:
         n_pix = world * B * W * H * args.steps
+        if args.scaling == "strong":
+            n_pix = cfg["total"] * W * H * args.steps
         value = n_pix / elapsed_max / 1e6
-        # roofline of the dominant kernel (the coding-unit kernel): algorithmic bytes per launch =
-        # SURVEY 8(d) per-frame figure (input planes read once + final stream written once) x frames per launch
-        k_ms = stage_ms["code_units"] / max(calls, 1)
-        alg_bytes = float(B * W * H * 2 + h_sizes_sum)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        pipe = "code_units_kernel<11> (wave pipeline, 11-wave workgroups)" if B == 1 else "code_units_kernel<8> (wave pipeline, 8-wave workgroups)"
-        kernel = {0: pipe + "; code_units_wg_kernel in progressive mode", 1: pipe, 2: "code_units_wg_kernel"}[stats["coder_mode"]]
+        src = ("input and output stream resident in HBM" if device_wl else
+               "frames and streams in page-locked HOST memory (icerx_compress_batch_uint16_devices: PCIe overlapped with the kernels)")
         line = {
             "metric": "Mpixels/s encode (bit-exact), 4096x4096 gray", "value": round(value, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": f"{cfg['what']}: {B} x {W}x{H} 8-bit gray (uint16 API) per GPU per step, "
-                                   f"{cfg['stages']} DWT stages, filter A, {cfg['segments']} segments, lossless quota 2*W*H; input and "
-                                   "output stream resident in HBM", "frames_per_gpu_per_step": B,
-                       "units_per_frame": units_per_frame,
-                       "parity": "every frame of every rank: rc, stream length and CRC-32 equal the reference golden (checked before timing)"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 4)},
-            "stage_ms_per_step": {k: round(v / max(calls, 1), 4) for k, v in stage_ms.items()},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": f"{cfg['what']}: {B} x {W}x{H} 8-bit gray (uint16 API) on rank 0 per step"
+                                   + (f" (the whole batch of {cfg['total']} split over {world} ranks)" if args.scaling == "strong" else " (every rank the same amount)")
+                                   + f", {cfg['stages']} DWT stages, filter A, {cfg['segments']} segments, lossless quota 2*W*H; {src}",
+                       "frames_per_gpu_per_step": B, "launches_per_step": launches_per_step, "units_per_frame": units_per_frame,
+                       "parity": "every frame of every rank: rc, stream length and CRC-32 equal the reference golden (checked before timing and again "
+                                 "on the output of the last timed step)"},
+            "parity_after_timing": parity_after,
             "step_ms": step_ms,
             "coder_events": {k: stats[k] for k in ("unit_timeouts", "fallback_batches", "slot_retries")},
         }
+        k_ms = 0.0
+        if device_wl:
+            # roofline of the dominant kernel (the coding-unit kernel): algorithmic bytes per launch =
+            # SURVEY 8(d) per-frame figure (input planes read once + final stream written once) x frames per launch
+            k_ms = stage_ms["code_units"] / max(calls, 1)
+            alg_bytes = float(B * W * H * 2 + h_sizes_sum) / launches_per_step
+            achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            pipe = "code_units_kernel<11> (wave pipeline, 11-wave workgroups)" if wl.launch == 1 else "code_units_kernel<8> (wave pipeline, 8-wave workgroups)"
+            kernel = {0: pipe + "; code_units_wg_kernel in progressive mode", 1: pipe, 2: "code_units_wg_kernel"}[stats["coder_mode"]]
+            line["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 4)}
+            line["stage_ms_per_step"] = {k: round(v / max(calls, 1) * launches_per_step, 4) for k, v in stage_ms.items()}
         if batched:
             line["batched"] = batched
         if batch_cfgs:
             line["batch_configs"] = batch_cfgs
-        if world == 1 and not args.no_traffic:
-            ctr, src = measure_traffic(args)
-            line["roofline"]["traffic_source"] = src + f"; sources {source_digest()}"
+        if batch_host:
+            line["batch_host"] = batch_host
+        line.update(extras)
+        if world == 1 and not args.no_traffic and device_wl:
+            ctr, src_note = measure_traffic(args)
+            line["roofline"]["traffic_source"] = src_note + f"; sources {source_digest()}"
             if ctr and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
                 line["roofline"]["traffic"] = int(2 * ctr["FETCH_SIZE"] * 1024 + ctr["WRITE_SIZE"] * 1024)
                 line["roofline"]["traffic_counters_KiB"] = {"FETCH_SIZE": round(ctr["FETCH_SIZE"], 1), "WRITE_SIZE": round(ctr["WRITE_SIZE"], 1)}
             if ctr and "SQ_INSTS_VALU" in ctr:
-                # issue roofline: a wave64 VALU instruction occupies one of the chip's 1024 SIMDs for 4 cycles
-                cyc = k_ms * 1e-3 * 2.4e9
-                line["roofline"]["issue"] = {
-                    "valu_wave_insts_per_launch": int(ctr["SQ_INSTS_VALU"]), "salu_insts_per_launch": int(ctr.get("SQ_INSTS_SALU", 0)),
-                    "lds_insts_per_launch": int(ctr.get("SQ_INSTS_LDS", 0)),
-                    "valu_busy_frac": round(ctr["SQ_INSTS_VALU"] * 4 / (CUS * SIMDS_PER_CU * cyc), 4),
-                    "note": "valu_busy_frac = VALU wave-instructions x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"}
-        if world == 1 and args.config == "C2":
+                cyc = k_ms * 1e-3 * CLOCK_HZ
+                issue = {"valu_wave_insts_per_launch": int(ctr["SQ_INSTS_VALU"]), "salu_insts_per_launch": int(ctr.get("SQ_INSTS_SALU", 0)),
+                         "lds_insts_per_launch": int(ctr.get("SQ_INSTS_LDS", 0))}
+                cpi = ISSUE_CYCLES.get("valu_int32")
+                if cpi:
+                    issue["valu_cycles_per_wave_inst"] = cpi
+                    issue["valu_cycles_source"] = ISSUE_CYCLES.get("source")
+                    issue["valu_busy_frac"] = round(ctr["SQ_INSTS_VALU"] * cpi / (CUS * SIMDS_PER_CU * cyc), 4)
+                    issue["note"] = ("valu_busy_frac = VALU wave-instructions x measured SIMD cycles per wave-instruction of the coder's class (32-bit integer) "
+                                     "/ (1024 SIMDs x kernel cycles at 2.4 GHz)")
+                if "SQ_WAVE_CYCLES" in ctr and ctr["SQ_WAVE_CYCLES"]:
+                    wc = ctr["SQ_WAVE_CYCLES"]
+                    issue["hw_wave_time_shares"] = {k: round(ctr[n] / wc, 4) for k, n in (("issuing_any", "SQ_ACTIVE_INST_ANY"), ("issuing_valu", "SQ_ACTIVE_INST_VALU"),
+                                                    ("issuing_scalar", "SQ_ACTIVE_INST_SCA"), ("issuing_lds", "SQ_ACTIVE_INST_LDS"), ("parked_waitcnt_or_sleep", "SQ_WAIT_ANY"),
+                                                    ("issue_stalled", "SQ_WAIT_INST_ANY")) if n in ctr}
+                    issue["hw_wave_quad_cycles_per_launch"] = int(wc)
+                    issue["hw_note"] = "shares of SQ_WAVE_CYCLES (summed over all resident waves; quad-cycle units): what the waves' time went into, no cycles-per-instruction assumption"
+                if "SQ_LDS_BANK_CONFLICT" in ctr and ctr.get("SQ_LDS_IDX_ACTIVE"):
+                    issue["lds_bank_conflict_share_of_lds_cycles"] = round(ctr["SQ_LDS_BANK_CONFLICT"] / ctr["SQ_LDS_IDX_ACTIVE"], 4)
+                line["roofline"]["issue"] = issue
+        if world == 1 and args.config == "C2" and device_wl and not args.no_extras:
             # PCIe-inclusive figures of the host-buffer entry point (never `value`): H2D frame + kernels + D2H stream,
             # caller buffers pageable (the runtime stages them) and page-locked (icerx_pin_host: DMA at link speed)
             host_frame = np.ascontiguousarray(wl.frames[:1].cpu().numpy().view(np.uint16))
@@ -405,15 +712,16 @@ def main():
                     api.unpin_host(host_frame); api.unpin_host(h_out)
             best = hb.get("pinned", hb["pageable"])
             line["host_buffers"] = {"ms_per_frame": best["ms_per_frame"], "value": best["value"], "unit": "Mpixels/s", "parity": all(v["parity"] for v in hb.values()),
-                                    "note": "icerx_encode_host: H2D of the frame, all kernels, D2H of size/rc/stream; caller buffers page-locked with "
-                                            "icerx_pin_host when available", "by_caller_memory": hb}
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(host_frame[0], wl.gold[0][1], cfg)
-                line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
-                try:
-                    line["cpu_all_cores"] = cpu_all_cores(cfg)
-                except Exception as exc:                                   # reported, never fatal for the GPU numbers
-                    line["cpu_all_cores"] = {"error": repr(exc)}
+                                    "note": "icerx_encode_host: H2D of the frame, all kernels, D2H of size/rc/stream, nothing overlapped (one frame); caller buffers "
+                                            "page-locked with icerx_pin_host when available", "by_caller_memory": hb}
+        if world == 1 and args.config == "C2" and device_wl and not args.no_cpu_baseline:
+            host_frame = np.ascontiguousarray(wl.frames[:1].cpu().numpy().view(np.uint16))
+            line["cpu_baseline"] = cpu_baseline(host_frame[0], wl.gold[0][1], cfg)
+            line["speedup_vs_cpu_1thread"] = round(value / line["cpu_baseline"]["value"], 2)
+            try:
+                line["cpu_all_cores"] = cpu_all_cores(cfg)
+            except Exception as exc:                                   # reported, never fatal for the GPU numbers
+                line["cpu_all_cores"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     wl.close()
     if world > 1:

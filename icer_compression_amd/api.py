@@ -78,6 +78,12 @@ def load_library() -> C.CDLL:
     L.icerx_encoder_destroy.restype = None
     L.icerx_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
+    L.icerx_encode_device_async.argtypes = L.icerx_encode_device.argtypes
+    L.icerx_encoder_wait.argtypes = [C.c_void_p]
+    L.icerx_compress_batch_uint16.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    L.icerx_compress_batch_uint16_devices.argtypes = L.icerx_compress_batch_uint16.argtypes[:-1] + [C.POINTER(C.c_int), C.c_int]
+    L.icerx_batch_release.restype = None
     L.icerx_encode_device_u8.argtypes = L.icerx_encode_device.argtypes
     L.icerx_encode_device_rgb8.argtypes = L.icerx_encode_device.argtypes
     L.icerx_encode_device_s8.argtypes = L.icerx_encode_device.argtypes
@@ -207,6 +213,18 @@ class Encoder:
         if rc != 0:
             raise IcerHipError(f"icerx_encode_device rc={rc}: {self.lib.icerx_last_error().decode()}")
 
+    def encode_device_async_ptrs(self, d_frames: int, n_frames: int, byte_quota: int, d_out: int, out_stride: int, d_sizes: int,
+                                 d_rcs: int, stream: int = 0) -> None:
+        """first half of encode_device_ptrs: returns once everything is enqueued; wait() completes it"""
+        rc = self.lib.icerx_encode_device_async(self.handle, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream)
+        if rc != 0:
+            raise IcerHipError(f"icerx_encode_device_async rc={rc}: {self.lib.icerx_last_error().decode()}")
+
+    def wait(self) -> None:
+        rc = self.lib.icerx_encoder_wait(self.handle)
+        if rc != 0:
+            raise IcerHipError(f"icerx_encoder_wait rc={rc}: {self.lib.icerx_last_error().decode()}")
+
     def encode_torch(self, frames, byte_quota: int, out, sizes, rcs) -> None:
         """frames: cuda int16/uint16 tensor (n, channels, h, w) or (n, h, w); out: cuda uint8 (n, stride);
         sizes: cuda int64 (n,); rcs: cuda int32 (n,).  Runs on torch's current stream."""
@@ -300,6 +318,24 @@ class Encoder:
         u, b, s = C.c_uint32(), C.c_uint32(), C.c_uint64()
         self.lib.icerx_info(self.handle, C.byref(u), C.byref(b), C.byref(s))
         return {"units_per_frame": u.value, "slot_bits_per_pixel": b.value, "slot_bytes_per_frame": s.value}
+
+
+def compress_batch(frames: np.ndarray, stages: int, filt: int, segments: int, byte_quota: int, out: np.ndarray, sizes: np.ndarray,
+                   rcs: np.ndarray, devices=None) -> int:
+    """icerx_compress_batch_uint16[_devices]: frames uint16 (n, h, w) or (n, channels, h, w) in host memory (page-locked for
+    DMA: pin_host), out uint8 (n, stride), sizes uint64 (n,), rcs int32 (n,); devices = list of HIP devices, None = all.
+    Returns the call's return code (0 = every frame coded; per-frame codes in rcs)."""
+    L = load_library()
+    n = frames.shape[0]
+    ch = 1 if frames.ndim == 3 else frames.shape[1]
+    h, w = frames.shape[-2:]
+    assert frames.dtype == np.uint16 and frames.flags["C_CONTIGUOUS"] and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
+    if devices is None:
+        return L.icerx_compress_batch_uint16(frames.ctypes.data, n, w, h, ch, stages, filt, segments, byte_quota, out.ctypes.data,
+                                             out.shape[1], sizes.ctypes.data, rcs.ctypes.data, 0)
+    dv = (C.c_int * len(devices))(*devices)
+    return L.icerx_compress_batch_uint16_devices(frames.ctypes.data, n, w, h, ch, stages, filt, segments, byte_quota, out.ctypes.data,
+                                                 out.shape[1], sizes.ctypes.data, rcs.ctypes.data, dv, len(devices))
 
 
 def process_stats():

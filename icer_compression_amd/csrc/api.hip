@@ -6,8 +6,11 @@
 
 #include <algorithm>
 #include <atomic>
-#include <thread>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
+#include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -126,6 +129,13 @@ struct icerx_encoder {
 
     int *h_flag = nullptr;              // pinned host words: slot-bound overflow flag of the last batch, units on its route list
     hipEvent_t done = nullptr;          // end of the last batch on its stream
+    bool wg_available = true;           // the workgroup coder's LDS block (> 64 KiB) was granted: progressive mode, hybrid launches, time-out fall-back
+    bool sleepy_wait = false;           // waits yield the core between polls (the per-device workers of a host batch) instead of spinning
+    struct Pending {                    // icerx_encode_device_async .. icerx_encoder_wait
+        bool active = false;
+        const uint16_t *d_frames = nullptr; int n_frames = 0; size_t quota = 0; uint8_t *d_out = nullptr; size_t out_stride = 0;
+        uint64_t *d_sizes = nullptr; int32_t *d_rcs = nullptr; void *stream = nullptr;
+    } pend;
 
     bool timing = false;
     hipEvent_t ev[ICERX_NUM_STAGES + 1] = {};
@@ -277,12 +287,12 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
-    const bool use_wg = e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive);
+    const bool use_wg = e->wg_available && (e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive));
     // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
     // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
-    const bool hybrid = !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames;
+    const bool hybrid = e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames;
     if (use_wg || hybrid) {
-        hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)e->plan.sig_blocks.size(), n_frames), dim3(256), 0, st,
+        hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,
                            e->plan.sig_bytes);
     }
@@ -418,11 +428,18 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     }
     CREATE_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
     // the workgroup coder's LDS block is above the 64 KiB a kernel gets without asking
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wgs_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)));
-    CREATE_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&e->join, hipEventDisableTiming));
+    // A device / runtime that refuses it loses only the paths that need that coder (progressive mode then runs on the
+    // pipeline, launches are not shared, a unit time-out becomes an error) -- reported by icerx_encoder_stats.
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wgs_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        e->wg_available = false;
+        if (e->coder_mode == 2) { set_error("ICER_HIP_CODER=wg, but this device does not grant the workgroup coder its LDS block"); icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
+        fprintf(stderr, "libicer_hip: the workgroup coder is not available on this device; the wave pipeline codes everything\n");
+    }
 #ifdef ICER_PHASE_TIMERS
     if (e->prof.ensure(kProfWords)) { icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
     CREATE_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
@@ -479,10 +496,87 @@ static void report_timeouts(icerx_encoder *e, int n_frames)
     }
 }
 
-// `stride_may_shrink`: the host wrappers size the output by min(quota, slot area); when a slot-bound retry
-// enlarges the slot area they must re-allocate, signalled by *regrow (the batch is then re-run by them).
+// One encode call = begin (everything enqueued on the stream, nothing waited for) + finish (wait, then the rare re-runs).
+// `flag` = two pinned host words that receive the batch's verdict: [0] bit 0 a coding unit outgrew its provisioned slot,
+// bit 1 a unit timed out; [1] units on the route list.
+static int encode_begin(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                        size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, hipStream_t st, int *flag, hipEvent_t done, bool *regrow)
+{
+    if (upload_units(e, byte_quota, st)) return ICER_FATAL_ERROR;
+    if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
+    if (out_stride < byte_quota && out_stride < e->plan.slot_bytes) {
+        if (regrow) { *regrow = true; return 0; }
+        set_error("icerx_encode_device: out_stride %zu smaller than the byte quota %zu", out_stride, byte_quota);
+        return ICER_INVALID_INPUT;
+    }
+    int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * e->channels + e->max_frames;
+    if (enqueue(e, d_frames, n_frames, byte_quota, d_out, out_stride, (unsigned long long *)d_sizes, d_rcs, st))
+        return ICER_FATAL_ERROR;
+    HIP_TRY(hipMemcpyAsync(flag, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (e->last_routed) HIP_TRY(hipMemcpyAsync(flag + 1, e->route_ctl.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(done, st));
+    return 0;
+}
+
+// Wait for an event.  The synchronous entry points spin on a query instead of blocking in hipStreamSynchronize: an
+// encode call is milliseconds and the wake-up latency of a blocking wait (measured: up to 3 ms per call on a busy host)
+// would be charged to every frame.  The per-device workers of a host batch (sleepy) give the core away between polls:
+// eight of them must not burn eight cores, and their waits are hidden behind the next sub-batch anyway.
+static int wait_event(hipEvent_t ev, bool sleepy)
+{
+    for (uint32_t polls = 0;; polls++) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return ICER_FATAL_ERROR; }
+        if (sleepy && polls > 64u) { const struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr); }
+        else cpu_relax();
+    }
+}
+
+// The verdict of a finished batch (encode_begin's flag words): 0 = done, 1 = run it again (the encoder has been adjusted:
+// larger slots, or the barrier-only coder for the next run), or an error code.
+static int encode_verdict(icerx_encoder *e, int n_frames, const int *flag)
+{
+    const int ovf = flag[0];
+    if (!ovf) {
+        if (e->last_routed) { e->n_routed_units += (uint64_t)(uint32_t)flag[1]; e->n_routed_launches++; }
+        return 0;
+    }
+    if (ovf & 2) {
+        // A wave of some coding unit of the eight-wave pipeline waited longer than its spin bound (seconds) and gave
+        // the unit up (seen once in ~60 000 randomised encodes in round 1, never reproduced).  The batch is coded again
+        // by the workgroup-window coder, which has no wave-to-wave hand-offs to wait for (barriers only) and produces
+        // the same streams: the caller gets its result, the event is counted (icerx_encoder_stats) and reported.
+        report_timeouts(e, n_frames);
+        e->n_timeouts++; g_stats[0]++;
+        if (e->wg_once || !e->wg_available) {          // (the window coder never reports a time-out)
+            e->wg_once = false;
+            set_error(e->wg_available ? "a coding unit timed out in the workgroup-window coder"
+                                      : "a coding unit timed out and the barrier-only coder is not available on this device");
+            return ICER_FATAL_ERROR;
+        }
+        e->n_fallbacks++; g_stats[1]++;
+        e->wg_once = true;
+        fprintf(stderr, "libicer_hip: a coding unit timed out; coding the batch again with the barrier-only coder\n");
+        e->ev_pending = false;
+        return 1;
+    }
+    e->n_slot_retries++; g_stats[2]++;
+    if (e->bits_per_pixel >= 24) {
+        set_error("coding-unit slot overflow at the theoretical bound");
+        return ICER_FATAL_ERROR;
+    }
+    // a unit produced more than the provisioned bits per pixel: enlarge the slots and redo the batch
+    e->ev_pending = false;
+    e->bits_per_pixel = e->bits_per_pixel * 2 > 24 ? 24 : e->bits_per_pixel * 2;
+    e->units_uploaded = false;
+    return 1;
+}
+
+// `regrow`: the host wrappers size the output by min(quota, slot area); when a slot-bound retry enlarges the slot area
+// they must re-allocate, signalled by *regrow (the batch is then re-run by them).
 static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
-                              size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream, bool *regrow)
+                              size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream, bool *regrow, bool already_begun = false)
 {
     if (!e || !d_frames || !d_out || !d_sizes || !d_rcs || n_frames < 1 || n_frames > e->max_frames) {
         set_error("icerx_encode_device: invalid arguments");
@@ -490,63 +584,22 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
     }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
-    if (accumulate_timing(e)) return ICER_FATAL_ERROR;
-    int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * e->channels + e->max_frames;
-    e->wg_once = false;
-    for (;;) {
-        if (upload_units(e, byte_quota, st)) return ICER_FATAL_ERROR;
-        if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
-        if (out_stride < byte_quota && out_stride < e->plan.slot_bytes) {
-            if (regrow) { *regrow = true; return 0; }
-            set_error("icerx_encode_device: out_stride %zu smaller than the byte quota %zu", out_stride, byte_quota);
-            return ICER_INVALID_INPUT;
+    if (!already_begun) {
+        if (e->pend.active) { set_error("icerx_encode_device: an asynchronous encode is pending on this encoder (icerx_encoder_wait)"); return ICER_INVALID_INPUT; }
+        if (accumulate_timing(e)) return ICER_FATAL_ERROR;
+        e->wg_once = false;
+    }
+    for (bool begun = already_begun;; begun = false) {
+        if (!begun) {
+            bool rg = false;
+            const int rc = encode_begin(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, st, e->h_flag, e->done, regrow ? &rg : nullptr);
+            if (rc) return rc;
+            if (rg) { *regrow = true; return 0; }
         }
-        if (enqueue(e, d_frames, n_frames, byte_quota, d_out, out_stride, (unsigned long long *)d_sizes, d_rcs, st))
-            return ICER_FATAL_ERROR;
-        // One word comes back: did a coding unit outgrow its provisioned slot?  The wait spins on an event query
-        // instead of blocking in hipStreamSynchronize: an encode call is tens of milliseconds and the wake-up
-        // latency of a blocking wait (measured: up to 3 ms per call on a busy host) would be charged to every frame.
-        HIP_TRY(hipMemcpyAsync(e->h_flag, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
-        if (e->last_routed) HIP_TRY(hipMemcpyAsync(e->h_flag + 1, e->route_ctl.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(e->done, st));
-        for (;;) {
-            const hipError_t q = hipEventQuery(e->done);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) { set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return ICER_FATAL_ERROR; }
-            cpu_relax();
-        }
-        const int ovf = *e->h_flag;
-        if (!ovf) {
-            if (e->last_routed) { e->n_routed_units += (uint64_t)(uint32_t)e->h_flag[1]; e->n_routed_launches++; }
-            break;
-        }
-        if (ovf & 2) {
-            // A wave of some coding unit of the eight-wave pipeline waited longer than its spin bound (seconds) and gave
-            // the unit up (seen once in ~60 000 randomised encodes in round 1, never reproduced).  The batch is coded again
-            // by the workgroup-window coder, which has no wave-to-wave hand-offs to wait for (barriers only) and produces
-            // the same streams: the caller gets its result, the event is counted (icerx_encoder_stats) and reported.
-            report_timeouts(e, n_frames);
-            e->n_timeouts++; g_stats[0]++;
-            if (e->wg_once) {                      // (can not happen: the window coder never reports a time-out)
-                e->wg_once = false;
-                set_error("a coding unit timed out in the workgroup-window coder");
-                return ICER_FATAL_ERROR;
-            }
-            e->n_fallbacks++; g_stats[1]++;
-            e->wg_once = true;
-            fprintf(stderr, "libicer_hip: a coding unit timed out; coding the batch again with the barrier-only coder\n");
-            e->ev_pending = false;
-            continue;
-        }
-        e->n_slot_retries++; g_stats[2]++;
-        if (e->bits_per_pixel >= 24) {
-            set_error("coding-unit slot overflow at the theoretical bound");
-            return ICER_FATAL_ERROR;
-        }
-        // a unit produced more than the provisioned bits per pixel: enlarge the slots and redo the batch
-        e->ev_pending = false;
-        e->bits_per_pixel = e->bits_per_pixel * 2 > 24 ? 24 : e->bits_per_pixel * 2;
-        e->units_uploaded = false;
+        if (wait_event(e->done, e->sleepy_wait)) return ICER_FATAL_ERROR;
+        const int v = encode_verdict(e, n_frames, e->h_flag);
+        if (v < 0) return v;
+        if (v == 0) break;
     }
     e->wg_once = false;
     return 0;
@@ -560,6 +613,37 @@ int icerx_encode_device(icerx_encoder *e, const uint16_t *d_frames, int n_frames
         return ICER_INVALID_INPUT;
     }
     return encode_device_impl(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, stream, nullptr);
+}
+
+// The same call in two halves, so that a caller can overlap its own copies (or another encoder's work) with the coding:
+// icerx_encode_device_async returns as soon as everything is enqueued on `stream`; icerx_encoder_wait returns once the
+// batch is complete there (and has re-run it in the rare cases icerx_encode_device does).  One pending call per encoder.
+int icerx_encode_device_async(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
+                              size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream)
+{
+    if (!e || !d_frames || !d_out || !d_sizes || !d_rcs || n_frames < 1 || n_frames > e->max_frames || e->sample_bits != 16) {
+        set_error("icerx_encode_device_async: invalid arguments");
+        return ICER_INVALID_INPUT;
+    }
+    if (e->pend.active) { set_error("icerx_encode_device_async: the previous asynchronous encode has not been waited for"); return ICER_INVALID_INPUT; }
+    HIP_TRY(hipSetDevice(e->device));
+    if (accumulate_timing(e)) return ICER_FATAL_ERROR;
+    e->wg_once = false;
+    const int rc = encode_begin(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, (hipStream_t)stream, e->h_flag, e->done, nullptr);
+    if (rc) return rc;
+    e->pend.active = true;
+    e->pend.d_frames = d_frames; e->pend.n_frames = n_frames; e->pend.quota = byte_quota; e->pend.d_out = d_out; e->pend.out_stride = out_stride;
+    e->pend.d_sizes = d_sizes; e->pend.d_rcs = d_rcs; e->pend.stream = stream;
+    return 0;
+}
+
+int icerx_encoder_wait(icerx_encoder *e)
+{
+    if (!e) return ICER_INVALID_INPUT;
+    if (!e->pend.active) return 0;
+    const icerx_encoder::Pending p = e->pend;
+    e->pend.active = false;
+    return encode_device_impl(e, p.d_frames, p.n_frames, p.quota, p.d_out, p.out_stride, p.d_sizes, p.d_rcs, p.stream, nullptr, true);
 }
 
 int icerx_encode_device_u8(icerx_encoder *e, const uint8_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
@@ -617,12 +701,6 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
     HIP_TRY(hipSetDevice(e->device));
     const size_t plane = e->w * e->h, P = (size_t)n_frames * e->channels;
     if (upload_units(e, byte_quota, nullptr)) return ICER_FATAL_ERROR;
-    // a frame's stream can be as long as the quota (or everything the slots can hold): the caller's rows must hold it
-    if (n_frames > 1 && out_stride < (byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes)) {
-        set_error("icerx_encode_host: out_stride %zu smaller than the largest possible stream (%zu bytes)", out_stride,
-                  byte_quota < e->plan.slot_bytes ? byte_quota : e->plan.slot_bytes);
-        return ICER_INVALID_INPUT;
-    }
     if (e->in.ensure((size_t)e->max_frames * e->channels * plane)) return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpy(e->in.p, frames, P * plane * 2, hipMemcpyHostToDevice));
     for (;;) {   // the device stride depends on the slot bound, which a retry may enlarge
@@ -635,11 +713,15 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
         if (!regrow) {
             HIP_TRY(hipMemcpy(sizes, e->sizes.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(rcs, e->rcs.p, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
+            // out_stride is the room the caller gives every frame: checked against the streams that came out (for one
+            // frame as for many), before anything is copied
             for (int f = 0; f < n_frames; f++)
-                if (sizes[f]) {
-                    if (sizes[f] > out_stride && n_frames > 1) { set_error("icerx_encode_host: stream of frame %d (%llu bytes) longer than out_stride", f, (unsigned long long)sizes[f]); return ICER_INVALID_INPUT; }
-                    HIP_TRY(hipMemcpy(out + (size_t)f * out_stride, e->out.p + (size_t)f * (ds + 4), sizes[f], hipMemcpyDeviceToHost));
+                if (sizes[f] > out_stride) {
+                    set_error("icerx_encode_host: stream of frame %d (%llu bytes) longer than out_stride %zu", f, (unsigned long long)sizes[f], out_stride);
+                    return ICER_OUTPUT_BUF_TOO_SMALL;
                 }
+            for (int f = 0; f < n_frames; f++)
+                if (sizes[f]) HIP_TRY(hipMemcpy(out + (size_t)f * out_stride, e->out.p + (size_t)f * (ds + 4), sizes[f], hipMemcpyDeviceToHost));
             break;
         }
     }
@@ -653,42 +735,270 @@ int icerx_device_count(void)
     return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
 }
 
+}  // extern "C"
+
 // Frames are independent and a frame's transform needs the whole frame, so the batch is cut into contiguous blocks
 // of frames, one per device (earlier devices take the larger blocks, icer_compression_amd/shard.py has the same rule);
-// one host thread and one icerx_encoder per device, no communication between them.  Every frame's bytes, length and
+// one host thread and one encoder per device, no communication between them.  Every frame's bytes, length and
 // return code equal a per-frame call of icer_compress_image_uint16.
+//
+// A device's block is coded in sub-batches through three streams, so that PCIe and the coder work at the same time:
+//     copy-in stream   H2D of sub-batch k+1        (two input buffers)
+//     encoder stream   all kernels of sub-batch k
+//     copy-out stream  D2H of the streams of k-1   (two output buffers; exactly size[f] bytes per frame)
+// The encoders and their staging buffers stay alive between calls (one per device, re-made when the geometry changes;
+// icerx_batch_release frees them): a call allocates nothing on the device.
+namespace {
+
+struct BatchDevice {
+    std::mutex mu;                       // one batch call at a time per device
+    int device = -1;
+    icerx_encoder *enc = nullptr;
+    int sub = 0;                         // frames per sub-batch (= the encoder's max_frames)
+    size_t quota = 0, dev_stride = 0;
+    hipStream_t s_in = nullptr, s_enc = nullptr, s_out = nullptr;
+    DevBuf<uint16_t> in[2];
+    DevBuf<uint8_t> out[2];
+    DevBuf<unsigned long long> d_sizes[2];
+    DevBuf<int32_t> d_rcs[2];
+    uint64_t *h_sizes = nullptr;         // pinned: [2][sub]
+    int32_t *h_rcs = nullptr;            // pinned: [2][sub]
+    int *h_flag = nullptr;               // pinned: [2][2]
+    hipEvent_t in_ready[2] = {}, coded[2] = {}, out_done[2] = {};
+    void release()
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (enc) { icerx_encoder_destroy(enc); enc = nullptr; }
+        for (int k = 0; k < 2; k++) {
+            in[k].release(); out[k].release(); d_sizes[k].release(); d_rcs[k].release();
+            if (in_ready[k]) (void)hipEventDestroy(in_ready[k]);
+            if (coded[k]) (void)hipEventDestroy(coded[k]);
+            if (out_done[k]) (void)hipEventDestroy(out_done[k]);
+            in_ready[k] = coded[k] = out_done[k] = nullptr;
+        }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_enc) (void)hipStreamDestroy(s_enc);
+        if (s_out) (void)hipStreamDestroy(s_out);
+        s_in = s_enc = s_out = nullptr;
+        if (h_sizes) (void)hipHostFree(h_sizes);
+        if (h_rcs) (void)hipHostFree(h_rcs);
+        if (h_flag) (void)hipHostFree(h_flag);
+        h_sizes = nullptr; h_rcs = nullptr; h_flag = nullptr;
+        sub = 0;
+    }
+};
+
+std::mutex g_pool_mutex;
+std::map<int, std::unique_ptr<BatchDevice>> g_pool;
+
+BatchDevice *pool_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    auto &slot = g_pool[device];
+    if (!slot) { slot.reset(new BatchDevice()); slot->device = device; }
+    return slot.get();
+}
+
+// frames per sub-batch: enough sub-batches for the three streams to overlap (>= 4 when the block allows), each small
+// enough that two input + two output sets are a modest share of HBM (ICER_HIP_BATCH_SUB pins it)
+int sub_batch_frames(int cnt, size_t frame_bytes)
+{
+    if (const char *sv = getenv("ICER_HIP_BATCH_SUB")) { const int v = atoi(sv); if (v >= 1) return v < cnt ? v : cnt; }
+    size_t by_mem = ((size_t)256 << 20) / (frame_bytes ? frame_bytes : 1);
+    if (by_mem < 1) by_mem = 1;
+    int by_overlap = (cnt + 3) / 4;
+    if (by_overlap < 1) by_overlap = 1;
+    int sub = (size_t)by_overlap < by_mem ? by_overlap : (int)by_mem;
+    // (a launch of one large gray frame is bound by the chain of its biggest coding units: prefer two per launch)
+    if (sub < 2 && cnt >= 2 && frame_bytes <= ((size_t)512 << 20)) sub = 2;
+    return sub;
+}
+
+int batch_prepare(BatchDevice *b, size_t w, size_t h, int channels, int stages, int filt, int segments, size_t quota, int sub)
+{
+    icerx_encoder *e = b->enc;
+    if (!e || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt || e->segments != segments ||
+        e->sample_bits != 16 || b->sub != sub) {
+        b->release();
+        const int rc = icerx_encoder_create(&e, b->device, w, h, channels, stages, filt, segments, sub);
+        if (rc) return rc;
+        b->enc = e;
+        b->sub = sub;
+        e->sleepy_wait = true;
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_enc, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
+            HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->coded[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->out_done[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipHostMalloc((void **)&b->h_sizes, 2 * (size_t)sub * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->h_rcs, 2 * (size_t)sub * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->h_flag, 4 * sizeof(int), hipHostMallocDefault));
+        b->quota = (size_t)-1;
+    }
+    HIP_TRY(hipSetDevice(b->device));
+    // slots for this quota, then output rows that hold the longest possible stream
+    if (upload_units(e, quota, b->s_enc)) return ICER_FATAL_ERROR;
+    const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
+    if (b->quota != quota || b->dev_stride < ds) {
+        for (int k = 0; k < 2; k++) if (b->out[k].ensure((size_t)sub * ds)) return ICER_FATAL_ERROR;
+        b->dev_stride = ds;
+        b->quota = quota;
+    }
+    return 0;
+}
+
+// one device's block of the batch: frames [0, cnt) at `frames`, rows of `out`
+int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, size_t h, int channels, int stages, int filt, int segments,
+                    size_t quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs)
+{
+    std::lock_guard<std::mutex> lk(b->mu);
+    const size_t frame_elems = w * h * (size_t)channels;
+    const int sub = sub_batch_frames(cnt, frame_elems * 2);
+    int rc = batch_prepare(b, w, h, channels, stages, filt, segments, quota, sub);
+    if (rc) return rc;
+    icerx_encoder *e = b->enc;
+    const int K = (cnt + sub - 1) / sub;
+    auto n_of = [&](int k) { return k == K - 1 ? cnt - k * sub : sub; };
+    // enqueue sub-batch k: its copy-in, then its kernels
+    auto issue = [&](int k) -> int {
+        const int s = k & 1, n = n_of(k);
+        // in[s] is free once the kernels of k - 2 are done, out[s] once the copy-out of k - 2 is
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->s_in, b->coded[s], 0));
+        HIP_TRY(hipMemcpyAsync(b->in[s].p, frames + (size_t)k * sub * frame_elems, (size_t)n * frame_elems * 2, hipMemcpyHostToDevice, b->s_in));
+        HIP_TRY(hipEventRecord(b->in_ready[s], b->s_in));
+        HIP_TRY(hipStreamWaitEvent(b->s_enc, b->in_ready[s], 0));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->s_enc, b->out_done[s], 0));
+        e->wg_once = false;
+        const int r = encode_begin(e, b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc,
+                                   b->h_flag + 2 * s, b->coded[s], nullptr);
+        if (r) return r;
+        // (after the `coded` record on purpose: the host reads these words only after its own wait below)
+        return 0;
+    };
+    if (accumulate_timing(e)) return ICER_FATAL_ERROR;
+    for (int k = 0; k < K && k < 2; k++) if ((rc = issue(k))) return rc;
+    for (int k = 0; k < K; k++) {
+        const int s = k & 1, n = n_of(k);
+        if (wait_event(b->coded[s], true)) return ICER_FATAL_ERROR;
+        int v = encode_verdict(e, n, b->h_flag + 2 * s);
+        if (v < 0) return v;
+        if (v == 1) {
+            // rare: larger slots, or the barrier-only coder after a time-out.  Let everything in flight finish (k + 1 was
+            // enqueued with the old slot table; its own verdict is read in its turn), then code k again, synchronously.
+            HIP_TRY(hipDeviceSynchronize());
+            for (;;) {
+                if (upload_units(e, quota, b->s_enc)) return ICER_FATAL_ERROR;
+                if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
+                const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
+                if (b->dev_stride < ds) {
+                    for (int q = 0; q < 2; q++) if (b->out[q].ensure((size_t)sub * ds)) return ICER_FATAL_ERROR;
+                    b->dev_stride = ds;
+                    if (k + 1 < K) {          // (k + 1 wrote rows of the old stride into a buffer that is gone: enqueue it again below)
+                        if ((rc = issue(k + 1))) return rc;
+                    }
+                }
+                if ((rc = encode_begin(e, b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc,
+                                       b->h_flag + 2 * s, b->coded[s], nullptr))) return rc;
+                if (wait_event(b->coded[s], true)) return ICER_FATAL_ERROR;
+                v = encode_verdict(e, n, b->h_flag + 2 * s);
+                if (v < 0) return v;
+                if (v == 0) break;
+            }
+            e->wg_once = false;
+        }
+        // lengths and return codes of k, then exactly the bytes of every stream
+        HIP_TRY(hipStreamWaitEvent(b->s_out, b->coded[s], 0));
+        HIP_TRY(hipMemcpyAsync(b->h_sizes + (size_t)s * sub, b->d_sizes[s].p, (size_t)n * 8, hipMemcpyDeviceToHost, b->s_out));
+        HIP_TRY(hipMemcpyAsync(b->h_rcs + (size_t)s * sub, b->d_rcs[s].p, (size_t)n * 4, hipMemcpyDeviceToHost, b->s_out));
+        HIP_TRY(hipStreamSynchronize(b->s_out));
+        for (int f = 0; f < n; f++) {
+            const uint64_t sz = b->h_sizes[(size_t)s * sub + f];
+            sizes[(size_t)k * sub + f] = sz;
+            rcs[(size_t)k * sub + f] = b->h_rcs[(size_t)s * sub + f];
+            if (sz > out_stride) {
+                set_error("icerx_compress_batch_uint16: stream of frame %d (%llu bytes) longer than out_stride %zu", k * sub + f, (unsigned long long)sz, out_stride);
+                (void)hipDeviceSynchronize();
+                return ICER_OUTPUT_BUF_TOO_SMALL;
+            }
+            if (sz) HIP_TRY(hipMemcpyAsync(out + ((size_t)k * sub + f) * out_stride, b->out[s].p + (size_t)f * b->dev_stride, sz, hipMemcpyDeviceToHost, b->s_out));
+        }
+        HIP_TRY(hipEventRecord(b->out_done[s], b->s_out));
+        if (k + 2 < K && (rc = issue(k + 2))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(b->s_out));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void icerx_batch_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (auto &kv : g_pool) if (kv.second) { std::lock_guard<std::mutex> lk2(kv.second->mu); kv.second->release(); }
+}
+
+int icerx_compress_batch_uint16_devices(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
+                                        int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,
+                                        const int *devices, int n_devices)
+{
+    if (!frames || !out || !sizes || !rcs || n_frames < 1 || !devices || n_devices < 1) { set_error("icerx_compress_batch_uint16: invalid arguments"); return ICER_INVALID_INPUT; }
+    const int have = icerx_device_count();
+    if (have <= 0) { set_error("no usable HIP device; this library has no CPU path"); return ICER_FATAL_ERROR; }
+    for (int d = 0; d < n_devices; d++)
+        if (devices[d] < 0 || devices[d] >= have) { set_error("icerx_compress_batch_uint16: device %d of %d present", devices[d], have); return ICER_INVALID_INPUT; }
+    const int g = n_devices > n_frames ? n_frames : n_devices;
+    try {
+        std::vector<int> rc((size_t)g, 0);
+        std::vector<std::string> err((size_t)g);
+        const size_t frame_elems = w * h * (size_t)channels;
+        auto work = [&](int d) {
+            const int base = n_frames / g, extra = n_frames % g;
+            const int lo = d * base + (d < extra ? d : extra), cnt = base + (d < extra ? 1 : 0);
+            int r;
+            try {
+                r = batch_on_device(pool_device(devices[d]), frames + (size_t)lo * frame_elems, cnt, w, h, channels, stages, filt, segments,
+                                    byte_quota, out + (size_t)lo * out_stride, out_stride, sizes + lo, rcs + lo);
+                if (r) err[(size_t)d] = icerx_last_error();      // (thread-local in the worker)
+            } catch (const std::exception &ex) { r = ICER_FATAL_ERROR; err[(size_t)d] = ex.what(); }
+            rc[(size_t)d] = r;
+        };
+        if (g == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int d = 0; d < g; d++) th.emplace_back(work, d);
+            for (auto &t : th) t.join();
+        }
+        int first = 0;
+        std::string all;
+        for (int d = 0; d < g; d++)
+            if (rc[(size_t)d]) { if (!first) first = rc[(size_t)d]; all += (all.empty() ? "device " : "; device ") + std::to_string(devices[d]) + ": " + err[(size_t)d]; }
+        if (first) { set_error("%s", all.c_str()); return first; }
+        return 0;
+    } catch (const std::exception &ex) {          // (std::thread / std::vector: nothing may cross the C boundary)
+        set_error("icerx_compress_batch_uint16: %s", ex.what());
+        return ICER_FATAL_ERROR;
+    }
+}
+
 int icerx_compress_batch_uint16(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
                                 int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,
                                 int n_gpus)
 {
-    if (!frames || !out || !sizes || !rcs || n_frames < 1 || n_gpus < 0) { set_error("icerx_compress_batch_uint16: invalid arguments"); return ICER_INVALID_INPUT; }
+    if (n_gpus < 0) { set_error("icerx_compress_batch_uint16: invalid arguments"); return ICER_INVALID_INPUT; }
     const int have = icerx_device_count();
     if (have <= 0) { set_error("no usable HIP device; this library has no CPU path"); return ICER_FATAL_ERROR; }
-    int g = n_gpus == 0 || n_gpus > have ? have : n_gpus;
-    if (g > n_frames) g = n_frames;
-    std::vector<int> rc((size_t)g, 0);
-    std::vector<std::string> err((size_t)g);
-    std::vector<std::thread> th;
-    const size_t frame_elems = w * h * (size_t)channels;
-    for (int d = 0; d < g; d++) {
-        const int base = n_frames / g, extra = n_frames % g;
-        const int lo = d * base + (d < extra ? d : extra), cnt = base + (d < extra ? 1 : 0);
-        th.emplace_back([=, &rc, &err] {
-            icerx_encoder *e = nullptr;
-            int r = icerx_encoder_create(&e, d, w, h, channels, stages, filt, segments, cnt);
-            if (r == 0) {
-                r = icerx_encode_host(e, frames + (size_t)lo * frame_elems, cnt, byte_quota, out + (size_t)lo * out_stride, out_stride,
-                                      sizes + lo, rcs + lo);
-                icerx_encoder_destroy(e);
-            }
-            if (r) err[(size_t)d] = icerx_last_error();          // (thread-local in the worker)
-            rc[(size_t)d] = r;
-        });
-    }
-    for (auto &t : th) t.join();
-    for (int d = 0; d < g; d++)
-        if (rc[(size_t)d]) { set_error("device %d: %s", d, err[(size_t)d].c_str()); return rc[(size_t)d]; }
-    return 0;
+    const int g = n_gpus == 0 || n_gpus > have ? have : n_gpus;
+    int devices[64];
+    for (int d = 0; d < g && d < 64; d++) devices[d] = d;
+    return icerx_compress_batch_uint16_devices(frames, n_frames, w, h, channels, stages, filt, segments, byte_quota, out, out_stride, sizes,
+                                               rcs, devices, g < 64 ? g : 64);
 }
 
 // Page-lock a caller buffer (frames in, streams out) so that the host-buffer entry points move it at PCIe speed by DMA

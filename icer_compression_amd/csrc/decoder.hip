@@ -308,7 +308,8 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         const char *mode = getenv("ICER_DEC_WAVE");
         // the wavefront-per-chain kernel unless ICER_DEC_WAVE=0 asks for the thread-per-chain one (tests) or the segment
         // rows do not fit the LDS ring
-        if (!(mode && mode[0] == '0') && ring_bytes <= 65536u) {
+        // (the kernel's static DecoderTables block counts against the same 64 KiB a launch gets without asking)
+        if (!(mode && mode[0] == '0') && ring_bytes + sizeof(DecoderTables) + 256u <= 65536u) {
             ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nc, ring_bytes, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
                              d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
         } else {

@@ -255,16 +255,15 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
 
 // ------------------------------------------------------------------------------------------ chunk tables
 // One byte per 64-pixel chunk of every (channel, level, subband, segment): the lowest bit plane from which the chunk
-// is blank (wg::chunk_blank_plane), for all bit planes of the family at once.  Work list (Plan::sig_blocks): one entry per
+// is blank (wg::chunk_blank_plane), for all bit planes of the family at once.  Work list (Plan::sig_blocks): one (unit, block) pair per
 // family and block of 64 chunks; grid = (entries, frames), block = 256 (16 chunks per wavefront).
 __global__ void __launch_bounds__(256)
 chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, int channels,
                  const UnitDesc *__restrict__ units, const uint32_t *__restrict__ blocks, const int *__restrict__ frame_skip,
                  uint8_t *__restrict__ sig, size_t sig_frame_stride)
 {
-    const uint32_t entry = blocks[blockIdx.x];
-    const UnitDesc u = units[entry >> 12];
-    const uint32_t frame = blockIdx.y, nchunks = (u.w * u.h + 63u) / 64u, first = (entry & 4095u) * 64u;
+    const UnitDesc u = units[blocks[2u * blockIdx.x]];
+    const uint32_t frame = blockIdx.y, nchunks = (u.w * u.h + 63u) / 64u, first = blocks[2u * blockIdx.x + 1u] * 64u;
     if (frame_skip[frame]) return;
     const uint16_t *seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
     uint8_t *out = sig + (size_t)frame * sig_frame_stride + u.sig_off;

@@ -149,7 +149,7 @@ struct Plan {
     std::vector<uint32_t> work_order;      // launch order (largest units first) -> index into units
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
     size_t sig_bytes = 0;                  // per-frame chunk-table area (UnitDesc::sig_off)
-    std::vector<uint32_t> sig_blocks;      // the work list of chunk_sig_kernel: unit << 12 | block of 64 chunks, one family member (plane 0) each
+    std::vector<uint32_t> sig_blocks;      // the work list of chunk_sig_kernel: pairs (unit, block of 64 chunks), one family member (plane 0) each
 };
 
 // quarter-octave size class of a unit (launch order treats units of one class as equally large)
@@ -265,7 +265,7 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
             const UnitDesc &u = p->units[i];
             if (u.lsb != 0u) continue;
             const uint32_t blocks = (((uint32_t)u.w * u.h + 63u) / 64u + 63u) / 64u;
-            for (uint32_t b = 0; b < blocks && b < 4096u; b++) p->sig_blocks.push_back((uint32_t)(i << 12) | b);
+            for (uint32_t b = 0; b < blocks; b++) { p->sig_blocks.push_back((uint32_t)i); p->sig_blocks.push_back(b); }
         }
     }
     // the launch is latency-bound by its largest units: give their waves issue priority over the small ones

@@ -127,6 +127,16 @@ void icerx_encoder_destroy(icerx_encoder *enc);
 int icerx_encode_device(icerx_encoder *enc, const uint16_t *d_frames, int n_frames, size_t byte_quota,
                         uint8_t *d_out, size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
 
+/* The same call in two halves.  icerx_encode_device_async returns as soon as all work is enqueued on `stream`;
+ * icerx_encoder_wait returns once it has completed there (re-running the batch in the rare cases the synchronous call
+ * does: a coding unit that outgrew its slot, a unit time-out).  Between the two the caller may enqueue its own copies
+ * on other streams or drive other encoders; the buffers passed in must stay valid and untouched until the wait returns.
+ * At most one pending call per encoder (a second async call, or a synchronous one, returns ICER_INVALID_INPUT);
+ * icerx_encoder_wait without a pending call returns 0. */
+int icerx_encode_device_async(icerx_encoder *enc, const uint16_t *d_frames, int n_frames, size_t byte_quota,
+                              uint8_t *d_out, size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
+int icerx_encoder_wait(icerx_encoder *enc);
+
 /* Front-end fusion: inputs as the reference's callers hold them BEFORE their app-side conversion,
  * converted on the device, so only 1 byte per sample crosses PCIe.
  *   icerx_encode_device_u8    8-bit gray frames (n_frames * w*h bytes), widened to the uint16 planes the uint16 API
@@ -146,19 +156,33 @@ int icerx_encode_device_rgb8(icerx_encoder *enc, const uint8_t *d_rgb, int n_fra
 int icerx_encode_device_s8(icerx_encoder *enc, const uint8_t *d_planes, int n_frames, size_t byte_quota, uint8_t *d_out,
                            size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);
 
-/* Host-buffer convenience wrapper: H2D, icerx_encode_device, D2H, synchronous. */
+/* Host-buffer convenience wrapper: H2D, icerx_encode_device, D2H, synchronous.  `out_stride` is the room of every
+ * frame's row in `out`: a stream longer than that is not copied and the call returns ICER_OUTPUT_BUF_TOO_SMALL (sizes /
+ * rcs are valid then); byte_quota or more always suffices. */
 int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, size_t byte_quota,
                       uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs);
 
 /* A batch of frames of one geometry from host memory over the GPUs of the node (BASELINE configs 4 and 5): contiguous
- * blocks of frames per device, one host thread and one encoder per device, no communication between devices.
- * frames: n_frames x channels planes of w*h uint16; out: n_frames rows of out_stride bytes (out_stride >= byte_quota);
- * n_gpus: devices to use (0 = all present; clamped to the number present and to n_frames).  sizes / rcs per frame equal
- * a per-frame call of icer_compress_image_[yuv_]uint16 (reference: icer.h:440-444).  Returns 0, or the first device's error. */
+ * blocks of frames per device, one host thread and one encoder per device, no communication between devices.  Every
+ * device codes its block in sub-batches through three streams -- upload of sub-batch k+1, kernels of k, download of the
+ * streams of k-1 at the same time -- so page-lock `frames` and `out` (icerx_pin_host) to let the copies run as DMA beside
+ * the kernels.  The per-device encoders and staging buffers are kept between calls (re-made when the geometry changes);
+ * icerx_batch_release frees them.
+ * frames: n_frames x channels planes of w*h uint16; out: n_frames rows of out_stride bytes (a stream longer than
+ * out_stride makes the call fail with ICER_OUTPUT_BUF_TOO_SMALL; byte_quota always suffices);
+ * n_gpus: devices to use (0 = all present; clamped to the number present and to n_frames) -- devices 0 .. n_gpus-1; the
+ * _devices variant names them (one process per GPU: pass that process's device).  sizes / rcs per frame equal a
+ * per-frame call of icer_compress_image_[yuv_]uint16 (reference: icer.h:440-444).  Returns 0, or the first failing
+ * device's error code (icerx_last_error lists every failing device).
+ * Env: ICER_HIP_BATCH_SUB=<frames per sub-batch>. */
 int icerx_device_count(void);
 int icerx_compress_batch_uint16(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
                                 int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,
                                 int n_gpus);
+int icerx_compress_batch_uint16_devices(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
+                                        int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,
+                                        const int *devices, int n_devices);
+void icerx_batch_release(void);
 
 /* Optional: page-lock a caller buffer that icerx_encode_host / the lib_icer-shaped entry points read frames from or
  * write streams to, so that it crosses PCIe by DMA at link speed (otherwise the runtime stages pageable memory through

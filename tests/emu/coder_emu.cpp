@@ -223,12 +223,12 @@ extern "C" int emu_plan_sig_blocks(size_t w, size_t h, int channels, int stages,
     int rc = build_plan(&plan, w, h, channels, stages, segments);
     if (rc) return rc;
     *sig_bytes = plan.sig_bytes;
-    int n = (int)plan.sig_blocks.size();
+    int n = (int)(plan.sig_blocks.size() / 2);
     for (int i = 0; i < n && i < cap; i++) {
-        const uint32_t e = plan.sig_blocks[i];
-        const UnitDesc &u = plan.units[e >> 12];
+        const uint32_t ui = plan.sig_blocks[2 * (size_t)i], blk = plan.sig_blocks[2 * (size_t)i + 1];
+        const UnitDesc &u = plan.units[ui];
         uint32_t *o = out + (size_t)i * 5;
-        o[0] = e >> 12; o[1] = e & 4095u; o[2] = u.sig_off; o[3] = (u.w * u.h + 63u) / 64u; o[4] = u.lsb;
+        o[0] = ui; o[1] = blk; o[2] = u.sig_off; o[3] = (u.w * u.h + 63u) / 64u; o[4] = u.lsb;
     }
     return n;
 }

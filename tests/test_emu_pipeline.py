@@ -112,7 +112,8 @@ def test_chunk_table_work_list_covers_every_family_once(emu):
     segment) exactly once, through that family's plane-0 unit; the families' table areas tile the per-frame area"""
     import ctypes as C
     emu.lib.emu_plan_sig_blocks.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
-    for (w, h, ch, st, sg) in [(4096, 4096, 1, 5, 10), (2048, 2048, 1, 4, 16), (517, 389, 3, 4, 7), (100, 75, 1, 3, 32), (8192, 8192, 1, 6, 32)]:
+    for (w, h, ch, st, sg) in [(4096, 4096, 1, 5, 10), (2048, 2048, 1, 4, 16), (517, 389, 3, 4, 7), (100, 75, 1, 3, 32), (8192, 8192, 1, 6, 32),
+                               (16384, 16384, 1, 2, 1)]:   # (a coding unit above 2^24 pixels: more than 4096 blocks of 64 chunks)
         buf = np.zeros((400000, 5), np.uint32)
         sig_bytes = C.c_size_t(0)
         n = emu.lib.emu_plan_sig_blocks(w, h, ch, st, sg, buf.ctypes.data, len(buf), C.byref(sig_bytes))

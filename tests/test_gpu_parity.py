@@ -170,6 +170,135 @@ def test_batch_over_devices_and_two_threads_from_c(oracle, tmp_path):
         off += size
 
 
+def test_async_halves_equal_the_synchronous_call(oracle):
+    """icerx_encode_device_async + icerx_encoder_wait: same streams as icerx_encode_device; a second call while one is
+    pending is refused; a wait without a pending call is a no-op"""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h, st, sg, n = 320, 200, 3, 7, 3
+    quota = 2 * w * h
+    frames = synth.gray_batch(n, w, h, 77, 1)
+    d_frames = torch.from_numpy(frames.view(np.int16)).to(dev)
+    out = torch.zeros((n, quota), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+    rcs = torch.zeros(n, dtype=torch.int32, device=dev)
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=n)
+    enc.wait()
+    side = torch.cuda.Stream(dev)
+    args = (d_frames.data_ptr(), n, quota, out.data_ptr(), out.stride(0), sizes.data_ptr(), rcs.data_ptr(), side.cuda_stream)
+    torch.cuda.synchronize()
+    enc.encode_device_async_ptrs(*args)
+    with pytest.raises(api.IcerHipError):
+        enc.encode_device_async_ptrs(*args)
+    with pytest.raises(api.IcerHipError):
+        enc.encode_device_ptrs(*args)
+    enc.wait()
+    enc.wait()
+    for k in range(n):
+        rc, stream, _ = oracle.compress([frames[k]], st, 0, sg, quota)
+        assert int(rcs[k]) == rc and out[k, : int(sizes[k])].cpu().numpy().tobytes() == stream
+    enc.close()
+
+
+@pytest.mark.parametrize("sub", ["1", "2", "5", ""])
+def test_host_batch_is_pipelined_in_sub_batches_and_exact(oracle, monkeypatch, sub):
+    """icerx_compress_batch_uint16_devices: a device's block goes through copy-in / kernels / copy-out streams in
+    sub-batches (ICER_HIP_BATCH_SUB pins their size: whole, ragged last one, one frame); pinned and pageable caller
+    memory; the pooled encoder is re-used by the next call and re-made for another geometry; a row too short for its
+    stream is an error, never an overrun"""
+    if sub:
+        monkeypatch.setenv("ICER_HIP_BATCH_SUB", sub)
+    n, w, h, st, sg = 5, 256, 192, 3, 6
+    quota = 2 * w * h
+    frames = synth.gray_batch(n, w, h, 303, 1)
+    want = [oracle.compress([frames[k]], st, 0, sg, quota) for k in range(n)]
+    for pinned in (False, True):
+        out = np.full((n, quota), 0xAB, np.uint8)
+        sizes, rcs = np.zeros(n, np.uint64), np.zeros(n, np.int32)
+        if pinned:
+            assert api.pin_host(frames) and api.pin_host(out)
+        for _ in range(2):
+            assert api.compress_batch(frames, st, 0, sg, quota, out, sizes, rcs, devices=[0]) == 0, api.load_library().icerx_last_error()
+            for k in range(n):
+                assert (int(rcs[k]), out[k, : int(sizes[k])].tobytes()) == (want[k][0], want[k][1]), k
+                assert (out[k, int(sizes[k]):] == 0xAB).all()           # exactly size bytes per row are written
+        if pinned:
+            api.unpin_host(frames); api.unpin_host(out)
+    # another geometry, colour, quota cut
+    yuv = np.stack([np.stack(synth.color_frame_yuv(160, 96, 5 + k)) for k in range(3)])
+    out = np.zeros((3, 9000), np.uint8)
+    sizes, rcs = np.zeros(3, np.uint64), np.zeros(3, np.int32)
+    assert api.compress_batch(yuv, 2, 0, 4, 9000, out, sizes, rcs, devices=[0]) == 0
+    for k in range(3):
+        rc, stream, _ = oracle.compress(list(yuv[k]), 2, 0, 4, 9000)
+        assert (int(rcs[k]), out[k, : int(sizes[k])].tobytes()) == (rc, stream)
+    # rows shorter than the streams
+    small = np.zeros((n, 1000), np.uint8)
+    sizes, rcs = np.zeros(n, np.uint64), np.zeros(n, np.int32)
+    assert api.compress_batch(frames, st, 0, sg, quota, small, sizes, rcs, devices=[0]) == api.ICER_OUTPUT_BUF_TOO_SMALL
+    api.load_library().icerx_batch_release()
+
+
+def test_host_batch_slot_retry_inside_the_pipeline(oracle, monkeypatch):
+    """a coding unit that outgrows its provisioned slot in the middle of a pipelined host batch: that sub-batch is coded
+    again with larger slots, the ones around it are unaffected"""
+    monkeypatch.setenv("ICER_HIP_SLOT_BPP", "1")
+    monkeypatch.setenv("ICER_HIP_BATCH_SUB", "2")
+    n, w, h = 6, 256, 256
+    frames = synth.gray_batch(n, w, h, 9, 1)
+    frames[3] = synth.gray_batch(1, w, h, 9, 0)[0]               # noise: needs more than 1 bit per pixel
+    out = np.zeros((n, 1 << 18), np.uint8)
+    sizes, rcs = np.zeros(n, np.uint64), np.zeros(n, np.int32)
+    assert api.compress_batch(frames, 1, 0, 1, 1 << 18, out, sizes, rcs, devices=[0]) == 0, api.load_library().icerx_last_error()
+    for k in range(n):
+        rc, stream, _ = oracle.compress([frames[k]], 1, 0, 1, 1 << 18)
+        assert (int(rcs[k]), out[k, : int(sizes[k])].tobytes()) == (rc, stream), k
+    assert api.process_stats()["slot_retries"] >= 1
+    api.load_library().icerx_batch_release()
+
+
+def test_encode_host_row_length_is_checked_for_one_frame_too(oracle):
+    frames = synth.gray_batch(1, 128, 128, 3, 0)
+    enc = api.Encoder(128, 128, 1, 2, 0, 2, max_frames=1)
+    out = np.zeros((1, 500), np.uint8)
+    sizes, rcs = np.zeros(1, np.uint64), np.zeros(1, np.int32)
+    rc = enc.lib.icerx_encode_host(enc.handle, frames.ctypes.data, 1, 1 << 16, out.ctypes.data, 500, sizes.ctypes.data, rcs.ctypes.data)
+    assert rc == api.ICER_OUTPUT_BUF_TOO_SMALL and int(sizes[0]) > 500 and not out.any()
+    big = np.zeros((1, int(sizes[0])), np.uint8)                   # a row of exactly the stream's length is enough
+    assert enc.lib.icerx_encode_host(enc.handle, frames.ctypes.data, 1, 1 << 16, big.ctypes.data, big.shape[1], sizes.ctypes.data, rcs.ctypes.data) == 0
+    assert big[0].tobytes() == oracle.compress([frames[0]], 2, 0, 2, 1 << 16)[1]
+    enc.close()
+
+
+def test_async_overlap_by_hand_from_c(oracle, tmp_path):
+    """tests/c_abi/async_overlap.c: two encoders, each with a stream and device buffers of its own, driven from plain C
+    through icerx_encode_device_async / icerx_encoder_wait with the HIP runtime's C API for the copies"""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "async_overlap")
+    libdir = os.path.join(root, "icer_compression_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "async_overlap.c"), "-L", libdir, "-licer_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    n, w, h, st, f, sg = 7, 224, 160, 3, 0, 5
+    q = 2 * w * h
+    frames = synth.gray_batch(n, w, h, 57, 1)
+    frames.astype("<u2").tofile(tmp_path / "in.raw")
+    r = subprocess.run([exe, str(tmp_path / "in.raw"), str(n), str(w), str(h), str(st), str(f), str(sg), str(q), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and f"ok frames={n}" in r.stdout, r.stdout + r.stderr
+    blob = (tmp_path / "out.bin").read_bytes()
+    off = 0
+    for k in range(n):
+        size, rc = struct.unpack_from("<Qi", blob, off)
+        off += 12
+        want = oracle.compress([frames[k]], st, f, sg, q)
+        assert (rc, blob[off: off + size]) == (want[0], want[1]), k
+        off += size
+
+
 def test_frontend_fusion_u8_and_rgb8(oracle):
     """next-3: 8-bit gray widening and packed RGB888 -> YCbCr on the device give the same streams as the
     reference callers' host-side conversion followed by the uint16 encoders."""
@@ -310,7 +439,7 @@ def test_cli_matches_reference_cli_semantics(oracle, tmp_path):
     exe = str(tmp_path / "icer_util_hip")
     libdir = os.path.join(root, "icer_compression_amd")
     subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "icer_util_hip.c"),
-                           "-L", libdir, "-licer_hip", "-Wl,-rpath," + libdir, "-o", exe])
+                           "-L", libdir, "-licer_hip", "-licer_hip_dec", "-Wl,-rpath," + libdir, "-o", exe])
     rng = np.random.default_rng(9)
     w, h = 200, 144
     gray = synth.gray_frame(w, h, 3, 1).astype(np.uint8)
@@ -343,7 +472,7 @@ def test_cli_matches_reference_cli_semantics(oracle, tmp_path):
         rc, stream, _ = oracle.compress(planes, st, f, sg, q)
         assert r.returncode == 0 and rc in (0, -5), r.stdout + r.stderr
         assert (tmp_path / "o.bin").read_bytes() == stream, (name, opts)
-    assert subprocess.run([exe, "decompress", "a", "b", "-G"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "decompress", str(tmp_path / "o.bin"), "b"], capture_output=True).returncode == 1      # needs -c or -G, like the reference's
     assert subprocess.run([exe, "compress", str(tmp_path / "g.pgm"), str(tmp_path / "o.bin"), "-c", "-G"], capture_output=True).returncode == 1
 
 
@@ -380,3 +509,55 @@ def test_round_trip_through_the_reference_decoder(reference):
         enc.close()
         drc, back = reference.decompress(stream, len(planes), st, f, sg)
         assert rc == 0 and drc == 0 and all(np.array_equal(a, b) for a, b in zip(back, planes))
+
+
+# ---- real image content: the reference repository's own fixtures (BASELINE configs[0]; tests/golden/fixture_*) ---------------
+from tests.test_reference_fixtures import FIXTURE_GOLDEN, fixture_planes  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURE_GOLDEN))
+def test_reference_fixtures_through_the_drop_in_entry_points(name):
+    """boat.512 / boatcolor.512 with the parameters of the reference's CLI and example programs through
+    icer_compress_image_[yuv_]uint16: the reference build's streams (seven filters: the CLI binary's own known answers,
+    SURVEY 8c), then decoded by libicer_hip_dec.so: the reference decoder's images"""
+    from icer_compression_amd import decoder
+    g = FIXTURE_GOLDEN[name]
+    planes = fixture_planes(name)
+    rc, stream, _ = api.compress(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+    assert (rc, len(stream), "%08x" % zlib.crc32(stream), hashlib.sha256(stream).hexdigest()[:16]) == (g["rc"], g["size"], g["crc32"], g["sha256_16"])
+    drc, w, h, back = decoder.decompress(stream, g["channels"], g["stages"], g["filt"], g["segments"])
+    hsh = hashlib.sha256()
+    for p in back:
+        hsh.update(p.tobytes())
+    assert (drc, w, h, hsh.hexdigest()[:16]) == (g["decoded_rc"], g["w"], g["h"], g["decoded_sha256_16"])
+
+
+def test_reference_fixtures_through_the_command_line_tool(tmp_path):
+    """the same files through tools/icer_util_hip (the reference's `icer_util compress` flags): boat.512 as PGM with
+    --grayscale -s 3 -g 10 -f A..Q, boatcolor.512 as PPM with -s 4 -g 10; and `decompress` of the results"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "icer_util_hip")
+    libdir = os.path.join(root, "icer_compression_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "icer_util_hip.c"),
+                           "-L", libdir, "-licer_hip", "-licer_hip_dec", "-Wl,-rpath," + libdir, "-o", exe])
+    z = np.load(os.path.join(root, "tests", "golden", "fixture_planes.npz"))
+    (tmp_path / "boat.pgm").write_bytes(b"P5 512 512 255\n" + z["boat512_gray"].tobytes())
+    (tmp_path / "boatcolor.ppm").write_bytes(b"P6 512 512 255\n" + z["boatcolor512_rgb"].tobytes())
+    for name, g in sorted(FIXTURE_GOLDEN.items()):
+        if not name.startswith("cli_"):
+            continue
+        src = "boat.pgm" if g["channels"] == 1 else "boatcolor.ppm"
+        opts = (["--grayscale"] if g["channels"] == 1 else []) + ["-s", str(g["stages"]), "-g", str(g["segments"]), "-f", "ABCDEFQ"[g["filt"]]]
+        r = subprocess.run([exe, "compress", str(tmp_path / src), str(tmp_path / "o.bin")] + opts, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        blob = (tmp_path / "o.bin").read_bytes()
+        assert (len(blob), hashlib.sha256(blob).hexdigest()[:16]) == (g["size"], g["sha256_16"]), name
+        # and back: the tool writes PGM / PPM; lossless for every filter but C (quirk W3)
+        out = "back.pgm" if g["channels"] == 1 else "back.ppm"
+        r = subprocess.run([exe, "decompress", str(tmp_path / "o.bin"), str(tmp_path / out)] + opts, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        back = (tmp_path / out).read_bytes()
+        if g["channels"] == 1 and g["filt"] != 2:
+            assert back.endswith(z["boat512_gray"].tobytes())

@@ -38,3 +38,46 @@ def test_boat_512_cli_known_answers(oracle, filt):
     rc, stream, _ = oracle.compress([img], 3, filt, 10, 512 * 512)
     assert rc == 0
     assert (len(stream), hashlib.sha256(stream).hexdigest()[:16]) == KAT[filt]
+
+
+# ---- the fixtures' pixel planes, committed (tests/golden/fixture_planes.npz, made by tests/golden/make_fixture_goldens.py):
+# the same known answers -- and the reference's parameters of its two example programs and of the colour CLI flow -- wherever
+# the tests run, with the reference build's encoder AND decoder verdicts (tests/golden/fixture_golden.json)
+import json  # noqa: E402
+
+GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLD_DIR, "fixture_golden.json")) as _fh:
+    FIXTURE_GOLDEN = json.load(_fh)
+
+
+def fixture_planes(name):
+    """uint16 planes of a case of fixture_golden.json"""
+    z = np.load(os.path.join(GOLD_DIR, "fixture_planes.npz"))
+    if FIXTURE_GOLDEN[name]["channels"] == 1:
+        return [z["boat512_gray"].astype(np.uint16)]
+    rgb = z["boatcolor512_rgb"]
+    r, g, b = (rgb[..., c].astype(np.int64) for c in range(3))
+    clip = lambda v: np.clip(v, 0, 255)
+    y = clip((19595 * r + 38470 * g + 7471 * b) >> 16)                       # CRGB2Y/Cb/Cr, example/inc/color_util.h:27-29
+    return [np.ascontiguousarray(p.astype(np.uint16)) for p in (y, clip(((36962 * (b - y)) >> 16) + 128), clip(((46727 * (r - y)) >> 16) + 128))]
+
+
+def test_committed_gray_plane_is_the_fixture():
+    if not os.path.exists(BOAT):
+        pytest.skip("reference fixture not mounted")
+    assert np.array_equal(load_bmp_gray(BOAT), fixture_planes("cli_gray_A")[0])
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURE_GOLDEN))
+def test_fixture_known_answers_oracle(oracle, name):
+    g = FIXTURE_GOLDEN[name]
+    planes = fixture_planes(name)
+    rc, stream, _ = oracle.compress(planes, g["stages"], g["filt"], g["segments"], g["quota"])
+    assert (rc, len(stream), hashlib.sha256(stream).hexdigest()[:16]) == (g["rc"], g["size"], g["sha256_16"])
+    if name.startswith("cli_gray"):
+        assert (g["size"], g["sha256_16"]) == KAT[g["filt"]]                 # the reference CLI binary's own output (SURVEY 8c)
+    drc, w, h, back = oracle.decompress(stream, g["channels"], g["stages"], g["filt"], g["segments"])
+    hsh = hashlib.sha256()
+    for p in back:
+        hsh.update(p.tobytes())
+    assert (drc, w, h, hsh.hexdigest()[:16]) == (g["decoded_rc"], g["w"], g["h"], g["decoded_sha256_16"])

@@ -1,8 +1,10 @@
 /*
- * icer_util_hip -- command-line encoder on top of libicer_hip.so with the options of the reference's
- * `icer_util compress` (example/src/icer_util.c:35-54 usage text, :367-477 option handling, :96-240 compress flow):
+ * icer_util_hip -- command-line codec on top of libicer_hip.so / libicer_hip_dec.so with the options of the reference's
+ * `icer_util` (example/src/icer_util.c:35-54 usage text, :367-477 option handling, :96-240 compress flow, :248-365
+ * decompress flow):
  *
- *     icer_util_hip compress <input> <output> [-s stages] [-f A..Q] [-g segments] [-t bytes] [-c | -G]
+ *     icer_util_hip compress   <input> <output> [-s stages] [-f A..Q] [-g segments] [-t bytes] [-c | -G]
+ *     icer_util_hip decompress <input> <output> [-s stages] [-f A..Q] [-g segments] (-c | -G)
  *
  * and the same .bin for the same pixels: 8-bit gray is widened to uint16 (icer_util.c:163-168), colour goes through the
  * integer RGB -> Y/Cb/Cr formulas of example/inc/color_util.h:27-29 (icer_util.c:69-94), the byte quota is the target
@@ -12,9 +14,12 @@
  * uncompressed formats it can parse itself -- binary PGM/PPM (P5/P6, maxval 255) and BMP (8-bit paletted, 24- and
  * 32-bit, BI_RGB) -- and applies stb_image's channel conversions where the requested mode differs from the file's
  * (gray -> colour: replicate; colour -> gray: (77 r + 150 g + 29 b) >> 8), which is what the reference's CLI gets.
- * `decompress` is outside this library's scope (encoder only): use the reference build for it.
+ * `decompress` (the reference: icer_util.c:248-365) needs -c or -G like the reference's, decodes with the stages / filter /
+ * segments given (they must be the ones of the stream), clamps gray samples to 255, converts colour back with
+ * CYCbCr2R/G/B (example/inc/color_util.h:31-33) and writes -- where the reference writes a BMP through stb_image_write --
+ * a 24-bit BMP when the output name ends in .bmp, else a binary PGM / PPM.
  *
- * Build:  gcc -O2 -I include tools/icer_util_hip.c -L icer_compression_amd -licer_hip -Wl,-rpath,$PWD/icer_compression_amd
+ * Build:  gcc -O2 -I include tools/icer_util_hip.c -L icer_compression_amd -licer_hip -licer_hip_dec -Wl,-rpath,$PWD/icer_compression_amd
  */
 #include <getopt.h>
 #include <stdint.h>
@@ -25,6 +30,7 @@
 #include <time.h>
 
 #include "icer_hip.h"
+#include "icer_hip_dec.h"
 
 typedef struct {
     int w, h, channels;       /* channels: 1 or 3 as stored in the file */
@@ -116,9 +122,86 @@ static enum icer_filter_types parse_filter(const char *s)
     return ICER_FILTER_A;
 }
 
+/* 24-bit bottom-up BMP (what stb_image_write makes of 1- and 3-channel data alike), or binary PGM / PPM */
+static int save_image(const char *path, const uint8_t *px, size_t w, size_t h, int channels)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const size_t len = strlen(path);
+    int ok = 1;
+    if (len >= 4 && strcasecmp(path + len - 4, ".bmp") == 0) {
+        const size_t stride = (3 * w + 3) & ~(size_t)3, total = 54 + stride * h;
+        uint8_t hdr[54] = {'B', 'M'};
+        const uint32_t f32[] = {(uint32_t)total, 0, 54, 40, (uint32_t)w, (uint32_t)h};
+        for (int i = 0; i < 6; i++) for (int b = 0; b < 4; b++) hdr[2 + 4 * i + b] = (uint8_t)(f32[i] >> (8 * b));
+        hdr[26] = 1; hdr[28] = 24;
+        ok = fwrite(hdr, 1, 54, f) == 54;
+        uint8_t *row = (uint8_t *)calloc(stride, 1);
+        for (size_t y = h; y-- > 0 && ok;) {
+            for (size_t x = 0; x < w; x++) {
+                const uint8_t *p = px + (y * w + x) * (size_t)channels;
+                row[3 * x] = channels == 3 ? p[2] : p[0]; row[3 * x + 1] = channels == 3 ? p[1] : p[0]; row[3 * x + 2] = p[0];
+            }
+            ok = fwrite(row, 1, stride, f) == stride;
+        }
+        free(row);
+    } else {
+        fprintf(f, "P%d %zu %zu 255\n", channels == 3 ? 6 : 5, w, h);
+        ok = fwrite(px, 1, w * h * (size_t)channels, f) == w * h * (size_t)channels;
+    }
+    return fclose(f) == 0 && ok ? 0 : -1;
+}
+
+/* the reference's decompress flow, example/src/icer_util.c:248-365 */
+static int decompress_file(const char *prog, const char *in, const char *out, int stages, enum icer_filter_types filt, int segments,
+                           int force_color, int force_gray)
+{
+    if (!force_color && !force_gray) { fprintf(stderr, "%s: decompress needs --color or --grayscale (the stream does not say)\n", prog); return 1; }
+    FILE *f = fopen(in, "rb");
+    if (!f) { fprintf(stderr, "%s: cannot open %s\n", prog, in); return 1; }
+    fseek(f, 0, SEEK_END);
+    const long len = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t *data = (uint8_t *)malloc((size_t)len + 1);
+    if (!data || fread(data, 1, (size_t)len, f) != (size_t)len) { fprintf(stderr, "%s: cannot read %s\n", prog, in); fclose(f); return 1; }
+    fclose(f);
+    printf("stream %s: %ld bytes\n", in, len);
+    size_t w = 0, h = 0, aw = 0, ah = 0;
+    if (icer_get_image_dimensions(data, (size_t)len, &w, &h) != ICER_RESULT_OK) { fprintf(stderr, "%s: no valid packet in %s\n", prog, in); return 1; }
+    printf("image %zu x %zu, decoding as %s with %d stages, filter %d, %d segments\n", w, h, force_color ? "Y Cb Cr" : "gray", stages, (int)filt, segments);
+    const size_t n = w * h;
+    uint16_t *pl[3] = {NULL, NULL, NULL};
+    for (int k = 0; k < 3; k++) pl[k] = (uint16_t *)calloc(n, sizeof(uint16_t));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int rc = force_color ? icer_decompress_image_yuv_uint16(pl[0], pl[1], pl[2], &aw, &ah, n, data, (size_t)len, (uint8_t)stages, filt, (uint8_t)segments)
+                               : icer_decompress_image_uint16(pl[0], &aw, &ah, n, data, (size_t)len, (uint8_t)stages, filt, (uint8_t)segments);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (rc != ICER_RESULT_OK) {
+        fprintf(stderr, "decode failed: status %d (%s); were -s -f -g the ones the stream was made with?\n", rc, icerx_decoder_last_error());
+        return 1;
+    }
+    printf("decode call took %.3f s\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    uint8_t *px = (uint8_t *)malloc(n * (force_color ? 3 : 1));
+    for (size_t i = 0; i < aw * ah; i++) {
+        if (force_color) {
+            const int y = pl[0][i], cb = pl[1][i], cr = pl[2][i];
+            px[3 * i] = (uint8_t)clip255(y + ((91881 * cr) >> 16) - 179);
+            px[3 * i + 1] = (uint8_t)clip255(y - ((22544 * cb + 46793 * cr) >> 16) + 135);
+            px[3 * i + 2] = (uint8_t)clip255(y + ((116129 * cb) >> 16) - 226);
+        } else px[i] = pl[0][i] > 255 ? 255 : (uint8_t)pl[0][i];
+    }
+    if (save_image(out, px, aw, ah, force_color ? 3 : 1)) { fprintf(stderr, "cannot write %s\n", out); return 1; }
+    printf("wrote %s (%zu x %zu, %s)\n", out, aw, ah, force_color ? "colour" : "gray");
+    for (int k = 0; k < 3; k++) free(pl[k]);
+    free(px);
+    free(data);
+    return 0;
+}
+
 static void usage(const char *prog)
 {
-    printf("usage: %s compress <input> <output> [options]\n\n", prog);
+    printf("usage: %s compress|decompress <input> <output> [options]\n\n", prog);
     printf("options:\n");
     printf("  -s, --stages <n>      DWT decomposition levels, 1..6 [4]\n");
     printf("  -f, --filter <type>   lifting filter: A B C D E F Q [A]\n");
@@ -127,8 +210,9 @@ static void usage(const char *prog)
     printf("  -G, --grayscale       encode one luminance plane\n");
     printf("  -t, --size <bytes>    byte quota of the stream [0 = lossless: one byte per sample]\n");
     printf("      --help            this text\n\n");
-    printf("input: binary PGM/PPM (maxval 255) or uncompressed 8/24/32-bit BMP.  Encoding runs on the GPU (libicer_hip.so);\n");
-    printf("decompress is not part of this library, use the reference's icer_util for it.\n");
+    printf("compress: input = binary PGM/PPM (maxval 255) or uncompressed 8/24/32-bit BMP; runs on the GPU (libicer_hip.so).\n");
+    printf("decompress: needs -c or -G and the -s -f -g the stream was made with; runs on the GPU (libicer_hip_dec.so);\n");
+    printf("            writes a 24-bit BMP (output name *.bmp) or a binary PGM / PPM.\n");
 }
 
 int main(int argc, char **argv)
@@ -155,8 +239,8 @@ int main(int argc, char **argv)
     if (force_color && force_gray) { fprintf(stderr, "%s: --color and --grayscale exclude each other\n", argv[0]); return 1; }
     if (optind + 2 >= argc) { fprintf(stderr, "%s: expected <operation> <input> <output>\n", argv[0]); usage(argv[0]); return 1; }
     const char *op = argv[optind], *in = argv[optind + 1], *out = argv[optind + 2];
-    if (strcmp(op, "decompress") == 0) { fprintf(stderr, "%s: 'decompress' is not part of this tool (see libicer_hip_dec.so / the reference's icer_util)\n", argv[0]); return 2; }
-    if (strcmp(op, "compress") != 0) { fprintf(stderr, "%s: the only operation is 'compress'\n", argv[0]); return 1; }
+    if (strcmp(op, "decompress") == 0) return decompress_file(argv[0], in, out, stages, filt, segments, force_color, force_gray);
+    if (strcmp(op, "compress") != 0) { fprintf(stderr, "%s: the operations are 'compress' and 'decompress'\n", argv[0]); return 1; }
     if (icer_init() != ICER_RESULT_OK) { fprintf(stderr, "%s: icer_init failed\n", argv[0]); return 1; }
 
     image_t im = {0, 0, 0, NULL};
