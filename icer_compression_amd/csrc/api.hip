@@ -113,6 +113,15 @@ struct icerx_encoder {
     DevBuf<uint32_t> sig_blocks;        // Plan::sig_blocks on the device
     DevBuf<uint8_t> route;              // max_frames * units: the coder of each unit when both share a launch
     DevBuf<uint32_t> route_list, route_ctl;   // the units of the workgroup coder (frame * units + unit), [length, cursor]
+    // sub-range splitting (coder_core.hpp "Sub-ranges"): launches of at most split_frames planes cut their dense units into
+    // pieces of about split_chunks chunks, one workgroup each (ICER_HIP_SPLIT=<chunks, 0 = off>, ICER_HIP_SPLIT_FRAMES)
+    uint32_t split_chunks = 3072;
+    int split_frames = 1;
+    bool last_split = false;
+    DevBuf<SubDesc> subs;
+    DevBuf<uint32_t> sub_order, snap_valid;
+    DevBuf<Snapshot> snaps;
+    DevBuf<SubRecord> sub_recs;
     hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
     hipEvent_t fork = nullptr, join = nullptr;
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
@@ -190,8 +199,16 @@ rgb8_to_ycbcr_kernel(const uint8_t *__restrict__ rgb, uint16_t *__restrict__ pla
 int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
 {
     if (e->units_uploaded && e->slot_quota == quota) return 0;
-    assign_slots(&e->plan, quota, e->bits_per_pixel);
+    // (sub-ranges are planned for encoders of a few planes only: they are used in launches of at most split_frames planes, and
+    // their private slot areas and snapshots are per frame)
+    const bool plan_split = e->wg_available && e->coder_mode == 0 && e->max_frames * e->channels <= 4 && e->split_frames > 0;
+    assign_slots(&e->plan, quota, e->bits_per_pixel, plan_split ? e->split_chunks : 0u);
     const size_t n = e->plan.units.size();
+    if (!e->plan.subs.empty()) {
+        if (e->subs.ensure(e->plan.subs.size()) || e->sub_order.ensure(e->plan.split_launch.size())) return ICER_FATAL_ERROR;
+        HIP_TRY(hipMemcpyAsync(e->subs.p, e->plan.subs.data(), e->plan.subs.size() * sizeof(SubDesc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e->sub_order.p, e->plan.split_launch.data(), e->plan.split_launch.size() * 4, hipMemcpyHostToDevice, st));
+    }
     if (e->units.ensure(n) || e->work_order.ensure(n) || e->final_order.ensure(n)) return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpyAsync(e->units.p, e->plan.units.data(), n * sizeof(UnitDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(e->work_order.p, e->plan.work_order.data(), n * 4, hipMemcpyHostToDevice, st));
@@ -290,7 +307,12 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     const bool use_wg = e->wg_available && (e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive));
     // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
     // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
-    const bool hybrid = e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames;
+    // a launch of very few planes (a single frame) cannot fill the chip with whole coding units: its dense units are cut into
+    // sub-ranges, one workgroup each, and its all-but-blank ones go to the small workgroup coder as in a batch
+    const bool split = e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->split_chunks && n_frames * C <= e->split_frames &&
+                       !e->plan.subs.empty() && e->hybrid_percent > 0;
+    e->last_split = split;
+    const bool hybrid = split || (e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames);
     if (use_wg || hybrid) {
         hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,
@@ -301,7 +323,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     if (hybrid) {
         HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
-                           (uint32_t)e->hybrid_percent, 16u, e->route.p, e->route_list.p, e->route_ctl.p);
+                           (uint32_t)(split && e->hybrid_percent > 90 ? 90 : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p);
         route = e->route.p;
         // the workgroup coder takes its list on a second stream, beside the pipeline kernel (it is submitted first: its
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
@@ -313,21 +335,35 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                            e->plan.sig_bytes, e->route_list.p, e->route_ctl.p);
         HIP_TRY(hipEventRecord(e->join, e->side_stream));
     }
+    SplitLaunch sp;
+    if (split) {
+        const size_t entries = e->plan.sub_entries;
+        if (e->snaps.ensure((size_t)e->max_frames * entries * kMaxSnaps) || e->snap_valid.ensure((size_t)e->max_frames * entries * kMaxSnaps) ||
+            e->sub_recs.ensure((size_t)e->max_frames * entries)) return ICER_FATAL_ERROR;
+        HIP_TRY(hipMemsetAsync(e->snap_valid.p, 0, (size_t)n_frames * entries * kMaxSnaps * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(e->sub_recs.p, 0, (size_t)n_frames * entries * sizeof(SubRecord), st));
+        sp.subs = e->subs.p; sp.launch = e->sub_order.p; sp.n_subs = (uint32_t)e->plan.subs.size(); sp.entries = (uint32_t)entries;
+        sp.snaps = e->snaps.p; sp.snap_valid = e->snap_valid.p; sp.recs = e->sub_recs.p;
+    }
     if (!use_wg) {
         // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
         // largest units, which the large shape (two pixel waves, golomb state wave + two workers) shortens; a batch wants
         // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|11 pins one (measurements).
-        const bool large = e->pipe_waves ? e->pipe_waves == kUnitWavesLarge : n_frames == 1;
+        // (a split launch fills the chip: the small shape's occupancy, measured 6.63 against 6.78 ms on the headline frame)
+        const bool large = e->pipe_waves ? e->pipe_waves == kUnitWavesLarge : (n_frames == 1 && !split);
         if (large)
-            hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units, n_frames), dim3(64 * kUnitWavesLarge), 0, st,
+            hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units + sp.n_subs, n_frames), dim3(64 * kUnitWavesLarge), 0, st,
                                reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                                progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route);
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp);
         else
-            hipLaunchKernelGGL(code_units_kernel<kUnitWavesSmall>, dim3(n_units, n_frames), dim3(64 * kUnitWavesSmall), 0, st,
+            hipLaunchKernelGGL(code_units_kernel<kUnitWavesSmall>, dim3(n_units + sp.n_subs, n_frames), dim3(64 * kUnitWavesSmall), 0, st,
                                reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
                                progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route);
+                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp);
+        if (split)
+            hipLaunchKernelGGL(splice_units_kernel, dim3(n_units, n_frames), dim3(64), 0, st, e->units.p, n_units, e->tables.p, e->means.p, skip, C,
+                               (uint32_t)W, (uint32_t)H, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, route, sp);
         if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join, 0));
     }
     if (use_wg)
@@ -400,6 +436,8 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *hy = getenv("ICER_HIP_HYBRID")) { const int v = atoi(hy); if (v >= 0 && v <= 100) e->hybrid_percent = v; }
     if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
+    if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }
+    if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -460,6 +498,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->sig_blocks.release(); e->route.release(); e->route_list.release(); e->route_ctl.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
+    e->subs.release(); e->sub_order.release(); e->snap_valid.release(); e->snaps.release(); e->sub_recs.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->done) (void)hipEventDestroy(e->done);
     if (e->fork) (void)hipEventDestroy(e->fork);

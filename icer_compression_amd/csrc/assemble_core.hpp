@@ -107,6 +107,65 @@ template <class SharedT> ICER_DEV void finish_unit_wave(SharedT &s, const Finish
 }
 
 // ------------------------------------------------------------------------------------------
+// Sub-ranges (coder_core.hpp): the payload of a unit that was coded by several workgroups.
+// Workgroup 0's bits are in the unit's own slot from bit 0; every workgroup that was matched into continues the
+// payload from the bit position of the matched snapshot in ITS slot.  Appends those pieces (bit-granular copies) to the
+// unit's slot and returns the payload length in bits, or kUnitTooBig / kUnitFailed as the coder reports them.
+//   rec[i]          what workgroup i left (SubRecord)
+//   snaps           [K][kMaxSnaps]
+//   sub_words[i]    payload words of workgroup i's private slot (i >= 1), sub_words[0] = the unit's payload words
+// One wavefront.
+// ------------------------------------------------------------------------------------------
+ICER_DEV uint32_t splice_unit_wave(uint32_t n_sub, const SubRecord *rec, const Snapshot *snaps, uint32_t *const *sub_words, uint32_t cap_words)
+{
+    DECL_LANE;
+    uint32_t *dst = sub_words[0];
+    uint32_t cur = 0, out_bits = 0;
+    // walk the chain: piece of workgroup `cur` = its bits [from, rec[cur].end_bits)
+    uint32_t from = 0;
+    for (uint32_t hop = 0; hop < n_sub; hop++) {
+        const SubRecord r = rec[cur];
+        if (!r.done) return kUnitFailed;
+        if (r.end_bits == kUnitTooBig || r.end_bits == kUnitFailed) return r.end_bits;
+        if (r.end_bits < from) return kUnitFailed;
+        const uint32_t len = r.end_bits - from;
+        if (((uint64_t)out_bits + len + 31u) / 32u > cap_words) return kUnitTooBig;
+        if (cur != 0 && len) {
+            // dst bits [out_bits, out_bits + len) = src bits [from, from + len)
+            const uint32_t *src = sub_words[cur];
+            const uint32_t w0 = out_bits >> 5, w1 = (out_bits + len + 31u) >> 5;         // dst words [w0, w1)
+            const uint32_t keep = out_bits & 31u;                                        // bits of dst[w0] that are already there
+            const uint32_t src_words = (r.end_bits + 31u) >> 5;
+            FOR_LANES
+            {
+                for (uint32_t w = w0 + (uint32_t)lane; w < w1; w += 64u) {
+                    // source bit that lands on bit 0 of dst word w (negative for the first word when keep != 0)
+                    const int64_t q = (int64_t)from + ((int64_t)w * 32 - (int64_t)out_bits);
+                    uint32_t v;
+                    if (q < 0) v = src[0] << (uint32_t)(-q);
+                    else {
+                        const uint32_t qi = (uint32_t)(q >> 5), sh = (uint32_t)q & 31u;
+                        const uint32_t lo = src[qi], hi = (sh && qi + 1u < src_words) ? src[qi + 1u] : 0u;
+                        v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+                    }
+                    // bits beyond the end of the piece are zero (so that the next piece can be OR-ed in)
+                    const uint32_t endbit = out_bits + len;
+                    if ((w + 1u) * 32u > endbit) v &= (endbit & 31u) ? ((1u << (endbit & 31u)) - 1u) : (w * 32u < endbit ? ~0u : 0u);
+                    if (w == w0 && keep) v = (v & ~((1u << keep) - 1u)) | (dst[w] & ((1u << keep) - 1u));
+                    dst[w] = v;
+                }
+            }
+            WAVE_SYNC();
+        }
+        out_bits += len;
+        if (r.match_sub == 0u) return out_bits;                             // this workgroup coded to the unit's end
+        from = snaps[r.match_sub * kMaxSnaps + r.match_snap].bitpos;
+        cur = r.match_sub;
+    }
+    return kUnitFailed;                                                     // (a chain longer than the unit has sub-ranges: corrupt records)
+}
+
+// ------------------------------------------------------------------------------------------
 // Quota walk + final offsets for one frame.
 //   bits[u]         payload bits of unit u (priority order), kUnitTooBig if it overflowed its slot
 //   final_order[j]  unit index of the j-th unit in final stream order

@@ -102,6 +102,23 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define kPollLimit kSpinLimit
 #endif
 
+// cross-WORKGROUP hand-off through global memory (sub-range snapshots): data stored before ICER_AGENT_PUBLISH is visible to a
+// workgroup on another compute unit that has seen the flag with ICER_AGENT_ACQUIRE (agent scope: the per-CU vector L1 and the
+// per-XCD L2 are not coherent by themselves, MI355X_MICROARCH.md "Correctness boundaries")
+#if defined(ICER_WAVE_EMU)
+#define ICER_AGENT_PUBLISH(ptr, v) { __atomic_store_n((ptr), (v), __ATOMIC_RELEASE); }
+#define ICER_AGENT_ACQUIRE(ptr) __atomic_load_n((ptr), __ATOMIC_ACQUIRE)
+#else
+#define ICER_AGENT_PUBLISH(ptr, v) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); if (lane == 0) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define ICER_AGENT_ACQUIRE(ptr) icer_agent_acquire_load(ptr)
+static __device__ __forceinline__ uint32_t icer_agent_acquire_load(const uint32_t *ptr)
+{
+    const uint32_t v = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return v;
+}
+#endif
+
 #if !defined(ICER_WAVE_EMU) || defined(ICER_WAVE_THREADS)
 // Every spin is bounded (kPollLimit polls, seconds of wall time): a wave that would wait longer declares the unit
 // failed (abort = 2), which every other wait observes; the host then reports ICER_FATAL_ERROR instead of hanging.
@@ -176,7 +193,7 @@ constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between
 // run lengths itself; three workgroups per CU, for batches (more waves per unit cost a batch a quarter of its throughput,
 // gpurun_out/r02r) -- and 11 waves -- two pixel waves, golomb state wave + two workers; two workgroups per CU, a shorter
 // chain per chunk, for a launch that cannot fill the chip anyway (a single frame).
-constexpr uint32_t kMaxPixelWaves = 2, kMaxGolombWorkers = 2;
+constexpr uint32_t kMaxPixelWaves = 8, kMaxGolombWorkers = 2;   // (8 pixel waves: the counts-only prefix pass of a sub-range workgroup)
 constexpr int kUnitWavesSmall = 8, kUnitWavesLarge = 11;
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
 constexpr int kProfWords = 9 * 32 + 4 * kTraceUnits + 16;     // + HW_ID of each wave of workgroup 0
@@ -197,6 +214,7 @@ struct EventSlot {              // count wave -> walker, golomb and merge waves
     uint8_t ev1[64];            // magnitude-bit event of pixel `lane`: 0x80 | bit << 5 | bin, 0 = none
     uint8_t ev2[64];            // sign event of pixel `lane`
     uint32_t blank;             // 1: the chunk is 64 zero events of context 0 and nothing else (PixelSlot::cn[17])
+    uint32_t cnt[kNumBins + 1]; // the adaptive counts after this chunk, context c: zero | total << 16 (sub-range splicing: part of the coder state)
     // bins 1..7, compacted per bin in coding order (rank = number of earlier events of the same bin):
     uint8_t rk1[64], rk2[64];   // rank of this lane's events inside their bin
     uint8_t binseq[8][128];     // rank -> position of the event
@@ -252,12 +270,64 @@ struct CoderShared {
     uint32_t hold_seq, hold_ack, drain_exit;
     uint32_t nchunks;           // chunks of the unit
     // progress counters of the three waves (chunks completed) and the per-chunk verdicts
-    uint32_t p_done[4];         // per pixel wave: 1 + the last chunk it has handed over
+    uint32_t p_done[kMaxPixelWaves];   // per pixel wave: 1 + the last chunk it has handed over
     uint32_t a_done, c_done, b_done, abort;
     uint32_t abort_site;        // who set abort = 2: source line | wave << 16 (GPU build; diagnostics only)
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
     // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
     uint32_t exact_seq, last_exact;
+};
+
+// ------------------------------------------------------------------------------------------
+// Sub-ranges: several workgroups per coding unit (launches too small to fill the chip: a single frame)
+// ------------------------------------------------------------------------------------------
+// A dense unit is a chain of thousands of chunks, and a frame has fewer such units than the chip has compute units.  The
+// unit's chunk range is therefore cut into K sub-ranges, each coded by a workgroup of its own, all at the same time.
+// Workgroup i (first chunk c_i) cannot know the coder state at c_i -- the open code word of every bin, the ring --, but:
+//   * the adaptive counts at c_i depend on the coefficients before c_i alone: the workgroup first runs the pixel and count
+//     stages over [0, c_i) with all its waves (count_wave_run(counts_only), a fraction of the full cost per chunk);
+//   * started COLD (no open words, empty ring) with the exact counts, its bins are the exact ones from the first event on,
+//     and its state converges to the true one: a Golomb bin is in step after its first one-event, a variable-to-variable
+//     bin once both walks meet in a tree node, the ring once every word that was open at c_i has been closed (on dense bit
+//     planes: after 66 chunks on average, 587 at most, tests/research/heal_experiment.c).
+// Exactness does not rest on that expectation.  Workgroup i writes SNAPSHOTS of its complete coder state (counts, every
+// bin's state and open slot, the ring from its oldest word to its tail, its bit position) every kSnapEvery chunks after c_i;
+// the workgroup before it keeps coding past c_i and compares ITS state with the snapshot at the same chunk.  Equal states
+// and equal input from there on give equal output, so it stops: the unit's payload is its bits up to that point followed
+// by workgroup i's bits from the snapshot's bit position on (splice_unit_wave).  Without a match (sparse planes, where words
+// stay open for thousands of chunks) it simply codes on -- through the whole unit if need be, which is what a unit that
+// is not split costs.  Nothing ever waits for another workgroup.
+#ifndef ICER_SNAP_EVERY
+#define ICER_SNAP_EVERY 64
+#endif
+constexpr uint32_t kSnapEvery = ICER_SNAP_EVERY;   // chunks between snapshots (the tests-only CPU build also runs with 4: small units)
+constexpr uint32_t kMaxSnaps = 16;              // snapshots per sub-range (up to 1024 chunks past its first chunk)
+constexpr uint32_t kMaxSubs = 8;                // sub-ranges per unit
+
+struct Snapshot {                               // global memory
+    uint32_t chunk;                             // state BEFORE this chunk
+    uint32_t bitpos;                            // the writer's payload bits so far (everything finished is popped)
+    uint32_t nring;                             // ring words from the oldest (open) word to the tail
+    uint32_t cnt[kNumBins];                     // adaptive counts (EventSlot::cnt)
+    uint32_t bin_state[kNumBins];               // CoderShared::bin_state >> 8
+    uint32_t open_off[kNumBins];                // ring offset of the bin's open word from the oldest word, ~0 = none
+    uint32_t pad[12];
+    uint16_t ring[kRingWords];
+};
+struct SubRecord {                              // what a workgroup of a split unit leaves behind (global memory)
+    uint32_t done;                              // 1 once the fields below are valid
+    uint32_t end_chunk;                         // it coded [its first chunk, end_chunk)
+    uint32_t end_bits;                          // payload bits in its slot (kUnitTooBig / kUnitFailed as unit_bits)
+    uint32_t match_sub, match_snap;             // stopped because its state equalled this snapshot (match_sub 0: ran to the unit's end)
+    uint32_t pad[3];
+};
+struct SubLayout {                              // one per (frame, split unit), built by the kernel from the plan's tables
+    uint32_t n_sub;                             // K
+    uint32_t index;                             // this workgroup's sub-range
+    uint32_t first[kMaxSubs + 1];               // first chunk of every sub-range; first[K] = chunks of the unit
+    Snapshot *snaps;                            // [K][kMaxSnaps] (row 0 unused)
+    uint32_t *snap_valid;                       // [K][kMaxSnaps], 1 once the snapshot is complete (agent-scope release / acquire)
+    SubRecord *rec;                             // [K]
 };
 
 struct UnitArgs {
@@ -273,6 +343,8 @@ struct UnitArgs {
     const uint32_t *done_bytes;
     uint32_t prio_index;
     uint64_t early_quota;
+    // sub-range splicing (see "Sub-ranges" below): null / 0 when the unit is coded by one workgroup from its first chunk
+    const SubLayout *sub = nullptr;
 };
 
 // Progressive mode.  The stream keeps units in priority order until the first one that does not fit the byte quota
@@ -562,6 +634,7 @@ struct PixelWave {                // next chunk's 3x3 coefficient window, one pi
     LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
     LANEVAR(uint32_t, has);                             // which neighbours exist: bit 0 W, 1 E, 2 N, 3 S
     LANEVAR(uint32_t, row); LANEVAR(uint32_t, col);     // raster coordinates of this lane's pixel in the next chunk
+    uint32_t fetched = ~0u;                             // chunk whose window is in the registers above (~0: none yet)
 };
 
 // fetch the 3x3 windows of the 64 pixels starting at BASE; (cw.row, cw.col) = raster coordinates of pixel
@@ -610,8 +683,9 @@ ICER_DEV void pixel_tables_init(CoderShared &s, const UnitArgs &a)
     WAVE_SYNC();
 }
 
-// pixel wave k of npw: its chunks (j % npw == k) among [j0, j1); its first call must include its first chunk, k
-ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw)
+// pixel wave k of npw: its chunks (j % npw == k) among [j0, j1); consecutive calls continue the window prefetch (cw.fetched)
+// `counts_only`: for the counts-only pass of the count wave -- the events' context / bit and the per-context totals, no ranks
+ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw, bool counts_only = false)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -619,13 +693,14 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
     const uint32_t lsb = (uint32_t)a.lsb;
     const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
     const uint32_t jfirst = j0 + (k + npw - j0 % npw) % npw;                        // first chunk >= j0 of this wave
-    if (jfirst == k && k * 64u < npix) {
+    if (cw.fetched != jfirst && jfirst * 64u < npix) {                                // (first call, or a new start: no window in flight)
         FOR_LANES
         {
-            const uint32_t np = k * 64u + (uint32_t)lane;
+            const uint32_t np = jfirst * 64u + (uint32_t)lane;
             LV(cw.row) = np / a.w; LV(cw.col) = np - LV(cw.row) * a.w;
         }
-        ICER_FETCH_WINDOW(k * 64u)
+        ICER_FETCH_WINDOW(jfirst * 64u)
+        cw.fetched = jfirst;
     }
 
     for (uint32_t j = jfirst; j < j1; j += npw) {
@@ -645,6 +720,7 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         }
         // this wave's next chunk's window is fetched while this one is processed (the LDS-only fences never drain vmcnt)
         if (base + 64u * npw < npix) ICER_FETCH_WINDOW(base + 64u * npw)
+        cw.fetched = j + npw;
 
         // ---- context formation (C1-C6) ------------------------------------------------------------
         FOR_LANES
@@ -718,14 +794,17 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
                 LV(w1) = 0; LV(w2) = 0; LV(cnw) = 0;
                 if (LV(valid1)) {
                     LV(w1) = 0x80u | (LV(bit1) << 5) | LV(ctx1);
-                    if (LV(ctx1) != 31u) {
+                    if (LV(ctx1) != 31u && !counts_only) {
                         const uint64_t m = ICER_MATCH(LV(ctx1), V, B0, B1, B2, B3);
                         LV(w1) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZM, lane) << 16);
                     }
                 }
                 if (LV(valid2)) {
-                    const uint64_t m = ICER_MATCH(LV(ctx2) - 12u, U, C0, C1, C2, 0ull);
-                    LV(w2) = 0x80u | (LV(bit2) << 5) | LV(ctx2) | ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZN, lane) << 16);
+                    LV(w2) = 0x80u | (LV(bit2) << 5) | LV(ctx2);
+                    if (!counts_only) {
+                        const uint64_t m = ICER_MATCH(LV(ctx2) - 12u, U, C0, C1, C2, 0ull);
+                        LV(w2) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZN, lane) << 16);
+                    }
                 }
                 if (lane < 12) {
                     const uint64_t m = ICER_MATCH((uint32_t)lane, V, B0, B1, B2, B3);
@@ -763,7 +842,9 @@ struct CountWave {              // lane c: adaptive counts of context c (icer_co
     LANEVAR(uint32_t, ctot);
 };
 
-ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1, uint32_t npw)
+// `counts_only`: advance the counts over [j0, j1) and nothing else -- no bins, no events for the other waves (the prefix pass of a
+// sub-range workgroup: the adaptive counts at its first chunk depend on the coefficients before it alone)
+ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1, uint32_t npw, bool counts_only = false)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -778,6 +859,39 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         if (ab_) break;
         ICER_TICK(2)
         const PixelSlot &in = s.pq[j % kQueueDepth];
+        if (counts_only) {
+            // the per-context totals of the chunk; its events are looked at only when a context reaches the rescale point
+            LANEVAR(uint32_t, cross);
+            FOR_LANES
+            {
+                const uint32_t w = lane < 17 ? (uint32_t)in.cn[lane] : 0u;
+                LV(cross) = 0;
+                if (lane < 17) {
+                    if (LV(ctot) + (w & 255u) < kRescaleCap) { LV(ctot) += w & 255u; LV(czer) += w >> 8; }
+                    else LV(cross) = 1;
+                }
+            }
+            uint64_t rem = BALLOT(LV(cross) != 0u);
+            if (rem) {
+                LANEVAR(uint32_t, v1); LANEVAR(uint32_t, c1); LANEVAR(uint32_t, b1); LANEVAR(uint32_t, v2); LANEVAR(uint32_t, c2); LANEVAR(uint32_t, b2);
+                LANEVAR(uint32_t, zo); LANEVAR(uint32_t, to);
+                FOR_LANES
+                {
+                    const uint32_t e1 = in.e[lane][0], e2 = in.e[lane][1];
+                    LV(v1) = (e1 >> 7) & 1u; LV(c1) = e1 & 31u; LV(b1) = (e1 >> 5) & 1u;
+                    LV(v2) = (e2 >> 7) & 1u; LV(c2) = e2 & 31u; LV(b2) = (e2 >> 5) & 1u;
+                    LV(zo) = 0; LV(to) = 0;
+                }
+                (void)zo; (void)to;             // (ICER_CTX_STEP also leaves what every event sees: not needed here)
+                for (; rem; rem &= rem - 1ull) {
+                    const uint32_t c = (uint32_t)ffs64(rem);
+                    if (c < 12u) ICER_CTX_STEP(c, LV(v1) && LV(c1) == c, LV(b1) == 0u, zo, to)
+                    else ICER_CTX_STEP(c, LV(v2) && LV(c2) == c, LV(b2) == 0u, zo, to)
+                }
+            }
+            ICER_PUBLISH(s.a_done, j + 1u)
+            continue;
+        }
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
         LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
@@ -862,6 +976,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
             q.ev1[lane] = (uint8_t)LV(ev1);
             q.ev2[lane] = (uint8_t)LV(ev2);
             if (lane == 0) q.blank = in.cn[17];
+            if (lane < kNumBins) q.cnt[lane] = LV(czer) | (LV(ctot) << 16);
         }
         ICER_PUBLISH(s.a_done, j + 1u)
     }
@@ -955,7 +1070,7 @@ struct WalkWave {
     uint32_t next, gen;         // next chunk to walk; generation (= number of exact-path chunks seen)
 };
 
-ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
+ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww, uint32_t j0 = 0)
 {
     DECL_LANE;
     FOR_LANES
@@ -964,7 +1079,7 @@ ICER_DEV void walk_wave_init(CoderShared &s, WalkWave &ww)
         LV(ww.cb) = (lane >= 1 && lane <= 7) ? (uint32_t)lane : (uint32_t)s.tab.cand_bin[lane];
         LV(ww.ce) = LV(ww.cb) ? (uint32_t)s.tab.node_c[LV(ww.cb) & 7u][s.tab.cand_node[lane]] & 7u : 0u;
     }
-    ww.next = 0;
+    ww.next = j0;
     ww.gen = 0;
 }
 
@@ -1136,9 +1251,9 @@ struct GolombWave {             // golomb state wave and golomb workers (the sta
     uint32_t next, gen;         // as WalkWave
 };
 
-ICER_DEV void golomb_wave_init(GolombWave &gw)
+ICER_DEV void golomb_wave_init(GolombWave &gw, uint32_t j0 = 0)
 {
-    gw.next = 0;
+    gw.next = j0;
     gw.gen = 0;
 }
 
@@ -1228,7 +1343,7 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
     // lengths from CoderShared::gk and leaves the new ones there itself
     const bool fused = ngw == 0u;
     const uint32_t step = fused ? 1u : ngw;
-    if (!fused && gw.next % ngw != k) gw.next = k;              // (first call)
+    if (!fused && gw.next % ngw != k) gw.next += (k + ngw - gw.next % ngw) % ngw;     // (first call: this worker's first chunk)
     for (;;) {
         const uint32_t ab_ = ICER_LOAD_CNT(s.abort), seq = ICER_LOAD_CNT(s.exact_seq), ad_ = ICER_LOAD_CNT(s.a_done);
         if (ab_) break;
@@ -1675,7 +1790,7 @@ ICER_DEV bool hybrid_chunk(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t t
 // Records wave: once the walker wave has walked chunk r, every event lane of bins 1..7 derives from the bin's
 // start flags whether a code word starts / ends at its event and, for an end, the finished ring word and the
 // position of the word's first event.  `max_steps` bounds one call in the emulation (the GPU passes ~0u).
-struct RecordsWave { uint32_t next = 0, gen = 0; };     // next chunk / generation, as WalkWave
+struct RecordsWave { uint32_t next = 0, gen = 0; };     // next chunk / generation, as WalkWave (next = the workgroup's first chunk)
 
 ICER_DEV void records_wave_run(CoderShared &s, const UnitArgs &a, RecordsWave &rw, uint32_t max_steps)
 {
@@ -1806,8 +1921,66 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
 #endif
 #define ICER_DRAIN_RELEASE(S) { ICER_PUBLISH((S).hold_seq, ((S).hold_seq | 1u) + 1u) }
 
-// chunks [j0, j1); returns false when the unit was abandoned (payload slot too small)
-ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
+// ---- sub-ranges: snapshots of the coder state and the comparison with them (see "Sub-ranges" above) -----------------
+// Is `nj` (the chunk about to start) a point where this workgroup writes a snapshot of its own (*write_m) or compares its
+// state with a snapshot of a later sub-range (*match_t, *match_m)?
+ICER_DEV bool sub_checkpoint(const SubLayout &L, uint32_t nj, int *write_m, uint32_t *match_t, int *match_m)
+{
+    *write_m = -1; *match_m = -1; *match_t = 0;
+    const uint32_t i = L.index, end = L.first[L.n_sub];
+    if (nj >= end) return false;
+    if (i >= 1u && nj > L.first[i]) {
+        const uint32_t d = nj - L.first[i];
+        if (d % kSnapEvery == 0u && d / kSnapEvery <= kMaxSnaps) *write_m = (int)(d / kSnapEvery) - 1;
+    }
+    uint32_t t = L.n_sub - 1u;
+    while (t > i && nj <= L.first[t]) t--;                      // the latest sub-range start this workgroup has passed
+    if (t > i) {
+        const uint32_t d = nj - L.first[t];
+        if (d % kSnapEvery == 0u && d / kSnapEvery <= kMaxSnaps) { *match_t = t; *match_m = (int)(d / kSnapEvery) - 1; }
+    }
+    return *write_m >= 0 || *match_m >= 0;
+}
+
+// The coder state before chunk `nj`, with the drain wave parked and everything finished popped: written to `out` (writer)
+// or compared with `ref` (returns true when equal).  `q` = the event slot of chunk nj - 1 (its counts), `tail` = the
+// allocation count.  One wavefront.
+ICER_DEV bool sub_state(CoderShared &s, const EventSlot &q, uint32_t tail, uint32_t nj, Snapshot *out, const Snapshot *ref)
+{
+    DECL_LANE;
+    const uint32_t popped = s.popped, nring = tail - popped;
+    LANEVAR(uint32_t, bad);
+    FOR_LANES
+    {
+        LV(bad) = 0;
+        if (lane < kNumBins) {
+            const uint32_t cnt = q.cnt[lane], st = lane >= 1 ? s.bin_state[lane] >> 8 : 0u;
+            const uint32_t off = (lane >= 1 && s.bin_slot[lane] >= 0) ? (((uint32_t)s.bin_slot[lane] - popped) & (uint32_t)(kRingWords - 1)) : ~0u;
+            if (out) { out->cnt[lane] = cnt; out->bin_state[lane] = st; out->open_off[lane] = off; }
+            else LV(bad) = (ref->cnt[lane] != cnt || ref->bin_state[lane] != st || ref->open_off[lane] != off) ? 1u : 0u;
+        }
+        if (lane == 0) {
+            if (out) { out->chunk = nj; out->bitpos = s.bitpos; out->nring = nring; }
+            else if (ref->chunk != nj || ref->nring != nring) LV(bad) = 1u;
+        }
+    }
+    if (!out && BALLOT(LV(bad) != 0u)) return false;
+    FOR_LANES
+    {
+        for (uint32_t k = (uint32_t)lane; k < nring; k += 64u) {
+            const uint16_t w = (uint16_t)RING_LD((popped + k) & (uint32_t)(kRingWords - 1));
+            if (out) out->ring[k] = w;
+            else if (ref->ring[k] != w) LV(bad) = 1u;
+        }
+    }
+    return out ? true : BALLOT(LV(bad) != 0u) == 0ull;
+}
+
+constexpr uint32_t kMergeAbandoned = 0, kMergeDone = 1, kMergeMatched = 2;
+
+// chunks [j0, j1); returns kMergeAbandoned when the unit was abandoned (payload slot too small), kMergeMatched when the
+// workgroup's state equalled a later sub-range's snapshot (it has written its SubRecord and stopped), else kMergeDone
+ICER_DEV uint32_t merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uint32_t j1)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -1816,7 +1989,7 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
     for (uint32_t j = j0; j < j1; j++) {
         MergeChunk c;
         uint32_t popped_seen;
-        if (!merge_gather(s, c, j, gen, &popped_seen ICER_TIMER_PASS)) { ICER_TIMERS_STORE(a.timers) return false; }
+        if (!merge_gather(s, c, j, gen, &popped_seen ICER_TIMER_PASS)) { ICER_TIMERS_STORE(a.timers) return kMergeAbandoned; }
         // If the ring cannot fill up inside this chunk no forced flush (E5) is possible and word boundaries depend
         // on each bin alone: the speculative results say how many words the chunk opens *if* no flush happens, and
         // if they all fit none happens.  The drain wave's pop count may lag, which only over-estimates the
@@ -1827,7 +2000,7 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         ICER_COUNT(31)
         if (tail - popped_seen + nstarts > (uint32_t)kRingWords) {
             ICER_DRAIN_HOLD(s, a)
-            if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return false; }
+            if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return kMergeAbandoned; }
             held = true;
             // (two rounds = 128 words is all a chunk can need; whatever else is finished is left to the drain wave)
             wave_drain(s, tail, 2u);
@@ -1859,12 +2032,51 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
             }
             ICER_TICK(16)
         }
+        // sub-ranges: a snapshot of the state before the next chunk, or the comparison with a later sub-range's one
+        if (a.sub) {
+            int write_m, match_m;
+            uint32_t match_t;
+            if (sub_checkpoint(*a.sub, j + 1u, &write_m, &match_t, &match_m)) {
+                WAVE_SYNC();
+                if (!held) {
+                    ICER_DRAIN_HOLD(s, a)
+                    if (ICER_LOAD_CNT(s.abort)) { ICER_TIMERS_STORE(a.timers) return kMergeAbandoned; }
+                    held = true;
+                }
+                wave_drain(s, tail, ~0u);                         // everything finished is popped: the state is canonical
+                const EventSlot &q = s.eq[j % kQueueDepth];
+                const SubLayout &L = *a.sub;
+                if (write_m >= 0) {
+                    const uint32_t slot = L.index * kMaxSnaps + (uint32_t)write_m;
+                    sub_state(s, q, tail, j + 1u, &L.snaps[slot], nullptr);
+                    ICER_AGENT_PUBLISH(&L.snap_valid[slot], 1u)
+                }
+                if (match_m >= 0) {
+                    const uint32_t slot = match_t * kMaxSnaps + (uint32_t)match_m;
+                    if (ICER_AGENT_ACQUIRE(&L.snap_valid[slot]) == 1u && sub_state(s, q, tail, j + 1u, nullptr, &L.snaps[slot])) {
+                        // same state, same input from here on: the other workgroup's bits continue this one's
+                        const bool fits = flush_stage(s, a, true);
+                        FOR_LANES
+                        {
+                            if (lane == 0) {
+                                SubRecord &r = L.rec[L.index];
+                                r.end_chunk = j + 1u; r.end_bits = fits ? s.bitpos : kUnitTooBig; r.match_sub = match_t; r.match_snap = (uint32_t)match_m;
+                            }
+                        }
+                        ICER_AGENT_PUBLISH(&L.rec[L.index].done, 1u)
+                        ICER_PUBLISH(s.abort, 4u)
+                        ICER_TIMERS_STORE(a.timers)
+                        return kMergeMatched;
+                    }
+                }
+            }
+        }
         if (held) {
             // what this wave drained while holding goes out now (the drain wave only flushes after its own pops)
             if (!flush_stage(s, a, false)) {
                 ICER_PUBLISH(s.abort, 1u)
                 ICER_TIMERS_STORE(a.timers)
-                return false;
+                return kMergeAbandoned;
             }
             ICER_PUBLISH(s.alloc, tail)
             ICER_DRAIN_RELEASE(s)
@@ -1883,7 +2095,7 @@ ICER_DEV bool merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, uin
         ICER_TICK(17)
     }
     ICER_TIMERS_STORE(a.timers)
-    return true;
+    return kMergeDone;
 }
 
 // end of unit: park the drain wave for good, force-complete whatever is still open (C8,
@@ -1907,7 +2119,8 @@ ICER_DEV uint32_t merge_wave_finish(CoderShared &s, const UnitArgs &a)
 }
 
 // state every wave relies on; run by ONE wave before the others start (a workgroup barrier follows on the GPU)
-ICER_DEV void unit_state_init(CoderShared &s)
+// (`j0`: the workgroup's first chunk -- 0 unless it codes a later sub-range of the unit)
+ICER_DEV void unit_state_init(CoderShared &s, uint32_t j0 = 0)
 {
     DECL_LANE;
     FOR_LANES
@@ -1916,7 +2129,8 @@ ICER_DEV void unit_state_init(CoderShared &s)
         if (lane < kNumBins) { s.bin_slot[lane] = -1; s.bin_state[lane] = 0; s.gk[lane] = 0; }
         if (lane == 0) {
             s.alloc = 0; s.popped = 0; s.bitpos = 0; s.flushed_words = 0; s.hold_seq = 0; s.hold_ack = 0; s.drain_exit = 0;
-            s.p_done[0] = s.p_done[1] = s.p_done[2] = s.p_done[3] = 0; s.a_done = 0; s.c_done = 0; s.b_done = 0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
+            for (uint32_t i = 0; i < kMaxPixelWaves; i++) s.p_done[i] = j0;
+            s.a_done = j0; s.c_done = j0; s.b_done = j0; s.abort = 0; s.abort_site = 0; s.exact_seq = 0; s.last_exact = 0;
             for (uint32_t i = 0; i < kQueueDepth; i++) { s.wq[i].tag = 0; s.rq[i].rtag = 0; s.rq[i].gtag = 0; s.kq[i].tag = 0; }
         }
     }

@@ -90,8 +90,19 @@ finalize_ll_kernel(uint16_t *__restrict__ coef, size_t plane, uint32_t w, uint32
     *q = (uint16_t)to_coder_word(v, sample_bits);
 }
 
+// Sub-range splitting of a launch (coder_core.hpp "Sub-ranges"); n_subs = 0: off
+struct SplitLaunch {
+    const SubDesc *subs = nullptr;          // Plan::subs
+    const uint32_t *launch = nullptr;       // Plan::split_launch: n_units + n_subs entries
+    uint32_t n_subs = 0;                    // extra workgroups per frame
+    uint32_t entries = 0;                   // Plan::sub_entries: per-frame entries of the arrays below
+    Snapshot *snaps = nullptr;              // [frames][entries][kMaxSnaps]
+    uint32_t *snap_valid = nullptr;         // [frames][entries][kMaxSnaps]
+    SubRecord *recs = nullptr;              // [frames][entries]
+};
+
 // a launch shared by the two coders (route_units_kernel): which one takes a unit
-constexpr uint8_t kRoutePipeline = 0, kRouteWindows = 1;
+constexpr uint8_t kRoutePipeline = 0, kRouteWindows = 1, kRouteNoSplit = 2;   // (2: the pipeline, but not worth splitting: 20 .. `percent` % blank chunks)
 
 // ------------------------------------------------------------------------------------------ coder
 // One workgroup = one coding unit of one frame: pixel, count, compaction, walker, golomb state + workers, merge, records and
@@ -106,27 +117,34 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                   size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route)
+                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp)
 {
     __shared__ CoderShared s;
     const uint32_t frame = blockIdx.y;
-    // (two coders share a launch: a unit belongs to the one route_units_kernel names -- 0 here)
-    if (route && route[(size_t)frame * n_units + (work_order ? work_order[blockIdx.x] : blockIdx.x)] != kRoutePipeline) return;
+    // A split launch (sp.n_subs > 0) has extra workgroups for its split units: an entry of sp.launch with bit 31 set codes a later
+    // sub-range of a unit (coder_core.hpp "Sub-ranges"), the others one unit from its first chunk as always.
+    const uint32_t entry = sp.n_subs ? sp.launch[blockIdx.x] : (work_order ? work_order[blockIdx.x] : blockIdx.x);   // (null: priority order = unit order)
+    const bool sub_block = sp.n_subs != 0u && (entry >> 31) != 0u;
+    const SubDesc sd = sub_block ? sp.subs[entry & 0x7FFFFFFFu] : SubDesc{};
+    const uint32_t ui = sub_block ? sd.unit : entry;
+    // (two coders share a launch: a unit belongs to the one route_units_kernel names)
+    const uint8_t rt = route ? route[(size_t)frame * n_units + ui] : kRoutePipeline;
+    if (rt == kRouteWindows) return;
+    if (sub_block && rt != kRoutePipeline) return;                  // only dense units are split
 #ifdef ICER_PHASE_TIMERS
     uint64_t *trace = (timers && frame == 0 && blockIdx.x < (uint32_t)kTraceUnits) ? timers + 9 * 32 + 4 * blockIdx.x : nullptr;
     if (trace && threadIdx.x == 0) {
         trace[0] = wall_clock64();
         trace[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
-        trace[3] = work_order ? work_order[blockIdx.x] : blockIdx.x;
+        trace[3] = entry;
     }
     if (timers && frame == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
         timers[9 * 32 + 4 * kTraceUnits + (threadIdx.x >> 6)] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
-    const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
     const uint32_t wave = threadIdx.x >> 6;
     // DWT / mean overflow: the reference emits nothing.
     if (frame_skip[frame]) {
-        if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = 0;
+        if (threadIdx.x == 0 && !sub_block) unit_bits[(size_t)frame * n_units + ui] = 0;
         return;
     }
     const UnitDesc u = units[ui];
@@ -179,6 +197,25 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     a.subband = (int)u.subband; a.lsb = (int)u.lsb;
     a.out_words = slot_words + kHeaderBytes / 4;
     a.cap_words = u.cap_words;
+    // this workgroup's place among the sub-ranges of a split unit
+    __shared__ SubLayout layout;
+    const bool split = sp.n_subs != 0u && u.n_sub > 1u && rt == kRoutePipeline;
+    if (split) {
+        if (threadIdx.x == 0) {
+            layout.n_sub = u.n_sub;
+            layout.index = sub_block ? sd.index : 0u;
+            for (uint32_t i = 0; i <= u.n_sub; i++) layout.first[i] = sub_first_chunk((u.w * u.h + 63u) / 64u, u.n_sub, i);
+            const size_t e = (size_t)frame * sp.entries + u.sub_entry;
+            layout.snaps = sp.snaps + e * kMaxSnaps;
+            layout.snap_valid = sp.snap_valid + e * kMaxSnaps;
+            layout.rec = sp.recs + e;
+        }
+        a.sub = &layout;
+        if (sub_block) {
+            a.out_words = reinterpret_cast<uint32_t *>(slots + (size_t)frame * slot_frame_stride + sd.slot_off);
+            a.cap_words = sd.cap_words;
+        }
+    }
     a.done_bytes = early_quota ? done_bytes + (size_t)frame * n_units : nullptr;
     a.prio_index = ui;
     a.early_quota = early_quota;
@@ -188,31 +225,74 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     if (wave == kCount) pixel_tables_init(s, a);
     __syncthreads();
 
+    // A later sub-range starts with the adaptive counts at its first chunk j0: they depend on the coefficients before it
+    // alone -- the pixel stage (all waves but one) and the counts of the count stage over [0, j0), nothing else.
+    uint32_t j0 = 0;
+    CountWave cs;
+    if (split && sub_block) {
+        j0 = layout.first[layout.index];
+        constexpr uint32_t npw1 = (uint32_t)(WAVES - 1) < kMaxPixelWaves ? (uint32_t)(WAVES - 1) : kMaxPixelWaves;
+        const uint32_t k = wave < kCount ? wave : wave - 1u;
+        if (wave == kCount) count_wave_run(s, a, cs, 0, j0, npw1, true);
+        else if (k < npw1) {
+            PixelWave pw;
+            pixel_wave_run(s, a, pw, 0, j0, k, npw1, true);
+        }
+        __syncthreads();
+        const uint32_t ab1 = s.abort;               // (a bounded spin expired in the prefix pass: the workgroup reports failure)
+        __syncthreads();
+        if (ab1) {
+            if (wave == kMerge) {
+                SubRecord &r = layout.rec[layout.index];
+                if ((threadIdx.x & 63) == 0) { r.end_chunk = j0; r.end_bits = kUnitFailed; r.match_sub = 0; r.match_snap = 0; }
+                const int lane = (int)(threadIdx.x & 63);
+                ICER_AGENT_PUBLISH(&r.done, 1u)
+            }
+            return;
+        }
+        if (wave == 0) unit_state_init(s, j0);
+        __syncthreads();
+    }
+
     if (wave == kPixel || wave == kPixel2) {
         PixelWave pw;
-        pixel_wave_run(s, a, pw, 0, nchunks, wave == kPixel ? 0u : 1u, npw);
+        pixel_wave_run(s, a, pw, j0, nchunks, wave == kPixel ? 0u : 1u, npw);
     } else if (wave == kCount) {
-        CountWave cs;
-        count_wave_run(s, a, cs, 0, nchunks, npw);
+        count_wave_run(s, a, cs, j0, nchunks, npw);
     } else if (wave == kWalker) {
         WalkWave ww;
-        walk_wave_init(s, ww);
+        walk_wave_init(s, ww, j0);
         walk_wave_run(s, a, ww, nchunks, ~0u);
     } else if (wave == kGolomb || wave == kGolomb2) {
         GolombWave gw;
-        golomb_wave_init(gw);
+        golomb_wave_init(gw, j0);
         golomb_wave_run(s, a, gw, nchunks, ~0u, wave == kGolomb ? 0u : 1u, ngw);
     } else if (wave == kGolombState) {
         GolombWave gw;
-        golomb_wave_init(gw);
+        golomb_wave_init(gw, j0);
         golomb_state_run(s, a, gw, nchunks, ~0u);
     } else if (wave == kRecords) {
         RecordsWave rw;
+        rw.next = j0;
         records_wave_run(s, a, rw, ~0u);
     } else if (wave == kDrain) {
         drain_wave_run(s, a, ~0u);
     } else if (wave == kCompact) {
-        compact_wave_run(s, a, 0, nchunks);
+        compact_wave_run(s, a, j0, nchunks);
+    } else if (split) {
+        // a workgroup of a split unit leaves its record; splice_units_kernel makes the unit's payload, header and CRCs
+        const uint32_t how = merge_wave_run(s, a, j0, nchunks);
+        if (how != kMergeMatched) {
+            uint32_t bits = how == kMergeDone ? merge_wave_finish(s, a) : kUnitTooBig;
+            if (s.abort == 2u) bits = kUnitFailed;
+            SubRecord &r = layout.rec[layout.index];
+            if ((threadIdx.x & 63) == 0) { r.end_chunk = nchunks; r.end_bits = bits; r.match_sub = 0; r.match_snap = 0; }
+            const int lane = (int)(threadIdx.x & 63);
+            ICER_AGENT_PUBLISH(&r.done, 1u)
+        }
+#ifdef ICER_PHASE_TIMERS
+        if (trace && (threadIdx.x & 63) == 0) { trace[1] = wall_clock64(); trace[3] |= (uint64_t)(how == kMergeMatched ? layout.rec[layout.index].end_chunk : nchunks) << 32; }
+#endif
     } else {
         uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
         if (s.abort == 2u) {                          // a bounded spin expired: internal error, never a silent hang
@@ -251,6 +331,45 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         if (trace && (threadIdx.x & 63) == 0) trace[1] = wall_clock64();
 #endif
     }
+}
+
+// The units of a split launch that were coded by several workgroups: their payload from the workgroups' pieces
+// (splice_unit_wave), then header and CRCs like any unit.  grid = (units, frames), block = 64; units that were not split
+// (or went to the other coder) return at once.
+__global__ void __launch_bounds__(64)
+splice_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const CoderTables *__restrict__ tables,
+                    const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels, uint32_t img_w, uint32_t img_h,
+                    uint8_t *__restrict__ slots, size_t slot_frame_stride, uint32_t *__restrict__ unit_bits,
+                    const uint8_t *__restrict__ route, SplitLaunch sp)
+{
+    struct SpliceShared { uint32_t crc_tab[256]; struct { uint32_t x2n[32]; } tab; };
+    __shared__ SpliceShared s;
+    const uint32_t frame = blockIdx.y, ui = blockIdx.x;
+    const UnitDesc u = units[ui];
+    if (u.n_sub <= 1u || frame_skip[frame]) return;
+    if (route && route[(size_t)frame * n_units + ui] != kRoutePipeline) return;
+    build_crc_table(s);
+    if (threadIdx.x < 32) s.tab.x2n[threadIdx.x] = tables->x2n[threadIdx.x];
+    __syncthreads();
+    uint8_t *fs = slots + (size_t)frame * slot_frame_stride;
+    uint32_t *slot_words = reinterpret_cast<uint32_t *>(fs + u.slot_off);
+    uint32_t *words[kMaxSubs];
+    words[0] = slot_words + kHeaderBytes / 4;
+    for (uint32_t i = 1; i < u.n_sub; i++) words[i] = reinterpret_cast<uint32_t *>(fs + sp.subs[u.sub_first + i - 1u].slot_off);
+    const size_t e = (size_t)frame * sp.entries + u.sub_entry;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the records, snapshots and payload words of other workgroups
+    const uint32_t bits = splice_unit_wave(u.n_sub, sp.recs + e, sp.snaps + e * kMaxSnaps, words, u.cap_words);
+    if (bits != kUnitTooBig && bits != kUnitFailed) {
+        __threadfence();
+        FinishArgs f;
+        f.slot_words = slot_words;
+        f.bits = bits;
+        f.mean = means[(size_t)frame * channels + u.chan];
+        f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
+        f.image_w = img_w; f.image_h = img_h;
+        finish_unit_wave(s, f);
+    }
+    if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
 }
 
 // ------------------------------------------------------------------------------------------ chunk tables
@@ -299,7 +418,9 @@ route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const u
     __syncthreads();
     if (threadIdx.x == 0) {
         const bool windows = nchunks >= min_chunks && total * 100u >= percent * nchunks;
-        route[(size_t)frame * n_units + blockIdx.x] = windows ? kRouteWindows : kRoutePipeline;
+        // (a unit with a fifth of its chunks blank and more: its words stay open for long stretches, sub-ranges would not
+        // meet -- see coder_core.hpp "Sub-ranges")
+        route[(size_t)frame * n_units + blockIdx.x] = windows ? kRouteWindows : (total * 5u >= nchunks ? kRouteNoSplit : kRoutePipeline);
         if (windows) list[atomicAdd(&list_ctl[0], 1u)] = frame * n_units + blockIdx.x;      // (code_units_wg_list_kernel)
     }
 }

@@ -35,6 +35,18 @@ struct UnitDesc {
     uint32_t sig_off;               // byte offset of the chunk table of the unit's family -- (channel, level, subband, segment), shared by
                                     // its bit planes -- in the frame's chunk-table area: one byte per 64-pixel chunk (chunk_blank_plane)
     uint64_t slot_off;              // byte offset of the slot (28-byte header + payload) in the frame's slot area
+    uint32_t n_sub;                 // sub-ranges the unit is cut into when a launch is too small to fill the chip (coder_core.hpp "Sub-ranges"); <= 1: none
+    uint32_t sub_first;             // index of its sub-range 1 in Plan::subs (sub-ranges 1 .. n_sub-1 are consecutive)
+    uint32_t sub_entry;             // index of its sub-range 0 in the per-frame arrays of records / snapshots (n_sub consecutive entries)
+    uint32_t pad_;
+};
+
+// One extra workgroup of a split unit: sub-range `index` >= 1 (device-visible)
+struct SubDesc {
+    uint32_t unit, index;
+    uint32_t cap_words;             // capacity of its private payload area (32-bit words)
+    uint32_t pad_;
+    uint64_t slot_off;              // byte offset of that area in the frame's slot area (after the units' slots)
 };
 
 struct SegmentGrid {
@@ -150,7 +162,17 @@ struct Plan {
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
     size_t sig_bytes = 0;                  // per-frame chunk-table area (UnitDesc::sig_off)
     std::vector<uint32_t> sig_blocks;      // the work list of chunk_sig_kernel: pairs (unit, block of 64 chunks), one family member (plane 0) each
+    std::vector<SubDesc> subs;             // sub-range workgroups of split launches: unit order, a unit's sub-ranges 1 .. n_sub-1 consecutive
+    std::vector<uint32_t> split_launch;    // launch order of a split launch: bit 31 set = sub-range workgroup (index into subs), else a unit;
+                                           // longest expected run first (a sub-range = its chunks + a tenth of its prefix pass)
+    uint32_t sub_entries = 0;              // per-frame entries of the record / snapshot arrays (sum of n_sub over the split units)
 };
+
+// first chunk of sub-range i of a unit of `nchunks` chunks cut into `n_sub` (i = n_sub: the end)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t sub_first_chunk(uint32_t nchunks, uint32_t n_sub, uint32_t i) { return (uint32_t)((uint64_t)nchunks * i / n_sub); }
 
 // quarter-octave size class of a unit (launch order treats units of one class as equally large)
 inline int size_class(uint64_t pixels)
@@ -280,7 +302,7 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
 // Slot capacities: a unit's payload can never be useful beyond (quota - 28) bytes (P3), and we
 // provision `bits_per_pixel` bits per pixel otherwise (overflow of that bound is detected and the
 // batch is re-run with a larger bound).
-inline void assign_slots(Plan *p, size_t quota, unsigned bits_per_pixel)
+inline void assign_slots(Plan *p, size_t quota, unsigned bits_per_pixel, uint32_t split_chunks = 0)
 {
     const uint64_t quota_cap = ((quota > (size_t)kHeaderBytes ? quota - kHeaderBytes : 0) + 3) / 4 + 1;   // words
     uint64_t off = 0;
@@ -293,6 +315,47 @@ inline void assign_slots(Plan *p, size_t quota, unsigned bits_per_pixel)
         off += kHeaderBytes + cap * 4;
     }
     p->slot_bytes = (size_t)off;
+    // sub-ranges (split launches): a unit of at least 2 * `split_chunks` chunks is cut into pieces of about that many (at most
+    // kMaxSubs = 8); piece i >= 1 gets a private payload area for the chunks from its first one to the unit's end (it may
+    // have to code all of them), behind the units' slots
+    p->subs.clear();
+    p->sub_entries = 0;
+    for (size_t ui = 0; ui < p->units.size(); ui++) {
+        UnitDesc &u = p->units[ui];
+        const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
+        uint32_t k = split_chunks ? nchunks / split_chunks : 0u;
+        if (k > 8u) k = 8u;
+        u.n_sub = k >= 2u ? k : 0u;
+        u.sub_first = (uint32_t)p->subs.size();
+        u.sub_entry = p->sub_entries;
+        if (u.n_sub) {
+            p->sub_entries += u.n_sub;
+            for (uint32_t i = 1; i < u.n_sub; i++) {
+                const uint32_t c = sub_first_chunk(nchunks, u.n_sub, i);
+                const uint64_t cap = (uint64_t)u.cap_words * (nchunks - c) / nchunks + 64u;
+                p->subs.push_back(SubDesc{(uint32_t)ui, i, (uint32_t)cap, 0u, off});
+                off += cap * 4;
+            }
+        }
+    }
+    p->slot_bytes = (size_t)off;              // (the frame's slot area includes the sub-ranges' private areas)
+    {
+        std::vector<std::pair<uint64_t, uint32_t>> cost;          // (expected chunks of work, launch entry)
+        for (size_t i = 0; i < p->subs.size(); i++) {
+            const UnitDesc &u = p->units[p->subs[i].unit];
+            const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
+            const uint32_t c0 = sub_first_chunk(nchunks, u.n_sub, p->subs[i].index), c1 = sub_first_chunk(nchunks, u.n_sub, p->subs[i].index + 1u);
+            cost.push_back({(uint64_t)(c1 - c0) * 10u + c0, 0x80000000u | (uint32_t)i});
+        }
+        for (uint32_t ui : p->work_order) {
+            const UnitDesc &u = p->units[ui];
+            const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
+            cost.push_back({(uint64_t)(u.n_sub > 1u ? sub_first_chunk(nchunks, u.n_sub, 1u) : nchunks) * 10u, ui});
+        }
+        std::stable_sort(cost.begin(), cost.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a.first > b.first; });
+        p->split_launch.clear();
+        for (const auto &c : cost) p->split_launch.push_back(c.second);
+    }
 }
 
 }  // namespace icer

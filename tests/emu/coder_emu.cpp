@@ -62,6 +62,27 @@ extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t st
     return res;
 }
 
+// the unit cut into n_sub sub-ranges, one emulated workgroup each, spliced (code_unit_emu_split); *matches = workgroups that
+// stopped at another one's snapshot
+extern "C" long emu_code_unit_split(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
+                                    uint8_t *out, size_t cap_bytes, uint32_t n_sub, uint32_t order, uint32_t *matches)
+{
+    memset(&g_sh, 0xA5, sizeof g_sh);
+    build_coder_tables(&g_sh.tab);
+    UnitArgs a;
+    a.seg = seg; a.stride = (uint32_t)stride; a.w = (uint32_t)w; a.h = (uint32_t)h;
+    a.subband = subband; a.lsb = lsb;
+    a.cap_words = (uint32_t)(cap_bytes / 4);
+    std::vector<uint32_t> words(a.cap_words + 1, 0xDEADBEEFu);
+    a.out_words = words.data();
+    a.timers = nullptr;
+    a.done_bytes = nullptr; a.prio_index = 0; a.early_quota = 0;
+    const uint32_t bits = code_unit_emu_split(g_sh, a, n_sub, order, matches);
+    const long res = bits == kUnitTooBig ? -5 : bits == kUnitFailed ? -10 : (long)bits;
+    if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
+    return res;
+}
+
 // the same under the random wave scheduler (code_unit_emu_random); -10 = the waves dead-locked
 extern "C" long emu_code_unit_random(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
                                      uint8_t *out, size_t cap_bytes, uint32_t seed)

@@ -4,6 +4,9 @@
 // after coder_core.hpp by the test translation units; nothing here is part of the product library.
 #pragma once
 #include "../../icer_compression_amd/csrc/coder_core.hpp"
+#include "../../icer_compression_amd/csrc/assemble_core.hpp"
+#include <string.h>
+#include <vector>
 
 namespace icer {
 
@@ -72,6 +75,93 @@ static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
         if (s.abort) return kUnitTooBig;
     }
     return merge_wave_finish(s, a);
+}
+
+// tests only: ONE workgroup of a split unit (coder_core.hpp "Sub-ranges"): the counts-only prefix pass over [0, j0) with
+// eight pixel waves, then the pipeline from j0 -- the waves interleaved as in code_unit_emu -- until its state equals a
+// later sub-range's snapshot or the unit ends.  Leaves its SubRecord.
+static inline void code_subrange_emu(CoderShared &s, const UnitArgs &a)
+{
+    const SubLayout &L = *a.sub;
+    const uint32_t j0 = L.first[L.index];
+    unit_state_init(s);
+    pixel_tables_init(s, a);
+    PixelWave pw[8];
+    CountWave cs;
+    if (j0) {
+        for (uint32_t j = 0; j < j0; j++) {
+            pixel_wave_run(s, a, pw[j % 8u], j, j + 1, j % 8u, 8u, true);
+            count_wave_run(s, a, cs, j, j + 1, 8u, true);
+        }
+        unit_state_init(s, j0);
+    }
+    PixelWave qw[4];
+    WalkWave ww;
+    GolombWave gs, gw[4];
+    RecordsWave rw;
+    rw.next = j0;
+    walk_wave_init(s, ww, j0);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    golomb_wave_init(gs, j0);
+    for (auto &g : gw) golomb_wave_init(g, j0);
+    uint32_t jp = j0, ja = j0, jc = j0, jb = j0;
+    uint32_t bits = 0;
+    bool ended = false;
+    while (jb < nchunks) {
+        while (jp < nchunks && jp < s.a_done + kQueueDepth) { pixel_wave_run(s, a, qw[jp % g_emu_npw], jp, jp + 1, jp % g_emu_npw, g_emu_npw); jp++; }
+        while (ja < jp && ja < s.b_done + kQueueDepth) { count_wave_run(s, a, cs, ja, ja + 1, g_emu_npw); ja++; }
+        while (jc < ja) { compact_wave_run(s, a, jc, jc + 1); jc++; }
+        walk_wave_run(s, a, ww, nchunks, kQueueDepth);
+        if (g_emu_ngw) golomb_state_run(s, a, gs, nchunks, kQueueDepth); else golomb_wave_run(s, a, gs, nchunks, kQueueDepth, 0, 0);
+        for (uint32_t k = 0; k < g_emu_ngw; k++) golomb_wave_run(s, a, gw[k], nchunks, kQueueDepth, k, g_emu_ngw);
+        records_wave_run(s, a, rw, kQueueDepth);
+        const uint32_t how = merge_wave_run(s, a, jb, jb + 1);
+        if (how == kMergeMatched) return;
+        if (how == kMergeAbandoned) { bits = kUnitTooBig; ended = true; break; }
+        jb++;
+        drain_wave_run(s, a, jb & 1u);
+        if (s.abort) { bits = kUnitTooBig; ended = true; break; }
+    }
+    if (!ended) bits = merge_wave_finish(s, a);
+    SubRecord &r = L.rec[L.index];
+    r.end_chunk = nchunks; r.end_bits = bits; r.match_sub = 0; r.match_snap = 0; r.done = 1;
+}
+
+// tests only: a unit cut into n_sub sub-ranges.  order 0: the workgroups run last sub-range first (every snapshot a
+// workgroup could meet exists when it gets there); 1: first sub-range first (no snapshot exists yet: nobody matches,
+// workgroup 0 codes the whole unit and the others' work is discarded -- the GPU's worst case); 2: odd ones first.
+static inline uint32_t code_unit_emu_split(CoderShared &s, const UnitArgs &a0, uint32_t n_sub, uint32_t order, uint32_t *matches)
+{
+    const uint32_t nchunks = (a0.w * a0.h + 63u) / 64u;
+    std::vector<Snapshot> snaps((size_t)n_sub * kMaxSnaps);
+    std::vector<uint32_t> valid((size_t)n_sub * kMaxSnaps, 0u);
+    std::vector<SubRecord> rec(n_sub);
+    memset(rec.data(), 0, rec.size() * sizeof(SubRecord));
+    std::vector<std::vector<uint32_t>> priv(n_sub);
+    uint32_t *words[kMaxSubs];
+    words[0] = a0.out_words;
+    SubLayout L;
+    L.n_sub = n_sub;
+    for (uint32_t i = 0; i <= n_sub; i++) L.first[i] = (uint32_t)((uint64_t)nchunks * i / n_sub);
+    L.snaps = snaps.data(); L.snap_valid = valid.data(); L.rec = rec.data();
+    std::vector<uint32_t> seq;
+    for (uint32_t i = 0; i < n_sub; i++) seq.push_back(order == 0 ? n_sub - 1 - i : i);
+    if (order == 2) { seq.clear(); for (uint32_t i = 1; i < n_sub; i += 2) seq.push_back(i); for (uint32_t i = 0; i < n_sub; i += 2) seq.push_back(i); }
+    for (uint32_t i : seq) {
+        UnitArgs a = a0;
+        L.index = i;
+        a.sub = &L;
+        if (i) {
+            priv[i].assign((size_t)a0.cap_words + 64, 0xDEADBEEFu);
+            words[i] = priv[i].data();
+            a.out_words = priv[i].data();
+            a.cap_words = a0.cap_words;
+        }
+        memset(&s.stage, 0xA5, sizeof s.stage);
+        code_subrange_emu(s, a);
+    }
+    if (matches) { *matches = 0; for (uint32_t i = 0; i < n_sub; i++) if (rec[i].match_sub) (*matches)++; }
+    return splice_unit_wave(n_sub, rec.data(), snaps.data(), words, a0.cap_words);
 }
 
 // tests only: the same eight waves under a RANDOM scheduler -- at every step one wave is picked at random and runs one

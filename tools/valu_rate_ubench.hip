@@ -40,6 +40,28 @@ constexpr int kUnroll = 64;       // instructions per iteration
 #define OP_SWIZ(a, b)    asm volatile("ds_swizzle_b32 %0, %0 offset:0x041F\n s_waitcnt lgkmcnt(0)" : "+v"(a))
 #define OP_DPP(a, b)     asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a))
 #define OP_READLANE(a, b) { uint32_t s_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s_) : "v"(a)); asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "s"(s_)); }   /* 2 instructions */
+#define OP_CNDMASK_SGPR(a, b) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a) : "v"(b) : )
+#define OP_CMPSEL(a, b)  asm volatile("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc")   /* 2 instructions */
+#define OP_CMPSEL64(a, b) asm volatile("v_cmp_lt_u32_e64 s[10:11], %1, %0\n v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a) : "v"(b) : "s10", "s11")   /* 2 instructions */
+#define OP_CMP64(a, b)   asm volatile("v_cmp_lt_u32_e64 s[10:11], %1, %0" : : "v"(a), "v"(b) : "s10", "s11")
+#define OP_OR(a, b)      asm volatile("v_or_b32 %0, %1, %0" : "+v"(a) : "v"(b))
+#define OP_XOR(a, b)     asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(b))
+#define OP_SUB(a, b)     asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(b))
+#define OP_MIN(a, b)     asm volatile("v_min_u32 %0, %0, %1" : "+v"(a) : "v"(b))
+#define OP_MOV(a, b)     asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(b))
+#define OP_LSHLADD(a, b) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b))
+#define OP_ANDOR(a, b)   asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b))
+#define OP_ADD3(a, b)    asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a) : "v"(b))
+#define OP_LSHLOR(a, b)  asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a) : "v"(b))
+#define OP_LSHR(a, b)    asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a))
+#define OP_FFBH(a, b)    asm volatile("v_ffbh_u32 %0, %0" : "+v"(a))
+#define OP_CVT(a, b)     asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a))
+#define OP_RCP(a, b)     asm volatile("v_rcp_f32 %0, %0" : "+v"(a))
+#define OP_MULF(a, b)    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b))
+#define OP_PERM(a, b)    asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b))
+#define OP_READFIRST(a, b) { uint32_t s_; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s_) : "v"(a)); asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "s"(s_)); }
+#define OP_DSREAD(a, b)  asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a))
+#define OP_DSREADU8(a, b) asm volatile("ds_read_u8 %0, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a))
 #define OP_SADD(a, b)    asm volatile("s_add_u32 %0, %0, 3" : "+s"(a))
 #define OP_SBCNT(a, b)   asm volatile("s_bcnt1_i32_b64 %0, %1" : "+s"(a) : "s"(b) : "scc")
 
@@ -89,6 +111,40 @@ VALU_KERNEL(k_bpermute, OP_BPERM, uint32_t)
 VALU_KERNEL(k_swizzle, OP_SWIZ, uint32_t)
 VALU_KERNEL(k_dpp, OP_DPP, uint32_t)
 VALU_KERNEL(k_readlane_add, OP_READLANE, uint32_t)
+VALU_KERNEL(k_cndmask_sgpr, OP_CNDMASK_SGPR, uint32_t)
+VALU_KERNEL(k_cmp_sel_vcc, OP_CMPSEL, uint32_t)
+VALU_KERNEL(k_cmp_sel_sgpr, OP_CMPSEL64, uint32_t)
+VALU_KERNEL(k_cmp_e64, OP_CMP64, uint32_t)
+VALU_KERNEL(k_or, OP_OR, uint32_t)
+VALU_KERNEL(k_xor, OP_XOR, uint32_t)
+VALU_KERNEL(k_sub, OP_SUB, uint32_t)
+VALU_KERNEL(k_min, OP_MIN, uint32_t)
+VALU_KERNEL(k_mov, OP_MOV, uint32_t)
+VALU_KERNEL(k_lshl_add, OP_LSHLADD, uint32_t)
+VALU_KERNEL(k_and_or, OP_ANDOR, uint32_t)
+VALU_KERNEL(k_add3, OP_ADD3, uint32_t)
+VALU_KERNEL(k_lshl_or, OP_LSHLOR, uint32_t)
+VALU_KERNEL(k_lshr, OP_LSHR, uint32_t)
+VALU_KERNEL(k_ffbh, OP_FFBH, uint32_t)
+VALU_KERNEL(k_cvt, OP_CVT, uint32_t)
+VALU_KERNEL(k_rcp, OP_RCP, float)
+VALU_KERNEL(k_mulf, OP_MULF, float)
+VALU_KERNEL(k_perm, OP_PERM, uint32_t)
+VALU_KERNEL(k_readfirst_add, OP_READFIRST, uint32_t)
+
+// compiler-made selects: what `c ? x : y` on lane values becomes
+template <int ILP> __global__ void __launch_bounds__(256) k_select_cpp(uint32_t *out, uint64_t *cyc)
+{
+    uint32_t a = threadIdx.x, b = blockIdx.x | 1u;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < kIters; it++) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) { a = (a & 4u) ? a + b : a ^ b; asm volatile("" : "+v"(a)); }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = a;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
 
 // scalar: s_add chain, s_bcnt1_i32_b64
 template <int ILP> __global__ void __launch_bounds__(256) k_sadd(uint32_t *out, uint64_t *cyc)
@@ -215,6 +271,13 @@ int main()
         C2(k_cmp_addc, 2, "v_cmp_ne_u32 vcc + v_addc_co_u32 (2 instructions)"), C2(k_dpp, 1, "v_mov_b32_dpp row_shr:1"),
         C2(k_readlane_add, 2, "v_readlane_b32 + v_add_u32 with the SGPR (2 instructions)"),
         C2(k_bpermute, 1, "ds_bpermute_b32 + s_waitcnt"), C2(k_swizzle, 1, "ds_swizzle_b32 + s_waitcnt"),
+        C2(k_cndmask_sgpr, 1, "v_cndmask_b32_e64 with an SGPR pair"), C2(k_cmp_sel_vcc, 2, "v_cmp_lt_u32 vcc + v_cndmask_b32 vcc (2 instructions)"),
+        C2(k_cmp_sel_sgpr, 2, "v_cmp_lt_u32_e64 s[10:11] + v_cndmask_b32_e64 (2 instructions)"), C2(k_cmp_e64, 1, "v_cmp_lt_u32_e64 into an SGPR pair"),
+        C2(k_or, 1, "v_or_b32"), C2(k_xor, 1, "v_xor_b32"), C2(k_sub, 1, "v_sub_u32"), C2(k_min, 1, "v_min_u32"), C2(k_mov, 1, "v_mov_b32"),
+        C2(k_lshl_add, 1, "v_lshl_add_u32"), C2(k_and_or, 1, "v_and_or_b32"), C2(k_add3, 1, "v_add3_u32"), C2(k_lshl_or, 1, "v_lshl_or_b32"),
+        C2(k_lshr, 1, "v_lshrrev_b32"), C2(k_ffbh, 1, "v_ffbh_u32"), C2(k_cvt, 1, "v_cvt_f32_u32"), C2(k_rcp, 1, "v_rcp_f32"), C2(k_mulf, 1, "v_mul_f32"),
+        C2(k_perm, 1, "v_perm_b32"), C2(k_readfirst_add, 2, "v_readfirstlane_b32 + v_add_u32 (2 instructions)"),
+        {"k_select_cpp dependent", k_select_cpp<1>, N * 4, "a = (a & 4) ? a + b : a ^ b as hipcc compiles it (v_and, v_cmp, v_add, v_xor, v_cndmask: ~4-5 instructions)"},
         C2(k_sadd, 1, "s_add_u32"),
         {"k_ballot_popc dependent", k_ballot_popc<1>, N * 4, "v_and -> v_cmp -> s_bcnt1_i32_b64 -> v_add (4 instructions, the coder's ballot + popcount)"},
         {"k_lds_chase dependent", k_lds_chase<1>, N, "ds_read_b32 whose address is the previous load (round trip)"},

@@ -22,14 +22,14 @@ def main():
         by.setdefault(c["case"], {})[c["waves_per_simd"]] = c
     # the coder's VALU mix is 32-bit integer ALU: price it at the mean saturated cost (8 waves per SIMD, independent streams) of the
     # plain integer classes
-    plain = ["k_and", "k_add", "k_lshl", "k_bfe", "k_cndmask", "k_mbcnt_lo", "k_mbcnt_hi", "k_bcnt"]
+    plain = ["k_and", "k_add", "k_or", "k_sub", "k_lshl", "k_lshr", "k_bfe", "k_cndmask_sgpr", "k_mbcnt_lo", "k_mbcnt_hi", "k_bcnt", "k_lshl_or", "k_and_or"]
     sat = [by[f"{k} x8 independent"][8]["simd_cycles_per_wave_inst"] for k in plain]
     res["bench_constants"] = {"valu_int32": round(sum(sat) / len(sat), 3),
                               "valu_fma_f32": by["k_fma x8 independent"][8]["simd_cycles_per_wave_inst"],
                               "lone_wave_dependent_int32": by["k_and dependent"][1]["wave_cycles_per_inst_s_memtime"],
                               "lds_round_trip_lone_wave": by["k_lds_chase dependent"][1]["wave_cycles_per_inst_s_memtime"],
                               "source": "profiles/r03_valu_rate_ubench.md (tools/valu_rate_ubench.py on this chip: mean saturated SIMD cycles per "
-                                        "wave64 instruction of v_and/v_add/v_lshl/v_bfe/v_cndmask/v_mbcnt/v_bcnt at 8 waves per SIMD)"}
+                                        "wave64 instruction of v_and/v_add/v_or/v_sub/v_lshl/v_lshr/v_bfe/v_cndmask/v_mbcnt/v_bcnt/v_lshl_or/v_and_or at 8 waves per SIMD)"}
     with open(os.path.join(outdir, "r03_valu_rate_ubench.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     lines = ["# Cost of one wave64 instruction on gfx950, by class and occupancy (tools/valu_rate_ubench.hip)", "",
