@@ -117,6 +117,7 @@ struct icerx_encoder {
     // pieces of about split_chunks chunks, one workgroup each (ICER_HIP_SPLIT=<chunks, 0 = off>, ICER_HIP_SPLIT_FRAMES)
     uint32_t split_chunks = 3072;
     int split_frames = 1;
+    int split_hybrid_percent = 90;      // ... whose units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_SPLIT_HYBRID)
     bool last_split = false;
     DevBuf<SubDesc> subs;
     DevBuf<uint32_t> sub_order, snap_valid;
@@ -323,7 +324,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     if (hybrid) {
         HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
-                           (uint32_t)(split && e->hybrid_percent > 90 ? 90 : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p);
+                           (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p);
         route = e->route.p;
         // the workgroup coder takes its list on a second stream, beside the pipeline kernel (it is submitted first: its
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
@@ -437,6 +438,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }
+    if (const char *sh = getenv("ICER_HIP_SPLIT_HYBRID")) { const int v = atoi(sh); if (v >= 1 && v <= 100) e->split_hybrid_percent = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);

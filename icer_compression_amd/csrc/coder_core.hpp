@@ -84,6 +84,14 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_IDLE_RESET
 #else
 #define ICER_EMU_COUNT(i)
+// (tools/handoff_isa_audit.py builds with -DICER_ISA_MARKERS: assembler comments around every hand-off site, nothing else)
+#ifdef ICER_ISA_MARKERS
+#define ICER_STR2(x) #x
+#define ICER_STR(x) ICER_STR2(x)
+#define ICER_MARK(what) asm volatile("; ICER_MARK " what " line " ICER_STR(__LINE__));
+#else
+#define ICER_MARK(what)
+#endif
 // counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -122,21 +130,21 @@ static __device__ __forceinline__ uint32_t icer_agent_acquire_load(const uint32_
 #if !defined(ICER_WAVE_EMU) || defined(ICER_WAVE_THREADS)
 // Every spin is bounded (kPollLimit polls, seconds of wall time): a wave that would wait longer declares the unit
 // failed (abort = 2), which every other wait observes; the host then reports ICER_FATAL_ERROR instead of hanging.
-#define ICER_SPIN(cond, SLEEP) { uint32_t spins_ = 0; while (!(cond)) { ICER_POLL_PAUSE(SLEEP); \
+#define ICER_SPIN(cond, SLEEP) { ICER_MARK("WAIT_BEGIN") uint32_t spins_ = 0; while (!(cond)) { ICER_POLL_PAUSE(SLEEP); \
         if (++spins_ > kPollLimit) { ICER_SET_ABORT2(); break; } } \
-    ICER_FENCE_ACQ(); }
+    ICER_FENCE_ACQ(); ICER_MARK("WAIT_END") }
 #define ICER_WAIT_UNTIL(cond) ICER_SPIN(cond, 1)
 // wait until PRED holds for V = the counter X, or the unit is abandoned; the counter and the abort word are read
 // together (one LDS round trip per poll) and AB receives the abort word
-#define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB; { uint32_t spins_ = 0; for (;;) {                          \
+#define ICER_WAIT_CNT(X, V, PRED, AB, SLEEP) uint32_t AB; { ICER_MARK("WAIT_BEGIN") uint32_t spins_ = 0; for (;;) {        \
         const uint32_t V = ICER_LOAD_CNT(X); AB = ICER_LOAD_CNT(s.abort);                                             \
         if ((PRED) || AB) break;                                                                                      \
         ICER_POLL_PAUSE(SLEEP);                                                                                       \
         if (++spins_ > kPollLimit) { ICER_SET_ABORT2(); AB = 2u; break; } }                                           \
-    ICER_FENCE_ACQ(); }
-#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); ICER_FENCE_REL(); ICER_LANE0 ICER_STORE_CNT(x, pv_); }
-#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); ICER_FENCE_REL(); ICER_LANE0 { ICER_STORE_CNT(x1, pv1_); ICER_STORE_CNT(x2, pv2_); } }
-#define ICER_ACQUIRE() ICER_FENCE_ACQ();
+    ICER_FENCE_ACQ(); ICER_MARK("WAIT_END") }
+#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); ICER_MARK("PUBLISH_BEGIN") ICER_FENCE_REL(); ICER_LANE0 ICER_STORE_CNT(x, pv_); ICER_MARK("PUBLISH_END") }
+#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); ICER_MARK("PUBLISH_BEGIN") ICER_FENCE_REL(); ICER_LANE0 { ICER_STORE_CNT(x1, pv1_); ICER_STORE_CNT(x2, pv2_); } ICER_MARK("PUBLISH_END") }
+#define ICER_ACQUIRE() { ICER_MARK("ACQUIRE") ICER_FENCE_ACQ(); }
 #define ICER_IDLE() { ICER_POLL_PAUSE(1); if (++idle_spins_ > kPollLimit) { ICER_SET_ABORT2(); break; } }
 #define ICER_IDLE_DECL uint32_t idle_spins_ = 0;
 #define ICER_IDLE_RESET idle_spins_ = 0;

@@ -7,7 +7,7 @@
 //           coalesced row reads, two samples (one 32-bit word) per lane where the rows are word-aligned;
 //   rows    every window row is lifted in two steps: first the pair averages (lows) and pair differences of the whole
 //           row -- each computed ONCE and left in LDS --, then the highs of the tile's KX pair columns from them
-//           (a high needs the four lows around it and two differences: dwt_core.hpp's rule, with the lows shared
+//           (a high needs the four lows around it and two differences, with the lows shared
 //           instead of recomputed by each of the four pairs that need them);
 //   columns the same two steps down the KX low columns and KX high columns for the tile's KY pair rows,
 //           giving LL/LH (from the low columns) and HL/HH (from the high columns);
@@ -18,7 +18,13 @@
 // The phase bodies are plain per-thread functions so the tests-only CPU build (tests/emu) can run them in a loop;
 // tests/test_emu_pipeline.py::test_dwt_core holds them to the oracle for every filter, odd sizes and int16 overflow.
 #pragma once
-#include "dwt_core.hpp"
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DWT_HD __host__ __device__ __forceinline__
+#else
+#define DWT_HD static inline
+#endif
 #include "icer_tables.hpp"
 
 namespace icer {
@@ -112,7 +118,12 @@ DWT_HD bool dwt_pair_step1(int32_t a, int32_t b, int n, int k, int32_t lim, int1
     return ovf;
 }
 
-// Step 2: the high of pair k from the line's lows and differences (dwt_core.hpp's boundary rules and quirk W3).
+// Step 2: the high of pair k from the line's lows and differences.  Output pair k of a line of n samples needs
+// x[2k-4 .. 2k+3] only, so the reference's in-place pair lift -> un-shuffle (icer_deinterleave_uint16, icer_wavelet.c:765-820)
+// -> predict collapses to this local rule.  Bit-exactness: lows / highs are stored truncated to int16 with a sticky
+// overflow flag on the untruncated value; r[j] = (int16)(low[j-1] - low[j]) wraps silently (get_r_int16 :206-208); boundary
+// rules k == 0, k == nh-1 (even n), missing d[k+1] (odd n) as :430-462; filter C (alpha_-1 != 0) at k == 1 uses d[1] where
+// the ICER paper has d[2] (reference quirk W3, offset = low_N at :437-440), and 0 when n == 5.
 // LO(j) / DI(j): low / difference of pair j, called with 0 <= j < ceil(n/2) only.
 template <class Lo, class Di>
 DWT_HD bool dwt_pair_step2(const Lo &LO, const Di &DI, int n, int k, int am1, int a0, int a1, int be, int32_t lim, int16_t *high)

@@ -14,7 +14,6 @@
 #include "coder_core.hpp"
 #include "coder_wg.hpp"
 #include "coder_wg_small.hpp"
-#include "dwt_core.hpp"
 #include "dwt_tile.hpp"
 #include "plan.hpp"
 

@@ -1,4 +1,4 @@
-// TESTS ONLY: builds the kernel cores (csrc/coder_core.hpp, assemble_core.hpp, dwt_core.hpp) and the
+// TESTS ONLY: builds the kernel cores (csrc/coder_core.hpp, assemble_core.hpp, dwt_tile.hpp) and the
 // host planner (csrc/plan.hpp) as a CPU lane-loop emulation (-DICER_WAVE_EMU, see csrc/wave.hpp), so
 // the wave-parallel algorithms can be compared with the oracle in a container without a GPU.
 // Not part of the product library; nothing here is reachable from libicer_hip.so.
@@ -7,7 +7,6 @@
 #include "../../icer_compression_amd/csrc/coder_core.hpp"
 #include "coder_emu_drivers.hpp"
 #include "../../icer_compression_amd/csrc/coder_wg.hpp"
-#include "../../icer_compression_amd/csrc/dwt_core.hpp"
 #include "../../icer_compression_amd/csrc/dwt_tile.hpp"
 #include "../../icer_compression_amd/csrc/plan.hpp"
 #include <stdlib.h>

@@ -20,7 +20,8 @@ def pipeline_shape(request, emu, monkeypatch):
 def test_dwt_core(emu, oracle):
     rng = np.random.default_rng(2)
     for filt in range(7):
-        for (w, h, st) in [(64, 64, 3), (37, 53, 2), (96, 40, 3), (25, 25, 2), (130, 70, 4), (5, 5, 1), (6, 7, 1), (11, 13, 2)]:
+        for (w, h, st) in [(64, 64, 3), (37, 53, 2), (96, 40, 3), (25, 25, 2), (130, 70, 4), (5, 5, 1), (6, 7, 1), (11, 13, 2),
+                           (300, 200, 2), (517, 389, 3), (264, 136, 1)]:      # (several tiles, interior ones on the unchecked fast path)
             for hi in (256, 65536):
                 img = rng.integers(0, hi, (h, w)).astype(np.uint16)
                 a, b = oracle.dwt(img, st, filt), emu.dwt(img, st, filt)

@@ -556,7 +556,8 @@ def test_reference_fixtures_through_the_command_line_tool(tmp_path):
         assert (len(blob), hashlib.sha256(blob).hexdigest()[:16]) == (g["size"], g["sha256_16"]), name
         # and back: the tool writes PGM / PPM; lossless for every filter but C (quirk W3)
         out = "back.pgm" if g["channels"] == 1 else "back.ppm"
-        r = subprocess.run([exe, "decompress", str(tmp_path / "o.bin"), str(tmp_path / out)] + opts, capture_output=True, text=True)
+        r = subprocess.run([exe, "decompress", str(tmp_path / "o.bin"), str(tmp_path / out)] + opts + ([] if g["channels"] == 1 else ["--color"]),
+                           capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         back = (tmp_path / out).read_bytes()
         if g["channels"] == 1 and g["filt"] != 2:
