@@ -438,7 +438,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }
-    if (const char *sh = getenv("ICER_HIP_SPLIT_HYBRID")) { const int v = atoi(sh); if (v >= 1 && v <= 100) e->split_hybrid_percent = v; }
+    if (const char *sh = getenv("ICER_HIP_SPLIT_HYBRID")) { const int v = atoi(sh); if (v >= 1 && v <= 101) e->split_hybrid_percent = v; }     // (101: no unit goes to the small coder)
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);

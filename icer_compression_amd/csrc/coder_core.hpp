@@ -49,6 +49,15 @@
 #include "icer_tables.hpp"
 #include "wave.hpp"
 
+// (tools/handoff_isa_audit.py builds with -DICER_ISA_MARKERS: assembler comments around every hand-off site, nothing else)
+#if defined(ICER_ISA_MARKERS) && !defined(ICER_WAVE_EMU)
+#define ICER_STR2(x) #x
+#define ICER_STR(x) ICER_STR2(x)
+#define ICER_MARK(what) asm volatile("; ICER_MARK " what " line " ICER_STR(__LINE__));
+#else
+#define ICER_MARK(what)
+#endif
+
 #if defined(ICER_WAVE_EMU) && defined(ICER_WAVE_THREADS)
 // tests only (tests/emu/threads_main.cpp): the lane-loop build with every wave on its own CPU thread and REAL waits --
 // the hand-off protocol under true concurrency, optionally under ThreadSanitizer (fence + relaxed atomic = the LDS
@@ -84,14 +93,6 @@ extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path
 #define ICER_IDLE_RESET
 #else
 #define ICER_EMU_COUNT(i)
-// (tools/handoff_isa_audit.py builds with -DICER_ISA_MARKERS: assembler comments around every hand-off site, nothing else)
-#ifdef ICER_ISA_MARKERS
-#define ICER_STR2(x) #x
-#define ICER_STR(x) ICER_STR2(x)
-#define ICER_MARK(what) asm volatile("; ICER_MARK " what " line " ICER_STR(__LINE__));
-#else
-#define ICER_MARK(what)
-#endif
 // counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
