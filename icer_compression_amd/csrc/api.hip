@@ -119,6 +119,7 @@ struct icerx_encoder {
     int split_frames = 1;
     int split_hybrid_percent = 90;      // ... whose units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_SPLIT_HYBRID)
     bool last_split = false;
+    int split_wgs = 0;                  // staying workgroups of the small coder in a split launch (0: one per compute unit)
     DevBuf<SubDesc> subs;
     DevBuf<uint32_t> sub_order, snap_valid;
     DevBuf<Snapshot> snaps;
@@ -330,7 +331,8 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
         HIP_TRY(hipEventRecord(e->fork, st));
         HIP_TRY(hipStreamWaitEvent(e->side_stream, e->fork, 0));
-        hipLaunchKernelGGL(code_units_wgs_list_kernel, dim3((unsigned)(e->n_cus * e->hybrid_wgs)), dim3(64 * wgs::kWgWaves), sizeof(wgs::Shared), e->side_stream,
+        // (a split launch wants the compute units' LDS for its pipeline workgroups: fewer staying workgroups of the small coder, ICER_HIP_SPLIT_WGS)
+        hipLaunchKernelGGL(code_units_wgs_list_kernel, dim3((unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs)), dim3(64 * wgs::kWgWaves), sizeof(wgs::Shared), e->side_stream,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,
                            e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,
                            e->plan.sig_bytes, e->route_list.p, e->route_ctl.p);
@@ -439,6 +441,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }
     if (const char *sh = getenv("ICER_HIP_SPLIT_HYBRID")) { const int v = atoi(sh); if (v >= 1 && v <= 101) e->split_hybrid_percent = v; }     // (101: no unit goes to the small coder)
+    if (const char *sw = getenv("ICER_HIP_SPLIT_WGS")) { const int v = atoi(sw); if (v >= 1 && v <= 4096) e->split_wgs = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);

@@ -15,7 +15,7 @@ from icer_compression_amd import api, build, synth  # noqa: E402
 
 def main():
     w, h, st, sg = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (4096, 4096, 5, 10)))
-    api.LIB_PATH = build.build_profiling_library()
+    api.LIB_PATH = os.environ.get("ICER_HIP_PROF_LIB") or build.build_profiling_library()       # (a profiling build of another source tree: experiments)
     lib = api.load_library()
     enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=1)
     frame = synth.gray_frame(w, h, 12345, 1)[None]
