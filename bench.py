@@ -44,6 +44,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (before the HIP runtime starts: the host-fed batch runs three encoder streams + their side streams; the runtime's default
+# of 4 hardware queues makes some of them take turns -- csrc/api.hip, RuntimeDefaults)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FILT = 0
 CONFIGS = {

@@ -6,4 +6,10 @@ Only what the encode hot path needs lives here:
   build.py   in-tree hipcc build
   synth.py   deterministic synthetic frames for tests and bench
 """
-from . import api, synth  # noqa: F401
+import os as _os
+
+# more hardware queues than the HIP runtime's default of 4 (read once, when the runtime starts): the host-fed batch keeps
+# several encoder streams busy at a time, csrc/api.hip RuntimeDefaults
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import api, synth  # noqa: F401,E402

@@ -786,34 +786,53 @@ int icerx_device_count(void)
 // one host thread and one encoder per device, no communication between them.  Every frame's bytes, length and
 // return code equal a per-frame call of icer_compress_image_uint16.
 //
-// A device's block is coded in sub-batches through three streams, so that PCIe and the coder work at the same time:
-//     copy-in stream   H2D of sub-batch k+1        (two input buffers)
-//     encoder stream   all kernels of sub-batch k
-//     copy-out stream  D2H of the streams of k-1   (two output buffers; exactly size[f] bytes per frame)
-// The encoders and their staging buffers stay alive between calls (one per device, re-made when the geometry changes;
+// A device's block is coded in sub-batches over kBatchSets (3) buffer sets, each with an encoder and an encoder stream of
+// its own, plus one copy-in and one copy-out stream:
+//     copy-in stream    H2D of the sub-batches ahead (set k % 3 is free when the kernels of k - 3 are done)
+//     encoder streams   all kernels of sub-batch k on stream k % 3: the kernels of two sets share the chip, so that the last
+//                       coding units of one launch do not leave it idle
+//     copy-out stream   D2H of the streams of the finished sub-batches (exactly size[f] bytes per frame)
+// (Streams are a scarce resource: the HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES = 4 hardware queues by default and
+// streams that share a queue run one after the other -- measured on C4 / C5: 0.80-0.85 x the device-resident rate with 4
+// queues, 0.92-0.95 x with 8.  The library asks for 8 when it is loaded before the runtime starts, see
+// icerx_runtime_defaults below; a caller that has already initialised HIP sets GPU_MAX_HW_QUEUES=8 itself.  Copies on the
+// encoder streams instead of streams of their own -- fewer streams -- measured slower: 0.78 x on C4.)
+// The encoders and their staging buffers stay alive between calls (per device, re-made when the geometry changes;
 // icerx_batch_release frees them): a call allocates nothing on the device.
 namespace {
+
+// Runs when the library is loaded: more hardware queues than the runtime's default of 4, unless the process has chosen a
+// number itself.  Takes effect when the HIP runtime has not been initialised yet (it reads the variable once).
+struct RuntimeDefaults {
+    RuntimeDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} icerx_runtime_defaults;
+
+constexpr int kBatchSets = 3;
 
 struct BatchDevice {
     std::mutex mu;                       // one batch call at a time per device
     int device = -1;
-    icerx_encoder *enc = nullptr;
-    int sub = 0;                         // frames per sub-batch (= the encoder's max_frames)
+    icerx_encoder *enc[kBatchSets] = {};   // sub-batch k runs on encoder k & 1, each on a stream of its own: the kernels of
+                                         // k + 1 fill the compute units that the last coding units of k leave idle
+    int sub = 0;                         // frames per sub-batch (= the encoders' max_frames)
     size_t quota = 0, dev_stride = 0;
-    hipStream_t s_in = nullptr, s_enc = nullptr, s_out = nullptr;
-    DevBuf<uint16_t> in[2];
-    DevBuf<uint8_t> out[2];
-    DevBuf<unsigned long long> d_sizes[2];
-    DevBuf<int32_t> d_rcs[2];
-    uint64_t *h_sizes = nullptr;         // pinned: [2][sub]
-    int32_t *h_rcs = nullptr;            // pinned: [2][sub]
-    int *h_flag = nullptr;               // pinned: [2][2]
-    hipEvent_t in_ready[2] = {}, coded[2] = {}, out_done[2] = {};
+    hipStream_t s_in = nullptr, s_enc[kBatchSets] = {}, s_out = nullptr;
+    int sets = 0;                        // buffer sets / encoders in use (2..kBatchSets)
+    DevBuf<uint16_t> in[kBatchSets];
+    DevBuf<uint8_t> out[kBatchSets];
+    DevBuf<unsigned long long> d_sizes[kBatchSets];
+    DevBuf<int32_t> d_rcs[kBatchSets];
+    uint64_t *h_sizes = nullptr;         // pinned: [sets][sub]
+    int32_t *h_rcs = nullptr;            // pinned: [sets][sub]
+    int *h_flag = nullptr;               // pinned: [sets][2]
+    hipEvent_t in_ready[kBatchSets] = {}, coded[kBatchSets] = {}, out_done[kBatchSets] = {};
     void release()
     {
         if (device >= 0) (void)hipSetDevice(device);
-        if (enc) { icerx_encoder_destroy(enc); enc = nullptr; }
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < kBatchSets; k++) {
+            if (enc[k]) { icerx_encoder_destroy(enc[k]); enc[k] = nullptr; }
+            if (s_enc[k]) (void)hipStreamDestroy(s_enc[k]);
+            s_enc[k] = nullptr;
             in[k].release(); out[k].release(); d_sizes[k].release(); d_rcs[k].release();
             if (in_ready[k]) (void)hipEventDestroy(in_ready[k]);
             if (coded[k]) (void)hipEventDestroy(coded[k]);
@@ -821,14 +840,13 @@ struct BatchDevice {
             in_ready[k] = coded[k] = out_done[k] = nullptr;
         }
         if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_enc) (void)hipStreamDestroy(s_enc);
         if (s_out) (void)hipStreamDestroy(s_out);
-        s_in = s_enc = s_out = nullptr;
+        s_in = s_out = nullptr;
         if (h_sizes) (void)hipHostFree(h_sizes);
         if (h_rcs) (void)hipHostFree(h_rcs);
         if (h_flag) (void)hipHostFree(h_flag);
         h_sizes = nullptr; h_rcs = nullptr; h_flag = nullptr;
-        sub = 0;
+        sub = 0; sets = 0;
     }
 };
 
@@ -843,14 +861,15 @@ BatchDevice *pool_device(int device)
     return slot.get();
 }
 
-// frames per sub-batch: enough sub-batches for the three streams to overlap (>= 4 when the block allows), each small
-// enough that two input + two output sets are a modest share of HBM (ICER_HIP_BATCH_SUB pins it)
+// frames per sub-batch: about eight sub-batches per block (measured on C4 / C5 with three sets in flight: 4 of 32 frames and
+// 2 of 8 are best, 8 / 1 cost 3-12 %), each small enough that three input + three output sets are a modest share of HBM
+// (ICER_HIP_BATCH_SUB pins it)
 int sub_batch_frames(int cnt, size_t frame_bytes)
 {
     if (const char *sv = getenv("ICER_HIP_BATCH_SUB")) { const int v = atoi(sv); if (v >= 1) return v < cnt ? v : cnt; }
     size_t by_mem = ((size_t)256 << 20) / (frame_bytes ? frame_bytes : 1);
     if (by_mem < 1) by_mem = 1;
-    int by_overlap = (cnt + 3) / 4;
+    int by_overlap = (cnt + 7) / 8;
     if (by_overlap < 1) by_overlap = 1;
     int sub = (size_t)by_overlap < by_mem ? by_overlap : (int)by_mem;
     // (a launch of one large gray frame is bound by the chain of its biggest coding units: prefer two per launch)
@@ -858,38 +877,42 @@ int sub_batch_frames(int cnt, size_t frame_bytes)
     return sub;
 }
 
-int batch_prepare(BatchDevice *b, size_t w, size_t h, int channels, int stages, int filt, int segments, size_t quota, int sub)
+int batch_prepare(BatchDevice *b, size_t w, size_t h, int channels, int stages, int filt, int segments, size_t quota, int sub, int sets)
 {
-    icerx_encoder *e = b->enc;
-    if (!e || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt || e->segments != segments ||
+    const icerx_encoder *e = b->enc[0];
+    if (!e || b->sets != sets || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt || e->segments != segments ||
         e->sample_bits != 16 || b->sub != sub) {
         b->release();
-        const int rc = icerx_encoder_create(&e, b->device, w, h, channels, stages, filt, segments, sub);
-        if (rc) return rc;
-        b->enc = e;
         b->sub = sub;
-        e->sleepy_wait = true;
+        b->sets = sets;
         HIP_TRY(hipSetDevice(b->device));
         HIP_TRY(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_enc, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < sets; k++) {
+            const int rc = icerx_encoder_create(&b->enc[k], b->device, w, h, channels, stages, filt, segments, sub);
+            if (rc) return rc;
+            b->enc[k]->sleepy_wait = true;
+            HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
             if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
             HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->coded[k], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->out_done[k], hipEventDisableTiming));
         }
-        HIP_TRY(hipHostMalloc((void **)&b->h_sizes, 2 * (size_t)sub * sizeof(uint64_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&b->h_rcs, 2 * (size_t)sub * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&b->h_flag, 4 * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->h_sizes, (size_t)sets * (size_t)sub * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->h_rcs, (size_t)sets * (size_t)sub * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->h_flag, (size_t)sets * 2 * sizeof(int), hipHostMallocDefault));
         b->quota = (size_t)-1;
     }
     HIP_TRY(hipSetDevice(b->device));
     // slots for this quota, then output rows that hold the longest possible stream
-    if (upload_units(e, quota, b->s_enc)) return ICER_FATAL_ERROR;
-    const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
+    size_t ds = 0;
+    for (int k = 0; k < sets; k++) {
+        if (upload_units(b->enc[k], quota, b->s_enc[k])) return ICER_FATAL_ERROR;
+        const size_t d = (quota < b->enc[k]->plan.slot_bytes ? quota : b->enc[k]->plan.slot_bytes) + 4;
+        if (d > ds) ds = d;
+    }
     if (b->quota != quota || b->dev_stride < ds) {
-        for (int k = 0; k < 2; k++) if (b->out[k].ensure((size_t)sub * ds)) return ICER_FATAL_ERROR;
+        for (int k = 0; k < sets; k++) if (b->out[k].ensure((size_t)sub * ds)) return ICER_FATAL_ERROR;
         b->dev_stride = ds;
         b->quota = quota;
     }
@@ -903,31 +926,34 @@ int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, s
     std::lock_guard<std::mutex> lk(b->mu);
     const size_t frame_elems = w * h * (size_t)channels;
     const int sub = sub_batch_frames(cnt, frame_elems * 2);
-    int rc = batch_prepare(b, w, h, channels, stages, filt, segments, quota, sub);
+    int sets = 3;                        // (ICER_HIP_BATCH_SETS: 2 or 3)
+    if (const char *sv = getenv("ICER_HIP_BATCH_SETS")) { const int v = atoi(sv); if (v >= 2 && v <= kBatchSets) sets = v; }
+    const int S = sets;
+    int rc = batch_prepare(b, w, h, channels, stages, filt, segments, quota, sub, sets);
     if (rc) return rc;
-    icerx_encoder *e = b->enc;
     const int K = (cnt + sub - 1) / sub;
     auto n_of = [&](int k) { return k == K - 1 ? cnt - k * sub : sub; };
     // enqueue sub-batch k: its copy-in, then its kernels
     auto issue = [&](int k) -> int {
-        const int s = k & 1, n = n_of(k);
-        // in[s] is free once the kernels of k - 2 are done, out[s] once the copy-out of k - 2 is
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->s_in, b->coded[s], 0));
+        const int s = k % S, n = n_of(k);
+        // in[s] is free once the kernels of k - S are done, out[s] once the copy-out of k - S is
+        if (k >= S) HIP_TRY(hipStreamWaitEvent(b->s_in, b->coded[s], 0));
         HIP_TRY(hipMemcpyAsync(b->in[s].p, frames + (size_t)k * sub * frame_elems, (size_t)n * frame_elems * 2, hipMemcpyHostToDevice, b->s_in));
         HIP_TRY(hipEventRecord(b->in_ready[s], b->s_in));
-        HIP_TRY(hipStreamWaitEvent(b->s_enc, b->in_ready[s], 0));
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(b->s_enc, b->out_done[s], 0));
-        e->wg_once = false;
-        const int r = encode_begin(e, b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc,
+        HIP_TRY(hipStreamWaitEvent(b->s_enc[s], b->in_ready[s], 0));
+        if (k >= S) HIP_TRY(hipStreamWaitEvent(b->s_enc[s], b->out_done[s], 0));
+        b->enc[s]->wg_once = false;
+        const int r = encode_begin(b->enc[s], b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc[s],
                                    b->h_flag + 2 * s, b->coded[s], nullptr);
         if (r) return r;
         // (after the `coded` record on purpose: the host reads these words only after its own wait below)
         return 0;
     };
-    if (accumulate_timing(e)) return ICER_FATAL_ERROR;
-    for (int k = 0; k < K && k < 2; k++) if ((rc = issue(k))) return rc;
+    for (int q = 0; q < S; q++) if (accumulate_timing(b->enc[q])) return ICER_FATAL_ERROR;
+    for (int k = 0; k < K && k < S; k++) if ((rc = issue(k))) return rc;
     for (int k = 0; k < K; k++) {
-        const int s = k & 1, n = n_of(k);
+        const int s = k % S, n = n_of(k);
+        icerx_encoder *e = b->enc[s];
         if (wait_event(b->coded[s], true)) return ICER_FATAL_ERROR;
         int v = encode_verdict(e, n, b->h_flag + 2 * s);
         if (v < 0) return v;
@@ -936,17 +962,16 @@ int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, s
             // enqueued with the old slot table; its own verdict is read in its turn), then code k again, synchronously.
             HIP_TRY(hipDeviceSynchronize());
             for (;;) {
-                if (upload_units(e, quota, b->s_enc)) return ICER_FATAL_ERROR;
+                if (upload_units(e, quota, b->s_enc[s])) return ICER_FATAL_ERROR;
                 if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
                 const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
                 if (b->dev_stride < ds) {
-                    for (int q = 0; q < 2; q++) if (b->out[q].ensure((size_t)sub * ds)) return ICER_FATAL_ERROR;
+                    for (int q = 0; q < S; q++) if (b->out[q].ensure((size_t)sub * ds)) return ICER_FATAL_ERROR;
                     b->dev_stride = ds;
-                    if (k + 1 < K) {          // (k + 1 wrote rows of the old stride into a buffer that is gone: enqueue it again below)
-                        if ((rc = issue(k + 1))) return rc;
-                    }
+                    // (the sub-batches after k that were in flight wrote rows of the old stride into buffers that are gone: enqueue them again)
+                    for (int q = k + 1; q < K && q < k + S; q++) if ((rc = issue(q))) return rc;
                 }
-                if ((rc = encode_begin(e, b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc,
+                if ((rc = encode_begin(e, b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc[s],
                                        b->h_flag + 2 * s, b->coded[s], nullptr))) return rc;
                 if (wait_event(b->coded[s], true)) return ICER_FATAL_ERROR;
                 v = encode_verdict(e, n, b->h_flag + 2 * s);
@@ -972,7 +997,7 @@ int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, s
             if (sz) HIP_TRY(hipMemcpyAsync(out + ((size_t)k * sub + f) * out_stride, b->out[s].p + (size_t)f * b->dev_stride, sz, hipMemcpyDeviceToHost, b->s_out));
         }
         HIP_TRY(hipEventRecord(b->out_done[s], b->s_out));
-        if (k + 2 < K && (rc = issue(k + 2))) return rc;
+        if (k + S < K && (rc = issue(k + S))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(b->s_out));
     return 0;

@@ -200,14 +200,17 @@ def test_async_halves_equal_the_synchronous_call(oracle):
     enc.close()
 
 
-@pytest.mark.parametrize("sub", ["1", "2", "5", ""])
+@pytest.mark.parametrize("sub", ["1", "2", "5", "", "1/2"])
 def test_host_batch_is_pipelined_in_sub_batches_and_exact(oracle, monkeypatch, sub):
     """icerx_compress_batch_uint16_devices: a device's block goes through copy-in / kernels / copy-out streams in
-    sub-batches (ICER_HIP_BATCH_SUB pins their size: whole, ragged last one, one frame); pinned and pageable caller
+    sub-batches over three buffer sets with an encoder each (ICER_HIP_BATCH_SUB pins their size: whole, ragged last one,
+    one frame; "1/2": one frame per sub-batch over two sets, ICER_HIP_BATCH_SETS); pinned and pageable caller
     memory; the pooled encoder is re-used by the next call and re-made for another geometry; a row too short for its
     stream is an error, never an overrun"""
     if sub:
-        monkeypatch.setenv("ICER_HIP_BATCH_SUB", sub)
+        monkeypatch.setenv("ICER_HIP_BATCH_SUB", sub.split("/")[0])
+    if "/" in sub:
+        monkeypatch.setenv("ICER_HIP_BATCH_SETS", sub.split("/")[1])
     n, w, h, st, sg = 5, 256, 192, 3, 6
     quota = 2 * w * h
     frames = synth.gray_batch(n, w, h, 303, 1)
