@@ -119,6 +119,7 @@ struct icerx_encoder {
     int split_frames = 1;
     int split_hybrid_percent = 90;      // ... whose units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_SPLIT_HYBRID)
     bool last_split = false;
+    bool lone_as_batch = false;         // ICER_HIP_LONE_AS_BATCH=1: single-frame launches with the batch build of the pipeline (measurements)
     int split_wgs = 0;                  // staying workgroups of the small coder in a split launch (0: one per compute unit)
     DevBuf<SubDesc> subs;
     DevBuf<uint32_t> sub_order, snap_valid;
@@ -269,6 +270,11 @@ void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStr
     *cw_io = cw; *ch_io = ch;
 }
 
+#ifndef ICER_LONE_PAD_BYTES
+#define ICER_LONE_PAD_BYTES 12288
+#endif
+constexpr int kLonePadBytes = ICER_LONE_PAD_BYTES;      // see enqueue: LDS padding of the pipeline's workgroups in a launch of one frame
+
 // enqueue the whole pipeline once; returns 0 or ICER_FATAL_ERROR
 int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
             unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
@@ -354,16 +360,20 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // the occupancy of the small one.  ICER_HIP_PIPE_WAVES=8|11 pins one (measurements).
         // (a split launch fills the chip: the small shape's occupancy, measured 6.63 against 6.78 ms on the headline frame)
         const bool large = e->pipe_waves ? e->pipe_waves == kUnitWavesLarge : (n_frames == 1 && !split);
-        if (large)
-            hipLaunchKernelGGL(code_units_kernel<kUnitWavesLarge>, dim3(n_units + sp.n_subs, n_frames), dim3(64 * kUnitWavesLarge), 0, st,
-                               reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                               progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp);
-        else
-            hipLaunchKernelGGL(code_units_kernel<kUnitWavesSmall>, dim3(n_units + sp.n_subs, n_frames), dim3(64 * kUnitWavesSmall), 0, st,
-                               reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                               progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                               e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp);
+        // A launch of one frame is bound by the chains of its largest units, not by occupancy: it runs the build without the
+        // register budget, padded to the LDS footprint of the queue-depth-8 build (49 KiB; the padding is static: the
+        // `dynamic LDS' launch parameter had no effect on a kernel that declares none).  Measured on the headline frame: 37 KiB
+        // 7.5 ms, 45.6 KiB 6.8 ms, 49.5 KiB 6.7-6.8 ms (profiles/r03_logs/r03_aa.log, r03_ab.log).
+        const bool lone = n_frames * C <= e->split_frames;
+#define ICER_LAUNCH_PIPE(NW, OCC, PAD)                                                                                                       \
+        hipLaunchKernelGGL((code_units_kernel<NW, OCC, PAD>), dim3(n_units + sp.n_subs, n_frames), dim3(64 * NW), 0, st,                     \
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,                  \
+                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp)
+        if (large) ICER_LAUNCH_PIPE(kUnitWavesLarge, 1, 0);
+        else if (lone && !e->lone_as_batch) ICER_LAUNCH_PIPE(kUnitWavesSmall, 1, kLonePadBytes);
+        else ICER_LAUNCH_PIPE(kUnitWavesSmall, 8, 0);
+#undef ICER_LAUNCH_PIPE
         if (split)
             hipLaunchKernelGGL(splice_units_kernel, dim3(n_units, n_frames), dim3(64), 0, st, e->units.p, n_units, e->tables.p, e->means.p, skip, C,
                                (uint32_t)W, (uint32_t)H, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, route, sp);
@@ -441,6 +451,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }
     if (const char *sh = getenv("ICER_HIP_SPLIT_HYBRID")) { const int v = atoi(sh); if (v >= 1 && v <= 101) e->split_hybrid_percent = v; }     // (101: no unit goes to the small coder)
+    if (const char *sw = getenv("ICER_HIP_LONE_AS_BATCH")) e->lone_as_batch = atoi(sw) != 0;
     if (const char *sw = getenv("ICER_HIP_SPLIT_WGS")) { const int v = atoi(sw); if (v >= 1 && v <= 4096) e->split_wgs = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {

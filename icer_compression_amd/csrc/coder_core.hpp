@@ -190,10 +190,12 @@ constexpr uint32_t kFailMagic = 0x1CEBAD00u;     // first word of the diagnostic
 constexpr uint32_t kFailWords = 16;
 constexpr uint32_t kSpinLimit = 1u << 25;
 #ifndef ICER_QUEUE_DEPTH
-#define ICER_QUEUE_DEPTH 8
+#define ICER_QUEUE_DEPTH 4
 #endif
-constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between the waves of a unit (8: 48 KiB of LDS per
-                                                     // workgroup, three per CU; measured 2-3 % faster than 4 on every configuration, gpurun_out/r02n)
+constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between the waves of a unit.  4: 37 KiB of LDS per workgroup, four per
+                                                     // CU (8: 48 KiB, three per CU).  Round 3, profiles/r03_logs/r03_x.log: the depth itself does
+                                                     // not matter (4 and 8 at three per CU are equal on C2 and C4); four workgroups per CU are
+                                                     // + 7 % on C4, + 3 % on C5 -- and - 14 % on a lone frame, which therefore pads its LDS (api.hip)
 // The pixel stage keeps no state from chunk to chunk, so several wavefronts can share it: wave k of `npw` takes the
 // chunks j with j % npw == k.  The Golomb stage (bins 0, 8..16) is split the same way: what carries over from chunk to
 // chunk is only the zero-run length of every bin, and that follows from the chunk's events by a few counts
@@ -285,6 +287,9 @@ struct CoderShared {
     // speculation control: the walker and golomb waves run ahead assuming the fast path; every chunk the merge
     // wave had to replay exactly bumps exact_seq, which invalidates all results produced for later chunks
     uint32_t exact_seq, last_exact;
+#ifdef ICER_LDS_PAD_BYTES                  // (experiments: occupancy at a fixed queue depth)
+    uint8_t lds_pad[ICER_LDS_PAD_BYTES];
+#endif
 };
 
 // ------------------------------------------------------------------------------------------

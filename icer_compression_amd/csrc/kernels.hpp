@@ -109,8 +109,13 @@ constexpr uint8_t kRoutePipeline = 0, kRouteWindows = 1, kRouteNoSplit = 2;   //
 // (three workgroups per CU: batches); WAVES = 11: two pixel waves, golomb state wave + two workers (two per CU, a
 // shorter chain per chunk: single frames).
 // grid = (units, frames), block = 64 * WAVES.
-template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
+// OCC = resident waves per SIMD the register budget is cut for.  8 (64 VGPRs; with 37 KiB of LDS: four workgroups of the
+// small shape per compute unit) is what a batch wants: + 7 % on C4, + 3 % on C5 over three per CU.  The budget costs ~ 280
+// more SGPR spills (v_writelane / v_readlane), and a lone frame -- bound by the chains of its largest units, not by
+// occupancy -- is 14 % slower with it: it runs the OCC = 1 build (profiles/r03_logs/r03_x.log, r03_y.log).
+// LDS_PAD = bytes of LDS the workgroup takes on top of what it uses (single-frame launches, api.hip enqueue).
+template <int WAVES, int OCC, int LDS_PAD>
+__global__ void __launch_bounds__(64 * WAVES, OCC)
 code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                   const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
@@ -119,6 +124,10 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp)
 {
     __shared__ CoderShared s;
+    if constexpr (LDS_PAD > 0) {
+        __shared__ uint32_t lds_pad[LDS_PAD / 4];
+        if (early_quota == ~0ull) lds_pad[threadIdx.x] = 1u;          // (never: keeps the array in the kernel's LDS size)
+    }
     const uint32_t frame = blockIdx.y;
     // A split launch (sp.n_subs > 0) has extra workgroups for its split units: an entry of sp.launch with bit 31 set codes a later
     // sub-range of a unit (coder_core.hpp "Sub-ranges"), the others one unit from its first chunk as always.
