@@ -652,7 +652,13 @@ def main():
             k_ms = stage_ms["code_units"] / max(calls, 1)
             alg_bytes = float(B * W * H * 2 + h_sizes_sum) / launches_per_step
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            pipe = "code_units_kernel<11> (wave pipeline, 11-wave workgroups)" if wl.launch == 1 else "code_units_kernel<8> (wave pipeline, 8-wave workgroups)"
+            li = wl.enc.launch_info()
+            pipe = f"code_units_kernel<{li['pipeline_waves']}> (wave pipeline, {li['pipeline_waves']}-wave workgroups)"
+            if li["split"]:
+                pipe += (f"; the dense coding units cut into sub-ranges, {li['sub_range_workgroups']} extra workgroups in the same launch, spliced by "
+                         "splice_units_kernel (inside the timed stage)")
+            if li["window_coder_beside"]:
+                pipe += "; the all-but-blank units by code_units_wgs_list_kernel on a second stream beside it (inside the timed stage)"
             kernel = {0: pipe + "; code_units_wg_kernel in progressive mode", 1: pipe, 2: "code_units_wg_kernel"}[stats["coder_mode"]]
             line["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,

@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     L.icerx_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.icerx_encoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.icerx_encoder_routing.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.icerx_encoder_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.icerx_process_stats.argtypes = [C.POINTER(C.c_uint64)]
     L.icerx_pin_host.argtypes = [C.c_void_p, C.c_size_t]
     L.icerx_unpin_host.argtypes = [C.c_void_p]
@@ -313,6 +314,12 @@ class Encoder:
         out = (C.c_uint64 * 2)()
         self.lib.icerx_encoder_routing(self.handle, out)
         return {"routed_units": out[0], "routed_calls": out[1]}
+
+    def launch_info(self):
+        """shape of the last launch (icerx_encoder_launch_info)"""
+        out = (C.c_uint32 * 4)()
+        self.lib.icerx_encoder_launch_info(self.handle, out)
+        return {"split": bool(out[0]), "sub_range_workgroups": int(out[1]), "pipeline_waves": int(out[2]), "window_coder_beside": bool(out[3])}
 
     def info(self):
         u, b, s = C.c_uint32(), C.c_uint32(), C.c_uint64()

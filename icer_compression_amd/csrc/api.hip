@@ -119,6 +119,8 @@ struct icerx_encoder {
     int split_frames = 1;
     int split_hybrid_percent = 90;      // ... whose units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_SPLIT_HYBRID)
     bool last_split = false;
+    int last_waves = 0;                 // last launch: wavefronts per pipeline workgroup (0: the workgroup coder alone)
+    uint32_t last_subs = 0;             // last launch: sub-range workgroups
     bool lone_as_batch = false;         // ICER_HIP_LONE_AS_BATCH=1: single-frame launches with the batch build of the pipeline (measurements)
     int split_wgs = 0;                  // staying workgroups of the small coder in a split launch (0: one per compute unit)
     DevBuf<SubDesc> subs;
@@ -370,6 +372,8 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,                  \
                            e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp)
+        e->last_waves = large ? kUnitWavesLarge : kUnitWavesSmall;
+        e->last_subs = sp.n_subs;
         if (large) ICER_LAUNCH_PIPE(kUnitWavesLarge, 1, 0);
         else if (lone && !e->lone_as_batch) ICER_LAUNCH_PIPE(kUnitWavesSmall, 1, kLonePadBytes);
         else ICER_LAUNCH_PIPE(kUnitWavesSmall, 8, 0);
@@ -379,6 +383,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                                (uint32_t)W, (uint32_t)H, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, route, sp);
         if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join, 0));
     }
+    if (use_wg) e->last_waves = 0, e->last_subs = 0;
     if (use_wg)
         hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
@@ -1043,9 +1048,10 @@ int icerx_compress_batch_uint16_devices(const uint16_t *frames, int n_frames, si
             const int lo = d * base + (d < extra ? d : extra), cnt = base + (d < extra ? 1 : 0);
             int r;
             try {
+                g_last_error.clear();                            // (thread-local: what this block's failure leaves, if anything)
                 r = batch_on_device(pool_device(devices[d]), frames + (size_t)lo * frame_elems, cnt, w, h, channels, stages, filt, segments,
                                     byte_quota, out + (size_t)lo * out_stride, out_stride, sizes + lo, rcs + lo);
-                if (r) err[(size_t)d] = icerx_last_error();      // (thread-local in the worker)
+                if (r) err[(size_t)d] = g_last_error.empty() ? "error code " + std::to_string(r) + " (lib_icer argument check)" : g_last_error;
             } catch (const std::exception &ex) { r = ICER_FATAL_ERROR; err[(size_t)d] = ex.what(); }
             rc[(size_t)d] = r;
         };
@@ -1143,6 +1149,13 @@ int icerx_encoder_routing(icerx_encoder *e, uint64_t out[2])
 {
     if (!e || !out) return ICER_INVALID_INPUT;
     out[0] = e->n_routed_units; out[1] = e->n_routed_launches;
+    return 0;
+}
+
+int icerx_encoder_launch_info(icerx_encoder *e, uint32_t out[4])
+{
+    if (!e || !out) return ICER_INVALID_INPUT;
+    out[0] = e->last_split ? 1u : 0u; out[1] = e->last_subs; out[2] = (uint32_t)e->last_waves; out[3] = e->last_routed ? 1u : 0u;
     return 0;
 }
 

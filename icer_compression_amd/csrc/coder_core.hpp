@@ -1891,10 +1891,18 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
     uint32_t idle = 0;
     for (uint32_t step = 0;;) {
         if (ICER_LOAD_CNT(s.abort)) break;
+        // drain_exit is read BEFORE hold_seq, and the load is complete before the next one is issued.  The merge wave ends a
+        // unit with "drain_exit = 1; hold_seq = odd; wait for hold_ack == hold_seq".  Read the other way round (round 1 and 2),
+        // this wave could see a hold it had already acknowledged (hs = 23), then -- the merge wave releasing that hold and
+        // ending the unit in between -- drain_exit = 1, acknowledge the stale 23 and leave, the merge wave waiting for 25 until
+        // its spin bound: the rare coding-unit time-out (one unit in ~10^5 whose last chunk took the exact path; seen once
+        // more at four workgroups per compute unit: profiles/r03_logs/r03_full_bench_timeout.err).  With this order
+        // drain_exit = 1 implies that the hold_seq read afterwards is the final request or the even value before it.
+        const uint32_t ex_ = ICER_LOAD_CNT(s.drain_exit);
+        ICER_ACQUIRE()
         const uint32_t hs = ICER_LOAD_CNT(s.hold_seq);
         if (hs & 1u) {
             // parked: the merge wave owns popped / bitpos / the bit stage until it releases the hold
-            const uint32_t ex_ = ICER_LOAD_CNT(s.drain_exit);
             // (end of unit: the payload words this wave stored are read back by the merge wave for the CRC; the hand-off
             // fences are LDS-only, so the stores are completed explicitly before the acknowledgement)
             if (ex_) ICER_GLOBAL_RELEASE();

@@ -4,6 +4,9 @@ quotas and content, HIP path through the C ABI vs the oracle.  Meant to shake ou
    python tests/stress_gpu.py [seconds] [seed]          (ICER_HIP_CODER=pipe|wg pins the coding-unit kernel)
 Fails on any mismatch and on any coding-unit time-out (icerx_process_stats), even though a time-out no longer fails the
 call.  tests/test_gpu_stress.py runs a bounded slice of it under pytest -m gpu.
+With ICER_STRESS_BATCH=<n> every gray 16-bit case becomes a batch of n frames (the same geometry, rolled content) through
+icerx_compress_batch_uint16_devices -- the batch build of the pipeline kernel, four workgroups per compute unit, sub-batches on
+three streams -- each frame against the oracle.
 With ICER_STRESS_DECODE=1 every stream the encoder produced is also decoded by libicer_hip_dec.so (both decode kernels)
 and compared with the decoder oracle."""
 import os
@@ -59,6 +62,23 @@ def main():
         u8 = rng.random() < 0.2                          # the uint8 twins on 6-bit versions of the same planes
         if u8:
             planes = [(p >> int(rng.choice([0, 2, 4]))).astype(np.uint8) for p in planes]
+        nb = int(os.environ.get("ICER_STRESS_BATCH", "0"))
+        if nb > 1 and not u8 and not color:
+            frames = np.stack([np.roll(img, (3 * k, 7 * k), (0, 1)) for k in range(nb)])
+            cap = min(quota, 2 * w * h + 64) + 64
+            out, sizes, rcs = np.zeros((nb, cap), np.uint8), np.zeros(nb, np.uint64), np.zeros(nb, np.int32)
+            rc = api.compress_batch(frames, st, filt, sg, quota, out, sizes, rcs, devices=[0])
+            n += 1
+            for k in range(nb):
+                b = orc.compress([frames[k]], st, filt, sg, quota)
+                # (an argument error -- too many segments / stages for the geometry -- is the call's return code, as the
+                # reference returns it for every frame)
+                if (rc != b[0] or b[0] not in (-3, -4)) if rc != 0 else (int(rcs[k]) != b[0] or out[k, : int(sizes[k])].tobytes() != b[1]):
+                    bad += 1
+                    print("BATCH MISMATCH", dict(w=w, h=h, stages=st, filt=filt, segments=sg, quota=quota, kind=int(kind), frame=k), "rc", rc, int(rcs[k]), b[0],
+                          api.load_library().icerx_last_error() if rc else "", flush=True)
+                    break
+            continue
         try:
             a = (api.compress_u8 if u8 else api.compress)(planes, st, filt, sg, quota)
         except Exception as exc:                                   # noqa: BLE001

@@ -13,19 +13,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("coder,seconds,seed", [("pipe8", 12, 101), ("pipe11", 12, 111), ("wg", 14, 202), ("auto", 10, 303), ("hybrid", 14, 404),
-                                                ("split", 14, 505)])
+                                                ("split", 14, 505), ("batch", 14, 606)])
 def test_randomised_encodes(coder, seconds, seed):
     """pipe8 / pipe11: the wave pipeline with its workgroup shape pinned (8 waves: batches, 11 waves: single frames --
     the drop-in entry points would always pick 11); wg: the barrier-only workgroup coder; auto: the library's own choice; hybrid: both coders in one launch (what a batch
     gets: the all-but-blank units go to the small workgroup coder beside the pipeline) forced on for single frames too;
     split: single gray frames with their coding units cut into sub-ranges of 128 chunks, one workgroup each, spliced where the
-    workgroups' coder states meet (what the headline frame gets with pieces of 3072 chunks)"""
+    workgroups' coder states meet (what the headline frame gets with pieces of 3072 chunks); batch: every gray case as a batch of
+    six frames through the pipelined host batch (the batch build of the pipeline kernel: four workgroups per compute unit)"""
     env = dict(os.environ, ICER_STRESS_BIG="0.08")
     env.pop("ICER_HIP_CODER", None)
     env.pop("ICER_HIP_PIPE_WAVES", None)
     env.pop("ICER_HIP_HYBRID", None)
     env.pop("ICER_HIP_HYBRID_FRAMES", None)
     env.pop("ICER_HIP_SPLIT", None)
+    env.pop("ICER_STRESS_BATCH", None)
     if coder.startswith("pipe"):
         env["ICER_HIP_CODER"] = "pipe"
         env["ICER_HIP_PIPE_WAVES"] = coder[4:]
@@ -35,6 +37,8 @@ def test_randomised_encodes(coder, seconds, seed):
     elif coder == "split":
         env["ICER_HIP_SPLIT"] = "128"
         env["ICER_STRESS_BIG"] = "0.3"
+    elif coder == "batch":
+        env["ICER_STRESS_BATCH"] = "6"
     elif coder != "auto":
         env["ICER_HIP_CODER"] = coder
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stress_gpu.py"), str(seconds), str(seed)], env=env,
