@@ -1,9 +1,11 @@
 // decoder_core.hpp -- device side of the ICER *decoder* (SURVEY.md 8f, row next-1): the consumer of the streams the
 // encoder hot path writes.  Plain per-thread code, shared between the gfx950 build (decoder.hip) and a g++ build
-// for tests/emu (the authoring container has no GPU); no wave-level cooperation yet.
+// for tests/emu (the authoring container has no GPU); the wave-level cooperation is in decoder_wave.hpp.
 //
-// STATUS: first correct version.  Checked bit-for-bit against the decoder oracle on the CPU build and, briefly, on an
-// MI355X (16-bit gray frames up to 4096 x 4096); not yet profiled.  It is not part of libicer_hip.so.
+// STATUS: bit-exact against the decoder oracle on the CPU build (tests/test_emu_decoder.py) and on an MI355X
+// (tests/test_gpu_decoder.py, default-on in the GPU gate); two decode kernels use it: one thread per chain (decoder.hip) and
+// one wavefront per chain with a lane per bit plane (decoder_wave.hpp, the default).  Numbers: DESIGN.md 6.2 / 6b.  It is
+// not part of libicer_hip.so.
 //
 // Restates, per segment ("chain": the bit planes of one segment of one subband of one channel, top plane first):
 //   entropy decoder        icer_decode_bit + bit readers            lib_icer/src/icer_decoding.c:12-194

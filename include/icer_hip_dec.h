@@ -3,10 +3,11 @@
  *
  * STATUS: bit-exact against the decoder oracle in its CPU builds (tests/test_emu_decoder.py) and on an MI355X
  * (tests/test_gpu_decoder.py: gray / YUV, 16 / 8 bit, damaged and truncated streams, wrong decode parameters, the golden
- * decoder digests up to 4096 x 4096, the batch object; profiles/r02_pytest_gpu_v2.log).  Speed: a chain (segment of a
- * subband) is a serial adaptive decode, so one stream alone runs at 12.8 Mpix/s on the 4096 x 4096 headline frame and 16
- * streams per call at 186 Mpix/s (tools/decode_bench.py, profiles/r02_decode_bench_v1.json).  It is a separate library so
- * that libicer_hip.so (the measured encoder) is unaffected.  See DESIGN.md 6b.
+ * decoder digests up to 4096 x 4096, the batch object; the reference-held fixtures of tests/test_gpu_parity.py).  Speed: a
+ * chain (segment of a subband) is a serial adaptive decode, so one stream alone runs at 26 Mpix/s on the 4096 x 4096
+ * headline frame (6.7 x the reference decoder on one core of the same box), 16 streams per call at 368 Mpix/s, 64 at
+ * 657 Mpix/s (bench.py `decode` object, tools/decode_bench.py).  It is a separate library so that
+ * libicer_hip.so (the measured encoder) is unaffected.  See DESIGN.md 6b.
  *
  * Same names, argument meaning and return codes as the decoding entry points of lib_icer
  * (TheRealOrange/icer_compression, lib_icer/inc/icer.h); the work runs on the GPU and there is no CPU fallback
