@@ -78,7 +78,8 @@
 constexpr uint32_t kPollLimit = 50u * 1000u * 1000u;
 #elif defined(ICER_WAVE_EMU)
 #include <assert.h>
-extern unsigned long long g_emu_chunks[2];          // tests only: [0] fast-path chunks, [1] exact-path chunks
+extern unsigned long long g_emu_chunks[4];          // tests only: [0] fast-path chunks, [1] exact-path chunks, golomb wave: [2] chunks in the general form (a sign
+                                                    // event in a Golomb bin), [3] in the reduced form
 #define ICER_EMU_COUNT(i) (g_emu_chunks[i]++)
 // cross-wave hand-off: the emulation runs the waves in an order in which every wait is already satisfied
 #define ICER_LOAD_CNT(x) (x)
@@ -582,6 +583,20 @@ ICER_DEV int last_le_own(uint64_t A1, uint64_t A2, int lane, uint32_t slot)
     const uint64_t c1 = A1 & le, c2 = A2 & (slot ? le : lt);
     const int k1 = c1 ? 2 * (63 - clz64(c1)) : -1, k2 = c2 ? 2 * (63 - clz64(c2)) + 1 : -1;
     return k1 > k2 ? k1 : k2;
+}
+// the same with events in the first position of a lane only (A2 = 0)
+ICER_DEV uint32_t cnt_lt1(uint64_t A1, uint32_t pos) { return (uint32_t)popc64(A1 & below64((pos + 1u) >> 1)); }
+ICER_DEV uint32_t cnt_lt_own1(uint64_t A1, int lane, uint32_t slot) { return (uint32_t)mbcnt64(A1, lane) + (slot ? own_bit(A1, lane) : 0u); }
+ICER_DEV int last_lt_own1(uint64_t A1, int lane, uint32_t slot)
+{
+    const uint64_t lt = lanes_below(lane);
+    const uint64_t c1 = A1 & (slot ? (lt << 1) | 1ull : lt);
+    return c1 ? 2 * (63 - clz64(c1)) : -1;
+}
+ICER_DEV int last_le_own1(uint64_t A1, int lane)
+{
+    const uint64_t c1 = A1 & ((lanes_below(lane) << 1) | 1ull);
+    return c1 ? 2 * (63 - clz64(c1)) : -1;
 }
 
 // drain finished words from the head of the ring, 64 per round: lengths -> prefix sum -> bit offsets,
@@ -1449,62 +1464,72 @@ ICER_DEV uint32_t golomb_wave_run(CoderShared &s, const UnitArgs &a, GolombWave 
             }
         } else {
             const uint64_t G1 = BALLOT((LV(ev1) & 0x98u) >= 0x88u), G2 = BALLOT((LV(ev2) & 0x98u) >= 0x88u);
-            if (G1 | G2) {
-                const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u);
-                const uint64_t J0 = BALLOT(LV(ev2) & 1u), J1 = BALLOT(LV(ev2) & 2u), J2 = BALLOT(LV(ev2) & 4u), J3 = BALLOT((LV(ev2) & 31u) == 16u);
-                const uint64_t O1 = G1 & BALLOT(LV(ev1) & 0x20u), O2 = G2 & BALLOT(LV(ev2) & 0x20u);       // one-events
-                // key of a bin: bin - 8 = 0..8, i.e. the low three bits of the bin number and "bin == 16"
-                LANEVAR(uint64_t, ma1); LANEVAR(uint64_t, mb1); LANEVAR(uint64_t, ma2); LANEVAR(uint64_t, mb2);   // events of this lane's bins
-#define ICER_GOLOMB_LANE(EV, SLOT, KA, FL, WD, MA, MB)                                                        \
+            // key of a bin: bin - 8 = 0..8, i.e. the low three bits of the bin number and "bin == 16".
+            // TWO = 0: no sign event of the chunk is in a Golomb bin (G2 == 0) -- the rule: a sign is close to a coin toss, its
+            // bins are the low ones -- and everything that concerns the second event of a lane drops out at compile time:
+            // about a third of this wave's instructions per dense chunk.  TWO = 1: the general form.
+#define ICER_GOLOMB_LANE(TWO, EV, SLOT, KA, FL, WD, MA, MB)                                                    \
                 if (((EV) & 0x98u) >= 0x88u) {                                                                \
                     const uint32_t b_ = (EV) & 31u, key_ = (b_ & 7u) | (b_ == 16u ? 8u : 0u);                  \
-                    const uint64_t m1_ = ICER_MATCH(key_, G1, K0, K1, K2, K3), m2_ = ICER_MATCH(key_, G2, J0, J1, J2, J3); \
+                    const uint64_t m1_ = ICER_MATCH(key_, G1, K0, K1, K2, K3), m2_ = (TWO) ? ICER_MATCH(key_, G2, J0, J1, J2, J3) : 0ull; \
                     MA = m1_; MB = m2_;                                                                         \
                     const uint64_t Z1 = m1_ & ~O1, Z2 = m2_ & ~O2;                                              \
-                    const uint32_t zb_ = cnt_lt_own(Z1, Z2, lane, (SLOT));                                      \
-                    const int lo_ = last_lt_own(m1_ & O1, m2_ & O2, lane, (SLOT));                               \
-                    const uint32_t z_ = lo_ >= 0 ? zb_ - cnt_lt(Z1, Z2, (uint32_t)lo_) : runs_in.gk[b_] + zb_;   \
+                    const uint32_t zb_ = (TWO) ? cnt_lt_own(Z1, Z2, lane, (SLOT)) : cnt_lt_own1(Z1, lane, (SLOT)); \
+                    const int lo_ = (TWO) ? last_lt_own(m1_ & O1, m2_ & O2, lane, (SLOT)) : last_lt_own1(m1_ & O1, lane, (SLOT)); \
+                    const uint32_t z_ = lo_ >= 0 ? zb_ - ((TWO) ? cnt_lt(Z1, Z2, (uint32_t)lo_) : cnt_lt1(Z1, (uint32_t)lo_)) : runs_in.gk[b_] + zb_; \
                     const uint32_t m = s.tab.gm[b_], inv = s.tab.ginv[b_];                                      \
                     const uint32_t kb_ = z_ - ((z_ * inv) >> 20) * m;                                           \
                     const uint32_t bit_ = ((EV) >> 5) & 1u;                                                     \
                     FL = (kb_ == 0u ? 1u : 0u) | ((bit_ || kb_ + 1u == m) ? 2u : 0u);                           \
                     WD = bit_ ? golomb_word(s.tab, (int)b_, kb_) : (kWordDone | (1u << 11) | 1u);               \
-                    const uint32_t before_ = cnt_lt_own(m1_, m2_, lane, (SLOT));                                \
-                    if (before_ + 1u == (uint32_t)(popc64(m1_) + popc64(m2_))) KA = (FL & 2u) ? 0u : kb_ + 1u;  \
+                    const uint32_t before_ = (TWO) ? cnt_lt_own(m1_, m2_, lane, (SLOT)) : cnt_lt_own1(m1_, lane, (SLOT)); \
+                    if (before_ + 1u == (uint32_t)(popc64(m1_) + ((TWO) ? popc64(m2_) : 0))) KA = (FL & 2u) ? 0u : kb_ + 1u;  \
                 }
-                FOR_LANES
-                {
-                    LV(ma1) = 0; LV(mb1) = 0; LV(ma2) = 0; LV(mb2) = 0; LV(ka1) = ~0u; LV(ka2) = ~0u;
-                    ICER_GOLOMB_LANE(LV(ev1), 0u, LV(ka1), LV(fl1), LV(wd1), LV(ma1), LV(mb1))
-                    ICER_GOLOMB_LANE(LV(ev2), 1u, LV(ka2), LV(fl2), LV(wd2), LV(ma2), LV(mb2))
-                }
-#undef ICER_GOLOMB_LANE
-                // word starts of the Golomb bins; an end event's word began at its bin's latest start, and so did the
-                // word a bin's last event leaves open
-                WAVE_SYNC();
-                const uint64_t SB1 = G1 & BALLOT(LV(fl1) & 1u), SB2 = G2 & BALLOT(LV(fl2) & 1u);
-                FOR_LANES
-                {
-                    if ((LV(ev1) & 0x98u) >= 0x88u && ((LV(fl1) & 2u) || LV(ka1) != ~0u)) {
-                        const int sp = last_le_own(SB1 & LV(ma1), SB2 & LV(mb1), lane, 0u);
-                        if (LV(fl1) & 2u) LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;
-                        if (LV(ka1) != ~0u) {
-                            const uint32_t b = LV(ev1) & 31u;
-                            if (fused) s.gk[b] = LV(ka1);
-                            o.binst[b] = st_pack(LV(ka1) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka1), 0u);
-                        }
-                    }
-                    if ((LV(ev2) & 0x98u) >= 0x88u && ((LV(fl2) & 2u) || LV(ka2) != ~0u)) {
-                        const int sp = last_le_own(SB1 & LV(ma2), SB2 & LV(mb2), lane, 1u);
-                        if (LV(fl2) & 2u) LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;
-                        if (LV(ka2) != ~0u) {
-                            const uint32_t b = LV(ev2) & 31u;
-                            if (fused) s.gk[b] = LV(ka2);
-                            o.binst[b] = st_pack(LV(ka2) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka2), 0u);
-                        }
-                    }
-                }
+#define ICER_GOLOMB_BINS(TWO)                                                                                  \
+            {                                                                                                  \
+                const uint64_t K0 = BALLOT(LV(ev1) & 1u), K1 = BALLOT(LV(ev1) & 2u), K2 = BALLOT(LV(ev1) & 4u), K3 = BALLOT((LV(ev1) & 31u) == 16u); \
+                const uint64_t J0 = (TWO) ? BALLOT(LV(ev2) & 1u) : 0ull, J1 = (TWO) ? BALLOT(LV(ev2) & 2u) : 0ull;     \
+                const uint64_t J2 = (TWO) ? BALLOT(LV(ev2) & 4u) : 0ull, J3 = (TWO) ? BALLOT((LV(ev2) & 31u) == 16u) : 0ull; \
+                const uint64_t O1 = G1 & BALLOT(LV(ev1) & 0x20u), O2 = (TWO) ? G2 & BALLOT(LV(ev2) & 0x20u) : 0ull;   /* one-events */ \
+                (void)J0; (void)J1; (void)J2; (void)J3; (void)O2;                                              \
+                LANEVAR(uint64_t, ma1); LANEVAR(uint64_t, mb1); LANEVAR(uint64_t, ma2); LANEVAR(uint64_t, mb2);   /* events of this lane's bins */ \
+                FOR_LANES                                                                                      \
+                {                                                                                              \
+                    LV(ma1) = 0; LV(mb1) = 0; LV(ma2) = 0; LV(mb2) = 0; LV(ka1) = ~0u; LV(ka2) = ~0u;          \
+                    ICER_GOLOMB_LANE(TWO, LV(ev1), 0u, LV(ka1), LV(fl1), LV(wd1), LV(ma1), LV(mb1))            \
+                    if (TWO) { ICER_GOLOMB_LANE(TWO, LV(ev2), 1u, LV(ka2), LV(fl2), LV(wd2), LV(ma2), LV(mb2)) } \
+                }                                                                                              \
+                /* word starts of the Golomb bins; an end event's word began at its bin's latest start, and so did the */ \
+                /* word a bin's last event leaves open */                                                       \
+                WAVE_SYNC();                                                                                   \
+                const uint64_t SB1 = G1 & BALLOT(LV(fl1) & 1u), SB2 = (TWO) ? G2 & BALLOT(LV(fl2) & 1u) : 0ull; \
+                (void)SB2;                                                                                     \
+                FOR_LANES                                                                                      \
+                {                                                                                              \
+                    if ((LV(ev1) & 0x98u) >= 0x88u && ((LV(fl1) & 2u) || LV(ka1) != ~0u)) {                     \
+                        const int sp = (TWO) ? last_le_own(SB1 & LV(ma1), SB2 & LV(mb1), lane, 0u) : last_le_own1(SB1 & LV(ma1), lane); \
+                        if (LV(fl1) & 2u) LV(sp1) = sp < 0 ? 255u : (uint32_t)sp;                               \
+                        if (LV(ka1) != ~0u) {                                                                  \
+                            const uint32_t b = LV(ev1) & 31u;                                                  \
+                            if (fused) s.gk[b] = LV(ka1);                                                      \
+                            o.binst[b] = st_pack(LV(ka1) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka1), 0u); \
+                        }                                                                                      \
+                    }                                                                                          \
+                    if ((TWO) && (LV(ev2) & 0x98u) >= 0x88u && ((LV(fl2) & 2u) || LV(ka2) != ~0u)) {            \
+                        const int sp = last_le_own(SB1 & LV(ma2), SB2 & LV(mb2), lane, 1u);                    \
+                        if (LV(fl2) & 2u) LV(sp2) = sp < 0 ? 255u : (uint32_t)sp;                               \
+                        if (LV(ka2) != ~0u) {                                                                  \
+                            const uint32_t b = LV(ev2) & 31u;                                                  \
+                            if (fused) s.gk[b] = LV(ka2);                                                      \
+                            o.binst[b] = st_pack(LV(ka2) ? (sp < 0 ? 255u : (uint32_t)sp) : 254u, LV(ka2), 0u); \
+                        }                                                                                      \
+                    }                                                                                          \
+                }                                                                                              \
             }
+            if (G2) { ICER_EMU_COUNT(2); ICER_GOLOMB_BINS(1) }
+            else if (G1) { ICER_EMU_COUNT(3); ICER_GOLOMB_BINS(0) }
+#undef ICER_GOLOMB_BINS
+#undef ICER_GOLOMB_LANE
         }
 #undef ICER_MATCH
         ICER_TICK(11)

@@ -113,6 +113,13 @@ def emu():
             return bits, bytes(out[: (max(bits, 0) + 7) // 8])
 
         @staticmethod
+        def chunk_stats(reset=True):
+            """[fast-path chunks, exact-path chunks, golomb wave: chunks in the general form, in the reduced form] since the last reset"""
+            out = (C.c_ulonglong * 4)()
+            L.emu_chunk_stats(out, 1 if reset else 0)
+            return list(out)
+
+        @staticmethod
         def dwt(img, stages, filt):
             b = np.ascontiguousarray(img, dtype=np.uint16).copy()
             rc = L.emu_dwt(b, b.shape[1], b.shape[0], stages, filt)

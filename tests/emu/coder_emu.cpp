@@ -40,8 +40,8 @@ static uint32_t wg_unit(const UnitArgs &a0)
     wg::unit_state_init(g_wsh, a);
     return wg::code_unit_wg(g_wsh, a, regs);
 }
-unsigned long long g_emu_chunks[2] = {0, 0};
-extern "C" void emu_chunk_stats(unsigned long long *out, int reset) { out[0] = g_emu_chunks[0]; out[1] = g_emu_chunks[1]; if (reset) g_emu_chunks[0] = g_emu_chunks[1] = 0; }
+unsigned long long g_emu_chunks[4] = {0, 0, 0, 0};
+extern "C" void emu_chunk_stats(unsigned long long *out, int reset) { for (int i = 0; i < 4; i++) { out[i] = g_emu_chunks[i]; if (reset) g_emu_chunks[i] = 0; } }
 
 extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb,
                               uint8_t *out, size_t cap_bytes)

@@ -51,6 +51,24 @@ def test_coding_units_random_planes_with_ring_pressure(emu, oracle):
                 assert emu.code_unit(plane, 0, 0, w, h, sb, lsb) == oracle.code_unit(plane, 0, 0, w, h, sb, lsb), (trial, sb, lsb)
 
 
+def test_coding_units_with_predictable_signs(emu, oracle):
+    """the golomb wave has two forms of its per-bin work: a reduced one for chunks without a sign event in a Golomb bin (the
+    rule: a sign is close to a coin toss) and the general one.  Planes whose signs are all alike make the sign contexts
+    confident, so their events reach the Golomb bins: both forms run (counted) and agree with the oracle."""
+    rng = np.random.default_rng(15)
+    emu.chunk_stats()
+    for trial, sign in enumerate((0, 1, 2)):
+        w, h = int(rng.integers(150, 330)), int(rng.integers(60, 200))
+        mag = rng.integers(0, 200, (h, w)).astype(np.uint16)
+        sg = np.full((h, w), sign & 1, np.uint16) if sign < 2 else ((np.add.outer(np.arange(h), np.arange(w)) // 3) & 1).astype(np.uint16)
+        plane = (mag | ((sg << 15) * (mag > 0))).astype(np.uint16)
+        for sb in (0, 1, 3):
+            for lsb in (0, 2, 4, 6):
+                assert emu.code_unit(plane, 0, 0, w, h, sb, lsb) == oracle.code_unit(plane, 0, 0, w, h, sb, lsb), (trial, sb, lsb)
+    st = emu.chunk_stats()
+    assert st[2] > 100 and st[3] > 100, st
+
+
 def test_slot_capacity_rule(emu, oracle):
     rng = np.random.default_rng(6)
     plane = rng.integers(0, 512, (40, 50)).astype(np.uint16)
