@@ -818,29 +818,47 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             const uint64_t U = BALLOT(LV(valid2) != 0u);
             const uint64_t C0 = BALLOT((LV(ctx2) - 12u) & 1u), C1 = BALLOT((LV(ctx2) - 12u) & 2u), C2 = BALLOT((LV(ctx2) - 12u) & 4u);
             const uint64_t ZN = BALLOT(LV(bit2) == 0u);
+            // The events of a context are matched once per CONTEXT, by lane c for context c (it needs them for the context's
+            // totals anyway); an event's lane fetches the mask of its context from that lane (two ds_bpermute) instead of
+            // matching its own key against the ballots again (22 VALU instructions per event position).
+            LANEVAR(uint32_t, om_lo); LANEVAR(uint32_t, om_hi); LANEVAR(uint32_t, g1l); LANEVAR(uint32_t, g1h); LANEVAR(uint32_t, g2l); LANEVAR(uint32_t, g2h);
+            LANEVAR(uint32_t, x1); LANEVAR(uint32_t, x2);
             FOR_LANES
             {
-                LV(w1) = 0; LV(w2) = 0; LV(cnw) = 0;
+                uint64_t m = 0, zs = ZM;
+                if (U) {
+                    // (magnitude contexts on lanes 0..11, sign contexts on lanes 12..16: one match on selected ballots)
+                    const bool sg = lane >= 12;
+                    const uint32_t key = sg ? (uint32_t)lane - 12u : (uint32_t)lane;
+                    const uint64_t vv = sg ? U : V, b0 = sg ? C0 : B0, b1 = sg ? C1 : B1, b2 = sg ? C2 : B2, b3 = sg ? 0ull : B3;
+                    if (lane <= 16) m = ICER_MATCH(key, vv, b0, b1, b2, b3);
+                    zs = sg ? ZN : ZM;
+                } else if (lane < 12) m = ICER_MATCH((uint32_t)lane, V, B0, B1, B2, B3);
+                LV(om_lo) = (uint32_t)m; LV(om_hi) = (uint32_t)(m >> 32);
+                LV(cnw) = (uint32_t)popc64(m) | ((uint32_t)popc64(m & zs) << 8);
+                LV(x1) = LV(ctx1) & 31u; LV(x2) = LV(ctx2) & 31u;                   // (context 31, uncoded: lane 31 holds an empty mask)
+                LV(g1l) = 0; LV(g1h) = 0; LV(g2l) = 0; LV(g2h) = 0;
+            }
+            if (!counts_only) {
+                WAVE_GATHER(g1l, om_lo, x1) WAVE_GATHER(g1h, om_hi, x1)
+                if (U) { WAVE_GATHER(g2l, om_lo, x2) WAVE_GATHER(g2h, om_hi, x2) }
+            }
+            FOR_LANES
+            {
+                LV(w1) = 0; LV(w2) = 0;
                 if (LV(valid1)) {
                     LV(w1) = 0x80u | (LV(bit1) << 5) | LV(ctx1);
                     if (LV(ctx1) != 31u && !counts_only) {
-                        const uint64_t m = ICER_MATCH(LV(ctx1), V, B0, B1, B2, B3);
+                        const uint64_t m = (uint64_t)LV(g1l) | ((uint64_t)LV(g1h) << 32);
                         LV(w1) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZM, lane) << 16);
                     }
                 }
                 if (LV(valid2)) {
                     LV(w2) = 0x80u | (LV(bit2) << 5) | LV(ctx2);
                     if (!counts_only) {
-                        const uint64_t m = ICER_MATCH(LV(ctx2) - 12u, U, C0, C1, C2, 0ull);
+                        const uint64_t m = (uint64_t)LV(g2l) | ((uint64_t)LV(g2h) << 32);
                         LV(w2) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZN, lane) << 16);
                     }
-                }
-                if (lane < 12) {
-                    const uint64_t m = ICER_MATCH((uint32_t)lane, V, B0, B1, B2, B3);
-                    LV(cnw) = (uint32_t)popc64(m) | ((uint32_t)popc64(m & ZM) << 8);
-                } else if (lane <= 16) {
-                    const uint64_t m = ICER_MATCH((uint32_t)lane - 12u, U, C0, C1, C2, 0ull);
-                    LV(cnw) = (uint32_t)popc64(m) | ((uint32_t)popc64(m & ZN) << 8);
                 }
             }
         }
@@ -1055,31 +1073,59 @@ ICER_DEV void compact_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0, u
         }
         WAVE_SYNC();
         // every event of bins 1..7 puts its input bit at its rank into the bin's bit string and its position
-        // into the bin's position list.  Rank = number of earlier events of the same bin; the lanes of a bin
-        // are found from per-bit ballots of the bin number (no loop over bins).
+        // into the bin's position list.  Rank = number of earlier events of the same bin.  The lanes of a bin are found from
+        // per-bit ballots of the bin number (no loop over bins) -- once per BIN, by lane b for bin b (which also needs them
+        // for the bin's event count); an event's lane then fetches the two masks of its bin (first / second position of a
+        // lane) from that lane: four ds_bpermute instead of matching its own key against the ballots again (2 x 16 VALU
+        // instructions per event position; the kernel is VALU-bound, its LDS pipe mostly idle).  Without an event of these bins
+        // in a second position (V2 == 0: the sign events of most chunks are in bin 0) half of it drops out.
         {
 #define ICER_MATCH3(KEY, V, B0, B1, B2) ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)))
             const uint64_t P0 = BALLOT(LV(ev1) & 1u), P1 = BALLOT(LV(ev1) & 2u), P2 = BALLOT(LV(ev1) & 4u);
-            const uint64_t Q0 = BALLOT(LV(ev2) & 1u), Q1 = BALLOT(LV(ev2) & 2u), Q2 = BALLOT(LV(ev2) & 4u);
+            LANEVAR(uint32_t, oa_lo); LANEVAR(uint32_t, oa_hi); LANEVAR(uint32_t, ob_lo); LANEVAR(uint32_t, ob_hi);   // lane b: the events of bin b
+            LANEVAR(uint32_t, i1); LANEVAR(uint32_t, i2);
+            LANEVAR(uint32_t, a1l); LANEVAR(uint32_t, a1h); LANEVAR(uint32_t, b1l); LANEVAR(uint32_t, b1h);
+            LANEVAR(uint32_t, a2l); LANEVAR(uint32_t, a2h); LANEVAR(uint32_t, b2l); LANEVAR(uint32_t, b2h);
+            if (V2) {
+                const uint64_t Q0 = BALLOT(LV(ev2) & 1u), Q1 = BALLOT(LV(ev2) & 2u), Q2 = BALLOT(LV(ev2) & 4u);
+                FOR_LANES
+                {
+                    const uint64_t ma = ICER_MATCH3((uint32_t)lane & 7u, V1, P0, P1, P2), mb = ICER_MATCH3((uint32_t)lane & 7u, V2, Q0, Q1, Q2);
+                    LV(oa_lo) = (uint32_t)ma; LV(oa_hi) = (uint32_t)(ma >> 32); LV(ob_lo) = (uint32_t)mb; LV(ob_hi) = (uint32_t)(mb >> 32);
+                    if (lane < 8) q.binn[lane] = (uint8_t)(popc64(ma) + popc64(mb));
+                    LV(i1) = LV(ev1) & 7u; LV(i2) = LV(ev2) & 7u;
+                }
+                WAVE_GATHER(a1l, oa_lo, i1) WAVE_GATHER(a1h, oa_hi, i1) WAVE_GATHER(b1l, ob_lo, i1) WAVE_GATHER(b1h, ob_hi, i1)
+                WAVE_GATHER(a2l, oa_lo, i2) WAVE_GATHER(a2h, oa_hi, i2) WAVE_GATHER(b2l, ob_lo, i2) WAVE_GATHER(b2h, ob_hi, i2)
+            } else {
+                FOR_LANES
+                {
+                    const uint64_t ma = ICER_MATCH3((uint32_t)lane & 7u, V1, P0, P1, P2);
+                    LV(oa_lo) = (uint32_t)ma; LV(oa_hi) = (uint32_t)(ma >> 32);
+                    if (lane < 8) q.binn[lane] = (uint8_t)popc64(ma);
+                    LV(i1) = LV(ev1) & 7u;
+                    LV(b1l) = 0; LV(b1h) = 0; LV(a2l) = 0; LV(a2h) = 0; LV(b2l) = 0; LV(b2h) = 0;
+                }
+                WAVE_GATHER(a1l, oa_lo, i1) WAVE_GATHER(a1h, oa_hi, i1)
+            }
             FOR_LANES
             {
                 if ((V1 >> lane) & 1ull) {
                     const uint32_t b = LV(ev1) & 7u;
-                    const uint32_t r = (uint32_t)(mbcnt64(ICER_MATCH3(b, V1, P0, P1, P2), lane) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
+                    const uint64_t m1 = (uint64_t)LV(a1l) | ((uint64_t)LV(a1h) << 32), m2 = (uint64_t)LV(b1l) | ((uint64_t)LV(b1h) << 32);
+                    const uint32_t r = (uint32_t)(mbcnt64(m1, lane) + mbcnt64(m2, lane));
                     q.rk1[lane] = (uint8_t)r;
                     q.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane);
                     if (LV(ev1) & 0x20u) LDS_OR(q.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
                 }
                 if ((V2 >> lane) & 1ull) {
                     const uint32_t b = LV(ev2) & 7u;
-                    const uint64_t m1 = ICER_MATCH3(b, V1, P0, P1, P2);          // this lane's own magnitude event comes first
-                    const uint32_t r = (uint32_t)(mbcnt64(m1, lane) + (int)((m1 >> lane) & 1ull) + mbcnt64(ICER_MATCH3(b, V2, Q0, Q1, Q2), lane));
+                    const uint64_t m1 = (uint64_t)LV(a2l) | ((uint64_t)LV(a2h) << 32), m2 = (uint64_t)LV(b2l) | ((uint64_t)LV(b2h) << 32);   // this lane's own magnitude event comes first
+                    const uint32_t r = (uint32_t)(mbcnt64(m1, lane) + (int)((m1 >> lane) & 1ull) + mbcnt64(m2, lane));
                     q.rk2[lane] = (uint8_t)r;
                     q.binseq[b][r] = (uint8_t)(2u * (uint32_t)lane + 1u);
                     if (LV(ev2) & 0x20u) LDS_OR(q.binbits[b][(r + 8u) >> 5], 1u << ((r + 8u) & 31u));
                 }
-                if (lane < 8)
-                    q.binn[lane] = (uint8_t)(popc64(ICER_MATCH3((uint32_t)lane, V1, P0, P1, P2)) + popc64(ICER_MATCH3((uint32_t)lane, V2, Q0, Q1, Q2)));
             }
 #undef ICER_MATCH3
         }
