@@ -149,7 +149,9 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     if (timers && frame == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
         timers[9 * 32 + 4 * kTraceUnits + (threadIdx.x >> 6)] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
-    const uint32_t wave = threadIdx.x >> 6;
+    // (as a scalar: the roles below are then uniform branches with a register allocation of their own -- seen as divergent,
+    // every role's loop kept alive what the later roles need: ~ 200 SGPR spills / reloads, v_writelane / v_readlane, in the loops)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // DWT / mean overflow: the reference emits nothing.
     if (frame_skip[frame]) {
         if (threadIdx.x == 0 && !sub_block) unit_bits[(size_t)frame * n_units + ui] = 0;
