@@ -105,6 +105,25 @@ def test_batch_routes_blank_units_to_the_small_coder(oracle):
     enc.close()
 
 
+def test_launch_info_reports_the_shape_of_a_launch(oracle, monkeypatch):
+    """icerx_encoder_launch_info: a lone gray frame whose units are large enough is cut into sub-ranges (ICER_HIP_SPLIT chunks
+    each; here 128 so that a small frame qualifies), 8-wave workgroups, window coder beside it; a batch is not split; the
+    streams are the reference's either way"""
+    monkeypatch.setenv("ICER_HIP_SPLIT", "128")
+    w, h, st, sg = 1024, 768, 2, 2
+    frames = synth.gray_batch(3, w, h, 11, 1)
+    want = [oracle.compress([frames[k]], st, 0, sg, 2 * w * h) for k in range(3)]
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=3)
+    assert enc.encode_host(frames[:1], 2 * w * h)[0] == (want[0][0], want[0][1])
+    li = enc.launch_info()
+    assert li["split"] and li["sub_range_workgroups"] > 0 and li["pipeline_waves"] == 8 and li["window_coder_beside"], li
+    got = enc.encode_host(frames, 2 * w * h)
+    assert [g for g in got] == [(r[0], r[1]) for r in want]
+    li = enc.launch_info()
+    assert not li["split"] and li["sub_range_workgroups"] == 0 and li["pipeline_waves"] == 8, li
+    enc.close()
+
+
 def test_batch_color(oracle):
     w, h = 128, 128
     fr = np.stack([np.stack(synth.color_frame_yuv(w, h, 50 + k)) for k in range(3)])
