@@ -379,7 +379,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         else ICER_LAUNCH_PIPE(kUnitWavesSmall, 8, 0);
 #undef ICER_LAUNCH_PIPE
         if (split)
-            hipLaunchKernelGGL(splice_units_kernel, dim3(n_units, n_frames), dim3(64), 0, st, e->units.p, n_units, e->tables.p, e->means.p, skip, C,
+            hipLaunchKernelGGL(splice_units_kernel, dim3(n_units, n_frames), dim3(64 * kSpliceWaves), 0, st, e->units.p, n_units, e->tables.p, e->means.p, skip, C,
                                (uint32_t)W, (uint32_t)H, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, route, sp);
         if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join, 0));
     }

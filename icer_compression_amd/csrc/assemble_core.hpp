@@ -10,6 +10,13 @@
 #pragma once
 #include "coder_core.hpp"
 
+// all wavefronts of the workgroup (the multi-wave forms of finish_unit_wave / splice_unit_wave; the CPU builds run one wave)
+#ifdef ICER_WAVE_EMU
+#define ICER_WG_BARRIER()
+#else
+#define ICER_WG_BARRIER() __syncthreads()
+#endif
+
 namespace icer {
 
 constexpr uint32_t kCrcPoly = 0xEDB88320u;     // reflected CRC-32, init/final 0xFFFFFFFF (= zlib crc32)
@@ -59,24 +66,43 @@ struct FinishArgs {
 
 // CRC-32 of the payload: every lane takes a contiguous piece, the 64 piece CRCs are combined with
 // crc(A||B) = crc(A) * x^(8|B|) + crc(B)  (valid for the init/final-xor form, cf. zlib crc32_combine)
-template <class SharedT> ICER_DEV void finish_unit_wave(SharedT &s, const FinishArgs &f)
+// `nwv` > 1: called by all nwv wavefronts of a workgroup (wave `wv`), which share the payload; `wg_parts`: nwv words of LDS.
+template <class SharedT> ICER_DEV void finish_unit_wave(SharedT &s, const FinishArgs &f, uint32_t wv = 0, uint32_t nwv = 1, uint32_t *wg_parts = nullptr)
 {
     DECL_LANE;
     const uint32_t n = (f.bits + 7u) >> 3;
-    const uint32_t piece = (((n + 63u) >> 6) + 3u) & ~3u;
+    const uint32_t nth = 64u * nwv;                               // threads sharing the payload
+    const uint32_t piece = (((n + nth - 1u) / nth) + 15u) & ~15u;
     const uint32_t *payload = f.slot_words + kHeaderBytes / 4;
+    const uint32_t nwords = (n + 3u) >> 2;                       // words that hold payload bytes (nothing behind them is read)
     LANEVAR(uint32_t, part);
     FOR_LANES
     {
-        const uint32_t start = (uint32_t)lane * piece;
+        const uint32_t start = (wv * 64u + (uint32_t)lane) * piece;
         const uint32_t end = start + piece < n ? start + piece : n;
         uint32_t c = 0;
         if (start < end) {
             c = 0xFFFFFFFFu;
-            for (uint32_t b = start; b < end; b += 4) {
-                uint32_t w = payload[b >> 2];
-                const uint32_t nb = end - b < 4u ? end - b : 4u;
-                for (uint32_t j = 0; j < nb; j++, w >>= 8) c = s.crc_tab[(c ^ w) & 0xFFu] ^ (c >> 8);
+            // four words per step, the next four already on their way: the loop is a chain of table look-ups per byte and
+            // would otherwise also wait for one load per word (a lane's piece is not in any cache: ~ 0.7 us each -- 190 us for
+            // the 70 KB of a level-1 unit of the headline frame, on the unit's critical path)
+            const uint32_t w0 = start >> 2;
+            uint32_t q0 = payload[w0], q1 = w0 + 1u < nwords ? payload[w0 + 1u] : 0u, q2 = w0 + 2u < nwords ? payload[w0 + 2u] : 0u,
+                     q3 = w0 + 3u < nwords ? payload[w0 + 3u] : 0u;
+            for (uint32_t b = start; b < end; b += 16u) {
+                uint32_t v[4] = {q0, q1, q2, q3};
+                const uint32_t wn = (b >> 2) + 4u;
+                if (b + 16u < end) {
+                    q0 = payload[wn];
+                    q1 = wn + 1u < nwords ? payload[wn + 1u] : 0u; q2 = wn + 2u < nwords ? payload[wn + 2u] : 0u; q3 = wn + 3u < nwords ? payload[wn + 3u] : 0u;
+                }
+                for (uint32_t k = 0; k < 4u; k++) {
+                    const uint32_t at = b + 4u * k;
+                    if (at >= end) break;
+                    uint32_t w = v[k];
+                    const uint32_t nb = end - at < 4u ? end - at : 4u;
+                    for (uint32_t j = 0; j < nb; j++, w >>= 8) c = s.crc_tab[(c ^ w) & 0xFFu] ^ (c >> 8);
+                }
             }
             c = ~c;
             if (n > end) c = gf_mulmod(gf_xpow_bytes(s.tab.x2n, n - end), c);
@@ -85,9 +111,18 @@ template <class SharedT> ICER_DEV void finish_unit_wave(SharedT &s, const Finish
     }
     uint32_t data_crc;
     WAVE_XOR(data_crc, part);
+    if (nwv > 1u) {
+        FOR_LANES
+        {
+            if (lane == 0) wg_parts[wv] = data_crc;
+        }
+        ICER_WG_BARRIER();
+        data_crc = 0;
+        for (uint32_t i = 0; i < nwv; i++) data_crc ^= wg_parts[i];
+    }
     FOR_LANES
     {
-        if (lane == 0) {
+        if (lane == 0 && wv == 0u) {
             uint32_t hw[6];
             hw[0] = 0x605Bu | ((f.mean & 0xFFu) << 16);            // preamble, ll_mean (QUIRK D1: via uint8_t)
             hw[1] = f.level | (f.subband << 8) | (f.seg << 16) | ((f.lsb | (f.chan << 4)) << 24);
@@ -116,7 +151,9 @@ template <class SharedT> ICER_DEV void finish_unit_wave(SharedT &s, const Finish
 //   sub_words[i]    payload words of workgroup i's private slot (i >= 1), sub_words[0] = the unit's payload words
 // One wavefront.
 // ------------------------------------------------------------------------------------------
-ICER_DEV uint32_t splice_unit_wave(uint32_t n_sub, const SubRecord *rec, const Snapshot *snaps, uint32_t *const *sub_words, uint32_t cap_words)
+// `nwv` > 1: called by all nwv wavefronts of a workgroup (wave `wv`), which share the copies.
+ICER_DEV uint32_t splice_unit_wave(uint32_t n_sub, const SubRecord *rec, const Snapshot *snaps, uint32_t *const *sub_words, uint32_t cap_words,
+                                   uint32_t wv = 0, uint32_t nwv = 1)
 {
     DECL_LANE;
     uint32_t *dst = sub_words[0];
@@ -138,24 +175,40 @@ ICER_DEV uint32_t splice_unit_wave(uint32_t n_sub, const SubRecord *rec, const S
             const uint32_t src_words = (r.end_bits + 31u) >> 5;
             FOR_LANES
             {
-                for (uint32_t w = w0 + (uint32_t)lane; w < w1; w += 64u) {
-                    // source bit that lands on bit 0 of dst word w (negative for the first word when keep != 0)
-                    const int64_t q = (int64_t)from + ((int64_t)w * 32 - (int64_t)out_bits);
-                    uint32_t v;
-                    if (q < 0) v = src[0] << (uint32_t)(-q);
-                    else {
-                        const uint32_t qi = (uint32_t)(q >> 5), sh = (uint32_t)q & 31u;
-                        const uint32_t lo = src[qi], hi = (sh && qi + 1u < src_words) ? src[qi + 1u] : 0u;
-                        v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+                // (two words per step and lane, their source words loaded before either is used: as in finish_unit_wave the loop
+                // would otherwise wait for memory once per word)
+                const uint32_t nth = 64u * nwv;
+                for (uint32_t wb = w0 + wv * 64u + (uint32_t)lane; wb < w1; wb += 2u * nth) {
+                    uint32_t lo[2] = {0u, 0u}, hi[2] = {0u, 0u}, sh[2] = {0u, 0u}, old0 = 0u;
+                    bool neg[2] = {false, false};
+                    for (uint32_t k = 0; k < 2u; k++) {
+                        const uint32_t w = wb + nth * k;
+                        if (w >= w1) break;
+                        // source bit that lands on bit 0 of dst word w (negative for the first word when keep != 0)
+                        const int64_t q = (int64_t)from + ((int64_t)w * 32 - (int64_t)out_bits);
+                        if (q < 0) { neg[k] = true; lo[k] = src[0]; sh[k] = (uint32_t)(-q); }
+                        else {
+                            const uint32_t qi = (uint32_t)(q >> 5);
+                            sh[k] = (uint32_t)q & 31u;
+                            lo[k] = src[qi];
+                            hi[k] = (sh[k] && qi + 1u < src_words) ? src[qi + 1u] : 0u;
+                        }
                     }
-                    // bits beyond the end of the piece are zero (so that the next piece can be OR-ed in)
-                    const uint32_t endbit = out_bits + len;
-                    if ((w + 1u) * 32u > endbit) v &= (endbit & 31u) ? ((1u << (endbit & 31u)) - 1u) : (w * 32u < endbit ? ~0u : 0u);
-                    if (w == w0 && keep) v = (v & ~((1u << keep) - 1u)) | (dst[w] & ((1u << keep) - 1u));
-                    dst[w] = v;
+                    if (wb == w0 && keep) old0 = dst[wb];
+                    for (uint32_t k = 0; k < 2u; k++) {
+                        const uint32_t w = wb + nth * k;
+                        if (w >= w1) break;
+                        uint32_t v = neg[k] ? lo[k] << sh[k] : (sh[k] ? (lo[k] >> sh[k]) | (hi[k] << (32u - sh[k])) : lo[k]);
+                        // bits beyond the end of the piece are zero (so that the next piece can be OR-ed in)
+                        const uint32_t endbit = out_bits + len;
+                        if ((w + 1u) * 32u > endbit) v &= (endbit & 31u) ? ((1u << (endbit & 31u)) - 1u) : (w * 32u < endbit ? ~0u : 0u);
+                        if (w == w0 && keep) v = (v & ~((1u << keep) - 1u)) | (old0 & ((1u << keep) - 1u));
+                        dst[w] = v;
+                    }
                 }
             }
             WAVE_SYNC();
+            if (nwv > 1u) ICER_WG_BARRIER();                                // (the next piece starts in the word this one ended in)
         }
         out_bits += len;
         if (r.match_sub == 0u) return out_bits;                             // this workgroup coded to the unit's end

@@ -345,14 +345,16 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
 
 // The units of a split launch that were coded by several workgroups: their payload from the workgroups' pieces
 // (splice_unit_wave), then header and CRCs like any unit.  grid = (units, frames), block = 64; units that were not split
-// (or went to the other coder) return at once.
-__global__ void __launch_bounds__(64)
+// (or went to the other coder) return at once.  Four wavefronts share a unit's copies and its CRC (a level-1 unit of the
+// headline frame: ~ 35 KB to move bit-granular and 70 KB to checksum, after the last coding unit of the frame has ended).
+constexpr uint32_t kSpliceWaves = 4;
+__global__ void __launch_bounds__(64 * kSpliceWaves)
 splice_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const CoderTables *__restrict__ tables,
                     const uint16_t *__restrict__ means, const int *__restrict__ frame_skip, int channels, uint32_t img_w, uint32_t img_h,
                     uint8_t *__restrict__ slots, size_t slot_frame_stride, uint32_t *__restrict__ unit_bits,
                     const uint8_t *__restrict__ route, SplitLaunch sp)
 {
-    struct SpliceShared { uint32_t crc_tab[256]; struct { uint32_t x2n[32]; } tab; };
+    struct SpliceShared { uint32_t crc_tab[256]; struct { uint32_t x2n[32]; } tab; uint32_t parts[kSpliceWaves]; };
     __shared__ SpliceShared s;
     const uint32_t frame = blockIdx.y, ui = blockIdx.x;
     const UnitDesc u = units[ui];
@@ -368,7 +370,8 @@ splice_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const 
     for (uint32_t i = 1; i < u.n_sub; i++) words[i] = reinterpret_cast<uint32_t *>(fs + sp.subs[u.sub_first + i - 1u].slot_off);
     const size_t e = (size_t)frame * sp.entries + u.sub_entry;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the records, snapshots and payload words of other workgroups
-    const uint32_t bits = splice_unit_wave(u.n_sub, sp.recs + e, sp.snaps + e * kMaxSnaps, words, u.cap_words);
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t bits = splice_unit_wave(u.n_sub, sp.recs + e, sp.snaps + e * kMaxSnaps, words, u.cap_words, wv, kSpliceWaves);
     if (bits != kUnitTooBig && bits != kUnitFailed) {
         __threadfence();
         FinishArgs f;
@@ -377,7 +380,8 @@ splice_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const 
         f.mean = means[(size_t)frame * channels + u.chan];
         f.level = u.level; f.subband = u.subband; f.seg = u.seg; f.lsb = u.lsb; f.chan = u.chan;
         f.image_w = img_w; f.image_h = img_h;
-        finish_unit_wave(s, f);
+        __syncthreads();                                                // (every wave's copies, before any wave's CRC piece)
+        finish_unit_wave(s, f, wv, kSpliceWaves, s.parts);
     }
     if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
 }
