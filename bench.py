@@ -19,7 +19,11 @@ Secondary objects of the same line (none of them is `value`):
   batch_host     the same shares fed from (page-locked) HOST memory through icerx_compress_batch_uint16_devices: upload,
                  kernels and download of the streams overlapped in sub-batches -- the one resource N GPUs of a node share
   C3             BASELINE configs[2]: 4096x4096 YUV, byte quota 70 000 (progressive early stop)
-  decode         the C2 stream back through libicer_hip_dec.so, with the reference decoder on one core
+  decode         the C2 stream back through libicer_hip_dec.so (SURVEY 8f next-1), with the reference decoder on one core;
+                 batch_configs[*].decode: this rank's C4 / C5 streams back through it in one call, every frame compared
+  dropin         the lib_icer entry points themselves as a reference user calls them (example/src/example_encode.c:36-77):
+                 icer_compress_image_uint16 on the C2 frame and icer_compress_image_yuv_uint16 on C3, pageable caller
+                 memory, coefficient write-back included
   host_buffers, cpu_baseline, cpu_all_cores, roofline.traffic / roofline.issue (child rocprofv3 passes)
 
 --config C4|C5 makes one of the batch configurations the timed workload; with --sweep it is run as every rank of an
@@ -45,7 +49,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # (before the HIP runtime starts: the host-fed batch runs three encoder streams + their side streams; the runtime's default
-# of 4 hardware queues makes some of them take turns -- csrc/api.hip, RuntimeDefaults)
+# of 4 hardware queues makes some of them take turns.  A process-wide choice, so the benchmark makes it, not the library.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FILT = 0
@@ -287,7 +291,7 @@ def measure_traffic(args):
     return res, note
 
 
-def run_timed(wl, steps, warmup, barrier, dev):
+def run_timed(wl, steps, warmup, barrier, dev, red_dev=None):
     import torch
     from icer_compression_amd import shard
     for _ in range(warmup):
@@ -309,10 +313,10 @@ def run_timed(wl, steps, warmup, barrier, dev):
     if wl.enc is not None:
         stage_ms, calls = wl.enc.timing_read(reset=True)
         wl.enc.timing_enable(False)
-    return shard.max_over_ranks(elapsed, dev), step_ms, stage_ms, calls
+    return shard.max_over_ranks(elapsed, red_dev if red_dev is not None else dev), step_ms, stage_ms, calls
 
 
-def c3_object(dev, local_rank, barrier, all_ranks_ok, world):
+def c3_object(dev, local_rank, barrier, all_ranks_ok, world, red_dev=None):
     """BASELINE configs[2]: one 4096x4096 YUV frame, 5 stages, 10 segments, byte quota 70 000 (the stream keeps the
     highest-priority packets up to the quota: icer_color.c:343-530), device-resident, against the reference golden"""
     import torch
@@ -341,7 +345,7 @@ def c3_object(dev, local_rank, barrier, all_ranks_ok, world):
     for _ in range(n):
         enc.encode_torch(d, g["quota"], out, sizes, rcs)
     barrier()
-    el = shard.max_over_ranks(time.perf_counter() - t, dev)
+    el = shard.max_over_ranks(time.perf_counter() - t, red_dev if red_dev is not None else dev)
     st, calls = enc.timing_read(reset=True)
     ok = ok and check()
     mode = enc.stats()["coder_mode"]
@@ -413,6 +417,86 @@ def decode_object(stream_dev, size, frame_dev, cfg, with_cpu):
     return obj
 
 
+def dropin_object(host_frame, gold, cfg, coef_expect, with_c3=True):
+    """The drop-in boundary as a reference user sees it: icer_init / icer_init_output_struct / icer_compress_image_uint16 with
+    PAGEABLE caller memory (example/src/example_encode.c:36-77, example/src/icer_util.c:186-206), whole call: upload, all
+    kernels, stream download and the coefficient planes written back over the caller's image (icer_wavelet.c:871-877).
+    `coef_expect`: the coefficient plane of the same frame read from the device-resident encoder (icerx_get_coefficients)."""
+    from icer_compression_amd import api, synth
+    W, H = cfg["w"], cfg["h"]
+    quota = 2 * W * H
+    api.icer_init()
+    buf = np.zeros(2 * quota + 64, np.uint8)
+    od = api.icer_output_data_buf_typedef()
+
+    def call():
+        img = host_frame.copy()                                   # (the call overwrites its input, as the reference does)
+        assert api.icer_init_output_struct(od, buf, buf.size, quota) == 0
+        t = time.perf_counter()
+        rc = api.icer_compress_image_uint16(img, W, H, cfg["stages"], FILT, cfg["segments"], od)
+        return time.perf_counter() - t, rc, img
+    call()
+    times, ok = [], True
+    for _ in range(5):
+        dt, rc, img = call()
+        times.append(dt)
+        stream = buf[quota: quota + od.size_used].tobytes()
+        ok = ok and rc == 0 and len(stream) == gold[0] and "%08x" % zlib.crc32(stream) == gold[1]
+    ok = ok and bool(np.array_equal(img, coef_expect))
+    t = min(times)
+    obj = {"workload": "icer_compress_image_uint16 on the timed workload's frame: pageable caller memory -> stream in the caller's buffer, coefficient planes "
+                       "written back over the caller's image; whole call", "ms_per_frame": round(t * 1e3, 3), "ms_per_frame_mean": round(sum(times) / len(times) * 1e3, 3),
+           "value": round(W * H / t / 1e6, 3), "unit": "Mpixels/s", "parity": bool(ok),
+           "parity_note": "rc, length and CRC-32 equal the reference golden in every call; the image left behind equals the device-resident encoder's coefficient plane",
+           "pcie_bytes_per_call": int(2 * W * H * 2 + gold[0])}
+    if with_c3:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as fh:
+                g = json.load(fh)["C3_4096_yuv_quota70000"]
+            planes = [np.ascontiguousarray(p) for p in synth.color_frame_yuv(g["w"], g["h"], synth.DEFAULT_SEED)]
+            cbuf = np.zeros(2 * g["quota"] + 64, np.uint8)
+            ts, okc = [], True
+            for k in range(4):
+                work = [p.copy() for p in planes]
+                assert api.icer_init_output_struct(od, cbuf, cbuf.size, g["quota"]) == 0
+                t0 = time.perf_counter()
+                rc = api.icer_compress_image_yuv_uint16(work[0], work[1], work[2], g["w"], g["h"], g["stages"], FILT, g["segments"], od)
+                if k:
+                    ts.append(time.perf_counter() - t0)
+                st = cbuf[g["quota"]: g["quota"] + od.size_used].tobytes()
+                okc = okc and rc == g["rc"] and len(st) == g["size"] and "%08x" % zlib.crc32(st) == g["crc32"]
+            obj["C3"] = {"workload": "icer_compress_image_yuv_uint16, BASELINE configs[2] (4096x4096 YUV, quota 70 000), pageable planes, three coefficient planes written back",
+                         "ms_per_frame": round(min(ts) * 1e3, 3), "value": round(g["w"] * g["h"] / min(ts) / 1e6, 3), "unit": "Mpixels/s", "parity": bool(okc)}
+        except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+            obj["C3"] = {"error": repr(exc)}
+    return obj
+
+
+def batch_decode_object(bw):
+    """SURVEY 8f next-1 'batched decode': the streams a device-resident batch workload has just produced (this rank's share of C4
+    or C5, still in HBM) back through libicer_hip_dec.so in ONE icerx_decode_device call; every decoded frame against the input"""
+    import torch
+    from icer_compression_amd import decoder
+    os.environ.setdefault("ICER_DEC_WAVE", "1")
+    c, W, H, B = bw.cfg, bw.w, bw.h, bw.B
+    sizes = [int(x) for x in bw.sizes.cpu().numpy()]
+    offs = [k * bw.out.stride(0) for k in range(B)]
+    d_out = torch.zeros((B, H * W), dtype=torch.int16, device=bw.out.device)
+    dec = decoder.Decoder(1, c["stages"], FILT, c["segments"])
+    times = []
+    for _ in range(2):                                            # (first call: allocations)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        rc, rcs, _, _ = dec.decode_device(B, bw.out.data_ptr(), offs, sizes, d_out.data_ptr(), W * H)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    ok = rc == 0 and all(r == 0 for r in rcs) and all(bool(torch.equal(d_out[k].view(H, W), bw.frames[k])) for k in range(B))
+    dec.close()
+    del d_out
+    return {"value": round(B * W * H / times[-1] / 1e6, 2), "unit": "Mpixels/s", "ms_per_call": round(times[-1] * 1e3, 2), "streams_per_call": B,
+            "parity": bool(ok), "parity_note": "every decoded frame equals the encoder's input (lossless streams)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,11 +530,23 @@ def main():
                              f"--nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One process per GPU.  A dry run of the multi-rank path on a box with FEWER GPUs than ranks (gpurun exposes one) maps
+    # rank r onto physical device r % devices: the library's logical devices (ICER_HIP_VIRTUAL_DEVICES) and the gloo backend
+    # for the three collectives of this file (RCCL refuses two ranks on one device).  Nothing else changes.
+    ndev = torch.cuda.device_count()
+    oversubscribed = world > ndev
+    if oversubscribed:
+        os.environ["ICER_HIP_VIRTUAL_DEVICES"] = str(world)
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
+    red_dev = dev                                                 # where the reduction tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if oversubscribed:
+            dist.init_process_group("gloo")
+            red_dev = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -462,7 +558,7 @@ def main():
         """parity is a property of the whole job: every rank's frames, MIN-reduced"""
         if world == 1:
             return ok
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
@@ -482,7 +578,7 @@ def main():
             wl = WL(args.config, r, dev, local_rank)
             wl.step()
             bad, nbytes = wl.verify()
-            t_el, _, _, _ = run_timed(wl, 2, 0, barrier, dev)
+            t_el, _, _, _ = run_timed(wl, 2, 0, barrier, dev, red_dev)
             bad2, _ = wl.verify()
             bad_all += bad + [b for b in bad2 if b not in bad]
             ms_all.append(round(t_el / 2 * 1e3, 3))
@@ -513,7 +609,7 @@ def main():
     if not all_ranks_ok(not bad):
         raise SystemExit(f"rank {rank}: frames {bad} are not bit-exact with the reference golden; no number reported")
 
-    elapsed_max, step_ms, stage_ms, calls = run_timed(wl, args.steps, args.warmup, barrier, dev)
+    elapsed_max, step_ms, stage_ms, calls = run_timed(wl, args.steps, args.warmup, barrier, dev, red_dev)
     # ... and again on what the LAST timed step left in the output buffers (the timed calls run with event timing on)
     bad_after, _ = wl.verify()
     parity_after = all_ranks_ok(not bad_after)
@@ -542,7 +638,7 @@ def main():
         for _ in range(nb):
             benc.encode_torch(bf, wl.quota, bout, bsizes, brcs)
         barrier()
-        tb = shard.max_over_ranks(time.perf_counter() - tb, dev)
+        tb = shard.max_over_ranks(time.perf_counter() - tb, red_dev)
         g = wl.gold[0]
         ok = bool((brcs.cpu().numpy() == 0).all()) and all(
             int(bsizes[k]) == g[0] and ("%08x" % zlib.crc32(bout[k, : g[0]].cpu().numpy().tobytes())) == g[1] for k in range(PB))
@@ -564,7 +660,7 @@ def main():
                 bw.step()
                 badf, out_bytes = bw.verify()
                 nst = 3
-                t_el, _, st_ms, cl = run_timed(bw, nst, 1, barrier, dev)
+                t_el, _, st_ms, cl = run_timed(bw, nst, 1, barrier, dev, red_dev)
                 badf2, _ = bw.verify()
                 ok = all_ranks_ok(not badf and not badf2)
                 c = bw.cfg
@@ -579,6 +675,11 @@ def main():
                     "bytes_out_rank0": out_bytes, "code_units_ms": round(st_ms["code_units"] / max(cl, 1), 3), "dwt_ms": round(st_ms["dwt"] / max(cl, 1), 3),
                     "coder": "code_units_kernel<8> for the dense coding units; the all-but-blank ones (>= 95 % blank chunks, listed on the "
                              "device by route_units_kernel) by code_units_wgs_list_kernel on a second stream beside it"}
+                if rank == 0 and not args.no_extras:
+                    try:
+                        batch_cfgs[name]["decode"] = batch_decode_object(bw)
+                    except Exception as exc:                           # noqa: BLE001 -- secondary figure
+                        batch_cfgs[name]["decode"] = {"error": repr(exc)}
                 if rank == 0 and world == 1:
                     ab = float(c["per_gpu"] * c["w"] * c["h"] * 2 + out_bytes)
                     kms = st_ms["code_units"] / max(cl, 1)
@@ -595,7 +696,7 @@ def main():
                 hw.step()
                 badh, _ = hw.verify()
                 nst = 3
-                t_el, _, _, _ = run_timed(hw, nst, 0, barrier, dev)
+                t_el, _, _, _ = run_timed(hw, nst, 0, barrier, dev, red_dev)
                 badh2, _ = hw.verify()
                 c = hw.cfg
                 pix = world * c["per_gpu"] * c["w"] * c["h"] * nst
@@ -615,7 +716,7 @@ def main():
     extras = {}
     if not args.no_extras and args.config == "C2" and device_wl:
         try:
-            extras["C3"] = c3_object(dev, local_rank, barrier, all_ranks_ok, world)
+            extras["C3"] = c3_object(dev, local_rank, barrier, all_ranks_ok, world, red_dev)
         except Exception as exc:                                       # noqa: BLE001 -- secondary figure
             extras["C3"] = {"error": repr(exc)}
         if rank == 0:
@@ -642,6 +743,7 @@ def main():
                        "parity": "every frame of every rank: rc, stream length and CRC-32 equal the reference golden (checked before timing and again "
                                  "on the output of the last timed step)"},
             "parity_after_timing": parity_after,
+            "physical_gpus": min(world, ndev),
             "step_ms": step_ms,
             "coder_events": {k: stats[k] for k in ("unit_timeouts", "fallback_batches", "slot_retries")},
         }
@@ -723,6 +825,16 @@ def main():
             line["host_buffers"] = {"ms_per_frame": best["ms_per_frame"], "value": best["value"], "unit": "Mpixels/s", "parity": all(v["parity"] for v in hb.values()),
                                     "note": "icerx_encode_host: H2D of the frame, all kernels, D2H of size/rc/stream, nothing overlapped (one frame); caller buffers "
                                             "page-locked with icerx_pin_host when available", "by_caller_memory": hb}
+        if oversubscribed:
+            line["note"] = (f"DRY RUN of the {world}-rank path on {ndev} physical GPU(s): ranks share devices (ICER_HIP_VIRTUAL_DEVICES={world}, gloo for the "
+                            "barrier / MAX / MIN reductions); the value is not a scaling point")
+        if world == 1 and args.config == "C2" and device_wl and not args.no_extras:
+            try:
+                wl.step()
+                torch.cuda.synchronize()
+                line["dropin"] = dropin_object(np.ascontiguousarray(wl.frames[0].cpu().numpy().view(np.uint16)), wl.gold[0], cfg, wl.enc.coefficients(0, 0))
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                line["dropin"] = {"error": repr(exc)}
         if world == 1 and args.config == "C2" and device_wl and not args.no_cpu_baseline:
             host_frame = np.ascontiguousarray(wl.frames[:1].cpu().numpy().view(np.uint16))
             line["cpu_baseline"] = cpu_baseline(host_frame[0], wl.gold[0][1], cfg)

@@ -6,10 +6,8 @@ Only what the encode hot path needs lives here:
   build.py   in-tree hipcc build
   synth.py   deterministic synthetic frames for tests and bench
 """
-import os as _os
+from . import api, synth  # noqa: F401
 
-# more hardware queues than the HIP runtime's default of 4 (read once, when the runtime starts): the host-fed batch keeps
-# several encoder streams busy at a time, csrc/api.hip RuntimeDefaults
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from . import api, synth  # noqa: F401,E402
+# (Importing the package does not touch the environment.  The host-fed batch wants GPU_MAX_HW_QUEUES=8 -- a process-wide
+# HIP runtime setting that has to be in place before the runtime starts: bench.py, tools/ and tests/conftest.py set it for
+# themselves, a host program does the same, INTEGRATION.md "Hardware queues".)

@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -79,10 +80,78 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// Logical devices.  ICER_HIP_VIRTUAL_DEVICES=<N> makes the library present N devices whatever the node has: logical device
+// d runs on physical device d % (devices present).  A dry run of every multi-device code path -- N host threads, N sets of
+// pooled encoders / streams / staging buffers, error aggregation -- on a box with a single GPU (tests, bench.py --gpus N
+// on one GPU); the streams are the same as with real devices, only slower.  Unset: logical = physical.
+int physical_device_count()
+{
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+int virtual_device_count()
+{
+    const char *v = getenv("ICER_HIP_VIRTUAL_DEVICES");
+    const int n = v ? atoi(v) : 0;
+    return n >= 1 && n <= 64 ? n : 0;
+}
+int logical_device_count()
+{
+    const int phys = physical_device_count(), virt = virtual_device_count();
+    return phys > 0 && virt > 0 ? virt : phys;
+}
+int physical_of(int logical)
+{
+    const int phys = physical_device_count();
+    return phys > 0 && virtual_device_count() > 0 ? logical % phys : logical;
+}
+
+// The host cores next to a GPU: the NUMA node of its PCI function (/sys/bus/pci/devices/<bus id>/numa_node) and that
+// node's cpulist.  A per-device worker thread of a host batch pins itself there before it allocates its page-locked
+// staging words, so that first touch puts them on that node and its polling does not cross sockets
+// (ICER_HIP_NUMA=0: off).  Best effort: any failure leaves the thread where it was.
+bool pin_thread_near_device(int physical)
+{
+    if (const char *v = getenv("ICER_HIP_NUMA")) if (atoi(v) == 0) return false;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, physical) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;           // (-1: the platform reports no affinity)
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    char list[1024] = {0};
+    const bool ok = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n_set = 0;
+    for (const char *c = list; *c;) {                   // "0-15,64-79"
+        char *end = nullptr;
+        const long lo = strtol(c, &end, 10);
+        if (end == c) break;
+        long hi = lo;
+        c = end;
+        if (*c == '-') { hi = strtol(c + 1, &end, 10); c = end; }
+        for (long k = lo; k <= hi && k < CPU_SETSIZE; k++) { CPU_SET((int)k, &set); n_set++; }
+        while (*c == ',' || *c == '\n' || *c == ' ') c++;
+    }
+    return n_set > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
+}
+
 }  // namespace
 
 struct icerx_encoder {
-    int device = 0;
+    int device = 0;                     // physical HIP device (hipSetDevice)
+    int logical_device = 0;             // what the caller named (ICER_HIP_VIRTUAL_DEVICES maps several onto one)
     size_t w = 0, h = 0;
     int channels = 1, stages = 0, filt = 0, segments = 0, max_frames = 0;
     int sample_bits = 16;               // 8: the uint8 twins (int8 storage, 7 bit planes)
@@ -129,6 +198,8 @@ struct icerx_encoder {
     DevBuf<SubRecord> sub_recs;
     hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t coef_ready = nullptr;    // the transform of the last enqueue is complete (coef, means, frame status): recorded before the coder
+    hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
     int hybrid_wgs = 1;                 // staying workgroups of the small coder per compute unit (ICER_HIP_HYBRID_WGS)
     int hybrid_frames = 2;              // ... in launches of at least this many planes (frames x channels; ICER_HIP_HYBRID_FRAMES): one gray frame alone is bound by its dense units
@@ -176,6 +247,16 @@ __global__ void __launch_bounds__(256) widen_s8_kernel(const uint8_t *__restrict
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (uint16_t)(int16_t)(int8_t)src[i];
 }
 
+// uint8 twins, the way back: the coder's 16-bit sign-magnitude words as the int8 sign-magnitude bytes the reference leaves in
+// the caller's image (icer_wavelet.c:852-858)
+__global__ void __launch_bounds__(256) narrow_sm8_kernel(const uint16_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t v = src[i];
+        dst[i] = (uint8_t)(((v >> 8) & 0x80u) | (v & 0x7Fu));
+    }
+}
+
 // 8-bit gray -> uint16 (what the reference's CLI does on the host, example/src/icer_util.c:163-168)
 __global__ void __launch_bounds__(256) widen_u8_kernel(const uint8_t *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
 {
@@ -206,7 +287,11 @@ int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
     if (e->units_uploaded && e->slot_quota == quota) return 0;
     // (sub-ranges are planned for encoders of a few planes only: they are used in launches of at most split_frames planes, and
     // their private slot areas and snapshots are per frame)
-    const bool plan_split = e->wg_available && e->coder_mode == 0 && e->max_frames * e->channels <= 4 && e->split_frames > 0;
+    // (... and only when a split launch is possible at all: one frame of the encoder must fit split_frames planes, and the
+    // routing that goes with it must be on -- a YUV encoder would otherwise carry sub-range areas in every frame's slots that
+    // no launch ever uses)
+    const bool plan_split = e->wg_available && e->coder_mode == 0 && e->max_frames * e->channels <= 4 && e->split_frames > 0 &&
+                            e->channels <= e->split_frames && e->hybrid_percent > 0 && e->split_chunks > 0;
     assign_slots(&e->plan, quota, e->bits_per_pixel, plan_split ? e->split_chunks : 0u);
     const size_t n = e->plan.units.size();
     if (!e->plan.subs.empty()) {
@@ -306,6 +391,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     hipLaunchKernelGGL(finalize_ll_kernel, dim3((llw + 63u) / 64u, (llh + 3u) / 4u, P), dim3(256), 0, st,
                        reinterpret_cast<uint16_t *>(e->coef.p), plane, (uint32_t)W, llw, llh, e->means.p, skip, C, e->sample_bits);
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
+    if (e->coef_ready) HIP_TRY(hipEventRecord(e->coef_ready, st));
 
     // ---- coding units
     // Progressive mode: with a byte quota far below the lossless size only the first part of the priority order can end
@@ -466,12 +552,16 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
 
     int count = 0;
     hipError_t he = hipGetDeviceCount(&count);
-    if (he != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    const int logical_count = he == hipSuccess && count > 0 ? logical_device_count() : 0;
+    if (he != hipSuccess || count <= 0 || device < 0 || device >= logical_count) {
         set_error("no usable HIP device (hipGetDeviceCount: %s, count=%d, requested=%d); this library has no CPU path",
                   hipGetErrorString(he), count, device);
         delete e;
         return ICER_FATAL_ERROR;
     }
+    e->logical_device = device;
+    device = physical_of(device);
+    e->device = device;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
     // (a failing HIP call below must not leak the object and what it has allocated so far)
 #define CREATE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); icerx_encoder_destroy(e); return ICER_FATAL_ERROR; } } while (0)
@@ -525,6 +615,9 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (e->fork) (void)hipEventDestroy(e->fork);
     if (e->join) (void)hipEventDestroy(e->join);
     if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+    if (e->coef_ready) (void)hipEventDestroy(e->coef_ready);
+    if (e->io_stream) (void)hipStreamDestroy(e->io_stream);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     delete e;
 }
@@ -713,6 +806,7 @@ int icerx_encode_device_u8(icerx_encoder *e, const uint8_t *d_frames, int n_fram
         set_error("icerx_encode_device_u8: invalid arguments (needs a 1-channel encoder)");
         return ICER_INVALID_INPUT;
     }
+    if (e->pend.active) { set_error("icerx_encode_device_u8: an asynchronous encode is pending on this encoder (icerx_encoder_wait)"); return ICER_INVALID_INPUT; }
     HIP_TRY(hipSetDevice(e->device));
     const size_t n = (size_t)n_frames * e->w * e->h;
     if (e->in.ensure((size_t)e->max_frames * e->w * e->h)) return ICER_FATAL_ERROR;
@@ -728,6 +822,7 @@ int icerx_encode_device_s8(icerx_encoder *e, const uint8_t *d_planes, int n_fram
         set_error("icerx_encode_device_s8: invalid arguments (needs an encoder created with sample_bits = 8)");
         return ICER_INVALID_INPUT;
     }
+    if (e->pend.active) { set_error("icerx_encode_device_s8: an asynchronous encode is pending on this encoder (icerx_encoder_wait)"); return ICER_INVALID_INPUT; }
     HIP_TRY(hipSetDevice(e->device));
     const size_t n = (size_t)n_frames * e->channels * e->w * e->h;
     if (e->in.ensure((size_t)e->max_frames * e->channels * e->w * e->h)) return ICER_FATAL_ERROR;
@@ -743,6 +838,7 @@ int icerx_encode_device_rgb8(icerx_encoder *e, const uint8_t *d_rgb, int n_frame
         set_error("icerx_encode_device_rgb8: invalid arguments (needs a 3-channel encoder)");
         return ICER_INVALID_INPUT;
     }
+    if (e->pend.active) { set_error("icerx_encode_device_rgb8: an asynchronous encode is pending on this encoder (icerx_encoder_wait)"); return ICER_INVALID_INPUT; }
     HIP_TRY(hipSetDevice(e->device));
     const size_t npix = e->w * e->h;
     if (e->in.ensure((size_t)e->max_frames * 3 * npix)) return ICER_FATAL_ERROR;
@@ -758,6 +854,7 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
         set_error("icerx_encode_host: invalid arguments (needs a 16-bit encoder, 1 <= n_frames <= max_frames)");
         return ICER_INVALID_INPUT;
     }
+    if (e->pend.active) { set_error("icerx_encode_host: an asynchronous encode is pending on this encoder (icerx_encoder_wait)"); return ICER_INVALID_INPUT; }
     HIP_TRY(hipSetDevice(e->device));
     const size_t plane = e->w * e->h, P = (size_t)n_frames * e->channels;
     if (upload_units(e, byte_quota, nullptr)) return ICER_FATAL_ERROR;
@@ -789,11 +886,7 @@ int icerx_encode_host(icerx_encoder *e, const uint16_t *frames, int n_frames, si
 }
 
 // ---- a batch over the GPUs of the node (SURVEY 8b "our additions", 8e) ---------------------------------------------
-int icerx_device_count(void)
-{
-    int count = 0;
-    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
-}
+int icerx_device_count(void) { return logical_device_count(); }
 
 }  // extern "C"
 
@@ -810,27 +903,35 @@ int icerx_device_count(void)
 //     copy-out stream   D2H of the streams of the finished sub-batches (exactly size[f] bytes per frame)
 // (Streams are a scarce resource: the HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES = 4 hardware queues by default and
 // streams that share a queue run one after the other -- measured on C4 / C5: 0.80-0.85 x the device-resident rate with 4
-// queues, 0.92-0.95 x with 8.  The library asks for 8 when it is loaded before the runtime starts, see
-// icerx_runtime_defaults below; a caller that has already initialised HIP sets GPU_MAX_HW_QUEUES=8 itself.  Copies on the
+// queues, 0.92-0.95 x with 8: GPU_MAX_HW_QUEUES=8 in the environment of the process, see warn_hw_queues_once.  Copies on the
 // encoder streams instead of streams of their own -- fewer streams -- measured slower: 0.78 x on C4.)
 // The encoders and their staging buffers stay alive between calls (per device, re-made when the geometry changes;
 // icerx_batch_release frees them): a call allocates nothing on the device.
 namespace {
 
-// Runs when the library is loaded: more hardware queues than the runtime's default of 4, unless the process has chosen a
-// number itself.  Takes effect when the HIP runtime has not been initialised yet (it reads the variable once).
-struct RuntimeDefaults {
-    RuntimeDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} icerx_runtime_defaults;
+// More hardware queues than the runtime's default of 4 is a PROCESS-wide choice (GPU_MAX_HW_QUEUES, read once when the HIP
+// runtime starts): the library does not make it behind the caller's back -- bench.py, the command-line tool and the tests
+// set GPU_MAX_HW_QUEUES=8 themselves, INTEGRATION.md tells a host program to -- it only says so, once, when a host batch
+// runs without it.
+void warn_hw_queues_once()
+{
+    static std::atomic<bool> said{false};
+    if (getenv("GPU_MAX_HW_QUEUES") || said.exchange(true)) return;
+    fprintf(stderr, "libicer_hip: GPU_MAX_HW_QUEUES is not set: the host-fed batch pipeline uses 5 streams per device and the HIP runtime's "
+                    "default of 4 hardware queues makes them take turns (measured 0.80-0.85 x instead of 0.92-0.95 x the device-resident rate); "
+                    "set GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP\n");
+}
 
 constexpr int kBatchSets = 3;
 
 struct BatchDevice {
     std::mutex mu;                       // one batch call at a time per device
-    int device = -1;
-    icerx_encoder *enc[kBatchSets] = {};   // sub-batch k runs on encoder k & 1, each on a stream of its own: the kernels of
+    int device = -1;                     // physical HIP device
+    int logical = -1;                    // the device number the caller used (key of the pool)
+    bool ready = false;                  // everything below exists (a rebuild that failed part-way leaves this false)
+    icerx_encoder *enc[kBatchSets] = {};   // sub-batch k runs on encoder k % sets, each on a stream of its own: the kernels of
                                          // k + 1 fill the compute units that the last coding units of k leave idle
-    int sub = 0;                         // frames per sub-batch (= the encoders' max_frames)
+    int sub = 0;                         // most frames per sub-batch (= the encoders' max_frames)
     size_t quota = 0, dev_stride = 0;
     hipStream_t s_in = nullptr, s_enc[kBatchSets] = {}, s_out = nullptr;
     int sets = 0;                        // buffer sets / encoders in use (2..kBatchSets)
@@ -844,6 +945,7 @@ struct BatchDevice {
     hipEvent_t in_ready[kBatchSets] = {}, coded[kBatchSets] = {}, out_done[kBatchSets] = {};
     void release()
     {
+        ready = false;
         if (device >= 0) (void)hipSetDevice(device);
         for (int k = 0; k < kBatchSets; k++) {
             if (enc[k]) { icerx_encoder_destroy(enc[k]); enc[k] = nullptr; }
@@ -862,18 +964,35 @@ struct BatchDevice {
         if (h_rcs) (void)hipHostFree(h_rcs);
         if (h_flag) (void)hipHostFree(h_flag);
         h_sizes = nullptr; h_rcs = nullptr; h_flag = nullptr;
-        sub = 0; sets = 0;
+        sub = 0; sets = 0; quota = 0; dev_stride = 0;
+    }
+    // after an error in the middle of a call: nothing of this device's pipeline may still be reading the caller's frames or
+    // writing the caller's rows when the API returns, and the pooled encoders must be idle for the next call
+    void quiesce()
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        for (int k = 0; k < kBatchSets; k++) {
+            if (s_enc[k]) (void)hipStreamSynchronize(s_enc[k]);
+            if (enc[k]) {
+                if (enc[k]->side_stream) (void)hipStreamSynchronize(enc[k]->side_stream);
+                enc[k]->pend.active = false; enc[k]->wg_once = false; enc[k]->ev_pending = false;
+            }
+        }
+        if (s_out) (void)hipStreamSynchronize(s_out);
+        (void)hipGetLastError();
     }
 };
 
 std::mutex g_pool_mutex;
 std::map<int, std::unique_ptr<BatchDevice>> g_pool;
 
-BatchDevice *pool_device(int device)
+// (keyed by the LOGICAL device: with ICER_HIP_VIRTUAL_DEVICES every logical device has a pipeline of its own)
+BatchDevice *pool_device(int logical)
 {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    auto &slot = g_pool[device];
-    if (!slot) { slot.reset(new BatchDevice()); slot->device = device; }
+    auto &slot = g_pool[logical];
+    if (!slot) { slot.reset(new BatchDevice()); slot->logical = logical; slot->device = physical_of(logical); }
     return slot.get();
 }
 
@@ -893,31 +1012,62 @@ int sub_batch_frames(int cnt, size_t frame_bytes)
     return sub;
 }
 
+// The sub-batches of a block of `cnt` frames, at most `sub` frames each.  Nothing overlaps the upload of the first sub-batch
+// or the download of the last one, so the block starts (and, with ramp = 2, ends) with smaller ones: 1, 2, 4, ... frames
+// up to `sub` (ICER_HIP_BATCH_RAMP=0: all of `sub` frames, 1: rising at the start -- the default --, 2: and falling at the end).
+void sub_batch_plan(int cnt, int sub, std::vector<int> *first, std::vector<int> *count)
+{
+    int ramp = 1;
+    if (const char *rv = getenv("ICER_HIP_BATCH_RAMP")) { const int v = atoi(rv); if (v >= 0 && v <= 2) ramp = v; }
+    std::vector<int> head, tail;
+    int left = cnt;
+    if (ramp >= 1 && sub >= 2 && cnt >= 2 * sub)
+        for (int n = 1; n < sub && left > sub; n *= 2) { head.push_back(n); left -= n; }
+    if (ramp >= 2 && sub >= 2 && left >= 2 * sub)
+        for (int n = 1; n < sub && left > sub; n *= 2) { tail.push_back(n); left -= n; }
+    std::vector<int> sizes(head);
+    while (left > 0) { const int n = left < sub ? left : sub; sizes.push_back(n); left -= n; }
+    for (size_t i = tail.size(); i-- > 0;) sizes.push_back(tail[i]);
+    first->clear(); count->clear();
+    int at = 0;
+    for (int n : sizes) { first->push_back(at); count->push_back(n); at += n; }
+}
+
+int batch_rebuild(BatchDevice *b, size_t w, size_t h, int channels, int stages, int filt, int segments, int sub, int sets)
+{
+    b->sub = sub;
+    b->sets = sets;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
+    for (int k = 0; k < sets; k++) {
+        const int rc = icerx_encoder_create(&b->enc[k], b->logical, w, h, channels, stages, filt, segments, sub);
+        if (rc) return rc;
+        b->enc[k]->sleepy_wait = true;
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
+        if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
+        HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->coded[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->out_done[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipHostMalloc((void **)&b->h_sizes, (size_t)sets * (size_t)sub * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&b->h_rcs, (size_t)sets * (size_t)sub * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&b->h_flag, (size_t)sets * 2 * sizeof(int), hipHostMallocDefault));
+    b->quota = (size_t)-1;
+    return 0;
+}
+
 int batch_prepare(BatchDevice *b, size_t w, size_t h, int channels, int stages, int filt, int segments, size_t quota, int sub, int sets)
 {
     const icerx_encoder *e = b->enc[0];
-    if (!e || b->sets != sets || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt || e->segments != segments ||
-        e->sample_bits != 16 || b->sub != sub) {
+    if (!b->ready || !e || b->sets != sets || e->w != w || e->h != h || e->channels != channels || e->stages != stages || e->filt != filt ||
+        e->segments != segments || e->sample_bits != 16 || b->sub != sub) {
         b->release();
-        b->sub = sub;
-        b->sets = sets;
-        HIP_TRY(hipSetDevice(b->device));
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
-        for (int k = 0; k < sets; k++) {
-            const int rc = icerx_encoder_create(&b->enc[k], b->device, w, h, channels, stages, filt, segments, sub);
-            if (rc) return rc;
-            b->enc[k]->sleepy_wait = true;
-            HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
-            if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
-            HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->coded[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->out_done[k], hipEventDisableTiming));
-        }
-        HIP_TRY(hipHostMalloc((void **)&b->h_sizes, (size_t)sets * (size_t)sub * sizeof(uint64_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&b->h_rcs, (size_t)sets * (size_t)sub * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&b->h_flag, (size_t)sets * 2 * sizeof(int), hipHostMallocDefault));
-        b->quota = (size_t)-1;
+        // (a rebuild that fails part-way -- the second encoder, a staging buffer, an event -- must not leave a half-built
+        // pipeline that the next call with the same geometry would take for a complete one)
+        const int rc = batch_rebuild(b, w, h, channels, stages, filt, segments, sub, sets);
+        if (rc) { b->release(); return rc; }
+        b->ready = true;
     }
     HIP_TRY(hipSetDevice(b->device));
     // slots for this quota, then output rows that hold the longest possible stream
@@ -935,40 +1085,31 @@ int batch_prepare(BatchDevice *b, size_t w, size_t h, int channels, int stages, 
     return 0;
 }
 
-// one device's block of the batch: frames [0, cnt) at `frames`, rows of `out`
-int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, size_t h, int channels, int stages, int filt, int segments,
-                    size_t quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs)
+// one device's block of the batch: frames [0, cnt) at `frames`, rows of `out` (the caller holds b->mu)
+int batch_run(BatchDevice *b, const uint16_t *frames, int cnt, size_t frame_elems, int sub, int S, size_t quota, uint8_t *out, size_t out_stride,
+              uint64_t *sizes, int32_t *rcs)
 {
-    std::lock_guard<std::mutex> lk(b->mu);
-    const size_t frame_elems = w * h * (size_t)channels;
-    const int sub = sub_batch_frames(cnt, frame_elems * 2);
-    int sets = 3;                        // (ICER_HIP_BATCH_SETS: 2 or 3)
-    if (const char *sv = getenv("ICER_HIP_BATCH_SETS")) { const int v = atoi(sv); if (v >= 2 && v <= kBatchSets) sets = v; }
-    const int S = sets;
-    int rc = batch_prepare(b, w, h, channels, stages, filt, segments, quota, sub, sets);
-    if (rc) return rc;
-    const int K = (cnt + sub - 1) / sub;
-    auto n_of = [&](int k) { return k == K - 1 ? cnt - k * sub : sub; };
+    int rc = 0;
+    std::vector<int> first, count;
+    sub_batch_plan(cnt, sub, &first, &count);
+    const int K = (int)first.size();
     // enqueue sub-batch k: its copy-in, then its kernels
     auto issue = [&](int k) -> int {
-        const int s = k % S, n = n_of(k);
+        const int s = k % S, n = count[(size_t)k];
         // in[s] is free once the kernels of k - S are done, out[s] once the copy-out of k - S is
         if (k >= S) HIP_TRY(hipStreamWaitEvent(b->s_in, b->coded[s], 0));
-        HIP_TRY(hipMemcpyAsync(b->in[s].p, frames + (size_t)k * sub * frame_elems, (size_t)n * frame_elems * 2, hipMemcpyHostToDevice, b->s_in));
+        HIP_TRY(hipMemcpyAsync(b->in[s].p, frames + (size_t)first[(size_t)k] * frame_elems, (size_t)n * frame_elems * 2, hipMemcpyHostToDevice, b->s_in));
         HIP_TRY(hipEventRecord(b->in_ready[s], b->s_in));
         HIP_TRY(hipStreamWaitEvent(b->s_enc[s], b->in_ready[s], 0));
         if (k >= S) HIP_TRY(hipStreamWaitEvent(b->s_enc[s], b->out_done[s], 0));
         b->enc[s]->wg_once = false;
-        const int r = encode_begin(b->enc[s], b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc[s],
-                                   b->h_flag + 2 * s, b->coded[s], nullptr);
-        if (r) return r;
-        // (after the `coded` record on purpose: the host reads these words only after its own wait below)
-        return 0;
+        return encode_begin(b->enc[s], b->in[s].p, n, quota, b->out[s].p, b->dev_stride, (uint64_t *)b->d_sizes[s].p, b->d_rcs[s].p, b->s_enc[s],
+                            b->h_flag + 2 * s, b->coded[s], nullptr);
     };
     for (int q = 0; q < S; q++) if (accumulate_timing(b->enc[q])) return ICER_FATAL_ERROR;
     for (int k = 0; k < K && k < S; k++) if ((rc = issue(k))) return rc;
     for (int k = 0; k < K; k++) {
-        const int s = k % S, n = n_of(k);
+        const int s = k % S, n = count[(size_t)k], f0 = first[(size_t)k];
         icerx_encoder *e = b->enc[s];
         if (wait_event(b->coded[s], true)) return ICER_FATAL_ERROR;
         int v = encode_verdict(e, n, b->h_flag + 2 * s);
@@ -1003,20 +1144,35 @@ int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, s
         HIP_TRY(hipStreamSynchronize(b->s_out));
         for (int f = 0; f < n; f++) {
             const uint64_t sz = b->h_sizes[(size_t)s * sub + f];
-            sizes[(size_t)k * sub + f] = sz;
-            rcs[(size_t)k * sub + f] = b->h_rcs[(size_t)s * sub + f];
+            sizes[(size_t)f0 + f] = sz;
+            rcs[(size_t)f0 + f] = b->h_rcs[(size_t)s * sub + f];
             if (sz > out_stride) {
-                set_error("icerx_compress_batch_uint16: stream of frame %d (%llu bytes) longer than out_stride %zu", k * sub + f, (unsigned long long)sz, out_stride);
-                (void)hipDeviceSynchronize();
+                set_error("icerx_compress_batch_uint16: stream of frame %d (%llu bytes) longer than out_stride %zu", f0 + f, (unsigned long long)sz, out_stride);
                 return ICER_OUTPUT_BUF_TOO_SMALL;
             }
-            if (sz) HIP_TRY(hipMemcpyAsync(out + ((size_t)k * sub + f) * out_stride, b->out[s].p + (size_t)f * b->dev_stride, sz, hipMemcpyDeviceToHost, b->s_out));
+            if (sz) HIP_TRY(hipMemcpyAsync(out + ((size_t)f0 + f) * out_stride, b->out[s].p + (size_t)f * b->dev_stride, sz, hipMemcpyDeviceToHost, b->s_out));
         }
         HIP_TRY(hipEventRecord(b->out_done[s], b->s_out));
         if (k + S < K && (rc = issue(k + S))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(b->s_out));
     return 0;
+}
+
+int batch_on_device(BatchDevice *b, const uint16_t *frames, int cnt, size_t w, size_t h, int channels, int stages, int filt, int segments,
+                    size_t quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs)
+{
+    std::lock_guard<std::mutex> lk(b->mu);
+    const size_t frame_elems = w * h * (size_t)channels;
+    const int sub = sub_batch_frames(cnt, frame_elems * 2);
+    int sets = 3;                        // (ICER_HIP_BATCH_SETS: 2 or 3)
+    if (const char *sv = getenv("ICER_HIP_BATCH_SETS")) { const int v = atoi(sv); if (v >= 2 && v <= kBatchSets) sets = v; }
+    int rc = batch_prepare(b, w, h, channels, stages, filt, segments, quota, sub, sets);
+    if (rc) return rc;
+    rc = batch_run(b, frames, cnt, frame_elems, sub, sets, quota, out, out_stride, sizes, rcs);
+    // every error exit of the pipeline ends here: drain the device's streams before the caller gets its buffers back
+    if (rc) b->quiesce();
+    return rc;
 }
 
 }  // namespace
@@ -1038,6 +1194,7 @@ int icerx_compress_batch_uint16_devices(const uint16_t *frames, int n_frames, si
     if (have <= 0) { set_error("no usable HIP device; this library has no CPU path"); return ICER_FATAL_ERROR; }
     for (int d = 0; d < n_devices; d++)
         if (devices[d] < 0 || devices[d] >= have) { set_error("icerx_compress_batch_uint16: device %d of %d present", devices[d], have); return ICER_INVALID_INPUT; }
+    warn_hw_queues_once();
     const int g = n_devices > n_frames ? n_frames : n_devices;
     try {
         std::vector<int> rc((size_t)g, 0);
@@ -1057,8 +1214,11 @@ int icerx_compress_batch_uint16_devices(const uint16_t *frames, int n_frames, si
         };
         if (g == 1) work(0);
         else {
+            // one host thread per device, on the cores next to that device (its NUMA node): the thread allocates the
+            // device's page-locked staging words and polls its events
             std::vector<std::thread> th;
-            for (int d = 0; d < g; d++) th.emplace_back(work, d);
+            for (int d = 0; d < g; d++)
+                th.emplace_back([&work, devices, d] { (void)pin_thread_near_device(physical_of(devices[d])); work(d); });
             for (auto &t : th) t.join();
         }
         int first = 0;
@@ -1241,31 +1401,72 @@ static int compress_planes(void *const planes[], int channels, size_t w, size_t 
         if (rc) return rc;
         g_cached = e;
     }
+    // The call as a reference user makes it (example/src/example_encode.c:36-77): pageable caller memory in, stream and
+    // coefficient planes out.  Everything runs on a stream of the encoder's own; the coefficient planes -- final once the
+    // transform is done, 0.2 ms into the call -- go back to the caller's image on a second stream WHILE the coder runs, so
+    // that of the three transfers only the upload and the (short) stream download are not hidden.
     const size_t plane = w * h, quota = od->size_allocated;
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->io_stream) HIP_TRY(hipStreamCreateWithFlags(&e->io_stream, hipStreamNonBlocking));
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->coef_ready) HIP_TRY(hipEventCreateWithFlags(&e->coef_ready, hipEventDisableTiming));
+    hipStream_t st = e->io_stream;
     if (e->in.ensure((size_t)channels * plane)) return ICER_FATAL_ERROR;
     if (sample_bits == 16) {
         for (int c = 0; c < channels; c++)
-            HIP_TRY(hipMemcpy(e->in.p + (size_t)c * plane, planes[c], plane * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(e->in.p + (size_t)c * plane, planes[c], plane * 2, hipMemcpyHostToDevice, st));
     } else {
         if (e->in8.ensure((size_t)channels * plane)) return ICER_FATAL_ERROR;
         for (int c = 0; c < channels; c++)
-            HIP_TRY(hipMemcpy(e->in8.p + (size_t)c * plane, planes[c], plane, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(e->in8.p + (size_t)c * plane, planes[c], plane, hipMemcpyHostToDevice, st));
         const size_t n = (size_t)channels * plane;
-        hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, nullptr, e->in8.p, e->in.p, n);
+        hipLaunchKernelGGL(widen_s8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, e->in8.p, e->in.p, n);
     }
     uint64_t size = 0;
     int32_t rc = 0;
-    for (;;) {
-        if (upload_units(e, quota, nullptr)) return ICER_FATAL_ERROR;
+    bool coef_back = false;              // the coefficient planes are in the caller's image already
+    for (bool first = true;; first = false) {
+        if (upload_units(e, quota, st)) return ICER_FATAL_ERROR;
         const size_t ds = (quota < e->plan.slot_bytes ? quota : e->plan.slot_bytes) + 4;
         if (e->out.ensure(ds)) return ICER_FATAL_ERROR;
         bool regrow = false;
-        const int r = encode_device_impl(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, nullptr, &regrow);
+        int r;
+        if (first) {
+            if (accumulate_timing(e)) return ICER_FATAL_ERROR;
+            e->wg_once = false;
+            r = encode_begin(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, st, e->h_flag, e->done, nullptr);
+            if (r) return r;
+            // beside the coder: the frame's status (an aborted frame keeps the caller's planes, see below), then the planes
+            int skip = 0;
+            const int *d_skip = e->flags.p + 2 * (size_t)e->max_frames * channels;
+            HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->coef_ready, 0));
+            HIP_TRY(hipMemcpyAsync(&skip, d_skip, sizeof(int), hipMemcpyDeviceToHost, e->copy_stream));
+            HIP_TRY(hipStreamSynchronize(e->copy_stream));
+            if (!skip) {
+                if (sample_bits == 16) {
+                    for (int c = 0; c < channels; c++)
+                        HIP_TRY(hipMemcpyAsync(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost, e->copy_stream));
+                } else {
+                    // what the reference leaves in the caller's image: int8 sign-magnitude bytes; narrowed on the device (in8 is
+                    // free again: the widening kernel has run, coef_ready lies behind it on the encode stream)
+                    const size_t n = (size_t)channels * plane;
+                    hipLaunchKernelGGL(narrow_sm8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, e->copy_stream,
+                                       reinterpret_cast<const uint16_t *>(e->coef.p), e->in8.p, n);
+                    for (int c = 0; c < channels; c++)
+                        HIP_TRY(hipMemcpyAsync(planes[c], e->in8.p + (size_t)c * plane, plane, hipMemcpyDeviceToHost, e->copy_stream));
+                }
+                HIP_TRY(hipStreamSynchronize(e->copy_stream));
+                coef_back = true;
+            }
+            r = encode_device_impl(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, st, &regrow, true);
+        } else
+            r = encode_device_impl(e, e->in.p, 1, quota, e->out.p, ds, (uint64_t *)e->sizes.p, e->rcs.p, st, &regrow);
         if (r) return r;
         if (!regrow) break;
     }
-    HIP_TRY(hipMemcpy(&size, e->sizes.p, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&rc, e->rcs.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&size, e->sizes.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&rc, e->rcs.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (rc == ICER_INTEGER_OVERFLOW) {
         // The reference aborts before any output; it leaves transformed (not sign-magnitude) data in
         // the planes it had already processed: channels up to the first DWT overflow, or all of them
@@ -1280,24 +1481,26 @@ static int compress_planes(void *const planes[], int channels, size_t w, size_t 
         {
             size_t cw2 = w, ch2 = h;
             int *scratch_flags = e->flags.p;
-            launch_dwt(e, reinterpret_cast<const uint16_t *>(e->in.p), 1, nullptr, 0, scratch_flags, &cw2, &ch2);
-            HIP_TRY(hipDeviceSynchronize());
+            launch_dwt(e, reinterpret_cast<const uint16_t *>(e->in.p), 1, st, 0, scratch_flags, &cw2, &ch2);
+            HIP_TRY(hipStreamSynchronize(st));
         }
         for (int c = 0; c <= last; c++)
             HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
         return rc;
     }
-    if (size) HIP_TRY(hipMemcpy(od->rearrange_start, e->out.p, size, hipMemcpyDeviceToHost));
-    if (sample_bits == 16) {
-        for (int c = 0; c < channels; c++)
-            HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
-    } else {
-        // what the reference leaves in the caller's image: int8 sign-magnitude bytes (icer_wavelet.c:852-858)
-        std::vector<uint16_t> tmp(plane);
-        for (int c = 0; c < channels; c++) {
-            HIP_TRY(hipMemcpy(tmp.data(), e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
-            uint8_t *dst = static_cast<uint8_t *>(planes[c]);
-            for (size_t i = 0; i < plane; i++) dst[i] = (uint8_t)(((tmp[i] >> 8) & 0x80u) | (tmp[i] & 0x7Fu));
+    if (size) HIP_TRY(hipMemcpyAsync(od->rearrange_start, e->out.p, size, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!coef_back) {                    // (not reached in practice: a frame that was not aborted has its planes back already)
+        if (sample_bits == 16) {
+            for (int c = 0; c < channels; c++)
+                HIP_TRY(hipMemcpy(planes[c], e->coef.p + (size_t)c * plane, plane * 2, hipMemcpyDeviceToHost));
+        } else {
+            const size_t n = (size_t)channels * plane;
+            hipLaunchKernelGGL(narrow_sm8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st,
+                               reinterpret_cast<const uint16_t *>(e->coef.p), e->in8.p, n);
+            for (int c = 0; c < channels; c++)
+                HIP_TRY(hipMemcpyAsync(planes[c], e->in8.p + (size_t)c * plane, plane, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
     }
     od->size_used = size;

@@ -77,6 +77,13 @@ def color_frame_yuv(w: int, h: int, seed: int = DEFAULT_SEED):
     return yy.astype(np.uint16), cb.astype(np.uint16), cr.astype(np.uint16)
 
 
+def gray_frame_12bit(w: int, h: int, seed: int = DEFAULT_SEED, mode: int = 1) -> np.ndarray:
+    """(h, w) uint16 frame with 12-bit content: the 8-bit frame in the upper bits, four more LCG bits below.  Its wavelet
+    coefficients exceed the 9 coded bit planes here and there (category 3, magnitudes >= 512), which 8-bit content never does."""
+    low = (lcg_draws(w * h, (seed ^ 0x5A5A5A5A) & 0xFFFFFFFF).reshape(h, w) & np.uint32(15)).astype(np.uint16)
+    return (gray_frame(w, h, seed, mode) << 4 | low).astype(np.uint16)
+
+
 def gray_frame_u8(w: int, h: int, seed: int = 12345, mode: int = 1) -> np.ndarray:
     """Input for the uint8 twins (int8 storage, 7 bit planes): the gray frame >> 2, i.e. 6-bit data."""
     return (gray_frame(w, h, seed, mode) >> 2).astype(np.uint8)

@@ -34,6 +34,18 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+def build_examples(force: bool = False) -> bool:
+    """The reference's own example programs, unmodified, linked with the reference build (_ref/ref_*) and with the product
+    libraries (_ref/hip_*): `make examples` (tests/test_gpu_examples.py).  Only where the reference sources are mounted and
+    the product libraries have been built; the binaries travel to the GPU box with the snapshot."""
+    progs = [os.path.join(HERE, "_ref", f"{k}_{p}") for k in ("ref", "hip") for p in ("compress", "decompress", "compress_color", "decompress_color", "icer_util")]
+    if not os.path.isdir("/root/reference/example/src") or not os.path.exists(REF_SO):
+        return all(os.path.exists(p) for p in progs)
+    if force or not all(os.path.exists(p) for p in progs):
+        subprocess.check_call(["make", "-C", HERE, "examples"], stdout=subprocess.DEVNULL)
+    return all(os.path.exists(p) for p in progs)
+
+
 def have_reference() -> bool:
     return os.path.exists(REF_SO)
 

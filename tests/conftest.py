@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the host-fed batch tests keep five streams per device busy: more hardware queues than the HIP runtime's default of 4 (a
+# process-wide setting, read once when the runtime starts; the library itself never touches the environment)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -41,6 +41,13 @@ CASES = [
     ("u8_512_yuv_quota", "yuv8", 512, 512, 3, 0, 8, 60000, 12345, 1),
     ("u8_256_yuv_5st_packet_table", "yuv8", 256, 256, 5, 0, 4, 1 << 20, 12345, 1),
     ("u8_512_gray_full_range_overflow", "gray8full", 512, 512, 3, 0, 10, 2 * 512 * 512, 12345, 0),
+    # the PRODUCTION sub-range split (a lone 4096 x 4096 plane: level-1 units of 6 554 chunks are cut at 3 072 chunks,
+    # csrc/api.hip split_chunks) through other tables than filter A / 8-bit content: the filter with the W3 quirk, 12-bit
+    # content (more than 9 planes of magnitude: category 3, large coefficients) through filter B, and the uint8 twin
+    # (7 planes, int8 storage, its own packet table)
+    ("split_4096_filtC", "gray", 4096, 4096, 5, 2, 10, 2 * 4096 * 4096, 12345, 1),
+    ("split_4096_12bit_filtB", "gray12", 4096, 4096, 5, 1, 10, 2 * 4096 * 4096, 12345, 1),
+    ("split_4096_u8_gray", "gray8", 4096, 4096, 5, 0, 10, 2 * 4096 * 4096, 12345, 1),
 ]
 
 
@@ -49,6 +56,8 @@ def planes_of(kind, w, h, seed, mode):
         return [synth.gray_frame(w, h, seed, mode)]
     if kind == "yuv":
         return list(synth.color_frame_yuv(w, h, seed))
+    if kind == "gray12":
+        return [synth.gray_frame_12bit(w, h, seed, mode)]
     if kind == "gray8":
         return [synth.gray_frame_u8(w, h, seed, mode)]
     if kind == "gray8full":

@@ -176,17 +176,25 @@ def test_batch_over_devices_and_two_threads_from_c(oracle, tmp_path):
     q = 2 * w * h
     frames = synth.gray_batch(n, w, h, 31, 1)
     frames.astype("<u2").tofile(tmp_path / "in.raw")
-    r = subprocess.run([exe, str(tmp_path / "in.raw"), str(n), str(w), str(h), str(st), str(f), str(sg), str(q), str(tmp_path / "out.bin")],
-                       capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and f"ok frames={n}" in r.stdout, r.stdout + r.stderr
-    blob = (tmp_path / "out.bin").read_bytes()
-    off = 0
-    for k in range(n):
-        size, rc = struct.unpack_from("<Qi", blob, off)
-        off += 12
-        want = oracle.compress([frames[k]], st, f, sg, q)
-        assert (rc, blob[off: off + size]) == (want[0], want[1]), k
-        off += size
+    # (second run: three LOGICAL devices on the node's physical ones -- the batch call's per-device threads and pipelines, and
+    # the second hand-driven encoder on "device 1", without a second GPU)
+    for virtual in (None, "3"):
+        env = dict(os.environ)
+        if virtual:
+            env["ICER_HIP_VIRTUAL_DEVICES"] = virtual
+        r = subprocess.run([exe, str(tmp_path / "in.raw"), str(n), str(w), str(h), str(st), str(f), str(sg), str(q), str(tmp_path / "out.bin")],
+                           capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0 and f"ok frames={n}" in r.stdout, r.stdout + r.stderr
+        if virtual:
+            assert "devices=3" in r.stdout and "second_thread_device=1" in r.stdout, r.stdout
+        blob = (tmp_path / "out.bin").read_bytes()
+        off = 0
+        for k in range(n):
+            size, rc = struct.unpack_from("<Qi", blob, off)
+            off += 12
+            want = oracle.compress([frames[k]], st, f, sg, q)
+            assert (rc, blob[off: off + size]) == (want[0], want[1]), k
+            off += size
 
 
 def test_async_halves_equal_the_synchronous_call(oracle):
@@ -387,6 +395,118 @@ def test_golden_vectors_full_size(golden, name):
     assert rc == g["rc"] and len(stream) == g["size"]
     assert "%08x" % zlib.crc32(stream) == g["crc32"]
     assert hashlib.sha256(stream).hexdigest()[:16] == g["sha256_16"]
+
+
+# ---- the production sub-range split through other tables (filter A / 8-bit content were its only goldens) --------
+SPLIT_GOLDEN = ["split_4096_filtC", "split_4096_12bit_filtB", "split_4096_u8_gray"]
+
+
+@pytest.mark.parametrize("name", SPLIT_GOLDEN)
+def test_production_split_through_other_tables(golden, name):
+    """A lone 4096 x 4096 plane is cut into sub-ranges at the PRODUCTION setting (3 072 chunks per piece, no env knob): the
+    reference build's streams for the filter with the W3 quirk, for 12-bit content through filter B, and for the uint8
+    twin's 7 planes -- and the launch really was a split one"""
+    import torch
+    g = golden[name]
+    w, h = g["w"], g["h"]
+    u8 = g["kind"] == "gray8"
+    plane = synth.gray_frame_u8(w, h, g["seed"], g["mode"]) if u8 else \
+        synth.gray_frame_12bit(w, h, g["seed"], g["mode"]) if g["kind"] == "gray12" else synth.gray_frame(w, h, g["seed"], g["mode"])
+    enc = api.Encoder(w, h, 1, g["stages"], g["filt"], g["segments"], max_frames=1, sample_bits=8 if u8 else 16)
+    if u8:
+        (rc, stream), = enc.encode_torch_s8(torch.from_numpy(plane[None]).cuda(), g["quota"])
+    else:
+        (rc, stream), = enc.encode_host(plane[None, None], g["quota"])
+    li, st = enc.launch_info(), enc.stats()
+    enc.close()
+    assert li["split"] and li["sub_range_workgroups"] > 0, li
+    assert st["unit_timeouts"] == 0 and st["fallback_batches"] == 0, st
+    assert (rc, len(stream), "%08x" % zlib.crc32(stream), hashlib.sha256(stream).hexdigest()[:16]) == (g["rc"], g["size"], g["crc32"], g["sha256_16"])
+
+
+# ---- a rank != 0 share of the two batch configurations (frames 32*rank .. / 8*rank ..), both ways -----------------------------
+@pytest.mark.parametrize("name,rank", [("C4", 5), ("C5", 3)])
+def test_batch_share_of_another_rank(name, rank):
+    """What rank `rank` of the 8-GPU job codes -- C4: frames 160..191 of the 256, C5: frames 24..31 of the 64 -- on this GPU:
+    device-resident launches (what bench.py times) AND icerx_compress_batch_uint16_devices from page-locked host memory,
+    every frame's return code, length and CRC-32 against the reference CPU encoder's (tests/golden/batch_golden.json)"""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cuda", 0)
+    wl = bench.Workload(name, rank, dev, 0)
+    assert wl.first == rank * bench.CONFIGS[name]["per_gpu"] and wl.B == bench.CONFIGS[name]["per_gpu"]
+    wl.step()
+    bad, nbytes = wl.verify()
+    stats = wl.enc.stats()
+    wl.close()
+    del wl
+    torch.cuda.empty_cache()
+    assert not bad and nbytes > 0, (name, rank, bad)
+    assert stats["unit_timeouts"] == 0, stats
+    hw = bench.HostWorkload(name, rank, dev, 0)
+    hw.step()
+    bad, _ = hw.verify()
+    hw.close()
+    assert not bad, (name, rank, bad)
+
+
+# ---- the multi-device code path on one GPU: ICER_HIP_VIRTUAL_DEVICES -----------------------------------------------------------
+def test_virtual_devices_batch(monkeypatch):
+    """ICER_HIP_VIRTUAL_DEVICES=4: icerx_compress_batch_uint16 over four logical devices (four host threads, four pooled
+    pipelines of 3 encoders / 5 streams / 3 staging sets on the one physical GPU) on C4-sized frames: frames 0..9 of the C4
+    batch against the reference goldens, blocks of 3 + 3 + 2 + 2; a named device list; an encoder on logical device 3; the
+    error of every failing device in the aggregated message; without the variable the node has its real device count"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    L = api.load_library()
+    real = L.icerx_device_count()
+    assert real >= 1
+    monkeypatch.setenv("ICER_HIP_VIRTUAL_DEVICES", "4")
+    assert L.icerx_device_count() == 4
+    c = bench.CONFIGS["C4"]
+    n, w, h = 10, c["w"], c["h"]
+    quota = 2 * w * h
+    frames = synth.gray_batch(n, w, h, synth.DEFAULT_SEED, 1)
+    gold = bench.frame_goldens("C4", 0, 0, n)
+    out = np.zeros((n, w * h), np.uint8)
+    sizes, rcs = np.zeros(n, np.uint64), np.zeros(n, np.int32)
+
+    def check():
+        for k in range(n):
+            assert int(rcs[k]) == 0 and int(sizes[k]) == gold[k][0] and "%08x" % zlib.crc32(out[k, : gold[k][0]].tobytes()) == gold[k][1], k
+    assert api.compress_batch(frames, c["stages"], 0, c["segments"], quota, out, sizes, rcs) == 0, L.icerx_last_error()      # all 4
+    check()
+    out[:] = 0; sizes[:] = 0
+    assert api.compress_batch(frames, c["stages"], 0, c["segments"], quota, out, sizes, rcs, devices=[3, 1]) == 0, L.icerx_last_error()
+    check()
+    # an encoder on a logical device
+    enc = api.Encoder(w, h, 1, c["stages"], 0, c["segments"], max_frames=1, device=3)
+    (rc, stream), = enc.encode_host(frames[:1], quota)
+    enc.close()
+    assert rc == 0 and len(stream) == gold[0][0] and "%08x" % zlib.crc32(stream) == gold[0][1]
+    with pytest.raises(api.IcerHipError):
+        api.Encoder(w, h, 1, c["stages"], 0, c["segments"], max_frames=1, device=4)
+    # every failing device is named: rows too short for the streams on all four
+    small = np.zeros((n, 1000), np.uint8)
+    assert api.compress_batch(frames, c["stages"], 0, c["segments"], quota, small, sizes, rcs) == api.ICER_OUTPUT_BUF_TOO_SMALL
+    msg = L.icerx_last_error().decode()
+    assert all(f"device {d}:" in msg for d in range(4)), msg
+    # ... and the pipelines are usable again afterwards (the error path drained them)
+    out[:] = 0; sizes[:] = 0
+    assert api.compress_batch(frames, c["stages"], 0, c["segments"], quota, out, sizes, rcs) == 0, L.icerx_last_error()
+    check()
+    L.icerx_batch_release()
+    monkeypatch.delenv("ICER_HIP_VIRTUAL_DEVICES")
+    assert L.icerx_device_count() == real
 
 
 # ---- uint8 twins (SURVEY 8f next-2) ------------------------------------------------------------------------------------
