@@ -429,15 +429,17 @@ def dropin_object(host_frame, gold, cfg, coef_expect, with_c3=True):
     buf = np.zeros(2 * quota + 64, np.uint8)
     od = api.icer_output_data_buf_typedef()
 
+    img = np.empty_like(host_frame)                               # the caller's image buffer, reused call after call
+
     def call():
-        img = host_frame.copy()                                   # (the call overwrites its input, as the reference does)
+        np.copyto(img, host_frame)                                # (the call overwrites its input, as the reference does)
         assert api.icer_init_output_struct(od, buf, buf.size, quota) == 0
         t = time.perf_counter()
         rc = api.icer_compress_image_uint16(img, W, H, cfg["stages"], FILT, cfg["segments"], od)
         return time.perf_counter() - t, rc, img
     call()
     times, ok = [], True
-    for _ in range(5):
+    for _ in range(6):
         dt, rc, img = call()
         times.append(dt)
         stream = buf[quota: quota + od.size_used].tobytes()
@@ -445,7 +447,7 @@ def dropin_object(host_frame, gold, cfg, coef_expect, with_c3=True):
     ok = ok and bool(np.array_equal(img, coef_expect))
     t = min(times)
     obj = {"workload": "icer_compress_image_uint16 on the timed workload's frame: pageable caller memory -> stream in the caller's buffer, coefficient planes "
-                       "written back over the caller's image; whole call", "ms_per_frame": round(t * 1e3, 3), "ms_per_frame_mean": round(sum(times) / len(times) * 1e3, 3),
+                       "written back over the caller's image; whole call", "ms_per_frame": round(t * 1e3, 3), "ms_per_frame_median": round(sorted(times)[len(times) // 2] * 1e3, 3),
            "value": round(W * H / t / 1e6, 3), "unit": "Mpixels/s", "parity": bool(ok),
            "parity_note": "rc, length and CRC-32 equal the reference golden in every call; the image left behind equals the device-resident encoder's coefficient plane",
            "pcie_bytes_per_call": int(2 * W * H * 2 + gold[0])}
@@ -695,8 +697,8 @@ def main():
                 hw = HostWorkload(name, rank, dev, local_rank)
                 hw.step()
                 badh, _ = hw.verify()
-                nst = 3
-                t_el, _, _, _ = run_timed(hw, nst, 0, barrier, dev, red_dev)
+                nst = 4
+                t_el, _, _, _ = run_timed(hw, nst, 1, barrier, dev, red_dev)
                 badh2, _ = hw.verify()
                 c = hw.cfg
                 pix = world * c["per_gpu"] * c["w"] * c["h"] * nst

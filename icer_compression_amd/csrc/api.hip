@@ -197,6 +197,7 @@ struct icerx_encoder {
     DevBuf<Snapshot> snaps;
     DevBuf<SubRecord> sub_recs;
     hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
+    bool side_stream_borrowed = false;  // ... on a stream another encoder owns (the pooled encoders of a host batch share one)
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t coef_ready = nullptr;    // the transform of the last enqueue is complete (coef, means, frame status): recorded before the coder
     hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
@@ -614,7 +615,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (e->done) (void)hipEventDestroy(e->done);
     if (e->fork) (void)hipEventDestroy(e->fork);
     if (e->join) (void)hipEventDestroy(e->join);
-    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+    if (e->side_stream && !e->side_stream_borrowed) (void)hipStreamDestroy(e->side_stream);
     if (e->coef_ready) (void)hipEventDestroy(e->coef_ready);
     if (e->io_stream) (void)hipStreamDestroy(e->io_stream);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -947,7 +948,7 @@ struct BatchDevice {
     {
         ready = false;
         if (device >= 0) (void)hipSetDevice(device);
-        for (int k = 0; k < kBatchSets; k++) {
+        for (int k = kBatchSets - 1; k >= 0; k--) {          // (encoder 0 owns the side stream the others borrow: last)
             if (enc[k]) { icerx_encoder_destroy(enc[k]); enc[k] = nullptr; }
             if (s_enc[k]) (void)hipStreamDestroy(s_enc[k]);
             s_enc[k] = nullptr;
@@ -1013,11 +1014,12 @@ int sub_batch_frames(int cnt, size_t frame_bytes)
 }
 
 // The sub-batches of a block of `cnt` frames, at most `sub` frames each.  Nothing overlaps the upload of the first sub-batch
-// or the download of the last one, so the block starts (and, with ramp = 2, ends) with smaller ones: 1, 2, 4, ... frames
-// up to `sub` (ICER_HIP_BATCH_RAMP=0: all of `sub` frames, 1: rising at the start -- the default --, 2: and falling at the end).
+// or the download of the last one, so the block may start (and, with ramp = 2, end) with smaller ones: 1, 2, 4, ... frames
+// up to `sub` (ICER_HIP_BATCH_RAMP=0: all of `sub` frames -- the default, see below --, 1: rising at the start, 2: and falling
+// at the end).
 void sub_batch_plan(int cnt, int sub, std::vector<int> *first, std::vector<int> *count)
 {
-    int ramp = 1;
+    int ramp = 0;                           // (measured, profiles/r04_logs/r04_a_host_batch_ramp.log: C5 the same with 0 / 1 / 2, C4 9 % slower with a ramp)
     if (const char *rv = getenv("ICER_HIP_BATCH_RAMP")) { const int v = atoi(rv); if (v >= 0 && v <= 2) ramp = v; }
     std::vector<int> head, tail;
     int left = cnt;
@@ -1044,6 +1046,13 @@ int batch_rebuild(BatchDevice *b, size_t w, size_t h, int channels, int stages, 
         const int rc = icerx_encoder_create(&b->enc[k], b->logical, w, h, channels, stages, filt, segments, sub);
         if (rc) return rc;
         b->enc[k]->sleepy_wait = true;
+        // (streams are scarce -- hardware queues, see above: the pipeline's encoders run their short list kernels on ONE side
+        // stream, the first encoder's; fork / join events stay per encoder)
+        if (k > 0 && b->enc[k]->side_stream && b->enc[0]->side_stream) {
+            (void)hipStreamDestroy(b->enc[k]->side_stream);
+            b->enc[k]->side_stream = b->enc[0]->side_stream;
+            b->enc[k]->side_stream_borrowed = true;
+        }
         HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
         if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
         HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));

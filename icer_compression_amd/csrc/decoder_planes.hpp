@@ -1,0 +1,326 @@
+// decoder_planes.hpp -- the decode kernel of round 4: one WAVEFRONT per packet (one bit plane of one segment), the nine
+// planes of a chain as the nine waves of a workgroup over a ring of rows in LDS.
+//
+// Replaces, for chains whose packets take the fast entropy path (>= kFastPacketBits bits each, decoder_core.hpp), the
+// lane-per-plane kernel of decoder_wave.hpp, whose nine lanes execute the union of each other's paths (~ 450 instructions
+// per decision round).  Here a decision is WAVE-UNIFORM: the wave's scalar unit runs the state machine of
+//   icer_decode_bit                       lib_icer/src/icer_decoding.c:108-194
+//   icer_decompress_bitplane_uint16/_8    icer_context_modeller.c:461-602 / :167-310
+// with real branches, and its 64 lanes are used for what is data-parallel:
+//   * register files indexed by lane: lane b holds bin b's pending bits / last-word index, lane k context k's counts, the
+//     code-word and bin look-up tables sit in five + three vector registers -- v_readlane / v_writelane with a scalar
+//     index, no LDS or scratch access on the decision chain;
+//   * the payload: 64 dwords per vector load, taken one v_readlane at a time, the next 256 bytes loaded a chunk ahead;
+//   * the context of 64 samples at a time: everything a sample's context needs except its LEFT neighbour's outcome in
+//     this very plane depends on rows r - 1 (done), r + 1 and the right neighbour (the plane above, a row ahead): computed
+//     by the 64 lanes in one go as two candidate contexts per sample (left insignificant / significant) and two sign
+//     contexts (left not negative / negative); the serial part selects.
+// Planes run a row (and up to 64 samples) behind the plane above -- the dependency rule of decoder_core.hpp, plane_needs --
+// and meet only through progress counters in LDS; the lowest running plane writes finished rows back to the channel plane
+// and recycles their ring slots.  Results are those of plane_decision / entropy_decode_fast (same arithmetic, same tables).
+//
+// Written with the SPMD macros of wave.hpp because this kernel has to be debugged in a container without a GPU: the same
+// source runs in the CPU lane-loop build (tests/emu/decoder_emu.cpp, mode 4), where the nine waves are stepped round-robin
+// (pw_step returns instead of waiting) and the images are compared with the decoder oracle.
+#pragma once
+#include "wave.hpp"
+
+#include "decoder_core.hpp"
+
+#ifdef ICER_WAVE_EMU
+#define PW_WRITELANE(X, L, V) ((X)[(L)] = (V))
+#define PW_UNIFORM(x) (x)
+#define PW_RCP(x) (1.0f / (x))
+#define PW_LDS_LOAD(x) (x)
+#define PW_LDS_STORE(x, v) ((x) = (v))
+#define PW_FENCE_ACQ()
+#define PW_FENCE_REL()
+#else
+#define PW_WRITELANE(X, L, V) ((X) = (uint32_t)__builtin_amdgcn_writelane((int)(V), (int)(L), (int)(X)))
+#define PW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define PW_RCP(x) __builtin_amdgcn_rcpf(x)
+#define PW_LDS_LOAD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define PW_LDS_STORE(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// LDS-only fences (lgkmcnt): the ring and the counters live in LDS; the row write-back to global memory needs no ordering
+#define PW_FENCE_ACQ() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+#define PW_FENCE_REL() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#endif
+
+namespace icer {
+
+constexpr uint32_t kPwBlock = 64;                       // samples per look at the neighbourhood
+constexpr uint32_t kPwWaves = (uint32_t)kPlanes;        // wavefronts per workgroup (one per bit plane)
+// Rows of the ring: the top plane holds rows r and r + 1, each plane below runs at least a row behind the one above, the
+// lowest still reads its row - 1: planes + 2 live rows when every plane is stopped at a row boundary (which is where a
+// stalled pipeline ends up, whatever the block size), so planes + 2 rows cannot lock up; two more keep the top plane from
+// waiting for every retired row.
+ICER_HD uint32_t pw_ring_rows(int planes) { return (uint32_t)planes + 4u; }
+ICER_HD uint32_t pw_ring_pitch(uint32_t w) { return (w + 2u + 1u) & ~1u; }       // a zero guard column on either side
+struct PwShared {                                       // control words of a chain (LDS)
+    uint32_t done[12];                                  // samples finished by plane job j (0 = top plane)
+    uint32_t retired;                                   // rows written back and recycled
+    uint32_t pad[3];
+};
+// LDS of a chain: PwShared | one zero row (what lies above row 0 and below row h - 1) | the ring
+ICER_HD size_t pw_lds_bytes(uint32_t w, int planes)
+{
+    return sizeof(PwShared) + (size_t)(pw_ring_rows(planes) + 1u) * pw_ring_pitch(w) * sizeof(uint16_t);
+}
+
+struct PlaneWave {
+    // wave-uniform
+    uint32_t j, nrun, lsb, w, h, pitch, rows, r, c, done, prev, sign_bit, mask, subband, retired;
+    uint64_t win;
+    uint32_t win_bits, words, pay_k, base, stream_len;
+    const uint8_t *stream;
+    uint16_t *seg;                                      // the segment in the channel plane (global memory)
+    size_t stride;
+    // register files, one entry per lane
+    LANEVAR(uint32_t, fst);                             // lane b: bits pending of bin b (int16) | pattern << 16
+    LANEVAR(uint32_t, idx);                             // lane b: `words` when bin b's last code word was read
+    LANEVAR(uint32_t, cnt);                             // lane k: context k's zero | total << 16
+    LANEVAR(uint32_t, pay); LANEVAR(uint32_t, pay2);    // payload dwords 64 * chunk + lane of this chunk and the next
+    LANEVAR(uint32_t, tg);                              // lane b: DecoderTables::gpk[b]
+    LANEVAR(uint32_t, tv0); LANEVAR(uint32_t, tv1);     // DecoderTables::v2vlut as 112 dwords
+    LANEVAR(uint32_t, bl0); LANEVAR(uint32_t, bl1); LANEVAR(uint32_t, bl2); LANEVAR(uint32_t, bl3); LANEVAR(uint32_t, bl4);   // binlut[257]
+};
+
+// payload dwords 64 * chunk + lane (bytes behind the stream read as zero, like entropy_byte)
+#define PW_LOAD_CHUNK(DST, CHUNK)                                                                          \
+    FOR_LANES                                                                                              \
+    {                                                                                                      \
+        const uint32_t at_ = p.base + 4u * ((CHUNK) * 64u + (uint32_t)lane);                               \
+        uint32_t v_ = 0;                                                                                   \
+        if (at_ + 4u <= p.stream_len) memcpy(&v_, p.stream + at_, 4);                                      \
+        else for (uint32_t i_ = 0; i_ < 4u; i_++) if (at_ + i_ < p.stream_len) v_ |= (uint32_t)p.stream[at_ + i_] << (8u * i_); \
+        LV(DST) = v_;                                                                                      \
+    }
+
+ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &c, int planes, int sign_bit, uint16_t *plane,
+                      size_t stride, const uint8_t *stream, uint32_t stream_len, const DecoderTables *t)
+{
+    DECL_LANE;
+    p.j = j; p.nrun = nrun; p.lsb = (uint32_t)planes - 1u - j; p.w = c.w; p.h = c.h;
+    p.pitch = pw_ring_pitch(c.w); p.rows = pw_ring_rows(planes);
+    p.r = 0; p.c = 0; p.done = 0; p.prev = 0; p.sign_bit = (uint32_t)sign_bit; p.mask = (1u << sign_bit) - 1u;
+    p.subband = c.subband; p.retired = 0;
+    p.stream = stream; p.stream_len = stream_len;
+    p.base = c.pkt[p.lsb] + (uint32_t)kHeaderBytes;
+    p.win = 0; p.win_bits = 0; p.words = 0; p.pay_k = 0;
+    p.seg = plane + c.first; p.stride = stride;
+    FOR_LANES
+    {
+        LV(p.fst) = 0; LV(p.idx) = 0;
+        LV(p.cnt) = 2u | (4u << 16);                                   // icer_init_context_model_vals, icer_context_modeller.c:607-613
+        LV(p.tg) = lane < kNumBins ? t->gpk[lane] : 0u;
+        const uint16_t *v = &t->v2vlut[0][0];
+        LV(p.tv0) = (uint32_t)v[2 * lane] | ((uint32_t)v[2 * lane + 1] << 16);
+        LV(p.tv1) = lane < 48 ? ((uint32_t)v[128 + 2 * lane] | ((uint32_t)v[128 + 2 * lane + 1] << 16)) : 0u;
+        LV(p.bl0) = t->binlut[lane]; LV(p.bl1) = t->binlut[64 + lane]; LV(p.bl2) = t->binlut[128 + lane]; LV(p.bl3) = t->binlut[192 + lane];
+        LV(p.bl4) = t->binlut[256];
+    }
+    PW_LOAD_CHUNK(p.pay, 0u)
+    PW_LOAD_CHUNK(p.pay2, 1u)
+}
+
+// one bit from the entropy decoder: entropy_decode_fast (decoder_core.hpp) on wave-uniform values
+ICER_DEV uint32_t pw_decode(PlaneWave &p, uint32_t zero, uint32_t total)
+{
+    DECL_LANE;
+    (void)lane;
+    const bool inv = zero < (total >> 1);
+    if (inv) zero = total - zero;
+    // pick_bin_plain: floor(zero * 65536 / total) by a float reciprocal estimate, corrected, then one look-up
+    const uint32_t a = zero << 16;
+    uint32_t q = PW_UNIFORM((uint32_t)((float)a * PW_RCP((float)total)));
+    int32_t rem = (int32_t)a - (int32_t)(q * total);
+    if (rem < 0) { q--; rem += (int32_t)total; }
+    if (rem < 0) { q--; rem += (int32_t)total; }
+    if (rem >= (int32_t)total) { q++; rem -= (int32_t)total; }
+    if (rem >= (int32_t)total) q++;
+    const uint32_t li = q >> 8;
+    const uint32_t e = li < 64u ? READLANE(p.bl0, li) : li < 128u ? READLANE(p.bl1, li - 64u) : li < 192u ? READLANE(p.bl2, li - 128u)
+                       : li < 256u ? READLANE(p.bl3, li - 192u) : READLANE(p.bl4, 0u);
+    const uint32_t bin = (e & 255u) + (q >= (e >> 8) ? 1u : 0u);
+    const uint32_t st = READLANE(p.fst, bin), last_word = READLANE(p.idx, bin);
+    int n = (int)(int16_t)(st & 0xFFFFu);
+    uint32_t pat = st >> 16;
+    if (n <= 0 || p.words - last_word >= (uint32_t)kRingWords) {
+        if (p.win_bits < 32u) {
+            const uint32_t nxt = READLANE(p.pay, p.pay_k & 63u);
+            p.win |= (uint64_t)nxt << p.win_bits;
+            p.win_bits += 32u;
+            p.pay_k++;
+            if ((p.pay_k & 63u) == 0u) {
+                FOR_LANES { LV(p.pay) = LV(p.pay2); }
+                const uint32_t chunk = (p.pay_k >> 6) + 1u;
+                PW_LOAD_CHUNK(p.pay2, chunk)
+            }
+        }
+        const uint32_t x = (uint32_t)p.win & 0x7FFu;
+        uint32_t len;
+        if (bin >= 8u) {
+            const uint32_t g = READLANE(p.tg, bin), m = g & 0xFFFu, l = (g >> 12) & 15u, gi = g >> 16;
+            const uint32_t rx = brev32(x);                                   // the low l / l + 1 bits, first bit on top
+            const uint32_t k0 = rx >> (32u - l);                             // (l >= 3)
+            const uint32_t k1 = ((rx >> (31u - l)) - gi) & 0xFFFFu;
+            const bool full = (x & 1u) != 0u, shortw = k0 < gi;
+            const uint32_t k = shortw ? k0 : k1;
+            len = full ? 1u : (shortw ? l : l + 1u);
+            pat = full ? 0u : 1u;
+            n = full ? (int)m : (int)(1u + k > 32767u ? 32767u : 1u + k);
+        } else if (bin >= 1u) {
+            const uint32_t ei = (bin - 1u) * 32u + (x & 31u), dw = ei >> 1;
+            const uint32_t two = dw < 64u ? READLANE(p.tv0, dw) : READLANE(p.tv1, dw - 64u);
+            const uint32_t ent = (two >> (16u * (ei & 1u))) & 0xFFFFu;
+            len = ent & 15u; n = (int)((ent >> 4) & 15u); pat = ent >> 8;
+        } else { len = 1u; n = 1; pat = x & 1u; }
+        p.win >>= len; p.win_bits -= len;
+        p.words++;
+        PW_WRITELANE(p.idx, bin, p.words);
+    }
+    const uint32_t top = (pat >> ((uint32_t)(n - 1) & 31u)) & 1u;
+    const uint32_t b = n > 0 ? (bin >= 8u ? (n == 1 ? pat : 0u) : top) : 0u;
+    PW_WRITELANE(p.fst, bin, ((uint32_t)(n - 1) & 0xFFFFu) | (pat << 16));
+    return inv ? (b ^ 1u) : b;
+}
+
+// counts of context `ctx` through one decision (dec_model_update)
+ICER_DEV uint32_t pw_modelled(PlaneWave &p, uint32_t ctx)
+{
+    DECL_LANE;
+    (void)lane;
+    const uint32_t zt = READLANE(p.cnt, ctx);
+    uint32_t zero = zt & 0xFFFFu, total = zt >> 16;
+    const uint32_t bit = pw_decode(p, zero, total);
+    total++;
+    zero += bit == 0u ? 1u : 0u;
+    if (total >= kRescaleCap) {
+        total >>= 1;
+        if (zero > total) zero >>= 1;
+    }
+    PW_WRITELANE(p.cnt, ctx, zero | (total << 16));
+    return bit;
+}
+
+// samples of the plane above that must be finished before this plane takes the block ending at column c_end of row r
+ICER_HD uint32_t pw_needs(uint32_t r, uint32_t c_end, uint32_t w, uint32_t h)
+{
+    if (r + 1u >= h) return w * h;
+    return (r + 1u) * w + (c_end + 1u < w ? c_end + 1u : w - 1u) + 1u;
+}
+
+// write rows [p.retired, upto) of the ring back to the channel plane, zero their slots, publish
+ICER_DEV void pw_retire(PlaneWave &p, PwShared &s, uint16_t *ring, uint32_t upto)
+{
+    DECL_LANE;
+    while (p.retired < upto) {
+        uint16_t *slot = ring + (size_t)(p.retired % p.rows) * p.pitch + 1u;
+        FOR_LANES
+        {
+            for (uint32_t x = (uint32_t)lane; x < p.w; x += 64u) { p.seg[(size_t)p.retired * p.stride + x] = slot[x]; slot[x] = 0; }
+        }
+        p.retired++;
+    }
+    WAVE_SYNC();
+    PW_FENCE_REL();
+    FOR_LANES { if (lane == 0) PW_LDS_STORE(s.retired, p.retired); }
+}
+
+// One step of a plane's wave: the next block of up to 64 samples of its row, if the plane above and the ring allow it.
+// Returns 0 = blocked (nothing done), 1 = progressed, 2 = the plane is finished.
+// `zero_row`, `ring`: LDS (pw_lds_bytes); every wave of the chain passes the same ones.
+ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ring)
+{
+    DECL_LANE;
+    const uint32_t w = p.w, h = p.h;
+    if (p.r >= h) return 2;
+    const uint32_t r = p.r, c0 = p.c, n = w - c0 < kPwBlock ? w - c0 : kPwBlock, c_end = c0 + n - 1u;
+    if (p.j > 0u) {
+        const uint32_t above = PW_LDS_LOAD(s.done[p.j - 1u]);
+        if (above < pw_needs(r, c_end, w, h)) return 0;
+    } else if (c0 == 0u && r + 1u < h) {
+        // the top plane is the first to touch row r + 1: its slot must have been recycled
+        const uint32_t ret = PW_LDS_LOAD(s.retired);
+        if (r + 1u >= ret + p.rows) return 0;
+    }
+    PW_FENCE_ACQ();
+    const uint32_t lsb = p.lsb, lsb1 = lsb + 1u, mask = p.mask, sb = p.sign_bit;
+    const uint16_t *rowU = r > 0u ? ring + (size_t)((r - 1u) % p.rows) * p.pitch : zero_row;
+    uint16_t *rowC = ring + (size_t)(r % p.rows) * p.pitch;
+    const uint16_t *rowD = r + 1u < h ? ring + (size_t)((r + 1u) % p.rows) * p.pitch : zero_row;
+    // ---- 64 lanes: what the contexts of the block's samples need from the rows around them
+    LANEVAR(uint32_t, desc); LANEVAR(uint32_t, curv); LANEVAR(uint32_t, outv);
+    const bool is_hl = p.subband == (uint32_t)kHL, is_hh = p.subband == (uint32_t)kHH;
+    FOR_LANES
+    {
+        const bool valid = (uint32_t)lane < n;
+        const uint32_t b = valid ? c0 + (uint32_t)lane + 1u : 1u;                  // (guard column at index 0)
+        const uint32_t ul = rowU[b - 1u], u = rowU[b], ur = rowU[b + 1u];
+        const uint32_t cur = rowC[b], right = rowC[b + 1u];
+        const uint32_t dl = rowD[b - 1u], d = rowD[b], dr = rowD[b + 1u];
+#define PW_SIG(v, pl) ((((v) & mask) >> (pl)) != 0u ? 1u : 0u)
+        const uint32_t su = PW_SIG(u, lsb), sul = PW_SIG(ul, lsb), sur = PW_SIG(ur, lsb);
+        const uint32_t sd = PW_SIG(d, lsb1), sdl = PW_SIG(dl, lsb1), sdr = PW_SIG(dr, lsb1), sr = PW_SIG(right, lsb1);
+#undef PW_SIG
+        const uint32_t nu = su & (u >> sb), nd = sd & (d >> sb), nr = sr & (right >> sb);
+        const uint32_t m = cur & mask;
+        const int msb = 31 - clz32(m | 1u);
+        int cat = msb < (int)lsb ? 0 : msb - (int)lsb;
+        if (cat > 3) cat = 3;
+        const uint32_t vv0 = su + sd, dd = sul + sur + sdl + sdr;
+        uint32_t ctxs[2], ses[2];
+        for (uint32_t left = 0; left < 2u; left++) {
+            uint32_t hh = left + sr, vv = vv0;
+            const bool any_hv = (left | sr | su | sd) != 0u;
+            if (is_hl) { const uint32_t x = hh; hh = vv; vv = x; }
+            const uint32_t ctx0 = is_hh ? dec_ctx_hh_packed(hh + vv, dd) : dec_ctx_plain_packed(hh, vv, dd);
+            ctxs[left] = cat == 0 ? ctx0 : cat == 1 ? (any_hv ? 10u : 9u) : 11u;
+            uint32_t sh = 2u - left - nr, sv = 2u - nu - nd;                       // (left: the left neighbour is negative)
+            if (is_hl) { const uint32_t x = sh; sh = sv; sv = x; }
+            constexpr uint64_t ksign = dec_pack_sign();
+            ses[left] = (uint32_t)(ksign >> (4u * (sh * 3u + sv))) & 15u;
+        }
+        LV(desc) = (uint32_t)cat | (ctxs[0] << 2) | (ctxs[1] << 6) | (ses[0] << 10) | (ses[1] << 14);
+        LV(curv) = cur;
+        LV(outv) = 0;
+    }
+    // ---- the wave's scalar side: the block's decisions one after the other
+    uint32_t prev = c0 == 0u ? 0u : p.prev;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t de = READLANE(desc, i), cur = READLANE(curv, i);
+        const uint32_t cat = de & 3u;
+        const uint32_t leftsig = ((prev & mask) >> lsb) != 0u ? 1u : 0u, leftneg = leftsig & (prev >> sb) & 1u;
+        uint32_t val;
+        if (cat == 3u) val = cur | (pw_decode(p, 1u, 2u) << lsb);                  // unmodelled (C2)
+        else {
+            const uint32_t ctx = (de >> (leftsig ? 6u : 2u)) & 15u;
+            const uint32_t bit = pw_modelled(p, ctx);
+            val = cur | (bit << lsb);
+            if (cat == 0u && bit != 0u) {
+                // the sample became significant: its sign (QUIRK C6: only negative significant neighbours count)
+                const uint32_t se = (de >> (leftneg ? 14u : 10u)) & 15u;
+                const uint32_t agree = pw_modelled(p, 12u + (se & 7u));
+                val |= ((agree ^ (se >> 3)) & 1u) << sb;
+            }
+        }
+        PW_WRITELANE(outv, i, val);
+        prev = val;
+    }
+    p.prev = prev;
+    FOR_LANES
+    {
+        if ((uint32_t)lane < n) rowC[c0 + (uint32_t)lane + 1u] = (uint16_t)LV(outv);
+    }
+    p.done += n;
+    const bool row_end = c_end + 1u >= w;
+    if (row_end) { p.r = r + 1u; p.c = 0; } else p.c = c0 + n;
+    WAVE_SYNC();
+    PW_FENCE_REL();
+    FOR_LANES { if (lane == 0) PW_LDS_STORE(s.done[p.j], p.done); }
+    // the lowest running plane is the last one to look at a row: after its row r, row r - 1 is dead
+    if (row_end && p.j + 1u == p.nrun) pw_retire(p, s, ring, p.r >= h ? h : (p.r >= 2u ? p.r - 1u : 0u));
+    return p.r >= h ? 2 : 1;
+}
+
+}  // namespace icer
