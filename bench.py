@@ -366,7 +366,6 @@ def decode_object(stream_dev, size, frame_dev, cfg, with_cpu):
     import torch
     from icer_compression_amd import decoder
     W, H = cfg["w"], cfg["h"]
-    os.environ.setdefault("ICER_DEC_WAVE", "1")
     dev = stream_dev.device
 
     def run(n, reps):
@@ -479,7 +478,6 @@ def batch_decode_object(bw):
     or C5, still in HBM) back through libicer_hip_dec.so in ONE icerx_decode_device call; every decoded frame against the input"""
     import torch
     from icer_compression_amd import decoder
-    os.environ.setdefault("ICER_DEC_WAVE", "1")
     c, W, H, B = bw.cfg, bw.w, bw.h, bw.B
     sizes = [int(x) for x in bw.sizes.cpu().numpy()]
     offs = [k * bw.out.stride(0) for k in range(B)]

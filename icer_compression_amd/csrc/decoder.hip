@@ -7,11 +7,15 @@
 //   | clamp, narrow, copy back.
 // First version: correctness before speed; every loop is bounded by the stream / image size and no
 // kernel waits on another thread.
-#ifndef ICER_HOST_MOCK
+#ifdef ICER_HOST_MOCK
+#define ICER_LAUNCH_PLANES(kernel, grid, shmem, ...) ICER_LAUNCH_WAVE(kernel, grid, shmem, __VA_ARGS__)
+#else
 #include <hip/hip_runtime.h>
 // kernel launches go through these two macros so that tests/emu/hip_mock.h (CPU, tests only) can stand in for them
 #define ICER_LAUNCH(kernel, grid, block, shmem, ...) kernel<<<(grid), (block), (shmem)>>>(__VA_ARGS__)
 #define ICER_LAUNCH_WAVE(kernel, grid, shmem, ...) kernel<<<(grid), 64, (shmem)>>>(__VA_ARGS__)
+// (a workgroup of one wavefront per bit plane; the CPU mock runs the waves of a workgroup in turns inside one call)
+#define ICER_LAUNCH_PLANES(kernel, grid, shmem, ...) kernel<<<(grid), 64 * kPwWaves, (shmem)>>>(__VA_ARGS__)
 #define ICER_DYNAMIC_LDS(T, name) extern __shared__ T name[]
 // the decoder tables of a workgroup: a copy in LDS (every decision looks them up; from global memory each look-up is a
 // chain of dependent loads)
@@ -32,6 +36,7 @@
 
 #include "../../include/icer_hip_dec.h"
 #include "decoder_wave.hpp"
+#include "decoder_planes.hpp"
 #include "decoder_core.hpp"
 #include "decoder_plan.hpp"
 
@@ -83,12 +88,16 @@ count_headers_kernel(const uint8_t *__restrict__ data, const FrameInfo *__restri
     if (at < cap) out[at] = c;
 }
 
+// payload CRCs: 64 threads per candidate, each a contiguous piece (payload_piece_crc), XOR-combined in the candidate's
+// crc_acc; the host compares it with the header's field.  grid = candidates, block = 64.
 __global__ void __launch_bounds__(64)
 check_payloads_kernel(const uint8_t *__restrict__ data, const FrameInfo *__restrict__ frames,
                       const uint32_t *__restrict__ crc_tab, PacketCandidate *__restrict__ cands, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) check_payload(crc_tab, data + frames[cands[i].frame].stream_off, &cands[i]);
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint32_t v = payload_piece_crc(crc_tab, data + frames[cands[i].frame].stream_off, cands[i], threadIdx.x, 64u);
+    if (v) atomicXor(&cands[i].crc_acc, v);
 }
 
 // plane of channel `chan` of frame `frame`: planes + (frame * channels + chan) * frame_stride, rows of the frame's width
@@ -123,6 +132,70 @@ decode_chains_wave_kernel(uint16_t *__restrict__ planes, size_t frame_stride, in
     uint16_t *ring = reinterpret_cast<uint16_t *>(lds + kStateBytes);
     decode_chain_wave(ring, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w, c, (int)c.subband,
                       data + f.stream_off, f.stream_len, lt, nplanes, sign_bit, nullptr, lds);
+}
+
+// one wavefront per bit plane, wave-uniform decisions (decoder_planes.hpp): grid = chains that take the fast entropy path,
+// block = 64 * kPwWaves, dynamic LDS = the widest chain's control words + row ring
+__global__ void __launch_bounds__(64 * kPwWaves)
+decode_chains_planes_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels,
+                            const ChainDesc *__restrict__ chains, const uint8_t *__restrict__ data,
+                            const FrameInfo *__restrict__ frames, const DecoderTables *__restrict__ tables, int nplanes,
+                            int sign_bit, uint32_t *__restrict__ err)
+{
+    ICER_DYNAMIC_LDS(uint8_t, lds);
+    const ChainDesc &c = chains[blockIdx.x];                  // (read in place: see pw_run_chain)
+    const FrameInfo f = frames[c.frame];
+#ifndef ICER_HOST_MOCK
+    {   // control words, zero row and ring start out zero
+        uint32_t *w = reinterpret_cast<uint32_t *>(lds);
+        const uint32_t words = (uint32_t)((pw_lds_bytes(c.w, nplanes) + 3u) / 4u);
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) w[i] = 0;
+        __syncthreads();
+    }
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    const uint32_t wave = 0;
+#endif
+    (void)pw_run_chain(lds, wave, c, nplanes, sign_bit, planes + ((size_t)c.frame * channels + c.chan) * frame_stride, f.w,
+                       data + f.stream_off, f.stream_len, tables, err);
+}
+
+// One level of the inverse transform for filters without a recurrence along the line (beta = 0 and alpha_-1 = 0: filter A --
+// every restored high then depends on the stored lows and highs alone, idwt_line's `dn` and filter-C terms drop out): one
+// thread per output PAIR instead of one per line.  `rows` = false: lines are columns (x = line, y = pair), true: lines are
+// rows.  grid = (ceil(cw / 64), ceil(pairs-or-lines / 4), frames * channels), block = (64, 4).
+__global__ void __launch_bounds__(256)
+idwt_pairs_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst, size_t frame_stride, int channels,
+                  const uint32_t *__restrict__ list, uint32_t image_w, uint32_t cw, uint32_t ch_rows, FilterTaps f,
+                  int bits, const uint32_t *__restrict__ pos_of, bool rows)
+{
+    const uint32_t gx = blockIdx.x * 64u + (threadIdx.x & 63u), gy = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const size_t base = ((size_t)list[blockIdx.z / (unsigned)channels] * channels + blockIdx.z % (unsigned)channels) * frame_stride;
+    // (x runs along a row of the image in both passes, so that a wavefront's accesses are contiguous)
+    const uint32_t n = rows ? cw : ch_rows, nl = (n + 1u) / 2u, nh = n / 2u;
+    const uint32_t line = rows ? gy : gx, k = rows ? gx : gy;
+    if (line >= (rows ? ch_rows : cw) || k >= nl) return;
+    const size_t stride = rows ? 1 : image_w;
+    const int16_t *s = src + base + (rows ? (size_t)line * image_w : (size_t)line);
+    int16_t *d = dst + base + (rows ? (size_t)line * image_w : (size_t)line);
+    const bool odd = (n & 1u) != 0;
+#define LO(i) ((int32_t)s[(size_t)(i) * stride])
+#define HI(i) ((int32_t)s[(size_t)(nl + (i)) * stride])
+#define RR(i) ((int32_t)(int16_t)(LO((i) - 1) - LO(i)))
+#define TR(v) (bits == 8 ? (int16_t)(int8_t)(v) : (int16_t)(v))
+    if (k >= nh) { d[(size_t)pos_of[nl - 1u] * stride] = (int16_t)LO(nl - 1u); return; }       // (odd length: the last low)
+    int32_t add;
+    if (k == 0) add = dec_floordiv(RR(1), 4);
+    else if (!odd && k == nh - 1u) add = dec_floordiv(RR(nh - 1u), 4);
+    else add = dec_floordiv(f.a0 * RR(k) + f.a1 * RR(k + 1u) + 8, 16);
+    const int32_t hi = TR(HI(k) + add);
+    const int32_t a = LO(k) + dec_floordiv(hi + 1, 2);
+    d[(size_t)pos_of[k] * stride] = TR(a);
+    d[(size_t)pos_of[nl + k] * stride] = TR(a - hi);
+#undef LO
+#undef HI
+#undef RR
+#undef TR
 }
 
 // sign-magnitude words -> int16, LL mean back in (grid.y = frame * channels + channel)
@@ -182,7 +255,8 @@ struct icerx_decoder {
     uint32_t crc_tab[256];
     // device buffers, grown on demand and kept
     struct Buf { void *p = nullptr; size_t cap = 0; };
-    Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list;
+    Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list, err;
+    bool planes_lds_raised = false;    // decode_chains_planes_kernel has been granted more than 64 KiB of dynamic LDS
 };
 
 namespace {
@@ -258,11 +332,12 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
             cap = count;                                    // (more header look-alikes than expected: once more, all of them)
         }
         if (count) {
-            ICER_LAUNCH(check_payloads_kernel, (count + 63u) / 64u, 64, 0, d_data, d_frames, (const uint32_t *)d->crc.p,
+            ICER_LAUNCH(check_payloads_kernel, count, 64, 0, d_data, d_frames, (const uint32_t *)d->crc.p,
                         (PacketCandidate *)d->cands.p, count);
             HIP_TRY(hipGetLastError());
             cands.resize(count);
             HIP_TRY(hipMemcpy(cands.data(), d->cands.p, sizeof(PacketCandidate) * count, hipMemcpyDeviceToHost));
+            for (PacketCandidate &c : cands) c.payload_ok = (c.fits && c.crc_acc == load_le32(c.hdr + 20)) ? 1u : 0u;   // (icer_compress.c:576-577)
             std::sort(cands.begin(), cands.end(), [](const PacketCandidate &a, const PacketCandidate &b) {
                 return a.frame != b.frame ? a.frame < b.frame : a.off < b.off;
             });
@@ -298,25 +373,64 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
     // (only the w * h samples of a frame are defined results; the rest of its slot is scratch)
     HIP_TRY(hipMemset(d_planes, 0, sizeof(uint16_t) * planes_total));
     if (!chains.empty()) {
+        // Which kernel decodes a chain (ICER_DEC_WAVE: 0 = one thread per chain, 1 = one wavefront per chain with a lane per
+        // bit plane, anything else / unset = one wavefront per bit plane wherever it applies):
+        //   wave-per-plane   chains whose packets all take the fast entropy path (ChainDesc::fast) and whose row ring fits LDS
+        //   the rest         the lane-per-plane kernel if ITS ring fits, else one thread per chain
+        const char *mode = getenv("ICER_DEC_WAVE");
+        const bool want_planes = !(mode && (mode[0] == '0' || mode[0] == '1')) && d->tables.lut_ok != 0u;
+        size_t planes_lds = 0;
+#ifdef ICER_HOST_MOCK
+        const size_t planes_lds_limit = (size_t)1 << 20;
+#else
+        const size_t planes_lds_limit = 150u * 1024u;
+#endif
+        std::stable_partition(chains.begin(), chains.end(), [&](const ChainDesc &c) {
+            return want_planes && c.fast && frames[c.frame].stream_len >= 4u && pw_lds_bytes(c.w, nplanes) <= planes_lds_limit; });
+        uint32_t n_fast = 0;
+        for (const ChainDesc &c : chains) {
+            if (!(want_planes && c.fast && frames[c.frame].stream_len >= 4u && pw_lds_bytes(c.w, nplanes) <= planes_lds_limit)) break;
+            planes_lds = std::max(planes_lds, pw_lds_bytes(c.w, nplanes));
+            n_fast++;
+        }
         const uint32_t nc = (uint32_t)chains.size();
         HIP_TRY(ensure(d->chains, sizeof(ChainDesc) * nc));
         HIP_TRY(hipMemcpy(d->chains.p, chains.data(), sizeof(ChainDesc) * nc, hipMemcpyHostToDevice));
-        // the planes of a segment side by side (one wavefront per chain) if the chain's row ring fits LDS
-        size_t ring_elems = 2;
-        for (const ChainDesc &c : chains) ring_elems = std::max(ring_elems, ring_elems_for(c.w, nplanes));
-        const size_t ring_bytes = ring_elems * sizeof(uint16_t) + kStateBytes;
-        const char *mode = getenv("ICER_DEC_WAVE");
-        // the wavefront-per-chain kernel unless ICER_DEC_WAVE=0 asks for the thread-per-chain one (tests) or the segment
-        // rows do not fit the LDS ring
-        // (the kernel's static DecoderTables block counts against the same 64 KiB a launch gets without asking)
-        if (!(mode && mode[0] == '0') && ring_bytes + sizeof(DecoderTables) + 256u <= 65536u) {
-            ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nc, ring_bytes, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
-                             d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
-        } else {
-            ICER_LAUNCH(decode_chains_kernel, (nc + 63u) / 64u, 64, plane_block_bytes(64u), d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
-                        nc, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
+        if (n_fast) {
+            HIP_TRY(ensure(d->err, sizeof(uint32_t)));
+            HIP_TRY(hipMemset(d->err.p, 0, sizeof(uint32_t)));
+#ifndef ICER_HOST_MOCK
+            if (planes_lds > 48u * 1024u && !d->planes_lds_raised) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_chains_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_lds_limit));
+                d->planes_lds_raised = true;
+            }
+#endif
+            ICER_LAUNCH_PLANES(decode_chains_planes_kernel, n_fast, planes_lds, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
+                               d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit, (uint32_t *)d->err.p);
+            HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipGetLastError());
+        if (n_fast < nc) {
+            const ChainDesc *rest = (const ChainDesc *)d->chains.p + n_fast;
+            const uint32_t nr = nc - n_fast;
+            // the planes of a segment side by side (one wavefront per chain) if the chain's row ring fits LDS
+            size_t ring_elems = 2;
+            for (uint32_t i = n_fast; i < nc; i++) ring_elems = std::max(ring_elems, ring_elems_for(chains[i].w, nplanes));
+            const size_t ring_bytes = ring_elems * sizeof(uint16_t) + kStateBytes;
+            // (the kernel's static DecoderTables block counts against the same 64 KiB a launch gets without asking)
+            if (!(mode && mode[0] == '0') && ring_bytes + sizeof(DecoderTables) + 256u <= 65536u) {
+                ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nr, ring_bytes, d_planes, frame_stride, channels, rest,
+                                 d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
+            } else {
+                ICER_LAUNCH(decode_chains_kernel, (nr + 63u) / 64u, 64, plane_block_bytes(64u), d_planes, frame_stride, channels, rest,
+                            nr, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        if (n_fast) {
+            uint32_t err = 0;
+            HIP_TRY(hipMemcpy(&err, d->err.p, sizeof err, hipMemcpyDeviceToHost));
+            if (err) { rc = fail("a bit-plane wave of the decoder waited longer than its spin bound (internal error)"); goto done; }
+        }
     }
 
     // 4. samples
@@ -346,8 +460,20 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
             HIP_TRY(ensure(d->list, sizeof(uint32_t) * list.size()));
             HIP_TRY(hipMemcpy(d->list.p, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice));
             const unsigned gy = (unsigned)(list.size() * (size_t)channels);
+            const bool pairwise = taps.be == 0 && taps.am1 == 0;      // (filter A: no recurrence along a line, idwt_pairs_kernel)
             for (size_t li = 0; li < plans[k].levels.size(); li++) {
                 const DecodeLevel &lv = plans[k].levels[li];
+                if (pairwise) {
+                    ICER_LAUNCH(idwt_pairs_kernel, dim3((lv.cw + 63u) / 64u, ((lv.ch + 1u) / 2u + 3u) / 4u, gy), dim3(256), 0, (const int16_t *)d_planes,
+                                (int16_t *)d->tmp.p, frame_stride, channels, (const uint32_t *)d->list.p, W, lv.cw, lv.ch, taps, bits,
+                                (const uint32_t *)d->pos.p + col_at[li], false);
+                    HIP_TRY(hipGetLastError());
+                    ICER_LAUNCH(idwt_pairs_kernel, dim3(((lv.cw + 1u) / 2u + 63u) / 64u, (lv.ch + 3u) / 4u, gy), dim3(256), 0, (const int16_t *)d->tmp.p,
+                                (int16_t *)d_planes, frame_stride, channels, (const uint32_t *)d->list.p, W, lv.cw, lv.ch, taps, bits,
+                                (const uint32_t *)d->pos.p + row_at[li], true);
+                    HIP_TRY(hipGetLastError());
+                    continue;
+                }
                 // columns: planes -> tmp, rows: tmp -> planes (only the level's region is touched)
                 ICER_LAUNCH(idwt_lines_kernel, dim3((lv.cw + 63u) / 64u, gy), 64, 0, (const int16_t *)d_planes, (int16_t *)d->tmp.p,
                             frame_stride, channels, (const uint32_t *)d->list.p, W, lv.cw, lv.ch, taps, bits,
@@ -442,7 +568,7 @@ void icerx_decoder_destroy(icerx_decoder *d)
 {
     if (!d) return;
     for (icerx_decoder::Buf *b : {&d->data, &d->frames, &d->crc, &d->dtables, &d->count, &d->cands, &d->chains, &d->work, &d->tmp,
-                                  &d->out8, &d->pos, &d->list})
+                                  &d->out8, &d->pos, &d->list, &d->err})
         if (b->p) (void)hipFree(b->p);
     delete d;
 }

@@ -93,6 +93,8 @@ struct ChainDesc {
     uint32_t first;             // index of the segment's first sample in that plane
     uint16_t w, h;              // segment size
     uint32_t pkt[kPlanes];      // per bit plane: byte offset of the packet (its header) in the stream, kNoPacket = absent
+    uint32_t fast;              // every packet the chain runs has >= kFastPacketBits bits: none of the reference's length tests
+                                // can fire, the chain may take the wave-per-plane kernel (decoder_planes.hpp)
 };
 
 // ------------------------------------------------------------------------------------------ entropy decoder

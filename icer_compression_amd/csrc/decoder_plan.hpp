@@ -23,6 +23,7 @@ struct PacketCandidate {
     uint32_t fits;          // the payload lies inside the stream
     uint32_t payload_ok;    // ... and its CRC-32 matches
     uint32_t frame;         // which stream of a batch
+    uint32_t crc_acc;       // device: CRC-32 of the payload, XOR-accumulated from the pieces of check_payloads_kernel
     uint8_t hdr[kHeaderBytes];  // copy of the header, so that the host planner never reads the (device-resident) stream
 };
 
@@ -57,6 +58,7 @@ ICER_HD bool header_candidate(const uint32_t *tab, const uint8_t *s, uint32_t le
     out->payload_bytes = bits / 8u + ((bits % 8u) ? 1u : 0u);
     out->fits = out->payload_bytes <= len - off - (uint32_t)kHeaderBytes;
     out->payload_ok = 0;
+    out->crc_acc = 0;
     return true;
 }
 // payload check of one candidate (icer_compress.c:576-577)
@@ -65,6 +67,42 @@ ICER_HD void check_payload(const uint32_t *tab, const uint8_t *s, PacketCandidat
     if (!c->fits) return;
     const uint8_t *p = s + c->off;
     c->payload_ok = load_le32(p + 20) == crc32_bytes(tab, p + kHeaderBytes, c->payload_bytes);
+}
+
+// ---- the payload CRC in pieces (device: check_payloads_kernel, 64 threads per candidate).  For the init / final-xor form
+// crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P (zlib's crc32_combine), so the CRC of a payload is the XOR of
+// its pieces' CRCs, each multiplied by x^(8 * bytes behind the piece).
+ICER_HD uint32_t dec_gf_mulmod(uint32_t a, uint32_t b)         // a(x) * b(x) mod P(x), reflected representation (bit 31 = x^0)
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m != 0; m >>= 1) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0) break;
+        }
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+ICER_HD uint32_t dec_gf_xpow_bytes(uint32_t nbytes)            // x^(8 * nbytes) mod P by repeated squaring
+{
+    uint32_t p = 0x80000000u, sq = 0x00800000u;                   // x^0, x^8
+    for (; nbytes != 0; nbytes >>= 1) {
+        if (nbytes & 1u) p = dec_gf_mulmod(sq, p);
+        sq = dec_gf_mulmod(sq, sq);
+    }
+    return p;
+}
+// piece `k` of `pieces` of candidate c's payload: its contribution to the payload CRC
+ICER_HD uint32_t payload_piece_crc(const uint32_t *tab, const uint8_t *s, const PacketCandidate &c, uint32_t k, uint32_t pieces)
+{
+    if (!c.fits) return 0;
+    const uint32_t n = c.payload_bytes, piece = (((n + pieces - 1u) / pieces) + 15u) & ~15u;
+    const uint32_t start = k * piece, end = start + piece < n ? start + piece : n;
+    if (start >= end) return 0;
+    uint32_t v = crc32_bytes(tab, s + c.off + (uint32_t)kHeaderBytes + start, end - start);
+    if (n > end) v = dec_gf_mulmod(dec_gf_xpow_bytes(n - end), v);
+    return v;
 }
 
 struct DecodeLevel { uint32_t cw, ch; };        // region of one inverse-transform level (deepest first)
@@ -89,9 +127,11 @@ inline void plan_decode(DecodePlan *pl, const std::vector<PacketCandidate> &cand
     if (stages < 1 || stages > kMaxStages) { pl->rc = kTooManyStages; return; }      // (reference: out-of-bounds table)
     // [chan][level][subband][segment][lsb] -> packet offset; the last packet of a kind wins
     std::vector<uint32_t> table((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1) * kPlanes, kNoPacket);
-    auto slot = [&](int ch, int lv, int sb, int sg, int lsb) -> uint32_t & {
-        return table[((((size_t)ch * (kMaxStages + 1) + lv) * 4 + sb) * (kMaxSegments + 1) + sg) * kPlanes + lsb];
+    std::vector<uint32_t> bits_tab(table.size(), 0u);              // ... and that packet's data_length
+    auto slot_index = [&](int ch, int lv, int sb, int sg, int lsb) {
+        return ((((size_t)ch * (kMaxStages + 1) + lv) * 4 + sb) * (kMaxSegments + 1) + sg) * kPlanes + lsb;
     };
+    auto slot = [&](int ch, int lv, int sb, int sg, int lsb) -> uint32_t & { return table[slot_index(ch, lv, sb, sg, lsb)]; };
     // the scan accepts a candidate when it starts at or behind the end of the previous packet and both CRCs hold;
     // anything else is stepped over byte by byte
     uint32_t cursor = 0;
@@ -99,7 +139,10 @@ inline void plan_decode(DecodePlan *pl, const std::vector<PacketCandidate> &cand
         if (c.off < cursor || !c.fits || !c.payload_ok) continue;
         const uint8_t *p = c.hdr;
         const int lv = p[4], sb = p[5], sg = p[6], lsb = p[7] & 15, ch = channels == 3 ? (p[7] >> 4) : 0;
-        if (lv <= kMaxStages && sb < 4 && sg <= kMaxSegments && lsb < kPlanes && ch < 3) slot(ch, lv, sb, sg, lsb) = c.off;
+        if (lv <= kMaxStages && sb < 4 && sg <= kMaxSegments && lsb < kPlanes && ch < 3) {
+            slot(ch, lv, sb, sg, lsb) = c.off;
+            bits_tab[slot_index(ch, lv, sb, sg, lsb)] = load_le32(p + 16);
+        }
         pl->w = load_le32(p + 8);
         pl->h = load_le32(p + 12);
         if (ch < 3) pl->mean[ch] = (uint16_t)(p[2] | (p[3] << 8));
@@ -132,6 +175,9 @@ inline void plan_decode(DecodePlan *pl, const std::vector<PacketCandidate> &cand
                     c.first = (uint32_t)((oy + rects[sg].y) * w + ox + rects[sg].x);
                     c.w = (uint16_t)rects[sg].w; c.h = (uint16_t)rects[sg].h;
                     for (int lsb = 0; lsb < kPlanes; lsb++) c.pkt[lsb] = lsb < planes ? slot(ch, lv, sb, (int)sg, lsb) : kNoPacket;
+                    c.fast = (c.w > 0 && c.h > 0) ? 1u : 0u;
+                    for (int lsb = planes - 1; lsb >= 0 && c.pkt[lsb] != kNoPacket; lsb--)
+                        if (bits_tab[slot_index(ch, lv, sb, (int)sg, lsb)] < kFastPacketBits) c.fast = 0u;
                     pl->chains.push_back(c);
                 }
             }

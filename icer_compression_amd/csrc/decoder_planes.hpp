@@ -8,7 +8,7 @@
 //   icer_decompress_bitplane_uint16/_8    icer_context_modeller.c:461-602 / :167-310
 // with real branches, and its 64 lanes are used for what is data-parallel:
 //   * register files indexed by lane: lane b holds bin b's pending bits / last-word index, lane k context k's counts, the
-//     code-word and bin look-up tables sit in five + three vector registers -- v_readlane / v_writelane with a scalar
+//     code-word tables and the bins' cut-offs sit in four vector registers -- v_readlane / v_writelane with a scalar
 //     index, no LDS or scratch access on the decision chain;
 //   * the payload: 64 dwords per vector load, taken one v_readlane at a time, the next 256 bytes loaded a chunk ahead;
 //   * the context of 64 samples at a time: everything a sample's context needs except its LEFT neighbour's outcome in
@@ -36,7 +36,9 @@
 #define PW_FENCE_ACQ()
 #define PW_FENCE_REL()
 #else
-#define PW_WRITELANE(X, L, V) ((X) = (uint32_t)__builtin_amdgcn_writelane((int)(V), (int)(L), (int)(X)))
+// (this compiler has no v_writelane builtin: a compare of the lane number with the scalar index and a select -- two vector
+// instructions, no inline-assembly hazards to mind)
+#define PW_WRITELANE(X, L, V) ((X) = ((uint32_t)lane == (uint32_t)(L)) ? (uint32_t)(V) : (X))
 #define PW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define PW_RCP(x) __builtin_amdgcn_rcpf(x)
 #define PW_LDS_LOAD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -82,7 +84,7 @@ struct PlaneWave {
     LANEVAR(uint32_t, pay); LANEVAR(uint32_t, pay2);    // payload dwords 64 * chunk + lane of this chunk and the next
     LANEVAR(uint32_t, tg);                              // lane b: DecoderTables::gpk[b]
     LANEVAR(uint32_t, tv0); LANEVAR(uint32_t, tv1);     // DecoderTables::v2vlut as 112 dwords
-    LANEVAR(uint32_t, bl0); LANEVAR(uint32_t, bl1); LANEVAR(uint32_t, bl2); LANEVAR(uint32_t, bl3); LANEVAR(uint32_t, bl4);   // binlut[257]
+    LANEVAR(uint32_t, tc);                              // lane k < 16: DecoderTables::cut[k]; the lanes above: 0xFFFFFFFF
 };
 
 // payload dwords 64 * chunk + lane (bytes behind the stream read as zero, like entropy_byte)
@@ -100,14 +102,18 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
                       size_t stride, const uint8_t *stream, uint32_t stream_len, const DecoderTables *t)
 {
     DECL_LANE;
-    p.j = j; p.nrun = nrun; p.lsb = (uint32_t)planes - 1u - j; p.w = c.w; p.h = c.h;
-    p.pitch = pw_ring_pitch(c.w); p.rows = pw_ring_rows(planes);
-    p.r = 0; p.c = 0; p.done = 0; p.prev = 0; p.sign_bit = (uint32_t)sign_bit; p.mask = (1u << sign_bit) - 1u;
-    p.subband = c.subband; p.retired = 0;
-    p.stream = stream; p.stream_len = stream_len;
-    p.base = c.pkt[p.lsb] + (uint32_t)kHeaderBytes;
+    // (every scalar of the wave's state is made uniform explicitly -- v_readfirstlane -- so that the decision chain below is
+    // compiled for the scalar unit with real branches; a value the compiler cannot prove uniform would drag it all onto EXEC
+    // masks)
+    p.j = PW_UNIFORM(j); p.nrun = PW_UNIFORM(nrun); p.lsb = PW_UNIFORM((uint32_t)planes - 1u - j);
+    p.w = PW_UNIFORM((uint32_t)c.w); p.h = PW_UNIFORM((uint32_t)c.h);
+    p.pitch = pw_ring_pitch(p.w); p.rows = PW_UNIFORM(pw_ring_rows(planes));
+    p.r = 0; p.c = 0; p.done = 0; p.prev = 0; p.sign_bit = PW_UNIFORM((uint32_t)sign_bit); p.mask = (1u << p.sign_bit) - 1u;
+    p.subband = PW_UNIFORM(c.subband); p.retired = 0;
+    p.stream = stream; p.stream_len = PW_UNIFORM(stream_len);
+    p.base = PW_UNIFORM(c.pkt[p.lsb]) + (uint32_t)kHeaderBytes;
     p.win = 0; p.win_bits = 0; p.words = 0; p.pay_k = 0;
-    p.seg = plane + c.first; p.stride = stride;
+    p.seg = plane + PW_UNIFORM(c.first); p.stride = stride;
     FOR_LANES
     {
         LV(p.fst) = 0; LV(p.idx) = 0;
@@ -116,8 +122,7 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
         const uint16_t *v = &t->v2vlut[0][0];
         LV(p.tv0) = (uint32_t)v[2 * lane] | ((uint32_t)v[2 * lane + 1] << 16);
         LV(p.tv1) = lane < 48 ? ((uint32_t)v[128 + 2 * lane] | ((uint32_t)v[128 + 2 * lane + 1] << 16)) : 0u;
-        LV(p.bl0) = t->binlut[lane]; LV(p.bl1) = t->binlut[64 + lane]; LV(p.bl2) = t->binlut[128 + lane]; LV(p.bl3) = t->binlut[192 + lane];
-        LV(p.bl4) = t->binlut[256];
+        LV(p.tc) = lane < 16 ? t->cut[lane] : 0xFFFFFFFFu;
     }
     PW_LOAD_CHUNK(p.pay, 0u)
     PW_LOAD_CHUNK(p.pay2, 1u)
@@ -127,21 +132,22 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
 ICER_DEV uint32_t pw_decode(PlaneWave &p, uint32_t zero, uint32_t total)
 {
     DECL_LANE;
-    (void)lane;
+    // (loop-carried scalars are re-asserted uniform here: one v_readfirstlane each keeps them -- and every branch on them --
+    // on the scalar unit)
+    p.words = PW_UNIFORM(p.words); p.win_bits = PW_UNIFORM(p.win_bits); p.pay_k = PW_UNIFORM(p.pay_k);
+    p.win = (uint64_t)PW_UNIFORM((uint32_t)p.win) | ((uint64_t)PW_UNIFORM((uint32_t)(p.win >> 32)) << 32);
     const bool inv = zero < (total >> 1);
     if (inv) zero = total - zero;
-    // pick_bin_plain: floor(zero * 65536 / total) by a float reciprocal estimate, corrected, then one look-up
+    // icer_compute_bin (icer_util.c:48-56): the number of cut-offs that zero / total reaches, zero * 65536 >= total * cut[k]
+    // (cut-offs ascending; products below 2^25).  On the scalar unit a binary search over the 16 cut-offs -- five compares,
+    // the cut-offs read from a vector register by lane -- is shorter than pick_bin_plain's division and table look-up.
     const uint32_t a = zero << 16;
-    uint32_t q = PW_UNIFORM((uint32_t)((float)a * PW_RCP((float)total)));
-    int32_t rem = (int32_t)a - (int32_t)(q * total);
-    if (rem < 0) { q--; rem += (int32_t)total; }
-    if (rem < 0) { q--; rem += (int32_t)total; }
-    if (rem >= (int32_t)total) { q++; rem -= (int32_t)total; }
-    if (rem >= (int32_t)total) q++;
-    const uint32_t li = q >> 8;
-    const uint32_t e = li < 64u ? READLANE(p.bl0, li) : li < 128u ? READLANE(p.bl1, li - 64u) : li < 192u ? READLANE(p.bl2, li - 128u)
-                       : li < 256u ? READLANE(p.bl3, li - 192u) : READLANE(p.bl4, 0u);
-    const uint32_t bin = (e & 255u) + (q >= (e >> 8) ? 1u : 0u);
+    uint32_t bin = 0;
+    bin += a >= total * READLANE(p.tc, bin + 7u) ? 8u : 0u;
+    bin += a >= total * READLANE(p.tc, bin + 3u) ? 4u : 0u;
+    bin += a >= total * READLANE(p.tc, bin + 1u) ? 2u : 0u;
+    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;
+    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;          // (lane 16 holds ~0: never reached)
     const uint32_t st = READLANE(p.fst, bin), last_word = READLANE(p.idx, bin);
     int n = (int)(int16_t)(st & 0xFFFFu);
     uint32_t pat = st >> 16;
@@ -189,7 +195,6 @@ ICER_DEV uint32_t pw_decode(PlaneWave &p, uint32_t zero, uint32_t total)
 ICER_DEV uint32_t pw_modelled(PlaneWave &p, uint32_t ctx)
 {
     DECL_LANE;
-    (void)lane;
     const uint32_t zt = READLANE(p.cnt, ctx);
     uint32_t zero = zt & 0xFFFFu, total = zt >> 16;
     const uint32_t bit = pw_decode(p, zero, total);
@@ -237,11 +242,11 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
     if (p.r >= h) return 2;
     const uint32_t r = p.r, c0 = p.c, n = w - c0 < kPwBlock ? w - c0 : kPwBlock, c_end = c0 + n - 1u;
     if (p.j > 0u) {
-        const uint32_t above = PW_LDS_LOAD(s.done[p.j - 1u]);
+        const uint32_t above = PW_UNIFORM(PW_LDS_LOAD(s.done[p.j - 1u]));
         if (above < pw_needs(r, c_end, w, h)) return 0;
     } else if (c0 == 0u && r + 1u < h) {
         // the top plane is the first to touch row r + 1: its slot must have been recycled
-        const uint32_t ret = PW_LDS_LOAD(s.retired);
+        const uint32_t ret = PW_UNIFORM(PW_LDS_LOAD(s.retired));
         if (r + 1u >= ret + p.rows) return 0;
     }
     PW_FENCE_ACQ();
@@ -305,7 +310,7 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
             }
         }
         PW_WRITELANE(outv, i, val);
-        prev = val;
+        prev = PW_UNIFORM(val);
     }
     p.prev = prev;
     FOR_LANES
@@ -322,5 +327,59 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
     if (row_end && p.j + 1u == p.nrun) pw_retire(p, s, ring, p.r >= h ? h : (p.r >= 2u ? p.r - 1u : 0u));
     return p.r >= h ? 2 : 1;
 }
+
+
+// All planes of one chain: the body of decode_chains_planes_kernel.  GPU build: called by every wavefront of the workgroup
+// (wave `wave` of kPwWaves; `lds` = pw_lds_bytes(c.w, planes) bytes, zeroed by the workgroup before); a wave that waits
+// longer than kPwSpinLimit polls gives up and raises *err (the host then fails the call loudly) -- never a hang.
+// CPU builds (tests only): one call runs the chain's waves in turns.  Returns false on a lock-up / time-out.
+constexpr uint32_t kPwSpinLimit = 1u << 22;
+#ifdef ICER_WAVE_EMU
+ICER_DEV bool pw_run_chain(uint8_t *lds, uint32_t /*wave*/, const ChainDesc &c, int planes, int sign_bit, uint16_t *plane, size_t stride,
+                           const uint8_t *stream, uint32_t stream_len, const DecoderTables *t, uint32_t * /*err*/)
+{
+    memset(lds, 0, pw_lds_bytes(c.w, planes));
+    PwShared &sh = *reinterpret_cast<PwShared *>(lds);
+    uint16_t *zero_row = reinterpret_cast<uint16_t *>(lds + sizeof(PwShared)), *ring = zero_row + pw_ring_pitch(c.w);
+    uint32_t nrun = 0;
+    while ((int)nrun < planes && c.pkt[planes - 1 - (int)nrun] != kNoPacket) nrun++;
+    PlaneWave pw[kPlanes];
+    for (uint32_t j = 0; j < nrun; j++) pw_init(pw[j], j, nrun, c, planes, sign_bit, plane, stride, stream, stream_len, t);
+    for (;;) {
+        bool progress = false, all_done = true;
+        for (uint32_t j = 0; j < nrun; j++) {
+            const int st = pw_step(pw[j], sh, zero_row, ring);
+            progress = progress || st == 1;
+            all_done = all_done && (st == 2 || pw[j].r >= pw[j].h);
+        }
+        if (all_done) return true;
+        if (!progress) return false;
+    }
+}
+#else
+ICER_DEV bool pw_run_chain(uint8_t *lds, uint32_t wave, const ChainDesc &c, int planes, int sign_bit, uint16_t *plane, size_t stride,
+                           const uint8_t *stream, uint32_t stream_len, const DecoderTables *t, uint32_t *err)
+{
+    // (`c` refers to global memory: a private copy indexed by a run-time plane number would live in scratch)
+    PwShared &sh = *reinterpret_cast<PwShared *>(lds);
+    uint16_t *zero_row = reinterpret_cast<uint16_t *>(lds + sizeof(PwShared)), *ring = zero_row + pw_ring_pitch(PW_UNIFORM((uint32_t)c.w));
+    uint32_t nrun = 0;
+    while ((int)nrun < planes && PW_UNIFORM(c.pkt[planes - 1 - (int)nrun]) != kNoPacket) nrun++;
+    if (wave >= nrun) return true;
+    PlaneWave p;
+    pw_init(p, wave, nrun, c, planes, sign_bit, plane, stride, stream, stream_len, t);
+    uint32_t spins = 0;
+    for (;;) {
+        const int st = pw_step(p, sh, zero_row, ring);
+        if (st == 2) return true;
+        if (st == 1) { spins = 0; continue; }
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kPwSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+#endif
 
 }  // namespace icer

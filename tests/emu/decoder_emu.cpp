@@ -2,6 +2,7 @@
 // compiled by g++ and driven the way decoder.hip drives them on the GPU: one "thread" per candidate, per chain, per
 // line.  Lets tests/test_emu_decoder.py check the device code against the decoder oracle without a GPU.
 #include "../../icer_compression_amd/csrc/decoder_wave.hpp"      // (lane-loop build of the SPMD macros: -DICER_WAVE_EMU)
+#include "../../icer_compression_amd/csrc/decoder_planes.hpp"
 #include "../../icer_compression_amd/csrc/decoder_core.hpp"
 #include "../../icer_compression_amd/csrc/decoder_plan.hpp"
 #include <stdlib.h>
@@ -59,6 +60,46 @@ static void decode_chain_lockstep(uint16_t *plane, size_t stride, const ChainDes
         }
 }
 
+// mode 4: the wave-per-plane kernel of decoder_planes.hpp.  Its waves only meet through counters; here they are stepped in
+// turns -- round-robin, or in an order drawn from g_order_seed (any order must give the same image) -- and a full round
+// without progress is a lock-up (reported through stats[3]).  Chains with a packet too short for the fast entropy path go
+// through the lane-per-plane kernel, as in decoder.hip.
+static unsigned g_order_seed = 0;
+extern "C" void emu_decoder_order_seed(unsigned s) { g_order_seed = s; }
+static bool chain_is_fast(const ChainDesc &c, const uint8_t *stream, uint32_t stream_len, const DecoderTables &t, int planes)
+{
+    if (!t.lut_ok || stream_len < 4u) return false;
+    for (int lsb = planes - 1; lsb >= 0 && c.pkt[lsb] != kNoPacket; lsb--)
+        if (packet_bits(stream, c.pkt[lsb]) < kFastPacketBits) return false;
+    return c.w > 0 && c.h > 0;
+}
+static void decode_chain_planes(uint16_t *plane, size_t stride, const ChainDesc &c, const uint8_t *stream, uint32_t stream_len,
+                                const DecoderTables &t, int planes, int sign_bit, unsigned long long *stats)
+{
+    std::vector<uint8_t> lds(pw_lds_bytes(c.w, planes), 0);
+    PwShared &sh = *reinterpret_cast<PwShared *>(lds.data());
+    uint16_t *zero_row = reinterpret_cast<uint16_t *>(lds.data() + sizeof(PwShared));
+    uint16_t *ring = zero_row + pw_ring_pitch(c.w);
+    uint32_t nrun = 0;
+    while ((int)nrun < planes && c.pkt[planes - 1 - (int)nrun] != kNoPacket) nrun++;
+    std::vector<PlaneWave> pw(nrun);
+    for (uint32_t j = 0; j < nrun; j++) pw_init(pw[j], j, nrun, c, planes, sign_bit, plane, stride, stream, stream_len, &t);
+    unsigned rng = g_order_seed * 2654435761u + 12345u;
+    for (;;) {
+        bool progress = false, all_done = true;
+        for (uint32_t k = 0; k < nrun; k++) {
+            uint32_t j = k;
+            if (g_order_seed) { rng = rng * 1664525u + 1013904223u; j = (rng >> 16) % nrun; }
+            const int st = pw_step(pw[j], sh, zero_row, ring);
+            if (st == 1) { progress = true; if (stats) { stats[0]++; } }
+        }
+        for (uint32_t j = 0; j < nrun; j++) all_done = all_done && pw[j].r >= pw[j].h;
+        if (all_done) break;
+        if (!progress && !g_order_seed) { if (stats) stats[3]++; break; }      // (a random order may simply not have picked the runnable wave)
+    }
+    if (stats) stats[1] += (unsigned long long)c.w * c.h * nrun;
+}
+
 // mode 1 / 2: decode chains with the lock-step schedule (planes top-down / bottom-up inside an iteration); mode 3: the
 // wave kernel of decoder_wave.hpp (LDS row ring).  stats: iterations, samples decoded, roll-backs, chains with rows left
 extern "C" void emu_decoder_mode(int lockstep) { g_lockstep = lockstep; g_stats[0] = g_stats[1] = g_stats[2] = g_stats[3] = 0; }
@@ -103,7 +144,8 @@ extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w,
     std::vector<uint16_t> ring(ring_elems);
     std::vector<uint8_t> state(kStateBytes);
     for (size_t i = 0; i < pl.chains.size(); i++) {
-        if (g_lockstep == 3) decode_chain_wave(ring.data(), planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats, state.data());
+        if (g_lockstep == 4 && chain_is_fast(pl.chains[i], data, (uint32_t)len, dt, nplanes)) decode_chain_planes(planes[pl.chains[i].chan], W, pl.chains[i], data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
+        else if (g_lockstep == 3 || g_lockstep == 4) decode_chain_wave(ring.data(), planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats, state.data());
         else if (g_lockstep) decode_chain_lockstep(planes[pl.chains[i].chan], W, pl.chains[i], (int)pl.chains[i].subband, data, (uint32_t)len, dt, nplanes, sign_bit, g_stats);
         else {
             PlaneDecoder job;

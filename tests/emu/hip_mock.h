@@ -36,6 +36,8 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+static inline uint32_t atomicXor(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o ^ v; return o; }
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
 
 #define ICER_MOCK_GRID(grid, block, shmem, per_block)                                          \
     do {                                                                                       \

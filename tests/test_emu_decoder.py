@@ -22,7 +22,7 @@ u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 @pytest.fixture(scope="module")
 def emu():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp", "wave.hpp", "plan.hpp",
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp", "decoder_planes.hpp", "wave.hpp", "plan.hpp",
                                                     "icer_tables.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-DICER_WAVE_EMU", "-o", LIB, SRC])
@@ -55,10 +55,11 @@ def same(a, b):
     return a[0] == b[0] and a[1:3] == b[1:3] and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
 
 
-@pytest.fixture(params=[0, 3], ids=["thread_per_chain", "wave_per_chain"])
+@pytest.fixture(params=[0, 3, 4], ids=["thread_per_chain", "wave_per_chain", "wave_per_plane"])
 def kernel(request, emu):
     """0: decode_chain (one thread per chain, plane after plane); 3: decode_chain_wave (planes side by side, one decision per
-    round: plane_decision / entropy_decode_fast)"""
+    round: plane_decision / entropy_decode_fast); 4: pw_step of decoder_planes.hpp (one wavefront per bit plane, wave-uniform
+    decisions, the planes' waves stepped in turns), chains with a very short packet through kernel 3"""
     emu.lib.emu_decoder_mode(request.param)
     yield request.param
     emu.lib.emu_decoder_mode(0)
@@ -190,6 +191,41 @@ def test_wave_kernel_on_very_narrow_segments(emu, orc):
         emu.lib.emu_decoder_mode(0)
 
 
+def test_wave_per_plane_kernel_schedules_and_shapes(emu, orc):
+    """decoder_planes.hpp: the waves of a chain meet only through progress counters, so the image must not depend on the order
+    in which they get to run (here: drawn at random, several seeds), and the ring of planes + 4 rows must never lock up --
+    segments from one sample wide (a block is then a whole row) to several blocks per row, rows that end inside a block,
+    8-bit streams (7 planes), quota-cut streams whose lower planes are missing, every subband's context tables"""
+    stats = (C.c_ulonglong * 4)()
+    rng = np.random.default_rng(31337)
+    cases = []
+    for w, h, st, sg in ((6, 180, 1, 6), (9, 150, 2, 8), (7, 96, 1, 3), (17, 120, 3, 9), (24, 160, 3, 32), (6, 6, 1, 1), (200, 6, 1, 2),
+                         (40, 130, 4, 20), (130, 70, 1, 1), (260, 48, 1, 2), (191, 33, 2, 3), (320, 200, 3, 4)):
+        img = rng.integers(0, 256, (h, w)).astype(np.uint16)
+        for quota in (4 * w * h + 40000, max(600, w * h // 3)):
+            rc, stream, _ = orc.compress([img], st, int(rng.integers(0, 7)), sg, quota)
+            if stream:
+                cases.append((stream, 1, st, sg, 16))
+    for _ in range(12):
+        planes, st, filt, sg, ch, bits, quota = random_case(rng)
+        rc, stream, _ = (orc.compress if bits == 16 else orc.compress_u8)(planes, st, filt, sg, quota)
+        if stream:
+            cases.append((stream, ch, st, sg, bits))
+    try:
+        for seed in (0, 1, 2, 77):
+            emu.lib.emu_decoder_mode(4)
+            emu.lib.emu_decoder_order_seed(seed)
+            for stream, ch, st, sg, bits in cases:
+                # (the filter only matters to the inverse transform: decode with filter A everywhere but for the random cases)
+                want = orc.decompress(stream, ch, st, 0, sg, bits=bits)
+                assert same(emu(stream, ch, st, 0, sg, bits=bits), want), (seed, len(stream), ch, st, sg, bits)
+            emu.lib.emu_decoder_stats(stats)
+            assert stats[0] > 0 and stats[3] == 0, (seed, list(stats))        # the new kernel ran, and never locked up
+    finally:
+        emu.lib.emu_decoder_order_seed(0)
+        emu.lib.emu_decoder_mode(0)
+
+
 def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
     """decoder.hip itself -- its C ABI, allocations, copies, launch geometries and clean-up -- compiled by g++ against
     tests/emu/hip_mock.h (device memory = poisoned host memory, a launch = a loop over the grid) and called through
@@ -214,7 +250,7 @@ def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
             dsg = sg if rng.random() < 0.9 else int(rng.integers(1, 33))
             h, w = planes[0].shape
             want = orc.decompress(stream, ch, st, filt, dsg, bufsize=w * h, bits=bits)
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):                         # thread per chain, lane per plane, wavefront per plane
                 os.environ["ICER_DEC_WAVE"] = mode
                 assert same(decoder.decompress(stream, ch, st, filt, dsg, bufsize=w * h, bits=bits, lib=lib), want), \
                     (mode, planes[0].shape, st, filt, sg, dsg, ch, bits, quota)
@@ -224,7 +260,7 @@ def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
         rc, stream, _ = orc.compress([img], 3, 1, 5, 2 * 160 * 120)
         for s in (b"", b"\x5b\x60" * 40, stream[: len(stream) // 2], stream[5:], b"\x00" * 9 + stream + b"\x5b\x60\x00",
                   b"".join(reversed(packets(stream)))):
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):
                 os.environ["ICER_DEC_WAVE"] = mode
                 assert same(decoder.decompress(s, 1, 3, 1, 5, bufsize=160 * 120, lib=lib),
                             orc.decompress(s, 1, 3, 1, 5, bufsize=160 * 120)), len(s)
@@ -242,7 +278,7 @@ def test_host_pipeline_on_a_mock_hip_runtime(orc, tmp_path):
             stride = 64 * 96 + 11
             want = [orc.decompress(s_, 1, 2, 0, 6, bufsize=stride, bits=bits) for s_ in streams]
             assert [w_[0] for w_ in want] == [0, -3, 0, -5, 0]        # (an empty stream: no size, so no segment grid)
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):
                 os.environ["ICER_DEC_WAVE"] = mode
                 dec = decoder.Decoder(1, 2, 0, 6, bits=bits, lib=lib)
                 rc, res = dec.decode_host(streams, stride)

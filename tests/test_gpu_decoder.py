@@ -1,7 +1,7 @@
 """GPU parity tests of the decoder (libicer_hip_dec.so through its C ABI) against the decoder oracle: random gray / YUV,
 uint16 / uint8 streams incl. quota-cut ones, wrong decode parameters, damaged / truncated / re-ordered streams, the golden
-decoder digests up to 4096 x 4096 and the batch decoder object, for both decode kernels.  First hardware run:
-profiles/r02_decoder_gpu_tests.log.  See DESIGN.md 6b.
+decoder digests up to 4096 x 4096 and the batch decoder object, for all three decode kernels (one thread per chain, one
+wavefront per chain with a lane per bit plane, one wavefront per bit plane -- the default since round 4).  See DESIGN.md 6b.
 """
 import hashlib
 import json
@@ -35,7 +35,7 @@ def same(a, b):
     return a[0] == b[0] and a[1:3] == b[1:3] and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
 
 
-@pytest.fixture(params=["0", "1"], ids=["thread-per-chain", "wave-per-chain"])
+@pytest.fixture(params=["0", "1", "2"], ids=["thread-per-chain", "wave-per-chain", "wave-per-plane"])
 def kernel(request):
     """ICER_DEC_WAVE: which decode kernel decoder.hip launches (read per call)"""
     old = os.environ.get("ICER_DEC_WAVE")

@@ -1,8 +1,7 @@
-"""The decoder's hardware-verified path, on by default: the plain-C decode example (tests/c_abi/dropin_decode_example.c) against
-libicer_hip_dec.so, both decode kernels, on the configurations of the decoder's first GPU run (profiles/
-r01_decoder_first_gpu_run.log) -- 16-bit gray frames, lossless streams.  The wider decoder tests (tests/test_gpu_decoder.py:
-YUV, uint8, damaged streams, the batch object) stay opt-in until they have run on hardware too.  The example runs in a
-child process, so a fault in the decoder cannot take the test session with it.
+"""The plain-C decode example (tests/c_abi/dropin_decode_example.c) against libicer_hip_dec.so, every decode kernel, on the
+configurations of the decoder's first GPU run (profiles/r01_decoder_first_gpu_run.log): 16-bit gray frames, lossless streams.
+The example runs in a child process, so a fault in the decoder cannot take the test session with it.  (The wide decoder suite
+-- YUV, uint8, damaged streams, goldens, the batch object -- is tests/test_gpu_decoder.py, also in the default `-m gpu` run.)
 """
 import os
 import subprocess
@@ -28,7 +27,7 @@ def exe(tmp_path_factory):
 
 
 @pytest.mark.parametrize("w,h,stages,segments,seed", [(320, 200, 3, 7, 5), (1024, 1024, 4, 16, 12345)])
-@pytest.mark.parametrize("kernel", ["0", "1"], ids=["thread-per-chain", "wave-per-chain"])
+@pytest.mark.parametrize("kernel", ["0", "1", "2"], ids=["thread-per-chain", "wave-per-chain", "wave-per-plane"])
 def test_decoder_on_the_gpu(exe, tmp_path, w, h, stages, segments, seed, kernel):
     orc = Oracle()
     img = synth.gray_frame(w, h, seed, 1)

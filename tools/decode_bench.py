@@ -38,7 +38,6 @@ def main():
     assert torch.cuda.is_available(), "needs a HIP device"
     dev = torch.device("cuda", 0)
     torch.zeros(1, device=dev)                                   # torch's HIP runtime first (see tests/conftest.py)
-    os.environ.setdefault("ICER_DEC_WAVE", "1")
     img = synth.gray_frame(W, H, 12345, 1)
     rc, stream, _ = api.compress([img], STAGES, FILT, SEGMENTS, 2 * W * H)
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["C2_4096_gray_5st_10seg"]
@@ -68,7 +67,9 @@ def main():
             "value": round(W * H / t1 / 1e6, 2), "ms_per_frame": round(t1 * 1e3, 2), "dtype": "int16", "data": "synthetic",
             "config": {"workload": "stream of BASELINE configs[1] (4096x4096 gray, 5 stages, filter A, 10 segments, lossless, 9 948 227 bytes = "
                                    "reference golden) resident in HBM -> uint16 planes in HBM; icerx_decode_device, whole call incl. the host's packet walk",
-                       "kernel": "one wavefront per chain, one lane per bit plane (decode_chains_wave_kernel)", "parity": bool(ok1 and okb)},
+                       "kernel": {"0": "one thread per chain (decode_chains_kernel)", "1": "one wavefront per chain, one lane per bit plane (decode_chains_wave_kernel)"}.get(
+                           os.environ.get("ICER_DEC_WAVE", ""), "one wavefront per bit plane, wave-uniform decisions (decode_chains_planes_kernel)"),
+                       "parity": bool(ok1 and okb)},
             "roofline": {"bound": "hbm", "achieved": round(alg / t1 / 1e9, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(alg / t1 / 1e9 / HBM_PEAK_GBPS, 7), "algorithmic_bytes_per_frame": alg,
                          "note": "whole call; a chain is a serial adaptive decode (one decision at a time per bit plane), far from bandwidth-bound"}}
