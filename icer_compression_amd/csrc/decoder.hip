@@ -256,6 +256,7 @@ struct icerx_decoder {
     // device buffers, grown on demand and kept
     struct Buf { void *p = nullptr; size_t cap = 0; };
     Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list, err;
+    int n_cus = 256;                   // compute units of the device
     bool planes_lds_raised = false;    // decode_chains_planes_kernel has been granted more than 64 KiB of dynamic LDS
 };
 
@@ -377,8 +378,17 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         // bit plane, anything else / unset = one wavefront per bit plane wherever it applies):
         //   wave-per-plane   chains whose packets all take the fast entropy path (ChainDesc::fast) and whose row ring fits LDS
         //   the rest         the lane-per-plane kernel if ITS ring fits, else one thread per chain
+        // Unset, the choice goes by load: a wave per plane decides ~ 2.2 x faster than a lane per plane (320 against 694 ms for
+        // the 160 chains of the 4096 x 4096 headline stream) but its decisions are scalar instructions, and a compute unit has
+        // ONE scalar unit: once a batch puts more than two chains on every compute unit the lane-per-plane kernel, whose nine
+        // planes share each vector instruction, gets more decisions out of the chip (64 streams per call: 657 against 339
+        // Mpix/s, profiles/r04_logs/r04_b_decode_bench_64.json).  ICER_DEC_WAVE=2 pins the wave-per-plane kernel.
         const char *mode = getenv("ICER_DEC_WAVE");
-        const bool want_planes = !(mode && (mode[0] == '0' || mode[0] == '1')) && d->tables.lut_ok != 0u;
+        size_t n_eligible = 0;
+        for (const ChainDesc &c : chains) n_eligible += c.fast ? 1u : 0u;
+        const bool by_load = !mode || !mode[0];
+        const bool want_planes = !(mode && (mode[0] == '0' || mode[0] == '1')) && d->tables.lut_ok != 0u &&
+                                 (!by_load || n_eligible <= 2u * (size_t)d->n_cus);
         size_t planes_lds = 0;
 #ifdef ICER_HOST_MOCK
         const size_t planes_lds_limit = (size_t)1 << 20;
@@ -548,6 +558,9 @@ int icerx_decoder_create(icerx_decoder **out, int device, int channels, int stag
 #endif
     icerx_decoder *d = new icerx_decoder;
     d->device = device; d->channels = channels; d->stages = stages; d->filt = filt; d->bits = sample_bits; d->segments = segments;
+#ifndef ICER_HOST_MOCK
+    { int cur = 0; hipDeviceProp_t prop; if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceProperties(&prop, cur) == hipSuccess && prop.multiProcessorCount > 0) d->n_cus = prop.multiProcessorCount; }
+#endif
     CoderTables ct;
     build_coder_tables(&ct);
     build_decoder_tables(&d->tables, ct);

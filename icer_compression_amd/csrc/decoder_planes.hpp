@@ -73,14 +73,14 @@ struct PlaneWave {
     // wave-uniform
     uint32_t j, nrun, lsb, w, h, pitch, rows, r, c, done, prev, sign_bit, mask, subband, retired;
     uint64_t win;
-    uint32_t win_bits, words, pay_k, base, stream_len;
+    uint32_t win_bits, words, pay_k, base, stream_len, bin_half;
     const uint8_t *stream;
     uint16_t *seg;                                      // the segment in the channel plane (global memory)
     size_t stride;
     // register files, one entry per lane
     LANEVAR(uint32_t, fst);                             // lane b: bits pending of bin b (int16) | pattern << 16
     LANEVAR(uint32_t, idx);                             // lane b: `words` when bin b's last code word was read
-    LANEVAR(uint32_t, cnt);                             // lane k: context k's zero | total << 16
+    LANEVAR(uint32_t, cnt);                             // lane k: context k's counts and bin (pw_cnt_pack)
     LANEVAR(uint32_t, pay); LANEVAR(uint32_t, pay2);    // payload dwords 64 * chunk + lane of this chunk and the next
     LANEVAR(uint32_t, tg);                              // lane b: DecoderTables::gpk[b]
     LANEVAR(uint32_t, tv0); LANEVAR(uint32_t, tv1);     // DecoderTables::v2vlut as 112 dwords
@@ -97,6 +97,33 @@ struct PlaneWave {
         else for (uint32_t i_ = 0; i_ < 4u; i_++) if (at_ + i_ < p.stream_len) v_ |= (uint32_t)p.stream[at_ + i_] << (8u * i_); \
         LV(DST) = v_;                                                                                      \
     }
+
+// icer_compute_bin (icer_util.c:48-56) of a FOLDED estimate (zero >= total / 2): the number of cut-offs that zero / total
+// reaches, zero * 65536 >= total * cut[k] (cut-offs ascending; products below 2^25).  On the scalar unit a binary search
+// over the 16 cut-offs -- five compares, the cut-offs read from a vector register by lane -- is shorter than
+// pick_bin_plain's division and table look-up.
+ICER_DEV uint32_t pw_bin_search(const PlaneWave &p, uint32_t zero, uint32_t total)
+{
+    const uint32_t a = zero << 16;
+    uint32_t bin = 0;
+    bin += a >= total * READLANE(p.tc, bin + 7u) ? 8u : 0u;
+    bin += a >= total * READLANE(p.tc, bin + 3u) ? 4u : 0u;
+    bin += a >= total * READLANE(p.tc, bin + 1u) ? 2u : 0u;
+    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;
+    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;          // (lane 16 is never reached)
+    return bin;
+}
+// ... and the same from a HINT (the context's bin before its counts moved by one event: the new one is the same or a
+// neighbour nearly always): walk up / down from it -- two failing compares in the usual case.  Exact for any hint.
+ICER_DEV uint32_t pw_bin_from(const PlaneWave &p, uint32_t zero, uint32_t total, uint32_t bin)
+{
+    const uint32_t a = zero << 16;
+    while (bin < 16u && a >= total * READLANE(p.tc, bin)) bin++;
+    while (bin > 0u && a < total * READLANE(p.tc, bin - 1u)) bin--;
+    return bin;
+}
+// a context's word in PlaneWave::cnt: zero | total << 10 | bin of the folded estimate << 20 | folded (inverted) << 25
+ICER_HD uint32_t pw_cnt_pack(uint32_t zero, uint32_t total, uint32_t bin, uint32_t inv) { return zero | (total << 10) | (bin << 20) | (inv << 25); }
 
 ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &c, int planes, int sign_bit, uint16_t *plane,
                       size_t stride, const uint8_t *stream, uint32_t stream_len, const DecoderTables *t)
@@ -117,37 +144,31 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
     FOR_LANES
     {
         LV(p.fst) = 0; LV(p.idx) = 0;
-        LV(p.cnt) = 2u | (4u << 16);                                   // icer_init_context_model_vals, icer_context_modeller.c:607-613
+        LV(p.cnt) = 0;
         LV(p.tg) = lane < kNumBins ? t->gpk[lane] : 0u;
         const uint16_t *v = &t->v2vlut[0][0];
         LV(p.tv0) = (uint32_t)v[2 * lane] | ((uint32_t)v[2 * lane + 1] << 16);
         LV(p.tv1) = lane < 48 ? ((uint32_t)v[128 + 2 * lane] | ((uint32_t)v[128 + 2 * lane + 1] << 16)) : 0u;
         LV(p.tc) = lane < 16 ? t->cut[lane] : 0xFFFFFFFFu;
     }
+    // every context starts at zero = 2 of total = 4 (icer_init_context_model_vals, icer_context_modeller.c:607-613); an
+    // unmodelled decision (category 3) presents 1 of 2
+    const uint32_t first = pw_cnt_pack(2u, 4u, pw_bin_search(p, 2u, 4u), 0u);
+    FOR_LANES { LV(p.cnt) = first; }
+    p.bin_half = pw_bin_search(p, 1u, 2u);
     PW_LOAD_CHUNK(p.pay, 0u)
     PW_LOAD_CHUNK(p.pay2, 1u)
 }
 
-// one bit from the entropy decoder: entropy_decode_fast (decoder_core.hpp) on wave-uniform values
-ICER_DEV uint32_t pw_decode(PlaneWave &p, uint32_t zero, uint32_t total)
+// one bit from the entropy decoder for an event of coder bin `bin` (`inv`: the estimate was folded, the served bit is
+// flipped): entropy_decode_fast (decoder_core.hpp) behind its bin selection, on wave-uniform values
+ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, bool inv)
 {
     DECL_LANE;
     // (loop-carried scalars are re-asserted uniform here: one v_readfirstlane each keeps them -- and every branch on them --
     // on the scalar unit)
     p.words = PW_UNIFORM(p.words); p.win_bits = PW_UNIFORM(p.win_bits); p.pay_k = PW_UNIFORM(p.pay_k);
     p.win = (uint64_t)PW_UNIFORM((uint32_t)p.win) | ((uint64_t)PW_UNIFORM((uint32_t)(p.win >> 32)) << 32);
-    const bool inv = zero < (total >> 1);
-    if (inv) zero = total - zero;
-    // icer_compute_bin (icer_util.c:48-56): the number of cut-offs that zero / total reaches, zero * 65536 >= total * cut[k]
-    // (cut-offs ascending; products below 2^25).  On the scalar unit a binary search over the 16 cut-offs -- five compares,
-    // the cut-offs read from a vector register by lane -- is shorter than pick_bin_plain's division and table look-up.
-    const uint32_t a = zero << 16;
-    uint32_t bin = 0;
-    bin += a >= total * READLANE(p.tc, bin + 7u) ? 8u : 0u;
-    bin += a >= total * READLANE(p.tc, bin + 3u) ? 4u : 0u;
-    bin += a >= total * READLANE(p.tc, bin + 1u) ? 2u : 0u;
-    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;
-    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;          // (lane 16 holds ~0: never reached)
     const uint32_t st = READLANE(p.fst, bin), last_word = READLANE(p.idx, bin);
     int n = (int)(int16_t)(st & 0xFFFFu);
     uint32_t pat = st >> 16;
@@ -191,21 +212,62 @@ ICER_DEV uint32_t pw_decode(PlaneWave &p, uint32_t zero, uint32_t total)
     return inv ? (b ^ 1u) : b;
 }
 
-// counts of context `ctx` through one decision (dec_model_update)
+// one decision of context `ctx`: its bin is kept with its counts (it only moves when they do), the counts go through
+// dec_model_update (QUIRK C5 included) and the bin of the new estimate is found from the old one
 ICER_DEV uint32_t pw_modelled(PlaneWave &p, uint32_t ctx)
 {
     DECL_LANE;
-    const uint32_t zt = READLANE(p.cnt, ctx);
-    uint32_t zero = zt & 0xFFFFu, total = zt >> 16;
-    const uint32_t bit = pw_decode(p, zero, total);
+    const uint32_t w = READLANE(p.cnt, ctx);
+    uint32_t zero = w & 1023u, total = (w >> 10) & 1023u;
+    const uint32_t bit = pw_decode_bin(p, (w >> 20) & 31u, ((w >> 25) & 1u) != 0u);
     total++;
     zero += bit == 0u ? 1u : 0u;
     if (total >= kRescaleCap) {
         total >>= 1;
         if (zero > total) zero >>= 1;
     }
-    PW_WRITELANE(p.cnt, ctx, zero | (total << 16));
+    const uint32_t inv = zero < (total >> 1) ? 1u : 0u;
+    const uint32_t nb = pw_bin_from(p, inv ? total - zero : zero, total, (w >> 20) & 31u);
+    PW_WRITELANE(p.cnt, ctx, pw_cnt_pack(zero, total, nb, inv));
     return bit;
+}
+
+// Runs of zero decisions.  In the upper bit planes most samples are insignificant with insignificant neighbours: context 0,
+// a near-certain zero, served from the pending zeros of a Golomb code word.  `rl` such samples lie ahead (the block's vector
+// pass counted them).  As long as the events stay in one Golomb bin (the estimate only rises with every zero, so it is
+// enough that the LAST event of the run still sees it), that bin has zeros pending (without its last-word rule coming
+// due: no code word is read, so `words` stands still) and the counts stay below the rescale point, t decisions are
+// t zeros and a few additions -- exactly what t calls of pw_modelled(0) would leave.  Returns t (0: does not apply).
+constexpr uint32_t kPwRunMin = 3;
+#ifdef ICER_WAVE_EMU
+static unsigned long long g_pw_run_stats[2];               // tests only: runs taken, decisions they stood for
+#define PW_RUN_STAT(t) (g_pw_run_stats[0]++, g_pw_run_stats[1] += (t))
+#else
+#define PW_RUN_STAT(t)
+#endif
+ICER_DEV uint32_t pw_zero_run(PlaneWave &p, uint32_t rl)
+{
+    DECL_LANE;
+    const uint32_t w = READLANE(p.cnt, 0u);
+    const uint32_t zero = w & 1023u, total = (w >> 10) & 1023u, bin = (w >> 20) & 31u;
+    if (((w >> 25) & 1u) != 0u || bin < 8u) return 0u;              // folded (a served 0 is a one-event), or not a Golomb bin
+    const uint32_t st = READLANE(p.fst, bin);
+    const int n = (int)(int16_t)(st & 0xFFFFu);
+    const uint32_t pat = st >> 16;
+    if (n <= 0 || PW_UNIFORM(p.words) - READLANE(p.idx, bin) >= (uint32_t)kRingWords) return 0u;
+    const uint32_t avail = pat ? (uint32_t)n - 1u : (uint32_t)n;      // zeros above the closing one-bit / a full run of m zeros
+    const uint32_t room = (kRescaleCap - 1u) - total;                 // events before the one that triggers the rescale
+    uint32_t t = rl < avail ? rl : avail;
+    t = t < room ? t : room;
+    if (bin < 16u) {
+        const uint32_t cut = READLANE(p.tc, bin);
+        while (t >= 2u && ((zero + t - 1u) << 16) >= (total + t - 1u) * cut) t >>= 1;
+    }
+    if (t < 2u) return 0u;
+    PW_WRITELANE(p.fst, bin, ((uint32_t)(n - (int)t) & 0xFFFFu) | (pat << 16));
+    PW_WRITELANE(p.cnt, 0u, pw_cnt_pack(zero + t, total + t, pw_bin_from(p, zero + t, total + t, bin), 0u));
+    PW_RUN_STAT(t);
+    return t;
 }
 
 // samples of the plane above that must be finished before this plane takes the block ending at column c_end of row r
@@ -255,7 +317,7 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
     uint16_t *rowC = ring + (size_t)(r % p.rows) * p.pitch;
     const uint16_t *rowD = r + 1u < h ? ring + (size_t)((r + 1u) % p.rows) * p.pitch : zero_row;
     // ---- 64 lanes: what the contexts of the block's samples need from the rows around them
-    LANEVAR(uint32_t, desc); LANEVAR(uint32_t, curv); LANEVAR(uint32_t, outv);
+    LANEVAR(uint32_t, desc); LANEVAR(uint32_t, curv); LANEVAR(uint32_t, outv); LANEVAR(uint32_t, elig);
     const bool is_hl = p.subband == (uint32_t)kHL, is_hh = p.subband == (uint32_t)kHH;
     FOR_LANES
     {
@@ -289,15 +351,34 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
         LV(desc) = (uint32_t)cat | (ctxs[0] << 2) | (ctxs[1] << 6) | (ses[0] << 10) | (ses[1] << 14);
         LV(curv) = cur;
         LV(outv) = 0;
+        LV(elig) = (valid && cat == 0 && ctxs[0] == 0u) ? 1u : 0u;                 // insignificant among insignificant neighbours
+    }
+    // (bits 18..24 of a sample's descriptor: how many such samples lie ahead from it on, itself included -- pw_zero_run)
+    const uint64_t E = BALLOT(LV(elig) != 0u);
+    FOR_LANES
+    {
+        const uint64_t rest = ~(E >> lane);
+        LV(desc) |= (uint32_t)(rest ? ffs64(rest) : 64 - lane) << 18;
     }
     // ---- the wave's scalar side: the block's decisions one after the other
     uint32_t prev = c0 == 0u ? 0u : p.prev;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t de = READLANE(desc, i), cur = READLANE(curv, i);
+    for (uint32_t i = 0; i < n;) {
+        const uint32_t de = READLANE(desc, i);
         const uint32_t cat = de & 3u;
         const uint32_t leftsig = ((prev & mask) >> lsb) != 0u ? 1u : 0u, leftneg = leftsig & (prev >> sb) & 1u;
+        const uint32_t rl = (de >> 18) & 127u;
+        if (rl >= kPwRunMin && leftsig == 0u) {
+            const uint32_t t = pw_zero_run(p, rl);
+            if (t) {                                                               // samples i .. i + t - 1 decode a zero: their words stay
+                FOR_LANES { if ((uint32_t)lane >= i && (uint32_t)lane < i + t) LV(outv) = LV(curv); }
+                prev = READLANE(curv, i + t - 1u);
+                i += t;
+                continue;
+            }
+        }
+        const uint32_t cur = READLANE(curv, i);
         uint32_t val;
-        if (cat == 3u) val = cur | (pw_decode(p, 1u, 2u) << lsb);                  // unmodelled (C2)
+        if (cat == 3u) val = cur | (pw_decode_bin(p, p.bin_half, false) << lsb);   // unmodelled: 1 of 2 (C2)
         else {
             const uint32_t ctx = (de >> (leftsig ? 6u : 2u)) & 15u;
             const uint32_t bit = pw_modelled(p, ctx);
@@ -311,6 +392,7 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
         }
         PW_WRITELANE(outv, i, val);
         prev = PW_UNIFORM(val);
+        i++;
     }
     p.prev = prev;
     FOR_LANES
@@ -373,7 +455,8 @@ ICER_DEV bool pw_run_chain(uint8_t *lds, uint32_t wave, const ChainDesc &c, int 
         const int st = pw_step(p, sh, zero_row, ring);
         if (st == 2) return true;
         if (st == 1) { spins = 0; continue; }
-        __builtin_amdgcn_s_sleep(2);
+        // (a waiting wave must not eat the compute unit's one scalar unit: the longer it has waited, the longer it sleeps)
+        if (spins < 8u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
         if (++spins > kPwSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;

@@ -113,6 +113,8 @@ extern "C" int emu_decoder_lut_ok(void)
     return (int)dt.lut_ok;
 }
 extern "C" void emu_decoder_stats(unsigned long long *out) { for (int i = 0; i < 4; i++) out[i] = g_stats[i]; }
+// the wave-per-plane kernel's zero runs since the process started: [runs taken, decisions they stood for]
+extern "C" void emu_decoder_run_stats(unsigned long long *out) { out[0] = icer::g_pw_run_stats[0]; out[1] = icer::g_pw_run_stats[1]; }
 
 // planes[c]: >= bufsize uint16 words; for sample_bits = 8 the low byte of each word is the uint8 result.
 extern "C" int emu_decompress(uint16_t *const planes[], int channels, size_t *w, size_t *h, size_t bufsize,

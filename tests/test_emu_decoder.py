@@ -221,6 +221,9 @@ def test_wave_per_plane_kernel_schedules_and_shapes(emu, orc):
                 assert same(emu(stream, ch, st, 0, sg, bits=bits), want), (seed, len(stream), ch, st, sg, bits)
             emu.lib.emu_decoder_stats(stats)
             assert stats[0] > 0 and stats[3] == 0, (seed, list(stats))        # the new kernel ran, and never locked up
+        runs = (C.c_ulonglong * 2)()
+        emu.lib.emu_decoder_run_stats(runs)
+        assert runs[0] > 100 and runs[1] > 5 * runs[0], list(runs)            # ... and took its zero-run shortcut (pw_zero_run)
     finally:
         emu.lib.emu_decoder_order_seed(0)
         emu.lib.emu_decoder_mode(0)
