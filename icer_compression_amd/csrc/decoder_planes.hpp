@@ -28,7 +28,7 @@
 #include "decoder_core.hpp"
 
 #ifdef ICER_WAVE_EMU
-#define PW_WRITELANE(X, L, V) ((X)[(L)] = (V))
+#define PW_WRITELANE(X, L, V) { (X)[(L)] = (V); }
 #define PW_UNIFORM(x) (x)
 #define PW_RCP(x) (1.0f / (x))
 #define PW_LDS_LOAD(x) (x)
@@ -38,7 +38,9 @@
 #else
 // (this compiler has no v_writelane builtin: a compare of the lane number with the scalar index and a select -- two vector
 // instructions, no inline-assembly hazards to mind)
-#define PW_WRITELANE(X, L, V) ((X) = ((uint32_t)lane == (uint32_t)(L)) ? (uint32_t)(V) : (X))
+// The value goes through v_readfirstlane first: a convergent operation, so the compiler cannot sink the (scalar) computation
+// of V into a block that only the one lane enters -- a per-lane branch around scalar code, see PW_LOAD_CHUNK.
+#define PW_WRITELANE(X, L, V) { const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(V)); (X) = ((uint32_t)lane == (uint32_t)(L)) ? wv_ : (X); }
 #define PW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define PW_RCP(x) __builtin_amdgcn_rcpf(x)
 #define PW_LDS_LOAD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -87,15 +89,18 @@ struct PlaneWave {
     LANEVAR(uint32_t, tc);                              // lane k < 16: DecoderTables::cut[k]; the lanes above: 0xFFFFFFFF
 };
 
-// payload dwords 64 * chunk + lane (bytes behind the stream read as zero, like entropy_byte)
+// payload dwords 64 * chunk + lane (bytes behind the stream read as zero, like entropy_byte): one unconditional load from
+// a clamped address and a shift -- NO per-lane branch (stream_len >= 4: a chain of this kernel has packets).
+// (Per-lane branches are kept out of this file's scalar paths altogether: where such a branch re-joins, the compiler's
+// uniformity analysis gives up on every value that merges there, and the decoder's state would leave the scalar unit.)
 #define PW_LOAD_CHUNK(DST, CHUNK)                                                                          \
     FOR_LANES                                                                                              \
     {                                                                                                      \
-        const uint32_t at_ = p.base + 4u * ((CHUNK) * 64u + (uint32_t)lane);                               \
-        uint32_t v_ = 0;                                                                                   \
-        if (at_ + 4u <= p.stream_len) memcpy(&v_, p.stream + at_, 4);                                      \
-        else for (uint32_t i_ = 0; i_ < 4u; i_++) if (at_ + i_ < p.stream_len) v_ |= (uint32_t)p.stream[at_ + i_] << (8u * i_); \
-        LV(DST) = v_;                                                                                      \
+        const uint32_t at_ = p.base + 4u * ((CHUNK) * 64u + (uint32_t)lane), last_ = p.stream_len - 4u;    \
+        const uint32_t from_ = at_ < last_ ? at_ : last_, skip_ = at_ < last_ ? 0u : at_ - last_;          \
+        uint32_t v_;                                                                                       \
+        memcpy(&v_, p.stream + from_, 4);                                                                  \
+        LV(DST) = skip_ >= 4u ? 0u : v_ >> (8u * skip_);                                                   \
     }
 
 // icer_compute_bin (icer_util.c:48-56) of a FOLDED estimate (zero >= total / 2): the number of cut-offs that zero / total
@@ -145,11 +150,13 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
     {
         LV(p.fst) = 0; LV(p.idx) = 0;
         LV(p.cnt) = 0;
-        LV(p.tg) = lane < kNumBins ? t->gpk[lane] : 0u;
+        LV(p.tg) = t->gpk[lane < kNumBins ? lane : 0];                 // (clamped indices, not guarded loads: no per-lane branch)
         const uint16_t *v = &t->v2vlut[0][0];
+        const int l1 = lane < 48 ? lane : 0;
         LV(p.tv0) = (uint32_t)v[2 * lane] | ((uint32_t)v[2 * lane + 1] << 16);
-        LV(p.tv1) = lane < 48 ? ((uint32_t)v[128 + 2 * lane] | ((uint32_t)v[128 + 2 * lane + 1] << 16)) : 0u;
-        LV(p.tc) = lane < 16 ? t->cut[lane] : 0xFFFFFFFFu;
+        LV(p.tv1) = (uint32_t)v[128 + 2 * l1] | ((uint32_t)v[128 + 2 * l1 + 1] << 16);
+        const uint32_t cutv = t->cut[lane < 16 ? lane : 0];
+        LV(p.tc) = lane < 16 ? cutv : 0xFFFFFFFFu;
     }
     // every context starts at zero = 2 of total = 4 (icer_init_context_model_vals, icer_context_modeller.c:607-613); an
     // unmodelled decision (category 3) presents 1 of 2
@@ -212,26 +219,6 @@ ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, bool inv)
     return inv ? (b ^ 1u) : b;
 }
 
-// one decision of context `ctx`: its bin is kept with its counts (it only moves when they do), the counts go through
-// dec_model_update (QUIRK C5 included) and the bin of the new estimate is found from the old one
-ICER_DEV uint32_t pw_modelled(PlaneWave &p, uint32_t ctx)
-{
-    DECL_LANE;
-    const uint32_t w = READLANE(p.cnt, ctx);
-    uint32_t zero = w & 1023u, total = (w >> 10) & 1023u;
-    const uint32_t bit = pw_decode_bin(p, (w >> 20) & 31u, ((w >> 25) & 1u) != 0u);
-    total++;
-    zero += bit == 0u ? 1u : 0u;
-    if (total >= kRescaleCap) {
-        total >>= 1;
-        if (zero > total) zero >>= 1;
-    }
-    const uint32_t inv = zero < (total >> 1) ? 1u : 0u;
-    const uint32_t nb = pw_bin_from(p, inv ? total - zero : zero, total, (w >> 20) & 31u);
-    PW_WRITELANE(p.cnt, ctx, pw_cnt_pack(zero, total, nb, inv));
-    return bit;
-}
-
 // Runs of zero decisions.  In the upper bit planes most samples are insignificant with insignificant neighbours: context 0,
 // a near-certain zero, served from the pending zeros of a Golomb code word.  `rl` such samples lie ahead (the block's vector
 // pass counted them).  As long as the events stay in one Golomb bin (the estimate only rises with every zero, so it is
@@ -283,15 +270,27 @@ ICER_DEV void pw_retire(PlaneWave &p, PwShared &s, uint16_t *ring, uint32_t upto
     DECL_LANE;
     while (p.retired < upto) {
         uint16_t *slot = ring + (size_t)(p.retired % p.rows) * p.pitch + 1u;
-        FOR_LANES
-        {
-            for (uint32_t x = (uint32_t)lane; x < p.w; x += 64u) { p.seg[(size_t)p.retired * p.stride + x] = slot[x]; slot[x] = 0; }
+        for (uint32_t x0 = 0; x0 < p.w; x0 += 64u) {
+            FOR_LANES
+            {
+                // (lanes past the row's end repeat its last sample: same value to the same address, and no per-lane branch)
+                const uint32_t x = x0 + (uint32_t)lane < p.w ? x0 + (uint32_t)lane : p.w - 1u;
+                p.seg[(size_t)p.retired * p.stride + x] = slot[x];
+            }
+        }
+        WAVE_SYNC();
+        for (uint32_t x0 = 0; x0 < p.w; x0 += 64u) {
+            FOR_LANES
+            {
+                const uint32_t x = x0 + (uint32_t)lane < p.w ? x0 + (uint32_t)lane : p.w - 1u;
+                slot[x] = 0;
+            }
         }
         p.retired++;
     }
     WAVE_SYNC();
     PW_FENCE_REL();
-    FOR_LANES { if (lane == 0) PW_LDS_STORE(s.retired, p.retired); }
+    FOR_LANES { PW_LDS_STORE(s.retired, p.retired); }          // (every lane: the same word, the same value)
 }
 
 // One step of a plane's wave: the next block of up to 64 samples of its row, if the plane above and the ring allow it.
@@ -361,34 +360,52 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
         LV(desc) |= (uint32_t)(rest ? ffs64(rest) : 64 - lane) << 18;
     }
     // ---- the wave's scalar side: the block's decisions one after the other
+    // (one decision per trip and ONE copy of the entropy decoder in the loop: a sample's magnitude bit, then -- when that made
+    // it significant -- its sign in the next trip; the kernel's code stays small and the decision chain short)
     uint32_t prev = c0 == 0u ? 0u : p.prev;
+    uint32_t val = 0, se = 0;
+    bool sign_next = false;
     for (uint32_t i = 0; i < n;) {
-        const uint32_t de = READLANE(desc, i);
-        const uint32_t cat = de & 3u;
-        const uint32_t leftsig = ((prev & mask) >> lsb) != 0u ? 1u : 0u, leftneg = leftsig & (prev >> sb) & 1u;
-        const uint32_t rl = (de >> 18) & 127u;
-        if (rl >= kPwRunMin && leftsig == 0u) {
-            const uint32_t t = pw_zero_run(p, rl);
-            if (t) {                                                               // samples i .. i + t - 1 decode a zero: their words stay
-                FOR_LANES { if ((uint32_t)lane >= i && (uint32_t)lane < i + t) LV(outv) = LV(curv); }
-                prev = READLANE(curv, i + t - 1u);
-                i += t;
-                continue;
+        uint32_t w, ctx = 0;
+        bool modelled = true;
+        if (!sign_next) {
+            const uint32_t de = READLANE(desc, i);
+            const uint32_t cat = de & 3u;
+            const uint32_t leftsig = ((prev & mask) >> lsb) != 0u ? 1u : 0u, leftneg = leftsig & (prev >> sb) & 1u;
+            const uint32_t rl = (de >> 18) & 127u;
+            if (rl >= kPwRunMin && leftsig == 0u) {
+                const uint32_t t = pw_zero_run(p, rl);
+                if (t) {                                                           // samples i .. i + t - 1 decode a zero: their words stay
+                    FOR_LANES { if ((uint32_t)lane >= i && (uint32_t)lane < i + t) LV(outv) = LV(curv); }
+                    prev = READLANE(curv, i + t - 1u);
+                    i += t;
+                    continue;
+                }
             }
+            val = READLANE(curv, i);
+            modelled = cat != 3u;                                                  // category 3: unmodelled, 1 of 2 (C2)
+            ctx = (de >> (leftsig ? 6u : 2u)) & 15u;
+            // (the sign's context, should the sample become significant: QUIRK C6, only negative significant neighbours count)
+            se = (cat == 0u ? 0x10u : 0u) | ((de >> (leftneg ? 14u : 10u)) & 15u);
+        } else ctx = 12u + (se & 7u);
+        w = modelled ? READLANE(p.cnt, ctx) : pw_cnt_pack(1u, 2u, p.bin_half, 0u);
+        const uint32_t bit = pw_decode_bin(p, (w >> 20) & 31u, ((w >> 25) & 1u) != 0u);
+        if (modelled) {                                                            // dec_model_update, and the bin of the new estimate
+            uint32_t zero = w & 1023u, total = ((w >> 10) & 1023u) + 1u;
+            zero += bit == 0u ? 1u : 0u;
+            if (total >= kRescaleCap) {
+                total >>= 1;
+                if (zero > total) zero >>= 1;
+            }
+            const uint32_t inv = zero < (total >> 1) ? 1u : 0u;
+            PW_WRITELANE(p.cnt, ctx, pw_cnt_pack(zero, total, pw_bin_from(p, inv ? total - zero : zero, total, (w >> 20) & 31u), inv));
         }
-        const uint32_t cur = READLANE(curv, i);
-        uint32_t val;
-        if (cat == 3u) val = cur | (pw_decode_bin(p, p.bin_half, false) << lsb);   // unmodelled: 1 of 2 (C2)
-        else {
-            const uint32_t ctx = (de >> (leftsig ? 6u : 2u)) & 15u;
-            const uint32_t bit = pw_modelled(p, ctx);
-            val = cur | (bit << lsb);
-            if (cat == 0u && bit != 0u) {
-                // the sample became significant: its sign (QUIRK C6: only negative significant neighbours count)
-                const uint32_t se = (de >> (leftneg ? 14u : 10u)) & 15u;
-                const uint32_t agree = pw_modelled(p, 12u + (se & 7u));
-                val |= ((agree ^ (se >> 3)) & 1u) << sb;
-            }
+        if (!sign_next) {
+            val |= bit << lsb;
+            if ((se & 0x10u) != 0u && bit != 0u) { sign_next = true; continue; }
+        } else {
+            val |= ((bit ^ (se >> 3)) & 1u) << sb;
+            sign_next = false;
         }
         PW_WRITELANE(outv, i, val);
         prev = PW_UNIFORM(val);
@@ -397,14 +414,16 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
     p.prev = prev;
     FOR_LANES
     {
-        if ((uint32_t)lane < n) rowC[c0 + (uint32_t)lane + 1u] = (uint16_t)LV(outv);
+        // (lanes past the block write a zero into the row's right guard column, which holds one anyway)
+        const bool valid = (uint32_t)lane < n;
+        rowC[valid ? c0 + (uint32_t)lane + 1u : w + 1u] = valid ? (uint16_t)LV(outv) : (uint16_t)0;
     }
     p.done += n;
     const bool row_end = c_end + 1u >= w;
     if (row_end) { p.r = r + 1u; p.c = 0; } else p.c = c0 + n;
     WAVE_SYNC();
     PW_FENCE_REL();
-    FOR_LANES { if (lane == 0) PW_LDS_STORE(s.done[p.j], p.done); }
+    FOR_LANES { PW_LDS_STORE(s.done[p.j], p.done); }           // (every lane: the same word, the same value)
     // the lowest running plane is the last one to look at a row: after its row r, row r - 1 is dead
     if (row_end && p.j + 1u == p.nrun) pw_retire(p, s, ring, p.r >= h ? h : (p.r >= 2u ? p.r - 1u : 0u));
     return p.r >= h ? 2 : 1;
@@ -450,18 +469,21 @@ ICER_DEV bool pw_run_chain(uint8_t *lds, uint32_t wave, const ChainDesc &c, int 
     if (wave >= nrun) return true;
     PlaneWave p;
     pw_init(p, wave, nrun, c, planes, sign_bit, plane, stride, stream, stream_len, t);
+    // (the loop must leave by wave-UNIFORM conditions only -- the lane-0 store of the error word comes after it: a per-lane
+    // branch inside the loop would make every value the loop carries, i.e. the whole decoder state, divergent for the compiler)
     uint32_t spins = 0;
+    bool ok = true;
     for (;;) {
         const int st = pw_step(p, sh, zero_row, ring);
-        if (st == 2) return true;
+        if (st == 2) break;
         if (st == 1) { spins = 0; continue; }
         // (a waiting wave must not eat the compute unit's one scalar unit: the longer it has waited, the longer it sleeps)
         if (spins < 8u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
-        if (++spins > kPwSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-            if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
+        spins++;
+        if (spins > kPwSpinLimit || ((spins & 255u) == 0u && PW_UNIFORM(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)) { ok = false; break; }
     }
+    if (!ok && (threadIdx.x & 63u) == 0u) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
 }
 #endif
 
