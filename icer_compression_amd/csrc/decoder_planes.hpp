@@ -38,9 +38,7 @@
 #else
 // (this compiler has no v_writelane builtin: a compare of the lane number with the scalar index and a select -- two vector
 // instructions, no inline-assembly hazards to mind)
-// The value goes through v_readfirstlane first: a convergent operation, so the compiler cannot sink the (scalar) computation
-// of V into a block that only the one lane enters -- a per-lane branch around scalar code, see PW_LOAD_CHUNK.
-#define PW_WRITELANE(X, L, V) { const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(V)); (X) = ((uint32_t)lane == (uint32_t)(L)) ? wv_ : (X); }
+#define PW_WRITELANE(X, L, V) { (X) = ((uint32_t)lane == (uint32_t)(L)) ? (uint32_t)(V) : (X); }
 #define PW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define PW_RCP(x) __builtin_amdgcn_rcpf(x)
 #define PW_LDS_LOAD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -82,7 +80,7 @@ struct PlaneWave {
     // register files, one entry per lane
     LANEVAR(uint32_t, fst);                             // lane b: bits pending of bin b (int16) | pattern << 16
     LANEVAR(uint32_t, idx);                             // lane b: `words` when bin b's last code word was read
-    LANEVAR(uint32_t, cnt);                             // lane k: context k's counts and bin (pw_cnt_pack)
+    LANEVAR(uint32_t, cnt);                             // lane k: context k's zero | total << 16
     LANEVAR(uint32_t, pay); LANEVAR(uint32_t, pay2);    // payload dwords 64 * chunk + lane of this chunk and the next
     LANEVAR(uint32_t, tg);                              // lane b: DecoderTables::gpk[b]
     LANEVAR(uint32_t, tv0); LANEVAR(uint32_t, tv1);     // DecoderTables::v2vlut as 112 dwords
@@ -104,31 +102,12 @@ struct PlaneWave {
     }
 
 // icer_compute_bin (icer_util.c:48-56) of a FOLDED estimate (zero >= total / 2): the number of cut-offs that zero / total
-// reaches, zero * 65536 >= total * cut[k] (cut-offs ascending; products below 2^25).  On the scalar unit a binary search
-// over the 16 cut-offs -- five compares, the cut-offs read from a vector register by lane -- is shorter than
-// pick_bin_plain's division and table look-up.
-ICER_DEV uint32_t pw_bin_search(const PlaneWave &p, uint32_t zero, uint32_t total)
-{
-    const uint32_t a = zero << 16;
-    uint32_t bin = 0;
-    bin += a >= total * READLANE(p.tc, bin + 7u) ? 8u : 0u;
-    bin += a >= total * READLANE(p.tc, bin + 3u) ? 4u : 0u;
-    bin += a >= total * READLANE(p.tc, bin + 1u) ? 2u : 0u;
-    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;
-    bin += a >= total * READLANE(p.tc, bin) ? 1u : 0u;          // (lane 16 is never reached)
-    return bin;
-}
-// ... and the same from a HINT (the context's bin before its counts moved by one event: the new one is the same or a
-// neighbour nearly always): walk up / down from it -- two failing compares in the usual case.  Exact for any hint.
-ICER_DEV uint32_t pw_bin_from(const PlaneWave &p, uint32_t zero, uint32_t total, uint32_t bin)
-{
-    const uint32_t a = zero << 16;
-    while (bin < 16u && a >= total * READLANE(p.tc, bin)) bin++;
-    while (bin > 0u && a < total * READLANE(p.tc, bin - 1u)) bin--;
-    return bin;
-}
-// a context's word in PlaneWave::cnt: zero | total << 10 | bin of the folded estimate << 20 | folded (inverted) << 25
-ICER_HD uint32_t pw_cnt_pack(uint32_t zero, uint32_t total, uint32_t bin, uint32_t inv) { return zero | (total << 10) | (bin << 20) | (inv << 25); }
+// reaches, zero * 65536 >= total * cut[k] (cut-offs ascending; products below 2^25).  Lane k holds cut-off k, so all sixteen
+// comparisons are ONE vector multiply and compare, and the bin is the population count of the ballot: four instructions,
+// no branch, no table in memory (pick_bin_plain's division + look-up is the per-lane form of the same thing).
+// (Lanes 16 and up hold 0xFFFFFFFF: total * that wraps to 2^32 - total, far above any zero << 16 <= 2^25 -- they never
+// count, without a per-lane guard.)
+#define PW_BIN(FZ, TOTAL) ((uint32_t)popc64(BALLOT((((FZ) << 16) >= (TOTAL) * LV(p.tc)))))
 
 ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &c, int planes, int sign_bit, uint16_t *plane,
                       size_t stride, const uint8_t *stream, uint32_t stream_len, const DecoderTables *t)
@@ -160,9 +139,8 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
     }
     // every context starts at zero = 2 of total = 4 (icer_init_context_model_vals, icer_context_modeller.c:607-613); an
     // unmodelled decision (category 3) presents 1 of 2
-    const uint32_t first = pw_cnt_pack(2u, 4u, pw_bin_search(p, 2u, 4u), 0u);
-    FOR_LANES { LV(p.cnt) = first; }
-    p.bin_half = pw_bin_search(p, 1u, 2u);
+    FOR_LANES { LV(p.cnt) = 2u | (4u << 16); }
+    p.bin_half = PW_BIN(1u, 2u);
     PW_LOAD_CHUNK(p.pay, 0u)
     PW_LOAD_CHUNK(p.pay2, 1u)
 }
@@ -172,10 +150,6 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
 ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, bool inv)
 {
     DECL_LANE;
-    // (loop-carried scalars are re-asserted uniform here: one v_readfirstlane each keeps them -- and every branch on them --
-    // on the scalar unit)
-    p.words = PW_UNIFORM(p.words); p.win_bits = PW_UNIFORM(p.win_bits); p.pay_k = PW_UNIFORM(p.pay_k);
-    p.win = (uint64_t)PW_UNIFORM((uint32_t)p.win) | ((uint64_t)PW_UNIFORM((uint32_t)(p.win >> 32)) << 32);
     const uint32_t st = READLANE(p.fst, bin), last_word = READLANE(p.idx, bin);
     int n = (int)(int16_t)(st & 0xFFFFu);
     uint32_t pat = st >> 16;
@@ -224,7 +198,7 @@ ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, bool inv)
 // pass counted them).  As long as the events stay in one Golomb bin (the estimate only rises with every zero, so it is
 // enough that the LAST event of the run still sees it), that bin has zeros pending (without its last-word rule coming
 // due: no code word is read, so `words` stands still) and the counts stay below the rescale point, t decisions are
-// t zeros and a few additions -- exactly what t calls of pw_modelled(0) would leave.  Returns t (0: does not apply).
+// t zeros and a few additions -- exactly what t single decisions of context 0 would leave.  Returns t (0: does not apply).
 constexpr uint32_t kPwRunMin = 3;
 #ifdef ICER_WAVE_EMU
 static unsigned long long g_pw_run_stats[2];               // tests only: runs taken, decisions they stood for
@@ -236,12 +210,14 @@ ICER_DEV uint32_t pw_zero_run(PlaneWave &p, uint32_t rl)
 {
     DECL_LANE;
     const uint32_t w = READLANE(p.cnt, 0u);
-    const uint32_t zero = w & 1023u, total = (w >> 10) & 1023u, bin = (w >> 20) & 31u;
-    if (((w >> 25) & 1u) != 0u || bin < 8u) return 0u;              // folded (a served 0 is a one-event), or not a Golomb bin
+    const uint32_t zero = w & 0xFFFFu, total = w >> 16;
+    if (zero < (total >> 1)) return 0u;                                // folded: a served 0 is a one-event
+    const uint32_t bin = PW_BIN(zero, total);
+    if (bin < 8u) return 0u;                                           // not a Golomb bin
     const uint32_t st = READLANE(p.fst, bin);
     const int n = (int)(int16_t)(st & 0xFFFFu);
     const uint32_t pat = st >> 16;
-    if (n <= 0 || PW_UNIFORM(p.words) - READLANE(p.idx, bin) >= (uint32_t)kRingWords) return 0u;
+    if (n <= 0 || p.words - READLANE(p.idx, bin) >= (uint32_t)kRingWords) return 0u;
     const uint32_t avail = pat ? (uint32_t)n - 1u : (uint32_t)n;      // zeros above the closing one-bit / a full run of m zeros
     const uint32_t room = (kRescaleCap - 1u) - total;                 // events before the one that triggers the rescale
     uint32_t t = rl < avail ? rl : avail;
@@ -252,7 +228,7 @@ ICER_DEV uint32_t pw_zero_run(PlaneWave &p, uint32_t rl)
     }
     if (t < 2u) return 0u;
     PW_WRITELANE(p.fst, bin, ((uint32_t)(n - (int)t) & 0xFFFFu) | (pat << 16));
-    PW_WRITELANE(p.cnt, 0u, pw_cnt_pack(zero + t, total + t, pw_bin_from(p, zero + t, total + t, bin), 0u));
+    PW_WRITELANE(p.cnt, 0u, (zero + t) | ((total + t) << 16));
     PW_RUN_STAT(t);
     return t;
 }
@@ -388,18 +364,20 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
             // (the sign's context, should the sample become significant: QUIRK C6, only negative significant neighbours count)
             se = (cat == 0u ? 0x10u : 0u) | ((de >> (leftneg ? 14u : 10u)) & 15u);
         } else ctx = 12u + (se & 7u);
-        w = modelled ? READLANE(p.cnt, ctx) : pw_cnt_pack(1u, 2u, p.bin_half, 0u);
-        const uint32_t bit = pw_decode_bin(p, (w >> 20) & 31u, ((w >> 25) & 1u) != 0u);
-        if (modelled) {                                                            // dec_model_update, and the bin of the new estimate
-            uint32_t zero = w & 1023u, total = ((w >> 10) & 1023u) + 1u;
-            zero += bit == 0u ? 1u : 0u;
-            if (total >= kRescaleCap) {
-                total >>= 1;
-                if (zero > total) zero >>= 1;
-            }
-            const uint32_t inv = zero < (total >> 1) ? 1u : 0u;
-            PW_WRITELANE(p.cnt, ctx, pw_cnt_pack(zero, total, pw_bin_from(p, inv ? total - zero : zero, total, (w >> 20) & 31u), inv));
-        }
+        // the estimate folded to >= 1/2, its bin, one bit from that bin's code words, the counts through dec_model_update
+        // (QUIRK C5 included) -- selects, no branches
+        w = READLANE(p.cnt, ctx);
+        uint32_t zero = w & 0xFFFFu, total = w >> 16;
+        const bool inv = modelled && zero < (total >> 1);
+        const uint32_t fz = inv ? total - zero : zero;
+        const uint32_t bin = modelled ? PW_BIN(fz, total) : p.bin_half;
+        const uint32_t bit = pw_decode_bin(p, bin, inv);
+        total++;
+        zero += bit == 0u ? 1u : 0u;
+        const bool resc = total >= kRescaleCap;
+        total = resc ? total >> 1 : total;
+        zero = (resc && zero > total) ? zero >> 1 : zero;
+        PW_WRITELANE(p.cnt, modelled ? ctx : 63u, zero | (total << 16));           // (lane 63: no context lives there)
         if (!sign_next) {
             val |= bit << lsb;
             if ((se & 0x10u) != 0u && bit != 0u) { sign_next = true; continue; }
