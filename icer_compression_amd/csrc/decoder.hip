@@ -378,17 +378,18 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         // bit plane, anything else / unset = one wavefront per bit plane wherever it applies):
         //   wave-per-plane   chains whose packets all take the fast entropy path (ChainDesc::fast) and whose row ring fits LDS
         //   the rest         the lane-per-plane kernel if ITS ring fits, else one thread per chain
-        // Unset, the choice goes by load: a wave per plane decides ~ 2.2 x faster than a lane per plane (320 against 694 ms for
-        // the 160 chains of the 4096 x 4096 headline stream) but its decisions are scalar instructions, and a compute unit has
-        // ONE scalar unit: once a batch puts more than two chains on every compute unit the lane-per-plane kernel, whose nine
-        // planes share each vector instruction, gets more decisions out of the chip (64 streams per call: 657 against 339
-        // Mpix/s, profiles/r04_logs/r04_b_decode_bench_64.json).  ICER_DEC_WAVE=2 pins the wave-per-plane kernel.
+        // Unset, the choice goes by load.  A wave per plane is the faster DECISION (303 against 628 ms for the 160 chains of
+        // the 4096 x 4096 headline stream) and a compute unit holds three such chains (27 wavefronts) without slowing any of
+        // them; beyond that chains queue up, while the lane-per-plane kernel keeps seven chains per compute unit going, each
+        // slowly.  Measured on the headline stream (profiles/r04_logs/r04_d_decode_*.json, r04_c_*.json): 4 streams per call
+        // 216 against 107 Mpix/s, 8 streams 270 against ~190, 16 streams 280 against 374 -- the cross-over lies near six chains
+        // per compute unit.  ICER_DEC_WAVE=2 pins the wave-per-plane kernel.
         const char *mode = getenv("ICER_DEC_WAVE");
         size_t n_eligible = 0;
         for (const ChainDesc &c : chains) n_eligible += c.fast ? 1u : 0u;
         const bool by_load = !mode || !mode[0];
         const bool want_planes = !(mode && (mode[0] == '0' || mode[0] == '1')) && d->tables.lut_ok != 0u &&
-                                 (!by_load || n_eligible <= 2u * (size_t)d->n_cus);
+                                 (!by_load || n_eligible <= 6u * (size_t)d->n_cus);
         size_t planes_lds = 0;
 #ifdef ICER_HOST_MOCK
         const size_t planes_lds_limit = (size_t)1 << 20;
