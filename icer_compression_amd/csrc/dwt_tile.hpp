@@ -233,4 +233,107 @@ DWT_HD bool dwt_tile_cols_step2(DwtTileShared &sh, const DwtStageArgs &a, int tx
     return ovf;
 }
 
+// ------------------------------------------------------------------------------------------ interior tiles
+// A tile whose whole input window lies inside the region and none of whose pairs sits at a line end -- nine tenths of the
+// tiles of a large stage -- needs none of the generic phases' bounds tests, clamps and boundary rules, and its phases map
+// threads to (row, pair) by shifts: 256 threads = 4 rows x 64 pairs per step.  Lows and differences travel as ONE 32-bit
+// LDS word per pair (low | difference << 16), so row step 2 reads four words where the generic phase reads six halves, and
+// row step 1 is done on the loaded words themselves: the input window never goes to LDS.  Same arithmetic, same results
+// (tests/test_emu_pipeline.py runs both paths against the oracle).
+struct DwtFastShared {
+    uint32_t rw[kWinH][kWinPX];           // row step 1: low | dif << 16 of every pair of every window row
+    uint32_t rr[kWinH][kTileKX];          // row pass: low | high << 16 of the tile's pair columns, per window row
+    uint32_t cl[kWinPY][kTileKX];         // column step 1 down the low columns: low | dif << 16
+    uint32_t chh[kWinPY][kTileKX];        // ... and down the high columns
+};
+
+DWT_HD bool dwt_tile_is_interior(const DwtStageArgs &a, int tx, int ty)
+{
+    const int x0 = tile_x0(tx), y0 = tile_y0(ty);
+    // (window inside the region; then every pair k of the tile has 2 <= k, k + 1 < n / 2 - 1 + 1, i.e. only the general rule applies)
+    return x0 >= 0 && y0 >= 0 && x0 + kWinW <= a.cw && y0 + kWinH <= a.ch && (a.src_stride & 1u) == 0u &&
+           (reinterpret_cast<uintptr_t>(a.src) & 3u) == 0u;
+}
+DWT_HD uint32_t dwt_pack(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+DWT_HD int32_t dwt_lo16(uint32_t w) { return (int32_t)(int16_t)(w & 0xFFFFu); }
+DWT_HD int32_t dwt_hi16(uint32_t w) { return (int32_t)(int16_t)(w >> 16); }
+// pair (a, b) -> low | dif << 16, overflow flag as dwt_pair_step1
+DWT_HD uint32_t dwt_fast_step1(int32_t a, int32_t b, int32_t lim, bool *ovf)
+{
+    const int32_t v = (a + b) >> 1, d = a - b;
+    *ovf |= v < -lim - 1 || v > lim || d < -lim - 1 || d > lim;
+    return dwt_pack(v, d);
+}
+// the general rule of dwt_pair_step2 from the four words around pair k: w0..w3 = pairs k - 2 .. k + 1
+DWT_HD int32_t dwt_fast_step2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const FilterTaps &f, int32_t lim, bool *ovf)
+{
+    const int32_t l0 = dwt_lo16(w0), l1 = dwt_lo16(w1), l2 = dwt_lo16(w2), l3 = dwt_lo16(w3);
+    const int32_t r_km1 = (int16_t)(l0 - l1), r_k = (int16_t)(l1 - l2), r_kp1 = (int16_t)(l2 - l3);
+    const int32_t sub = (f.am1 * r_km1 + f.a0 * r_k + f.a1 * r_kp1 - f.be * dwt_hi16(w3) + 8) >> 4;
+    const int32_t h = dwt_hi16(w2) - sub;
+    *ovf |= h < -lim - 1 || h > lim;
+    return h;
+}
+
+// phase F1, thread t: load the window as 32-bit words and leave low | dif of every pair in LDS
+DWT_HD bool dwt_fast_rows_step1(DwtFastShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+{
+    const int x0 = tile_x0(tx), y0 = tile_y0(ty);
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(a.src + (size_t)y0 * a.src_stride + x0);
+    const size_t row_words = a.src_stride >> 1;
+    const int p = t & 63, r0 = t >> 6;
+    bool ovf = false;
+    for (int r = r0; r < kWinH; r += 4) {
+        const uint32_t w = base[(size_t)r * row_words + p];
+        sh.rw[r][p] = dwt_fast_step1((int16_t)(w & 0xFFFFu), (int16_t)(w >> 16), a.lim, &ovf);
+    }
+    if (t < 4 * kWinH) {                                      // the four pairs beyond the 64th of every row
+        const int r = t >> 2, q = 64 + (t & 3);
+        const uint32_t w = base[(size_t)r * row_words + q];
+        sh.rw[r][q] = dwt_fast_step1((int16_t)(w & 0xFFFFu), (int16_t)(w >> 16), a.lim, &ovf);
+    }
+    return ovf;
+}
+// phase F2: row highs of the tile's 64 pair columns for every window row (pair kk of the tile = window pair kk + 2)
+DWT_HD bool dwt_fast_rows_step2(DwtFastShared &sh, const DwtStageArgs &a, int t)
+{
+    const int kk = t & 63, r0 = t >> 6;
+    bool ovf = false;
+    for (int r = r0; r < kWinH; r += 4) {
+        const uint32_t *q = &sh.rw[r][kk];
+        const int32_t h = dwt_fast_step2(q[0], q[1], q[2], q[3], a.f, a.lim, &ovf);
+        sh.rr[r][kk] = dwt_pack(dwt_lo16(q[2]), h);
+    }
+    return ovf;
+}
+// phase F3: step 1 down the low and the high columns (window pair rows q = 0 .. 19)
+DWT_HD bool dwt_fast_cols_step1(DwtFastShared &sh, const DwtStageArgs &a, int t)
+{
+    const int kk = t & 63, q0 = t >> 6;
+    bool ovf = false;
+    for (int q = q0; q < kWinPY; q += 4) {
+        const uint32_t u = sh.rr[2 * q][kk], v = sh.rr[2 * q + 1][kk];
+        sh.cl[q][kk] = dwt_fast_step1(dwt_lo16(u), dwt_lo16(v), a.lim, &ovf);
+        sh.chh[q][kk] = dwt_fast_step1(dwt_hi16(u), dwt_hi16(v), a.lim, &ovf);
+    }
+    return ovf;
+}
+// phase F4: column highs and the four stores (tile pair row jj = window pair row jj + 2)
+DWT_HD bool dwt_fast_cols_step2(DwtFastShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
+{
+    const int nlw = (a.cw + 1) >> 1, nlh = (a.ch + 1) >> 1;
+    const int kk = t & 63, j0 = t >> 6, kx = tx * kTileKX + kk;
+    bool ovf = false;
+    for (int jj = j0; jj < kTileKY; jj += 4) {
+        const int ky = ty * kTileKY + jj;
+        const int32_t hl = dwt_fast_step2(sh.cl[jj][kk], sh.cl[jj + 1][kk], sh.cl[jj + 2][kk], sh.cl[jj + 3][kk], a.f, a.lim, &ovf);
+        const int32_t hh = dwt_fast_step2(sh.chh[jj][kk], sh.chh[jj + 1][kk], sh.chh[jj + 2][kk], sh.chh[jj + 3][kk], a.f, a.lim, &ovf);
+        a.ll[(size_t)ky * a.ll_stride + kx] = (int16_t)dwt_lo16(sh.cl[jj + 2][kk]);
+        a.coef[(size_t)(nlh + ky) * a.coef_stride + kx] = to_coder_word((int16_t)hl, a.sm);
+        a.coef[(size_t)ky * a.coef_stride + nlw + kx] = to_coder_word((int16_t)dwt_lo16(sh.chh[jj + 2][kk]), a.sm);
+        a.coef[(size_t)(nlh + ky) * a.coef_stride + nlw + kx] = to_coder_word((int16_t)hh, a.sm);
+    }
+    return ovf;
+}
+
 }  // namespace icer

@@ -72,6 +72,7 @@ def emu():
     L.emu_compress.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                C.c_size_t, C.c_uint, u8p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.emu_plan_units.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.emu_dwt_fast_tiles.restype = C.c_ulonglong
 
     class Emu:
         lib = L

@@ -104,6 +104,10 @@ extern "C" long emu_code_unit_random(const uint16_t *seg, size_t w, size_t h, si
 // forward DWT with the structure of the product: one fused LDS-tile pass per stage (csrc/dwt_tile.hpp), the LL
 // band handed from stage to stage through a side buffer, the three detail bands written in place
 static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim, int sm);
+static int g_dwt_fast = 1;                 // interior tiles take the fast phases (0: every tile the generic ones)
+static unsigned long long g_dwt_fast_tiles = 0;
+extern "C" void emu_dwt_fast(int on) { g_dwt_fast = on; }
+extern "C" unsigned long long emu_dwt_fast_tiles(void) { return g_dwt_fast_tiles; }
 extern "C" int emu_dwt(uint16_t *img, size_t w, size_t h, int stages, int filt) { return emu_dwt_lim(img, w, h, stages, filt, 32767, 0); }
 // sm: how the detail bands are stored (DwtStageArgs::sm; 0 = plain two's complement, what oracle.dwt returns)
 static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, int32_t lim, int sm)
@@ -128,6 +132,16 @@ static int emu_dwt_lim(uint16_t *img, size_t w, size_t h, int stages, int filt, 
         for (int ty = 0; ty < (nlh + kTileKY - 1) / kTileKY; ty++)
             for (int tx = 0; tx < (nlw + kTileKX - 1) / kTileKX; tx++) {
                 memset(&sh, 0x5A, sizeof sh);
+                if (g_dwt_fast && dwt_tile_is_interior(a, tx, ty)) {     // (as dwt_tile_kernel does)
+                    static DwtFastShared fs;
+                    memset(&fs, 0x5A, sizeof fs);
+                    for (int t = 0; t < kTileThreads; t++) ovf |= dwt_fast_rows_step1(fs, a, tx, ty, t);
+                    for (int t = 0; t < kTileThreads; t++) ovf |= dwt_fast_rows_step2(fs, a, t);
+                    for (int t = 0; t < kTileThreads; t++) ovf |= dwt_fast_cols_step1(fs, a, t);
+                    for (int t = 0; t < kTileThreads; t++) ovf |= dwt_fast_cols_step2(fs, a, tx, ty, t);
+                    g_dwt_fast_tiles++;
+                    continue;
+                }
                 for (int t = 0; t < kTileThreads; t++) dwt_tile_load(sh, a, tx, ty, t);
                 for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_rows_step1(sh, a, tx, ty, t);
                 for (int t = 0; t < kTileThreads; t++) ovf |= dwt_tile_rows_step2(sh, a, tx, ty, t);

@@ -21,11 +21,21 @@ def test_dwt_core(emu, oracle):
     rng = np.random.default_rng(2)
     for filt in range(7):
         for (w, h, st) in [(64, 64, 3), (37, 53, 2), (96, 40, 3), (25, 25, 2), (130, 70, 4), (5, 5, 1), (6, 7, 1), (11, 13, 2),
-                           (300, 200, 2), (517, 389, 3), (264, 136, 1)]:      # (several tiles, interior ones on the unchecked fast path)
+                           (300, 200, 2), (517, 389, 3), (264, 136, 1), (700, 300, 2)]:   # (the last four: tiles on the interior fast path too)
             for hi in (256, 65536):
                 img = rng.integers(0, hi, (h, w)).astype(np.uint16)
                 a, b = oracle.dwt(img, st, filt), emu.dwt(img, st, filt)
                 assert a[0] == b[0] and np.array_equal(a[1], b[1]), (filt, w, h, st, hi)
+    # both tile paths ran: interior tiles through dwt_fast_*, and the very same frames through the generic phases alone
+    assert emu.lib.emu_dwt_fast_tiles() > 50
+    emu.lib.emu_dwt_fast(0)
+    try:
+        for filt in (0, 2, 5):
+            img = rng.integers(0, 65536, (300, 700)).astype(np.uint16)
+            a, b = oracle.dwt(img, 2, filt), emu.dwt(img, 2, filt)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    finally:
+        emu.lib.emu_dwt_fast(1)
 
 
 def test_coding_units_small_and_degenerate(emu, oracle):
