@@ -66,7 +66,8 @@ int icer_init_output_struct(icer_output_data_buf_typedef *out, uint8_t *data, si
 
 /* replaces icer_compress_image_uint16, icer.h:440-441 (lib_icer/src/icer_compress.c:279-426).
  * `image` (host memory, w*h uint16, row-major) is overwritten with the sign-magnitude wavelet
- * coefficients exactly as the reference leaves it.  Returns ICER_RESULT_OK or
+ * coefficients exactly as the reference leaves it (written back while the coder is still running: of the
+ * call's three transfers only the upload and the stream download are not hidden; bench.py `dropin`).  Returns ICER_RESULT_OK or
  * ICER_BYTE_QUOTA_EXCEEDED with a valid stream in output_data->rearrange_start[0..size_used),
  * or an error code with size_used == 0. */
 int icer_compress_image_uint16(uint16_t *image, size_t image_w, size_t image_h, uint8_t stages,
@@ -174,7 +175,14 @@ int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, 
  * _devices variant names them (one process per GPU: pass that process's device).  sizes / rcs per frame equal a
  * per-frame call of icer_compress_image_[yuv_]uint16 (reference: icer.h:440-444).  Returns 0, or the first failing
  * device's error code (icerx_last_error lists every failing device).
- * Env: ICER_HIP_BATCH_SUB=<frames per sub-batch>. */
+ * Env: ICER_HIP_BATCH_SUB=<frames per sub-batch>, ICER_HIP_BATCH_RAMP=<0|1|2> (smaller sub-batches at the start / and the
+ * end of a block; 0 = off is the default), ICER_HIP_NUMA=0 (do not pin the per-device host threads to their GPU's NUMA node).
+ * The pipeline keeps six streams per device busy: export GPU_MAX_HW_QUEUES=8 before the process initialises HIP (the library
+ * does not touch the environment; it prints one line when the variable is unset) -- INTEGRATION.md "Hardware queues".
+ *
+ * icerx_device_count(): devices the batch calls and icerx_encoder_create accept (0 .. count-1).  ICER_HIP_VIRTUAL_DEVICES=<N>
+ * makes that N LOGICAL devices mapped round-robin onto the physical ones: a dry run of every multi-device code path (N host
+ * threads, N pooled pipelines, error aggregation) on a node with fewer GPUs; streams are unaffected. */
 int icerx_device_count(void);
 int icerx_compress_batch_uint16(const uint16_t *frames, int n_frames, size_t w, size_t h, int channels, int stages, int filt,
                                 int segments, size_t byte_quota, uint8_t *out, size_t out_stride, uint64_t *sizes, int32_t *rcs,

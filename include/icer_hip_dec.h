@@ -3,11 +3,15 @@
  *
  * STATUS: bit-exact against the decoder oracle in its CPU builds (tests/test_emu_decoder.py) and on an MI355X
  * (tests/test_gpu_decoder.py: gray / YUV, 16 / 8 bit, damaged and truncated streams, wrong decode parameters, the golden
- * decoder digests up to 4096 x 4096, the batch object; the reference-held fixtures of tests/test_gpu_parity.py).  Speed: a
- * chain (segment of a subband) is a serial adaptive decode, so one stream alone runs at 26 Mpix/s on the 4096 x 4096
- * headline frame (6.7 x the reference decoder on one core of the same box), 16 streams per call at 368 Mpix/s, 64 at
- * 657 Mpix/s (bench.py `decode` object, tools/decode_bench.py).  It is a separate library so that
- * libicer_hip.so (the measured encoder) is unaffected.  See DESIGN.md 6b.
+ * decoder digests up to 4096 x 4096, the batch object, all three decode kernels; the reference-held fixtures and the
+ * reference's own example programs linked against this library, tests/test_gpu_parity.py / test_gpu_examples.py).
+ * Speed (round 4, bench.py `decode` object and tools/decode_bench.py): a chain (segment of a subband) is a serial
+ * adaptive decode, one decision at a time per bit plane.  One 4096 x 4096 headline stream: 55 Mpix/s (303 ms; one wavefront per
+ * bit plane with wave-uniform decisions, decoder_planes.hpp) = 14 x the reference decoder on one core of the same box; the
+ * kernels around the chains (payload CRCs, inverse DWT, sample post-processing) take 0.6 ms together.  Batches: 4 streams per
+ * call 216 Mpix/s, 16 per call 375, 64 per call 657 (beyond six chains per compute unit the lane-per-plane kernel of
+ * decoder_wave.hpp takes over; chosen per call, ICER_DEC_WAVE=0|1|2 pins one).  A separate library, so that libicer_hip.so
+ * (the measured encoder) is unaffected.
  *
  * Same names, argument meaning and return codes as the decoding entry points of lib_icer
  * (TheRealOrange/icer_compression, lib_icer/inc/icer.h); the work runs on the GPU and there is no CPU fallback
