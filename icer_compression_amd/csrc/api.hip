@@ -192,6 +192,7 @@ struct icerx_encoder {
     uint32_t last_subs = 0;             // last launch: sub-range workgroups
     bool lone_as_batch = false;         // ICER_HIP_LONE_AS_BATCH=1: single-frame launches with the batch build of the pipeline (measurements)
     int split_wgs = 0;                  // staying workgroups of the small coder in a split launch (0: one per compute unit)
+    int list_waves = 0;                 // wavefronts per workgroup of the list kernel: 0 = by launch (1 for a split launch, 2 for a batch), ICER_HIP_LIST_WAVES
     DevBuf<SubDesc> subs;
     DevBuf<uint32_t> sub_order, snap_valid;
     DevBuf<Snapshot> snaps;
@@ -427,10 +428,21 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         HIP_TRY(hipEventRecord(e->fork, st));
         HIP_TRY(hipStreamWaitEvent(e->side_stream, e->fork, 0));
         // (a split launch wants the compute units' LDS for its pipeline workgroups: fewer staying workgroups of the small coder, ICER_HIP_SPLIT_WGS)
-        hipLaunchKernelGGL(code_units_wgs_list_kernel, dim3((unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs)), dim3(64 * wgs::kWgWaves), sizeof(wgs::Shared), e->side_stream,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,
-                           e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,
-                           e->plan.sig_bytes, e->route_list.p, e->route_ctl.p);
+        // Which instance: measured (profiles/r04_logs/r04_h_list_waves.log).  A batch runs the ONE-wave instance: C4 + 4.2 %,
+        // C5 + 2.0 % -- its list is thousands of all-blank units (a first window, then closed-form runs: nothing for a second
+        // wave to do but wait at the barriers), and one resident wave of ~ 180 registers leaves the pipeline's workgroups more
+        // of the compute unit than two of 204.  The launch of a single frame keeps the TWO-wave instance (6.4 against 7.8 ms):
+        // its list is led by a few long 90-95 %-blank chains, where the second wave's chunk is progress.
+        // ICER_HIP_LIST_WAVES=1|2 pins one.
+        const unsigned list_grid = (unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs);
+        const int list_waves = e->list_waves ? e->list_waves : (split ? 2 : 1);
+#define ICER_LAUNCH_LIST(I, NS)                                                                                                          \
+        hipLaunchKernelGGL((code_units_list_kernel<I>), dim3(list_grid), dim3(64 * NS::kWgWaves), sizeof(NS::Shared), e->side_stream,    \
+                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,     \
+                           e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,                     \
+                           e->plan.sig_bytes, e->route_list.p, e->route_ctl.p, e->prof.p ? e->prof.p + kProfWgsOffset : nullptr)
+        if (list_waves == 1) ICER_LAUNCH_LIST(WgOne, wg1); else ICER_LAUNCH_LIST(WgSmall, wgs);
+#undef ICER_LAUNCH_LIST
         HIP_TRY(hipEventRecord(e->join, e->side_stream));
     }
     SplitLaunch sp;
@@ -546,6 +558,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *sw = getenv("ICER_HIP_LONE_AS_BATCH")) e->lone_as_batch = atoi(sw) != 0;
     if (const char *sw = getenv("ICER_HIP_SPLIT_WGS")) { const int v = atoi(sw); if (v >= 1 && v <= 4096) e->split_wgs = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
+    if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2) e->list_waves = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -581,7 +594,8 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     // A device / runtime that refuses it loses only the paths that need that coder (progressive mode then runs on the
     // pipeline, launches are not shared, a unit time-out becomes an error) -- reported by icerx_encoder_stats.
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wgs_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgOne>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg1::Shared)) != hipSuccess ||
         hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->join, hipEventDisableTiming) != hipSuccess) {
@@ -1344,6 +1358,14 @@ int icerx_prof_read(icerx_encoder *e, uint64_t out[9 * 32], int reset)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpy(out, e->prof.p, 9 * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
+    return 0;
+}
+// the same for the small window coder beside the pipeline (code_units_wgs_list_kernel): 9 rows of 32
+int icerx_prof_read_wgs(icerx_encoder *e, uint64_t out[9 * 32], int reset)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(out, e->prof.p + kProfWgsOffset, 9 * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(e->prof.p + kProfWgsOffset, 0, 9 * 32 * sizeof(uint64_t)));
     return 0;
 }
 // per workgroup of frame 0 (launch position b < kTraceUnits): start / end (100 MHz wall clock), HW_ID | XCC_ID << 32, unit index

@@ -77,11 +77,15 @@
 #ifdef ICER_PHASE_TIMERS
 // profiling build only (libicer_hip_prof.so): cycles since the previous tick go to bucket k of this wave
 #define WG_TICK(k) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); R.tacc[k] += (uint32_t)(t_ - R.tlast); R.tlast = t_; }
+#define WG_COUNT(k) { R.tacc[k] += 1u; }
 #endif
 #define WG_GLOBAL_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #endif
 #ifndef WG_TICK
 #define WG_TICK(k)
+#endif
+#ifndef WG_COUNT
+#define WG_COUNT(k)
 #endif
 
 #define ICER_WG_NS wg

@@ -1710,6 +1710,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                         WG_STAT(4);
                     }
                     WG_TICK(12)
+                    WG_COUNT(13)
                 WG_BARRIER
                 if (s.stop) return kUnitStopped;
                 WG_EACH_WAVE
@@ -1893,7 +1894,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
         WG_GLOBAL_RELEASE();
 #if defined(ICER_PHASE_TIMERS) && !defined(ICER_WAVE_EMU)
         R.tacc[11] = windows;
-        if (a.timers && lane == 0) for (int i_ = 0; i_ < 13; i_++) atomicAdd((unsigned long long *)&a.timers[i_], (unsigned long long)R.tacc[i_]);
+        if (a.timers && lane == 0) for (int i_ = 0; i_ < 14; i_++) atomicAdd((unsigned long long *)&a.timers[i_], (unsigned long long)R.tacc[i_]);
 #endif
     WG_BARRIER
     if (WG_UNIFORM(too_big)) return kUnitTooBig;

@@ -504,6 +504,14 @@ struct WgSmall {
     static __device__ __forceinline__ uint32_t code(Shared &s, const UnitArgs &a, Wave &r) { return wgs::code_unit_wg(s, a, r); }
 };
 
+struct WgOne {
+    using Shared = wg1::Shared; using UnitArgs = wg1::UnitArgs; using Wave = wg1::Wave;
+    static constexpr uint32_t kWaves = wg1::kWgWaves;
+    static __device__ __forceinline__ void init(Shared &s, const UnitArgs &a) { wg1::unit_state_init(s, a); }
+    static __device__ __forceinline__ bool spent(const UnitArgs &a) { return wg1::quota_already_spent(a); }
+    static __device__ __forceinline__ uint32_t code(Shared &s, const UnitArgs &a, Wave &r) { return wg1::code_unit_wg(s, a, r); }
+};
+
 // one coding unit of one frame by the calling workgroup; the tables and the CRC table are in `s` already
 template <class I>
 __device__ __forceinline__ void wg_code_one_unit(typename I::Shared &s, const WgLaunch &L, uint32_t frame, uint32_t ui)
@@ -578,7 +586,7 @@ __device__ __forceinline__ void wg_shared_tables(typename I::Shared &s, const Co
     const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
     uint32_t *dst = reinterpret_cast<uint32_t *>(&s.tab);
     for (uint32_t i = threadIdx.x; i < sizeof(CoderTables) / 4; i += 64 * I::kWaves) dst[i] = src[i];
-    if ((threadIdx.x >> 6) == 1) build_crc_table(s);
+    if ((threadIdx.x >> 6) == (I::kWaves > 1u ? 1u : 0u)) build_crc_table(s);
 }
 
 __global__ void __launch_bounds__(64 * wg::kWgWaves)
@@ -599,25 +607,27 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
     wg_code_one_unit<WgFull>(s, L, blockIdx.y, ui);
 }
 
-// The coder's small instance (icer::wgs: two wavefronts, 40 KiB of LDS) over a LIST of (frame, unit) pairs -- the units
+// The coder's small instances (icer::wgs: two wavefronts, 40 KiB of LDS; icer::wg1: one) over a LIST of (frame, unit) pairs -- the units
 // route_units_kernel found to be all but blank -- by workgroups that stay: each takes the next entry until the list is
 // used up, so the tables and the CRC table are set up once per workgroup and not once per (quickly coded) unit.  The
 // kernel runs beside the pipeline kernel, whose workgroups leave room for it on every compute unit.
 // grid = a few workgroups per compute unit, block = 128, LDS = sizeof(wgs::Shared).
-__global__ void __launch_bounds__(64 * wgs::kWgWaves)
-code_units_wgs_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
-                           const UnitDesc *__restrict__ units, uint32_t n_units,
-                           const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
-                           const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
-                           size_t slot_frame_stride, uint32_t *__restrict__ unit_bits,
-                           const uint8_t *__restrict__ sig, size_t sig_frame_stride,
-                           const uint32_t *__restrict__ list, uint32_t *__restrict__ list_ctl)
+template <class I>
+__global__ void __launch_bounds__(64 * I::kWaves)
+code_units_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
+                       const UnitDesc *__restrict__ units, uint32_t n_units,
+                       const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
+                       const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
+                       size_t slot_frame_stride, uint32_t *__restrict__ unit_bits,
+                       const uint8_t *__restrict__ sig, size_t sig_frame_stride,
+                       const uint32_t *__restrict__ list, uint32_t *__restrict__ list_ctl, uint64_t *__restrict__ timers)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
-    wgs::Shared &s = *reinterpret_cast<wgs::Shared *>(wg_lds);
+    typename I::Shared &s = *reinterpret_cast<typename I::Shared *>(wg_lds);
     __shared__ uint32_t next_entry;
-    wg_shared_tables<WgSmall>(s, tables);
-    const WgLaunch L{coef, plane, img_w, img_h, channels, units, n_units, means, frame_skip, slots, slot_frame_stride, unit_bits, nullptr,
+    wg_shared_tables<I>(s, tables);
+    // (`timers`: profiling build only -- the per-phase cycle counters of the level-1 units, rows of their own behind the pipeline's)
+    const WgLaunch L{coef, plane, img_w, img_h, channels, units, n_units, means, frame_skip, slots, slot_frame_stride, unit_bits, timers,
                      nullptr, 0ull, sig, sig_frame_stride};
     const uint32_t count = list_ctl[0];                       // entries in the list (route_units_kernel is done)
     for (;;) {
@@ -627,7 +637,7 @@ code_units_wgs_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint
         const uint32_t at = next_entry;
         if (at >= count) break;
         const uint32_t e = list[at];
-        wg_code_one_unit<WgSmall>(s, L, e / n_units, e % n_units);
+        wg_code_one_unit<I>(s, L, e / n_units, e % n_units);
     }
 }
 

@@ -14,9 +14,10 @@ from icer_compression_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=[16, 2], ids=["16_waves", "2_waves"])
+@pytest.fixture(scope="module", params=[16, 2, 1], ids=["16_waves", "2_waves", "1_wave"])
 def wg(request):
-    """the two instances the product builds: icer::wg (16 wavefronts per workgroup) and icer::wgs (2, coder_wg_small.hpp)"""
+    """the instances the product builds: icer::wg (16 wavefronts per workgroup), icer::wgs (2, coder_wg_small.hpp) and
+    icer::wg1 (a single wavefront: no barrier skew at all, coder_wg_small.hpp)"""
     src = os.path.join(ROOT, "tests", "emu", "wg_emu.cpp")
     so = os.path.join(ROOT, "tests", "emu", f"libwg_emu_{request.param}.so")
     csrc = os.path.join(ROOT, "icer_compression_amd", "csrc")
