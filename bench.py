@@ -674,7 +674,7 @@ def main():
                                    "before and after the timed launches",
                     "bytes_out_rank0": out_bytes, "code_units_ms": round(st_ms["code_units"] / max(cl, 1), 3), "dwt_ms": round(st_ms["dwt"] / max(cl, 1), 3),
                     "coder": "code_units_kernel<8> for the dense coding units; the all-but-blank ones (>= 95 % blank chunks, listed on the "
-                             "device by route_units_kernel) by code_units_wgs_list_kernel on a second stream beside it"}
+                             "device by route_units_kernel) by code_units_list_kernel<WgOne> (one wavefront per staying workgroup) on a second stream beside it"}
                 if rank == 0 and not args.no_extras:
                     try:
                         batch_cfgs[name]["decode"] = batch_decode_object(bw)
@@ -760,7 +760,7 @@ def main():
                 pipe += (f"; the dense coding units cut into sub-ranges, {li['sub_range_workgroups']} extra workgroups in the same launch, spliced by "
                          "splice_units_kernel (inside the timed stage)")
             if li["window_coder_beside"]:
-                pipe += "; the all-but-blank units by code_units_wgs_list_kernel on a second stream beside it (inside the timed stage)"
+                pipe += "; the all-but-blank units by code_units_list_kernel (the small window coder: two-wave workgroups for a lone frame, one-wave ones in a batch) on a second stream beside it (inside the timed stage)"
             kernel = {0: pipe + "; code_units_wg_kernel in progressive mode", 1: pipe, 2: "code_units_wg_kernel"}[stats["coder_mode"]]
             line["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,

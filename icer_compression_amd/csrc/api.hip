@@ -192,6 +192,8 @@ struct icerx_encoder {
     uint32_t last_subs = 0;             // last launch: sub-range workgroups
     bool lone_as_batch = false;         // ICER_HIP_LONE_AS_BATCH=1: single-frame launches with the batch build of the pipeline (measurements)
     int split_wgs = 0;                  // staying workgroups of the small coder in a split launch (0: one per compute unit)
+    int nosplit_percent = 20;           // split launches: units with at least this share of blank chunks are not cut into sub-ranges (their words stay
+                                        // open for long stretches: the pieces would not meet; ICER_HIP_NOSPLIT)
     int list_waves = 0;                 // wavefronts per workgroup of the list kernel: 0 = by launch (1 for a split launch, 2 for a batch), ICER_HIP_LIST_WAVES
     DevBuf<SubDesc> subs;
     DevBuf<uint32_t> sub_order, snap_valid;
@@ -421,7 +423,8 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     if (hybrid) {
         HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
-                           (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p);
+                           (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p,
+                           (uint32_t)e->nosplit_percent);
         route = e->route.p;
         // the workgroup coder takes its list on a second stream, beside the pipeline kernel (it is submitted first: its
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
@@ -558,6 +561,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *sw = getenv("ICER_HIP_LONE_AS_BATCH")) e->lone_as_batch = atoi(sw) != 0;
     if (const char *sw = getenv("ICER_HIP_SPLIT_WGS")) { const int v = atoi(sw); if (v >= 1 && v <= 4096) e->split_wgs = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
+    if (const char *ns = getenv("ICER_HIP_NOSPLIT")) { const int v = atoi(ns); if (v >= 1 && v <= 101) e->nosplit_percent = v; }
     if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2) e->list_waves = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
@@ -1360,7 +1364,7 @@ int icerx_prof_read(icerx_encoder *e, uint64_t out[9 * 32], int reset)
     if (reset) HIP_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
     return 0;
 }
-// the same for the small window coder beside the pipeline (code_units_wgs_list_kernel): 9 rows of 32
+// the same for the small window coder beside the pipeline (code_units_list_kernel): 9 rows of 32
 int icerx_prof_read_wgs(icerx_encoder *e, uint64_t out[9 * 32], int reset)
 {
     HIP_TRY(hipSetDevice(e->device));

@@ -208,7 +208,7 @@ constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between
 constexpr uint32_t kMaxPixelWaves = 8, kMaxGolombWorkers = 2;   // (8 pixel waves: the counts-only prefix pass of a sub-range workgroup)
 constexpr int kUnitWavesSmall = 8, kUnitWavesLarge = 11;
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
-constexpr int kProfWgsOffset = 9 * 32 + 4 * kTraceUnits + 16;   // the small window coder's rows (code_units_wgs_list_kernel), one per bit plane
+constexpr int kProfWgsOffset = 9 * 32 + 4 * kTraceUnits + 16;   // the small window coder's rows (code_units_list_kernel), one per bit plane
 constexpr int kProfWords = kProfWgsOffset + 9 * 32;              // (the first part: pipeline rows, workgroup trace, HW_ID of each wave of workgroup 0)
 
 // ring word: open  -> owner bin (bit 15 clear)

@@ -455,7 +455,7 @@ chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w
 __global__ void __launch_bounds__(256)
 route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const uint8_t *__restrict__ sig, size_t sig_frame_stride,
                    uint32_t percent, uint32_t min_chunks, uint8_t *__restrict__ route, uint32_t *__restrict__ list,
-                   uint32_t *__restrict__ list_ctl)
+                   uint32_t *__restrict__ list_ctl, uint32_t nosplit_percent)
 {
     const UnitDesc u = units[blockIdx.x];
     const uint32_t frame = blockIdx.y, nfull = (u.w * u.h) / 64u, nchunks = (u.w * u.h + 63u) / 64u;
@@ -472,7 +472,7 @@ route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const u
         const bool windows = nchunks >= min_chunks && total * 100u >= percent * nchunks;
         // (a unit with a fifth of its chunks blank and more: its words stay open for long stretches, sub-ranges would not
         // meet -- see coder_core.hpp "Sub-ranges")
-        route[(size_t)frame * n_units + blockIdx.x] = windows ? kRouteWindows : (total * 5u >= nchunks ? kRouteNoSplit : kRoutePipeline);
+        route[(size_t)frame * n_units + blockIdx.x] = windows ? kRouteWindows : (total * 100u >= nosplit_percent * nchunks ? kRouteNoSplit : kRoutePipeline);
         if (windows) list[atomicAdd(&list_ctl[0], 1u)] = frame * n_units + blockIdx.x;      // (code_units_wg_list_kernel)
     }
 }

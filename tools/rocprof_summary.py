@@ -18,7 +18,8 @@ import sys
 
 def short(name: str) -> str:
     n = name.replace("(anonymous namespace)::", "").split("(")[0]
-    return n.split("::")[-1] if "::" in n else n
+    head = n.split("<")[0]                                  # (template arguments may hold namespaces of their own)
+    return head.split("::")[-1].replace("void ", "") + n[len(head):].replace("icer::", "")
 
 
 def main():

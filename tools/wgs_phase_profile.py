@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown of code_units_wgs_list_kernel -- the two-wave window coder that takes the all-but-blank units beside
+"""Per-phase cycle breakdown of code_units_list_kernel -- the two-wave window coder that takes the all-but-blank units beside
 the pipeline kernel -- on a lone frame (split launch), level-1 units, one column per bit plane (profiling build, s_memtime ticks).
     python tools/wgs_phase_profile.py [w h stages segments]      (needs a GPU)"""
 import ctypes as C
