@@ -65,7 +65,7 @@ def main():
         nb = int(os.environ.get("ICER_STRESS_BATCH", "0"))
         if nb > 1 and not u8 and not color:
             frames = np.stack([np.roll(img, (3 * k, 7 * k), (0, 1)) for k in range(nb)])
-            cap = min(quota, 2 * w * h + 64) + 64
+            cap = quota + 64                             # (a stream never exceeds its quota; 2wh + 64 is NOT a bound: 32 segments of a 66 x 8 frame are mostly packet headers)
             out, sizes, rcs = np.zeros((nb, cap), np.uint8), np.zeros(nb, np.uint64), np.zeros(nb, np.int32)
             rc = api.compress_batch(frames, st, filt, sg, quota, out, sizes, rcs, devices=[0])
             n += 1
