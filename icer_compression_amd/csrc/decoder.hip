@@ -9,6 +9,7 @@
 // kernel waits on another thread.
 #ifdef ICER_HOST_MOCK
 #define ICER_LAUNCH_PLANES(kernel, grid, shmem, ...) ICER_LAUNCH_WAVE(kernel, grid, shmem, __VA_ARGS__)
+#define ICER_LAUNCH_WAVE_ON(stream, kernel, grid, shmem, ...) ICER_LAUNCH_WAVE(kernel, grid, shmem, __VA_ARGS__)
 #else
 #include <hip/hip_runtime.h>
 // kernel launches go through these two macros so that tests/emu/hip_mock.h (CPU, tests only) can stand in for them
@@ -16,6 +17,7 @@
 #define ICER_LAUNCH_WAVE(kernel, grid, shmem, ...) kernel<<<(grid), 64, (shmem)>>>(__VA_ARGS__)
 // (a workgroup of one wavefront per bit plane; the CPU mock runs the waves of a workgroup in turns inside one call)
 #define ICER_LAUNCH_PLANES(kernel, grid, shmem, ...) kernel<<<(grid), 64 * kPwWaves, (shmem)>>>(__VA_ARGS__)
+#define ICER_LAUNCH_WAVE_ON(stream, kernel, grid, shmem, ...) kernel<<<(grid), 64, (shmem), (stream)>>>(__VA_ARGS__)
 #define ICER_DYNAMIC_LDS(T, name) extern __shared__ T name[]
 // the decoder tables of a workgroup: a copy in LDS (every decision looks them up; from global memory each look-up is a
 // chain of dependent loads)
@@ -258,6 +260,10 @@ struct icerx_decoder {
     Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list, err;
     int n_cus = 256;                   // compute units of the device
     bool planes_lds_raised = false;    // decode_chains_planes_kernel has been granted more than 64 KiB of dynamic LDS
+    // the lane-per-plane kernel is launched once per size class of row ring, side by side (decode_batch)
+    static constexpr int kRingClasses = 4;
+    hipStream_t side[kRingClasses] = {};
+    bool side_ok = false;
 };
 
 namespace {
@@ -378,18 +384,24 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         // bit plane, anything else / unset = one wavefront per bit plane wherever it applies):
         //   wave-per-plane   chains whose packets all take the fast entropy path (ChainDesc::fast) and whose row ring fits LDS
         //   the rest         the lane-per-plane kernel if ITS ring fits, else one thread per chain
-        // Unset, the choice goes by load.  A wave per plane is the faster DECISION (303 against 628 ms for the 160 chains of
-        // the 4096 x 4096 headline stream) and a compute unit holds three such chains (27 wavefronts) without slowing any of
-        // them; beyond that chains queue up, while the lane-per-plane kernel keeps seven chains per compute unit going, each
-        // slowly.  Measured on the headline stream (profiles/r04_logs/r04_d_decode_*.json, r04_c_*.json): 4 streams per call
-        // 216 against 107 Mpix/s, 8 streams 270 against ~190, 16 streams 280 against 374 -- the cross-over lies near six chains
-        // per compute unit.  ICER_DEC_WAVE=2 pins the wave-per-plane kernel.
+        // Unset, the choice goes by load.  A wave per plane is the faster DECISION (303 against 634 ms for the 160 chains of
+        // the 4096 x 4096 headline stream), but a compute unit's throughput with it saturates near ONE long chain (what the
+        // waves of several chains share is the compute unit's scalar unit: 0.6-0.75 scalar instructions per cycle at 8-16
+        // streams, profiles/r04_logs/r04_l_planes_sq_counters.log; the wait loops are not it, r04_m), while the lane-per-plane
+        // kernel keeps seven long chains per compute unit going (LDS for their row rings), each at half the speed.  With the
+        // chains in longest-first order (below; profiles/r04_logs/r04_k_*.json, r04_m_*.json), streams per call -> Mpix/s:
+        //   wave per plane   4: 220   8: 437   16: 525-586   32: 537   64: 519
+        //   lane per plane   4: 107            16: 435       32: 922   64: 885-921   128: 1036
+        // -- the cross-over lies near 20 streams = 12 chains per compute unit (24 streams by this rule: 686).  ICER_DEC_WAVE=2
+        // pins the wave-per-plane kernel, ICER_DEC_PLANES_PER_CU moves the cross-over.
         const char *mode = getenv("ICER_DEC_WAVE");
         size_t n_eligible = 0;
         for (const ChainDesc &c : chains) n_eligible += c.fast ? 1u : 0u;
         const bool by_load = !mode || !mode[0];
+        size_t per_cu = 12u;
+        if (const char *pc = getenv("ICER_DEC_PLANES_PER_CU")) { const long v = atol(pc); if (v >= 1 && v <= 1000000) per_cu = (size_t)v; }
         const bool want_planes = !(mode && (mode[0] == '0' || mode[0] == '1')) && d->tables.lut_ok != 0u &&
-                                 (!by_load || n_eligible <= 6u * (size_t)d->n_cus);
+                                 (!by_load || n_eligible <= per_cu * (size_t)d->n_cus);
         size_t planes_lds = 0;
 #ifdef ICER_HOST_MOCK
         const size_t planes_lds_limit = (size_t)1 << 20;
@@ -405,6 +417,38 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
             n_fast++;
         }
         const uint32_t nc = (uint32_t)chains.size();
+        // Longest chains first within either kernel's share (a chain's time goes with its samples): the level-1 chains of
+        // every stream start at once, one or two per compute unit, and the short ones fill the gaps -- in stream order the
+        // long chains of the later streams of a batch started when those of the first were half-way.
+        {
+            const char *ord = getenv("ICER_DEC_ORDER");
+            if (!(ord && ord[0] == '0')) {
+                auto longer = [](const ChainDesc &a, const ChainDesc &b) { return (uint32_t)a.w * a.h > (uint32_t)b.w * b.h; };
+                std::stable_sort(chains.begin(), chains.begin() + n_fast, longer);
+                std::stable_sort(chains.begin() + n_fast, chains.end(), longer);
+            }
+        }
+        // The lane-per-plane kernel's share by size class of row ring (a launch reserves the LDS of its widest chain for every
+        // workgroup, and LDS is what bounds the chains a compute unit holds: 7 of the headline stream's level-1 chains, but 14
+        // of level 2 and 28 of level 3): class k = rings of at most limit >> k bytes, widest class first, each class a launch
+        // of its own on a stream of its own, all of them side by side.
+        uint32_t class_end[icerx_decoder::kRingClasses];
+        {
+            size_t widest = 2;
+            for (uint32_t i = n_fast; i < nc; i++) widest = std::max(widest, ring_elems_for(chains[i].w, nplanes));
+            auto cls = [&](const ChainDesc &c) {
+                const size_t e = ring_elems_for(c.w, nplanes);
+                int k = 0;
+                while (k + 1 < icerx_decoder::kRingClasses && e * 2u <= (widest >> k)) k++;
+                return k;
+            };
+            std::stable_sort(chains.begin() + n_fast, chains.end(), [&](const ChainDesc &a, const ChainDesc &b) { return cls(a) < cls(b); });
+            uint32_t at = n_fast;
+            for (int k = 0; k < icerx_decoder::kRingClasses; k++) {
+                while (at < nc && cls(chains[at]) == k) at++;
+                class_end[k] = at;
+            }
+        }
         HIP_TRY(ensure(d->chains, sizeof(ChainDesc) * nc));
         HIP_TRY(hipMemcpy(d->chains.p, chains.data(), sizeof(ChainDesc) * nc, hipMemcpyHostToDevice));
         if (n_fast) {
@@ -429,8 +473,27 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
             const size_t ring_bytes = ring_elems * sizeof(uint16_t) + kStateBytes;
             // (the kernel's static DecoderTables block counts against the same 64 KiB a launch gets without asking)
             if (!(mode && mode[0] == '0') && ring_bytes + sizeof(DecoderTables) + 256u <= 65536u) {
-                ICER_LAUNCH_WAVE(decode_chains_wave_kernel, nr, ring_bytes, d_planes, frame_stride, channels, rest,
-                                 d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
+#ifndef ICER_HOST_MOCK
+                if (!d->side_ok) {
+                    for (hipStream_t &st : d->side) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    d->side_ok = true;
+                }
+#endif
+                // (everything the null stream did so far is complete: the upload of `chains` above was a blocking copy)
+                uint32_t from = n_fast;
+                for (int k = 0; k < icerx_decoder::kRingClasses; k++) {
+                    const uint32_t to = class_end[k];
+                    if (to == from) continue;
+                    size_t elems = 2;
+                    for (uint32_t i = from; i < to; i++) elems = std::max(elems, ring_elems_for(chains[i].w, nplanes));
+                    ICER_LAUNCH_WAVE_ON(d->side[k], decode_chains_wave_kernel, to - from, elems * sizeof(uint16_t) + kStateBytes, d_planes, frame_stride, channels,
+                                        (const ChainDesc *)d->chains.p + from, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
+                    HIP_TRY(hipGetLastError());
+                    from = to;
+                }
+#ifndef ICER_HOST_MOCK
+                for (hipStream_t st : d->side) HIP_TRY(hipStreamSynchronize(st));
+#endif
             } else {
                 ICER_LAUNCH(decode_chains_kernel, (nr + 63u) / 64u, 64, plane_block_bytes(64u), d_planes, frame_stride, channels, rest,
                             nr, d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit);
@@ -584,6 +647,9 @@ void icerx_decoder_destroy(icerx_decoder *d)
     for (icerx_decoder::Buf *b : {&d->data, &d->frames, &d->crc, &d->dtables, &d->count, &d->cands, &d->chains, &d->work, &d->tmp,
                                   &d->out8, &d->pos, &d->list, &d->err})
         if (b->p) (void)hipFree(b->p);
+#ifndef ICER_HOST_MOCK
+    if (d->side_ok) for (hipStream_t st : d->side) (void)hipStreamDestroy(st);
+#endif
     delete d;
 }
 

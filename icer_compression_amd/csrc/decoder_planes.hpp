@@ -272,19 +272,28 @@ ICER_DEV void pw_retire(PlaneWave &p, PwShared &s, uint16_t *ring, uint32_t upto
 // One step of a plane's wave: the next block of up to 64 samples of its row, if the plane above and the ring allow it.
 // Returns 0 = blocked (nothing done), 1 = progressed, 2 = the plane is finished.
 // `zero_row`, `ring`: LDS (pw_lds_bytes); every wave of the chain passes the same ones.
+// What the wave's next block waits for: a word of LDS that only grows, and the value it must have reached.
+//   plane j > 0     the plane above must have decoded row r + 1 up to one column past the block's end (pw_needs)
+//   the top plane   is the first to touch row r + 1: that row's ring slot must have been recycled, r + 1 < retired + rows
+// (*need = 0: nothing to wait for.)
+ICER_DEV const uint32_t *pw_wait_for(const PlaneWave &p, const PwShared &s, uint32_t *need)
+{
+    const uint32_t r = p.r, c0 = p.c, n = p.w - c0 < kPwBlock ? p.w - c0 : kPwBlock;
+    if (p.j > 0u) { *need = pw_needs(r, c0 + n - 1u, p.w, p.h); return &s.done[p.j - 1u]; }
+    *need = (c0 == 0u && r + 1u < p.h && r + 2u > p.rows) ? r + 2u - p.rows : 0u;
+    return &s.retired;
+}
+
 ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ring)
 {
     DECL_LANE;
     const uint32_t w = p.w, h = p.h;
     if (p.r >= h) return 2;
     const uint32_t r = p.r, c0 = p.c, n = w - c0 < kPwBlock ? w - c0 : kPwBlock, c_end = c0 + n - 1u;
-    if (p.j > 0u) {
-        const uint32_t above = PW_UNIFORM(PW_LDS_LOAD(s.done[p.j - 1u]));
-        if (above < pw_needs(r, c_end, w, h)) return 0;
-    } else if (c0 == 0u && r + 1u < h) {
-        // the top plane is the first to touch row r + 1: its slot must have been recycled
-        const uint32_t ret = PW_UNIFORM(PW_LDS_LOAD(s.retired));
-        if (r + 1u >= ret + p.rows) return 0;
+    {
+        uint32_t need;
+        const uint32_t *word = pw_wait_for(p, s, &need);
+        if (PW_UNIFORM(PW_LDS_LOAD(*word)) < need) return 0;
     }
     PW_FENCE_ACQ();
     const uint32_t lsb = p.lsb, lsb1 = lsb + 1u, mask = p.mask, sb = p.sign_bit;
@@ -412,7 +421,7 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
 // (wave `wave` of kPwWaves; `lds` = pw_lds_bytes(c.w, planes) bytes, zeroed by the workgroup before); a wave that waits
 // longer than kPwSpinLimit polls gives up and raises *err (the host then fails the call loudly) -- never a hang.
 // CPU builds (tests only): one call runs the chain's waves in turns.  Returns false on a lock-up / time-out.
-constexpr uint32_t kPwSpinLimit = 1u << 22;
+constexpr uint32_t kPwSpinLimit = 1u << 20;       // (polls; the late ones sleep 8 k cycles each: seconds)
 #ifdef ICER_WAVE_EMU
 ICER_DEV bool pw_run_chain(uint8_t *lds, uint32_t /*wave*/, const ChainDesc &c, int planes, int sign_bit, uint16_t *plane, size_t stride,
                            const uint8_t *stream, uint32_t stream_len, const DecoderTables *t, uint32_t * /*err*/)
@@ -449,16 +458,26 @@ ICER_DEV bool pw_run_chain(uint8_t *lds, uint32_t wave, const ChainDesc &c, int 
     pw_init(p, wave, nrun, c, planes, sign_bit, plane, stride, stream, stream_len, t);
     // (the loop must leave by wave-UNIFORM conditions only -- the lane-0 store of the error word comes after it: a per-lane
     // branch inside the loop would make every value the loop carries, i.e. the whole decoder state, divergent for the compiler)
-    uint32_t spins = 0;
+    // A waiting wave must not eat the compute unit's ONE scalar unit: with two long chains on a compute unit that unit is
+    // what they share (profiles/r04_logs/r04_l_planes_sq_counters.log: 0.6-0.75 scalar instructions per cycle and compute
+    // unit, and the five upper planes of a chain mostly wait).  So the wait is a loop of its own over ONE word of LDS --
+    // what the block needs is computed once (pw_wait_for), a poll is a load, a compare and a sleep -- and the sleep grows
+    // with the time waited: 128 cycles for the first polls (a neighbour about to publish), then 1 k, then 8 k cycles.  A
+    // long sleep costs a waiting wave nothing: it waits because it is the faster one of a pair and has a row of slack.
     bool ok = true;
-    for (;;) {
-        const int st = pw_step(p, sh, zero_row, ring);
-        if (st == 2) break;
-        if (st == 1) { spins = 0; continue; }
-        // (a waiting wave must not eat the compute unit's one scalar unit: the longer it has waited, the longer it sleeps)
-        if (spins < 8u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
-        spins++;
-        if (spins > kPwSpinLimit || ((spins & 255u) == 0u && PW_UNIFORM(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)) { ok = false; break; }
+    while (p.r < p.h) {
+        uint32_t need;
+        const uint32_t *word = pw_wait_for(p, sh, &need);
+        uint32_t spins = 0;
+        while (PW_UNIFORM(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
+            if (spins < 6u) __builtin_amdgcn_s_sleep(2);
+            else if (spins < 12u) __builtin_amdgcn_s_sleep(16);
+            else __builtin_amdgcn_s_sleep(127);
+            spins++;
+            if (spins > kPwSpinLimit || ((spins & 63u) == 0u && PW_UNIFORM(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)) { ok = false; break; }
+        }
+        if (!ok) break;
+        if (pw_step(p, sh, zero_row, ring) == 0) { ok = false; break; }     // (cannot be: the condition just held and only grows)
     }
     if (!ok && (threadIdx.x & 63u) == 0u) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return ok;

@@ -8,10 +8,12 @@
  * Speed (round 4, bench.py `decode` object and tools/decode_bench.py): a chain (segment of a subband) is a serial
  * adaptive decode, one decision at a time per bit plane.  One 4096 x 4096 headline stream: 55 Mpix/s (303 ms; one wavefront per
  * bit plane with wave-uniform decisions, decoder_planes.hpp) = 14 x the reference decoder on one core of the same box; the
- * kernels around the chains (payload CRCs, inverse DWT, sample post-processing) take 0.6 ms together.  Batches: 4 streams per
- * call 216 Mpix/s, 16 per call 375, 64 per call 657 (beyond six chains per compute unit the lane-per-plane kernel of
- * decoder_wave.hpp takes over; chosen per call, ICER_DEC_WAVE=0|1|2 pins one).  A separate library, so that libicer_hip.so
- * (the measured encoder) is unaffected.
+ * kernels around the chains (payload CRCs, inverse DWT, sample post-processing) take 0.6 ms together.  Batches (chains of all
+ * streams launched longest first): 4 streams per call 220 Mpix/s, 8: 437 (eight streams in the time of one), 16: 586, 24: 686,
+ * 32: 922, 64: 890, 128: 1 036 -- beyond twelve chains per compute unit the lane-per-plane kernel of decoder_wave.hpp takes
+ * over, launched once per size class of row ring (chosen per call; ICER_DEC_WAVE=0|1|2 pins a kernel, ICER_DEC_PLANES_PER_CU
+ * moves the cross-over, ICER_DEC_ORDER=0 keeps stream order).  A separate library, so that libicer_hip.so (the measured
+ * encoder) is unaffected.
  *
  * Same names, argument meaning and return codes as the decoding entry points of lib_icer
  * (TheRealOrange/icer_compression, lib_icer/inc/icer.h); the work runs on the GPU and there is no CPU fallback

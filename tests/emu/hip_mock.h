@@ -35,6 +35,7 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+typedef void *hipStream_t;                       // (launches of the mock are plain calls: a stream is a name only)
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t atomicXor(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o ^ v; return o; }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }

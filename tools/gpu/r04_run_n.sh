@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 4, call N: lane-per-plane kernel launched per size class of row ring; decoder tests, then the default policy at 1 / 16 / 32 / 64 streams
+set -u
+O=gpurun_out/r04_n; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_zz_decoder_probe.py -q -x -p no:cacheprovider > $O/pytest_dec.log 2>&1; echo "pytest rc=$?"; tail -n 2 $O/pytest_dec.log
+run() { # name batch env...
+  local name=$1; shift; local b=$1; shift
+  env "$@" timeout 300 python tools/decode_bench.py --batch $b --reps 2 --no-cpu-baseline > $O/$name.json 2>> $O/err.log
+  python - $O/$name.json $name <<'PY'
+import json,sys
+try:
+    l=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], l['value'], l['ms_per_frame'], l.get('batched'), l['config']['parity'])
+except Exception as e: print(sys.argv[2], 'parse', e)
+PY
+}
+run lanes_64 64 ICER_DEC_WAVE=1
+run lanes_32 32 ICER_DEC_WAVE=1
+run lanes_16 16 ICER_DEC_WAVE=1
+run auto_16 16 X=0
+run auto_24 24 X=0
+run auto_64 64 X=0
+run lanes_128 128 ICER_DEC_WAVE=1
+tail -n 3 $O/err.log
