@@ -1372,6 +1372,16 @@ int icerx_prof_read_wgs(icerx_encoder *e, uint64_t out[9 * 32], int reset)
     if (reset) HIP_TRY(hipMemset(e->prof.p + kProfWgsOffset, 0, 9 * 32 * sizeof(uint64_t)));
     return 0;
 }
+// per list entry of code_units_list_kernel (frame 0, position < kListTrace): start / end (100 MHz wall clock), workgroup | unit << 32,
+// lsb | level << 8 | subband << 16 | segment << 24 | chunks << 32
+int icerx_prof_list_trace(icerx_encoder *e, uint64_t *out, int n_entries, int reset)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    if (n_entries > kListTrace) n_entries = kListTrace;
+    HIP_TRY(hipMemcpy(out, e->prof.p + kProfWgsOffset + 9 * 32, (size_t)n_entries * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(e->prof.p + kProfWgsOffset + 9 * 32, 0, (size_t)kListTrace * 4 * sizeof(uint64_t)));
+    return n_entries;
+}
 // per workgroup of frame 0 (launch position b < kTraceUnits): start / end (100 MHz wall clock), HW_ID | XCC_ID << 32, unit index
 int icerx_prof_trace(icerx_encoder *e, uint64_t *out, int n_blocks)
 {

@@ -209,7 +209,8 @@ constexpr uint32_t kMaxPixelWaves = 8, kMaxGolombWorkers = 2;   // (8 pixel wave
 constexpr int kUnitWavesSmall = 8, kUnitWavesLarge = 11;
 constexpr int kTraceUnits = 4096;           // profiling build: workgroups of frame 0 whose start / end times are recorded
 constexpr int kProfWgsOffset = 9 * 32 + 4 * kTraceUnits + 16;   // the small window coder's rows (code_units_list_kernel), one per bit plane
-constexpr int kProfWords = kProfWgsOffset + 9 * 32;              // (the first part: pipeline rows, workgroup trace, HW_ID of each wave of workgroup 0)
+constexpr int kListTrace = 4096;            // profiling build: list entries of code_units_list_kernel whose start / end times are recorded (frame 0)
+constexpr int kProfWords = kProfWgsOffset + 9 * 32 + 4 * kListTrace;              // (the first part: pipeline rows, workgroup trace, HW_ID of each wave of workgroup 0)
 
 // ring word: open  -> owner bin (bit 15 clear)
 //            done  -> 0x8000 | nbits << 11 | code (<= 10 bits)

@@ -637,7 +637,19 @@ code_units_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t
         const uint32_t at = next_entry;
         if (at >= count) break;
         const uint32_t e = list[at];
+#ifdef ICER_PHASE_TIMERS
+        const uint64_t t_start = wall_clock64();
+#endif
         wg_code_one_unit<I>(s, L, e / n_units, e % n_units);
+#ifdef ICER_PHASE_TIMERS
+        // (the list's timeline: when which workgroup coded which unit -- tools/list_trace.py)
+        if (timers && threadIdx.x == 0 && at < (uint32_t)kListTrace && e < n_units) {
+            const UnitDesc &ud = units[e];
+            uint64_t *tr = timers + 9 * 32 + 4 * at;
+            tr[0] = t_start; tr[1] = wall_clock64(); tr[2] = blockIdx.x | ((uint64_t)e << 32);
+            tr[3] = (uint64_t)ud.lsb | ((uint64_t)ud.level << 8) | ((uint64_t)ud.subband << 16) | ((uint64_t)ud.seg << 24) | ((uint64_t)((ud.w * ud.h + 63u) / 64u) << 32);
+        }
+#endif
     }
 }
 
