@@ -31,16 +31,30 @@
 #define PW_WRITELANE(X, L, V) { (X)[(L)] = (V); }
 #define PW_UNIFORM(x) (x)
 #define PW_RCP(x) (1.0f / (x))
+#define PW_UMIN(a, b) ((a) < (b) ? (a) : (b))
+#define PW_SGPR(x)
 #define PW_LDS_LOAD(x) (x)
 #define PW_LDS_STORE(x, v) ((x) = (v))
 #define PW_FENCE_ACQ()
 #define PW_FENCE_REL()
 #else
-// (this compiler has no v_writelane builtin: a compare of the lane number with the scalar index and a select -- two vector
-// instructions, no inline-assembly hazards to mind)
-#define PW_WRITELANE(X, L, V) { (X) = ((uint32_t)lane == (uint32_t)(L)) ? (uint32_t)(V) : (X); }
+// v_writelane_b32: this clang has no builtin for it, but the LLVM intrinsic is reachable by name; the compiler then minds the
+// M0 / lane-select hazards itself.  (The first versions used a compare of the lane number and a select: three vector
+// instructions per write on gfx9 -- a second scalar operand does not fit a VALU instruction's constant bus, so the value went
+// through a v_mov -- and, worse, the compiler then computed the value's whole uniform chain on the vector unit.)
+extern "C" __device__ int pw_writelane_i32(int value, int lane_select, int old) __asm("llvm.amdgcn.writelane.i32");
+#define PW_WRITELANE(X, L, V) { (X) = (uint32_t)pw_writelane_i32((int)(V), (int)(L), (int)(X)); }
 #define PW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define PW_RCP(x) __builtin_amdgcn_rcpf(x)
+// (a minimum of three uniform values: the instruction selector takes v_min3_u32 -- there is no scalar one -- and the pass that
+// legalises the copy back then moves every scalar user of the result, loop counter included, onto the vector unit)
+static __device__ __forceinline__ uint32_t pw_smin(uint32_t a, uint32_t b) { uint32_t r; asm("s_min_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+#define PW_UMIN(a, b) pw_smin((a), (b))
+// "this value lives in a scalar register here" (no instruction): where the compiler would rather continue a uniform
+// computation on the vector unit because its result ends up in a vector instruction anyway -- the decision chain then pays a
+// vector instruction's 8 cycles per step and a v_readfirstlane hand-over where the scalar side needs the value again
+#define PW_SGPR(x) asm volatile("" : "+s"(x))
+
 #define PW_LDS_LOAD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define PW_LDS_STORE(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 // LDS-only fences (lgkmcnt): the ring and the counters live in LDS; the row write-back to global memory needs no ordering
@@ -145,9 +159,14 @@ ICER_DEV void pw_init(PlaneWave &p, uint32_t j, uint32_t nrun, const ChainDesc &
     PW_LOAD_CHUNK(p.pay2, 1u)
 }
 
+// a < b as a 0 / 1 word, for values below 2^31: the borrow of a - b.  (Written as a comparison the compiler keeps the truth value
+// as a lane mask once it meets another one and turns it into a number with v_cndmask -- on the vector unit, where everything
+// computed from it then stays: the served bit, the sample word, the counts.  As arithmetic the chain stays scalar.)
+ICER_DEV uint32_t pw_lt(uint32_t a, uint32_t b) { uint32_t d = a - b; PW_SGPR(d); return d >> 31; }     // (the barrier: or the optimiser turns it back into a comparison)
+
 // one bit from the entropy decoder for an event of coder bin `bin` (`inv`: the estimate was folded, the served bit is
 // flipped): entropy_decode_fast (decoder_core.hpp) behind its bin selection, on wave-uniform values
-ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, bool inv)
+ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, uint32_t inv)
 {
     DECL_LANE;
     const uint32_t st = READLANE(p.fst, bin), last_word = READLANE(p.idx, bin);
@@ -187,10 +206,13 @@ ICER_DEV uint32_t pw_decode_bin(PlaneWave &p, uint32_t bin, bool inv)
         p.words++;
         PW_WRITELANE(p.idx, bin, p.words);
     }
-    const uint32_t top = (pat >> ((uint32_t)(n - 1) & 31u)) & 1u;
+    uint32_t nm1 = (uint32_t)n;
+    PW_SGPR(nm1);               // (hides that n - 1 and the test n > 0 below are one subtraction-with-borrow: that one the instruction selector puts on the vector unit, and every value behind it)
+    nm1 -= 1u;
+    const uint32_t top = (pat >> (nm1 & 31u)) & 1u;
     const uint32_t b = n > 0 ? (bin >= 8u ? (n == 1 ? pat : 0u) : top) : 0u;
-    PW_WRITELANE(p.fst, bin, ((uint32_t)(n - 1) & 0xFFFFu) | (pat << 16));
-    return inv ? (b ^ 1u) : b;
+    PW_WRITELANE(p.fst, bin, (nm1 & 0xFFFFu) | (pat << 16));
+    return b ^ inv;
 }
 
 // Runs of zero decisions.  In the upper bit planes most samples are insignificant with insignificant neighbours: context 0,
@@ -220,8 +242,7 @@ ICER_DEV uint32_t pw_zero_run(PlaneWave &p, uint32_t rl)
     if (n <= 0 || p.words - READLANE(p.idx, bin) >= (uint32_t)kRingWords) return 0u;
     const uint32_t avail = pat ? (uint32_t)n - 1u : (uint32_t)n;      // zeros above the closing one-bit / a full run of m zeros
     const uint32_t room = (kRescaleCap - 1u) - total;                 // events before the one that triggers the rescale
-    uint32_t t = rl < avail ? rl : avail;
-    t = t < room ? t : room;
+    uint32_t t = PW_UMIN(PW_UMIN(rl, avail), room);
     if (bin < 16u) {
         const uint32_t cut = READLANE(p.tc, bin);
         while (t >= 2u && ((zero + t - 1u) << 16) >= (total + t - 1u) * cut) t >>= 1;
@@ -351,8 +372,7 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
     uint32_t val = 0, se = 0;
     bool sign_next = false;
     for (uint32_t i = 0; i < n;) {
-        uint32_t w, ctx = 0;
-        bool modelled = true;
+        uint32_t w, ctx = 0, mod = 1u;                                             // mod: 1 = a modelled decision
         if (!sign_next) {
             const uint32_t de = READLANE(desc, i);
             const uint32_t cat = de & 3u;
@@ -368,25 +388,25 @@ ICER_DEV int pw_step(PlaneWave &p, PwShared &s, uint16_t *zero_row, uint16_t *ri
                 }
             }
             val = READLANE(curv, i);
-            modelled = cat != 3u;                                                  // category 3: unmodelled, 1 of 2 (C2)
+            mod = (6u - cat) >> 2;                                                 // category 3: unmodelled, 1 of 2 (C2) -- cat != 3 as a 0 / 1 word
             ctx = (de >> (leftsig ? 6u : 2u)) & 15u;
             // (the sign's context, should the sample become significant: QUIRK C6, only negative significant neighbours count)
             se = (cat == 0u ? 0x10u : 0u) | ((de >> (leftneg ? 14u : 10u)) & 15u);
         } else ctx = 12u + (se & 7u);
         // the estimate folded to >= 1/2, its bin, one bit from that bin's code words, the counts through dec_model_update
-        // (QUIRK C5 included) -- selects, no branches
+        // (QUIRK C5 included) -- selects, no branches, every step a scalar instruction (PW_FLAG)
         w = READLANE(p.cnt, ctx);
         uint32_t zero = w & 0xFFFFu, total = w >> 16;
-        const bool inv = modelled && zero < (total >> 1);
-        const uint32_t fz = inv ? total - zero : zero;
-        const uint32_t bin = modelled ? PW_BIN(fz, total) : p.bin_half;
+        const uint32_t inv = pw_lt(zero, total >> 1) & mod;
+        const uint32_t fz = zero ^ ((zero ^ (total - zero)) & (0u - inv));
+        const uint32_t bin = (PW_BIN(fz, total) & (0u - mod)) | (p.bin_half & (mod - 1u));
         const uint32_t bit = pw_decode_bin(p, bin, inv);
         total++;
-        zero += bit == 0u ? 1u : 0u;
-        const bool resc = total >= kRescaleCap;
-        total = resc ? total >> 1 : total;
-        zero = (resc && zero > total) ? zero >> 1 : zero;
-        PW_WRITELANE(p.cnt, modelled ? ctx : 63u, zero | (total << 16));           // (lane 63: no context lives there)
+        zero += bit ^ 1u;
+        const uint32_t resc = pw_lt(kRescaleCap - 1u, total);
+        total >>= resc;
+        zero >>= resc & pw_lt(total, zero);
+        PW_WRITELANE(p.cnt, ctx | (63u & (mod - 1u)), zero | (total << 16));       // (unmodelled: lane 63, no context lives there)
         if (!sign_next) {
             val |= bit << lsb;
             if ((se & 0x10u) != 0u && bit != 0u) { sign_next = true; continue; }
