@@ -361,7 +361,7 @@ def c3_object(dev, local_rank, barrier, all_ranks_ok, world, red_dev=None):
 
 def decode_object(stream_dev, size, frame_dev, cfg, with_cpu):
     """the C2 stream (already in HBM: the encoder's output) -> uint16 planes in HBM through
-    libicer_hip_dec.so (icerx_decode_device, whole call); 1 stream and 16 streams per call; every decoded frame equals
+    libicer_hip_dec.so (icerx_decode_device, whole call); 1, 8, 16 and 64 streams per call; every decoded frame equals
     the encoder's input; the reference decoder (oracle/_ref) on one host core on the same stream beside it"""
     import torch
     from icer_compression_amd import decoder
@@ -385,11 +385,17 @@ def decode_object(stream_dev, size, frame_dev, cfg, with_cpu):
         return min(times[1:]), ok
     t1, ok1 = run(1, 2)
     tb, okb = run(16, 2)
+    t8, ok8 = run(8, 1)
+    t64, ok64 = run(64, 1)
+    okb = okb and ok8 and ok64
     alg = float(size + W * H * 2)
     obj = {"metric": "Mpixels/s decode (bit-exact)", "workload": f"the stream of the timed workload ({size} bytes = the reference golden) resident in HBM -> uint16 planes "
            "in HBM; icerx_decode_device, whole call incl. the packet walk", "value": round(W * H / t1 / 1e6, 2), "unit": "Mpixels/s",
            "ms_per_frame": round(t1 * 1e3, 2), "parity": bool(ok1 and okb), "parity_note": "every decoded frame equals the encoder's input",
+           "streams_8_per_call": {"value": round(8 * W * H / t8 / 1e6, 2), "ms_per_call": round(t8 * 1e3, 2)},
            "streams_16_per_call": {"value": round(16 * W * H / tb / 1e6, 2), "ms_per_call": round(tb * 1e3, 2)},
+           "streams_64_per_call": {"value": round(64 * W * H / t64 / 1e6, 2), "ms_per_call": round(t64 * 1e3, 2),
+                                   "note": "chains of all streams launched longest first; from 20 streams per call on the lane-per-plane kernel, once per size class of row ring"},
            "roofline_frac": round(alg / t1 / 1e9 / HBM_PEAK_GBPS, 7)}
     if with_cpu:
         try:
