@@ -7,7 +7,7 @@ call.  tests/test_gpu_stress.py runs a bounded slice of it under pytest -m gpu.
 With ICER_STRESS_BATCH=<n> every gray 16-bit case becomes a batch of n frames (the same geometry, rolled content) through
 icerx_compress_batch_uint16_devices -- the batch build of the pipeline kernel, four workgroups per compute unit, sub-batches on
 three streams -- each frame against the oracle.
-With ICER_STRESS_DECODE=1 every stream the encoder produced is also decoded by libicer_hip_dec.so (both decode kernels)
+With ICER_STRESS_DECODE=1 every stream the encoder produced is also decoded by libicer_hip_dec.so (all three decode kernels)
 and compared with the decoder oracle."""
 import os
 import sys
@@ -91,7 +91,7 @@ def main():
         if decode and same and a[1] and len({p[7] >> 4 for p in _packets(a[1])}) >= len(planes):
             bits = 8 if u8 else 16
             want = orc.decompress(a[1], len(planes), st, filt, sg, bufsize=w * h, bits=bits)
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):
                 os.environ["ICER_DEC_WAVE"] = mode
                 got = decoder.decompress(a[1], len(planes), st, filt, sg, bufsize=w * h, bits=bits)
                 if not (got[0] == want[0] and got[1:3] == want[1:3] and all(np.array_equal(x, y) for x, y in zip(got[3], want[3]))):

@@ -12,11 +12,13 @@ timeout 500 python bench.py --sweep --config C5 --no-cpu-baseline > $O/sweep_c5.
 timeout 400 bash tools/profile_round.sh ${T}_prof > $O/profile_round.log 2>&1
 mkdir -p $O/profiles_new; cp profiles/${T}_prof* profiles/latest_pmc.json $O/profiles_new/ 2>/dev/null
 timeout 300 python tools/decode_bench.py --batch 64 --reps 2 > $O/decode_bench_64.json 2> $O/decode_bench.err
-timeout 200 python tools/decode_bench.py --batch 4 --reps 2 --no-cpu-baseline > $O/decode_bench_4.json 2>> $O/decode_bench.err
+timeout 200 python tools/decode_bench.py --batch 8 --reps 2 --no-cpu-baseline > $O/decode_bench_8.json 2>> $O/decode_bench.err
+timeout 200 python tools/decode_bench.py --batch 32 --reps 2 --no-cpu-baseline > $O/decode_bench_32.json 2>> $O/decode_bench.err
 timeout 150 python tests/stress_gpu_diff.py 100 888001 > $O/stress_diff.log 2>&1
 ICER_HIP_HYBRID=90 ICER_HIP_HYBRID_FRAMES=1 ICER_STRESS_BIG=0.3 timeout 100 python tests/stress_gpu.py 60 888003 > $O/stress_hybrid.log 2>&1
 ICER_HIP_SPLIT=128 ICER_STRESS_BIG=0.3 timeout 100 python tests/stress_gpu.py 60 888004 > $O/stress_split.log 2>&1
 ICER_STRESS_BATCH=6 ICER_STRESS_BIG=0.1 timeout 100 python tests/stress_gpu.py 60 888005 > $O/stress_batch.log 2>&1
+ICER_STRESS_DECODE=1 ICER_STRESS_BIG=0.1 timeout 160 python tests/stress_gpu.py 120 888006 > $O/stress_decode.log 2>&1
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline --no-traffic > $O/bench_2ranks_1gpu.json 2> $O/bench_2ranks.err; echo "2-rank rc=$?"
 find gpurun_out -name "*.db" -delete
 python - "$O" <<'PY'
@@ -37,4 +39,4 @@ for n in ('sweep_c4','sweep_c5'):
         s=json.loads(open(f'{O}/{n}.json').read().strip().splitlines()[-1]); print(n, s['frames_checked'], s['parity'], s['value'])
     except Exception as e: print(n, 'parse', e)
 PY
-tail -n 2 $O/stress_diff.log $O/stress_hybrid.log $O/stress_split.log $O/stress_batch.log; head -n 14 $O/profiles_new/${T}_prof_rocprof.md; cut -c1-300 $O/decode_bench_64.json
+tail -n 2 $O/stress_diff.log $O/stress_hybrid.log $O/stress_split.log $O/stress_batch.log $O/stress_decode.log; head -n 14 $O/profiles_new/${T}_prof_rocprof.md; cut -c1-300 $O/decode_bench_64.json
