@@ -475,7 +475,14 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
             if (!(mode && mode[0] == '0') && ring_bytes + sizeof(DecoderTables) + 256u <= 65536u) {
 #ifndef ICER_HOST_MOCK
                 if (!d->side_ok) {
-                    for (hipStream_t &st : d->side) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    bool made = true;
+                    for (hipStream_t &st : d->side) made = made && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+                    if (!made) {                                    // (none is kept half-made: the next call tries again)
+                        for (hipStream_t &st : d->side) { if (st) (void)hipStreamDestroy(st); st = nullptr; }
+                        (void)hipGetLastError();
+                        rc = fail("the decoder could not create its side streams");
+                        goto done;
+                    }
                     d->side_ok = true;
                 }
 #endif
@@ -580,6 +587,10 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
             }
     }
 done:
+#ifndef ICER_HOST_MOCK
+    // (an error exit may leave launches of the size classes behind on the side streams: nothing of this call runs on after it)
+    if (rc != ICER_RESULT_OK && d->side_ok) { for (hipStream_t st : d->side) (void)hipStreamSynchronize(st); (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+#endif
     return rc;
 }
 

@@ -230,7 +230,6 @@ static unsigned long long g_pw_run_stats[2];               // tests only: runs t
 #endif
 ICER_DEV uint32_t pw_zero_run(PlaneWave &p, uint32_t rl)
 {
-    DECL_LANE;
     const uint32_t w = READLANE(p.cnt, 0u);
     const uint32_t zero = w & 0xFFFFu, total = w >> 16;
     if (zero < (total >> 1)) return 0u;                                // folded: a served 0 is a one-event
