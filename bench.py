@@ -316,7 +316,7 @@ def run_timed(wl, steps, warmup, barrier, dev, red_dev=None):
     return shard.max_over_ranks(elapsed, red_dev if red_dev is not None else dev), step_ms, stage_ms, calls
 
 
-def pingpong_object(bw, name, rank, dev, local_rank, barrier, all_ranks_ok, world, red_dev=None):
+def pingpong_object(bw, name, rank, dev, local_rank, barrier, all_ranks_ok, world, red_dev=None, n=6):
     """The rank's share of a batch configuration and the NEXT share of it, coded by two encoders in turns through the
     asynchronous half of the API (icerx_encode_device_async on a stream each; the host waits for launch k - 1 after it has
     submitted launch k): the tail of a launch -- its last long coding units, with most of the chip idle -- hides behind the
@@ -326,7 +326,17 @@ def pingpong_object(bw, name, rank, dev, local_rank, barrier, all_ranks_ok, worl
     c = bw.cfg
     other = Workload(name, rank, dev, local_rank, first=(bw.first + c["per_gpu"]) % c["total"])
     wls = [bw, other]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    # two plain HIP streams, made here and destroyed below: torch.cuda.Stream() would take them from torch's pool, whose first use
+    # creates 64 streams that live as long as the process -- and the hardware queues (GPU_MAX_HW_QUEUES) are shared out over all
+    # live streams: legs that follow (the host-fed pipeline overlaps five) then find theirs doubled up (measured: 0.66 x)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    streams = [ctypes.c_void_p() for _ in range(2)]
+    for st_ in streams:
+        if hip.hipStreamCreateWithFlags(ctypes.byref(st_), 1) != 0:             # hipStreamNonBlocking
+            raise RuntimeError("hipStreamCreateWithFlags failed")
     other.step()
     bad0, _ = other.verify()
     for w in wls:
@@ -335,7 +345,7 @@ def pingpong_object(bw, name, rank, dev, local_rank, barrier, all_ranks_ok, worl
     def launch(i):
         w = wls[i]
         w.enc.encode_device_async_ptrs(w.frames.data_ptr(), w.B, w.quota, w.out.data_ptr(), w.out.stride(0), w.sizes.data_ptr(), w.rcs.data_ptr(),
-                                       streams[i].cuda_stream)
+                                       streams[i].value)
 
     def run(n):
         launch(0)
@@ -343,7 +353,6 @@ def pingpong_object(bw, name, rank, dev, local_rank, barrier, all_ranks_ok, worl
             launch(k & 1)
             wls[(k - 1) & 1].enc.wait()
         wls[(n - 1) & 1].enc.wait()
-    n = 6
     run(2)
     torch.cuda.synchronize(dev)
     barrier()
@@ -355,6 +364,8 @@ def pingpong_object(bw, name, rank, dev, local_rank, barrier, all_ranks_ok, worl
     bad = [w.verify()[0] for w in wls]
     ok = all_ranks_ok(not bad0 and not bad[0] and not bad[1])
     other.close()
+    for st_ in streams:
+        hip.hipStreamDestroy(st_)
     return {"value": round(world * n * c["per_gpu"] * c["w"] * c["h"] / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_launch": round(t_el / n * 1e3, 3), "launches": n,
             "parity": ok, "frames_checked_per_rank": 2 * c["per_gpu"],
             "note": "two encoders, two streams, icerx_encode_device_async / icerx_encoder_wait; every frame of both shares equals the reference's after the timed launches"}
@@ -671,32 +682,6 @@ def main():
     stats = wl.enc.stats() if device_wl else api.process_stats()
     launches_per_step = (B + wl.launch - 1) // wl.launch if device_wl else 1
 
-    # secondary figure: the C2 geometry with several frames per launch; one frame alone cannot fill 256 CUs because its
-    # largest coding units form a serial chain
-    batched = None
-    if args.batched_probe > 1 and args.config == "C2" and device_wl:
-        PB = args.batched_probe
-        bf = synth.gray_frames_torch(1, W, H, synth.DEFAULT_SEED, dev, 1).repeat(PB, 1, 1).contiguous()
-        bout = torch.empty((PB, wl.quota), dtype=torch.uint8, device=dev)
-        bsizes = torch.zeros(PB, dtype=torch.int64, device=dev)
-        brcs = torch.zeros(PB, dtype=torch.int32, device=dev)
-        benc = api.Encoder(W, H, 1, cfg["stages"], FILT, cfg["segments"], max_frames=PB, device=local_rank)
-        benc.encode_torch(bf, wl.quota, bout, bsizes, brcs)
-        barrier()
-        tb = time.perf_counter()
-        nb = max(2, args.steps // 2)
-        for _ in range(nb):
-            benc.encode_torch(bf, wl.quota, bout, bsizes, brcs)
-        barrier()
-        tb = shard.max_over_ranks(time.perf_counter() - tb, red_dev)
-        g = wl.gold[0]
-        ok = bool((brcs.cpu().numpy() == 0).all()) and all(
-            int(bsizes[k]) == g[0] and ("%08x" % zlib.crc32(bout[k, : g[0]].cpu().numpy().tobytes())) == g[1] for k in range(PB))
-        batched = {"frames_per_gpu_per_launch": PB, "value": round(world * PB * W * H * nb / tb / 1e6, 3), "unit": "Mpixels/s",
-                   "ms_per_launch": round(tb / nb * 1e3, 3), "parity": all_ranks_ok(ok), "frames_checked_per_rank": PB}
-        benc.close()
-        del bf, bout
-
     # the batch configurations BASELINE.json names for 8 GPUs, as this GPU's share of them: device-resident, and fed from
     # page-locked host memory through the overlapped batch call
     batch_cfgs, batch_host, kept = {}, {}, {}
@@ -729,12 +714,11 @@ def main():
                     ab = float(c["per_gpu"] * c["w"] * c["h"] * 2 + out_bytes)
                     kms = st_ms["code_units"] / max(cl, 1)
                     batch_cfgs[name]["roofline_frac"] = round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)
-                if args.no_extras:
-                    bw.close()
-                else:
-                    kept[name] = bw                                    # (its decode and two-in-flight legs come after the host-fed legs, below)
+                bw.close()
                 del bw
                 torch.cuda.empty_cache()
+                if not args.no_extras:
+                    kept[name] = True                                  # (its decode and two-in-flight legs come after the host-fed legs, below)
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 batch_cfgs[name] = {"error": repr(exc)}
             if args.no_extras:
@@ -761,10 +745,17 @@ def main():
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 batch_host[name] = {"error": repr(exc)}
         # The legs that create streams of their own (the decoder's side streams, the two encoders in turns) come after the
-        # host-fed legs, which overlap five streams per device on the runtime's eight hardware queues: a precaution.  (The
-        # host-fed rate itself moves with the box a run lands on -- 0.85-0.94 x of the device-resident rate over the runs of
-        # round 4, together with the other PCIe figures of the line, `dropin` and `host_buffers`.)
-        for name, bw in kept.items():
+        # host-fed legs, and nothing but the timed workload's encoder is alive while those run: the host-fed pipeline overlaps
+        # five streams per device on the runtime's eight hardware queues, and every other live stream of the process -- idle or
+        # not -- takes part in how the runtime shares the queues out.  Alone in a process the host-fed legs reach 0.94 x of the
+        # device-resident rate; after other legs of this script they measured 0.66-0.90 x (profiles/r04_logs/r04_z*_bench.json).
+        for name in list(kept):
+            try:
+                bw = Workload(name, rank, dev, local_rank)
+                bw.step()
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                batch_cfgs[name]["two_launches_in_flight"] = {"error": repr(exc)}
+                continue
             if rank == 0:
                 try:
                     batch_cfgs[name]["decode"] = batch_decode_object(bw)
@@ -777,6 +768,46 @@ def main():
             bw.close()
         kept.clear()
         torch.cuda.empty_cache()
+
+    # secondary figure: a STREAM of single frames (not `value`, which times one frame at a time): two encoders taking the frames in
+    # turns, two launches in flight.  (First among the secondary legs: the two launches overlap only while their streams sit on
+    # hardware queues of their own, and which queue a stream gets goes by how many the process has created before -- measured
+    # with tools/batch_pingpong_probe.py: 4.15 ms per frame with GPU_MAX_HW_QUEUES = 8, 6.46 with 4, 8.7 with 2.)
+    streaming = None
+    if not args.no_extras and args.config == "C2" and device_wl:
+        try:
+            streaming = pingpong_object(wl, "C2", rank, dev, local_rank, barrier, all_ranks_ok, world, red_dev, n=32)
+            streaming["workload"] = "a stream of 4096x4096 frames (the timed workload's frame), two single-frame launches in flight: frames per second, not the latency of one"
+            streaming["ms_per_frame"] = streaming.pop("ms_per_launch")
+            streaming["frames_in_flight"] = 2
+        except Exception as exc:                                       # noqa: BLE001 -- secondary figure
+            streaming = {"error": repr(exc)}
+
+    # secondary figure: the C2 geometry with several frames per launch; one frame alone cannot fill 256 CUs because its
+    # largest coding units form a serial chain
+    batched = None
+    if args.batched_probe > 1 and args.config == "C2" and device_wl:
+        PB = args.batched_probe
+        bf = synth.gray_frames_torch(1, W, H, synth.DEFAULT_SEED, dev, 1).repeat(PB, 1, 1).contiguous()
+        bout = torch.empty((PB, wl.quota), dtype=torch.uint8, device=dev)
+        bsizes = torch.zeros(PB, dtype=torch.int64, device=dev)
+        brcs = torch.zeros(PB, dtype=torch.int32, device=dev)
+        benc = api.Encoder(W, H, 1, cfg["stages"], FILT, cfg["segments"], max_frames=PB, device=local_rank)
+        benc.encode_torch(bf, wl.quota, bout, bsizes, brcs)
+        barrier()
+        tb = time.perf_counter()
+        nb = max(2, args.steps // 2)
+        for _ in range(nb):
+            benc.encode_torch(bf, wl.quota, bout, bsizes, brcs)
+        barrier()
+        tb = shard.max_over_ranks(time.perf_counter() - tb, red_dev)
+        g = wl.gold[0]
+        ok = bool((brcs.cpu().numpy() == 0).all()) and all(
+            int(bsizes[k]) == g[0] and ("%08x" % zlib.crc32(bout[k, : g[0]].cpu().numpy().tobytes())) == g[1] for k in range(PB))
+        batched = {"frames_per_gpu_per_launch": PB, "value": round(world * PB * W * H * nb / tb / 1e6, 3), "unit": "Mpixels/s",
+                   "ms_per_launch": round(tb / nb * 1e3, 3), "parity": all_ranks_ok(ok), "frames_checked_per_rank": PB}
+        benc.close()
+        del bf, bout
 
     extras = {}
     if not args.no_extras and args.config == "C2" and device_wl:
@@ -837,6 +868,8 @@ def main():
             line["batch_configs"] = batch_cfgs
         if batch_host:
             line["batch_host"] = batch_host
+        if streaming:
+            line["streaming"] = streaming
         line.update(extras)
         if world == 1 and not args.no_traffic and device_wl:
             ctr, src_note = measure_traffic(args)
