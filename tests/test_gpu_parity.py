@@ -227,6 +227,45 @@ def test_async_halves_equal_the_synchronous_call(oracle):
     enc.close()
 
 
+def test_two_encoders_take_launches_in_turns(oracle):
+    """the streaming pattern of INTEGRATION.md 4 / bench.py `two_launches_in_flight`: two encoders, a plain HIP stream each,
+    launch k is submitted before the host waits for launch k - 1; every stream of every launch equals the oracle's"""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h, st, sg, n, launches = 448, 320, 4, 9, 4, 7
+    quota = 2 * w * h
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    streams = [ctypes.c_void_p() for _ in range(2)]
+    for s_ in streams:
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(s_), 1) == 0
+    encs = [api.Encoder(w, h, 1, st, 0, sg, max_frames=n) for _ in range(2)]
+    frames = [synth.gray_batch(n, w, h, 500 + 10 * k, 1) for k in range(launches)]
+    d_frames = [torch.from_numpy(f.view(np.int16)).to(dev) for f in frames]
+    outs = [torch.zeros((n, quota), dtype=torch.uint8, device=dev) for _ in range(launches)]
+    sizes = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(launches)]
+    rcs = [torch.full((n,), -99, dtype=torch.int32, device=dev) for _ in range(launches)]
+    torch.cuda.synchronize()
+    for k in range(launches):
+        encs[k & 1].encode_device_async_ptrs(d_frames[k].data_ptr(), n, quota, outs[k].data_ptr(), outs[k].stride(0), sizes[k].data_ptr(), rcs[k].data_ptr(),
+                                             streams[k & 1].value)
+        if k:
+            encs[(k - 1) & 1].wait()                   # (launch k - 1 is complete; launch k is in flight)
+            for i in range(n):                           # ... and may be consumed while launch k runs
+                rc, stream, _ = oracle.compress([frames[k - 1][i]], st, 0, sg, quota)
+                assert int(rcs[k - 1][i]) == rc and outs[k - 1][i, : int(sizes[k - 1][i])].cpu().numpy().tobytes() == stream, (k - 1, i)
+    encs[(launches - 1) & 1].wait()
+    for i in range(n):
+        rc, stream, _ = oracle.compress([frames[-1][i]], st, 0, sg, quota)
+        assert int(rcs[-1][i]) == rc and outs[-1][i, : int(sizes[-1][i])].cpu().numpy().tobytes() == stream
+    for e in encs:
+        e.close()
+    for s_ in streams:
+        assert hip.hipStreamDestroy(s_) == 0
+
+
 @pytest.mark.parametrize("sub", ["1", "2", "5", "", "1/2"])
 def test_host_batch_is_pipelined_in_sub_batches_and_exact(oracle, monkeypatch, sub):
     """icerx_compress_batch_uint16_devices: a device's block goes through copy-in / kernels / copy-out streams in
