@@ -856,7 +856,7 @@ def main():
                 pipe += (f"; the dense coding units cut into sub-ranges, {li['sub_range_workgroups']} extra workgroups in the same launch, spliced by "
                          "splice_units_kernel (inside the timed stage)")
             if li["window_coder_beside"]:
-                pipe += "; the all-but-blank units by code_units_list_kernel (the small window coder: two-wave workgroups for a lone frame, one-wave ones in a batch) on a second stream beside it (inside the timed stage)"
+                pipe += "; the all-but-blank units by code_units_list_kernel (the small window coder: four-wave workgroups for a lone frame, one-wave ones in a batch) on a second stream beside it (inside the timed stage)"
             kernel = {0: pipe + "; code_units_wg_kernel in progressive mode", 1: pipe, 2: "code_units_wg_kernel"}[stats["coder_mode"]]
             line["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,

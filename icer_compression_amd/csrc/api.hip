@@ -194,11 +194,14 @@ struct icerx_encoder {
     int split_wgs = 0;                  // staying workgroups of the small coder in a split launch (0: one per compute unit)
     int nosplit_percent = 20;           // split launches: units with at least this share of blank chunks are not cut into sub-ranges (their words stay
                                         // open for long stretches: the pieces would not meet; ICER_HIP_NOSPLIT)
-    int list_waves = 0;                 // wavefronts per workgroup of the list kernel: 0 = by launch (1 for a split launch, 2 for a batch), ICER_HIP_LIST_WAVES
+    int list_waves = 0;                 // wavefronts per workgroup of the list kernel: 0 = by launch (4 for a split launch, 1 for a batch), ICER_HIP_LIST_WAVES = 1 | 2 | 4
     DevBuf<SubDesc> subs;
     DevBuf<uint32_t> sub_order, snap_valid;
     DevBuf<Snapshot> snaps;
     DevBuf<SubRecord> sub_recs;
+#ifdef ICER_EXPERIMENT_PREFIX_CACHE
+    DevBuf<uint32_t> prefix_cache;      // (experiment build only: kernels.hpp SplitLaunch::prefix_cache)
+#endif
     hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
     bool side_stream_borrowed = false;  // ... on a stream another encoder owns (the pooled encoders of a host batch share one)
     hipEvent_t fork = nullptr, join = nullptr;
@@ -434,17 +437,18 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // Which instance: measured (profiles/r04_logs/r04_h_list_waves.log).  A batch runs the ONE-wave instance: C4 + 4.2 %,
         // C5 + 2.0 % -- its list is thousands of all-blank units (a first window, then closed-form runs: nothing for a second
         // wave to do but wait at the barriers), and one resident wave of ~ 180 registers leaves the pipeline's workgroups more
-        // of the compute unit than two of 204.  The launch of a single frame keeps the TWO-wave instance (6.4 against 7.8 ms):
-        // its list is led by a few long 90-95 %-blank chains, where the second wave's chunk is progress.
-        // ICER_HIP_LIST_WAVES=1|2 pins one.
+        // of the compute unit than two of 204.  The launch of a single frame wants MORE waves per listed unit (7.8 ms with one,
+        // 6.4 with two, 6.07 with FOUR, 8.7 with eight -- LDS; profiles/r04_logs/r04_zh_list_kernel_width.log): its list is led by
+        // fifty long mid-sparse chains, where every further wave's chunk of a window is progress.
+        // ICER_HIP_LIST_WAVES=1|2|4 pins one.
         const unsigned list_grid = (unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs);
-        const int list_waves = e->list_waves ? e->list_waves : (split ? 2 : 1);
+        const int list_waves = e->list_waves ? e->list_waves : (split ? 4 : 1);
 #define ICER_LAUNCH_LIST(I, NS)                                                                                                          \
         hipLaunchKernelGGL((code_units_list_kernel<I>), dim3(list_grid), dim3(64 * NS::kWgWaves), sizeof(NS::Shared), e->side_stream,    \
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,     \
                            e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,                     \
                            e->plan.sig_bytes, e->route_list.p, e->route_ctl.p, e->prof.p ? e->prof.p + kProfWgsOffset : nullptr)
-        if (list_waves == 1) ICER_LAUNCH_LIST(WgOne, wg1); else ICER_LAUNCH_LIST(WgSmall, wgs);
+        if (list_waves == 1) ICER_LAUNCH_LIST(WgOne, wg1); else if (list_waves == 4) ICER_LAUNCH_LIST(WgFour, wg4); else ICER_LAUNCH_LIST(WgSmall, wgs);
 #undef ICER_LAUNCH_LIST
         HIP_TRY(hipEventRecord(e->join, e->side_stream));
     }
@@ -457,6 +461,13 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         HIP_TRY(hipMemsetAsync(e->sub_recs.p, 0, (size_t)n_frames * entries * sizeof(SubRecord), st));
         sp.subs = e->subs.p; sp.launch = e->sub_order.p; sp.n_subs = (uint32_t)e->plan.subs.size(); sp.entries = (uint32_t)entries;
         sp.snaps = e->snaps.p; sp.snap_valid = e->snap_valid.p; sp.recs = e->sub_recs.p;
+#ifdef ICER_EXPERIMENT_PREFIX_CACHE
+        if (!e->prefix_cache.p) {
+            if (e->prefix_cache.ensure((size_t)e->max_frames * entries * 36)) return ICER_FATAL_ERROR;
+            HIP_TRY(hipMemsetAsync(e->prefix_cache.p, 0, (size_t)e->max_frames * entries * 36 * sizeof(uint32_t), st));
+        }
+        sp.prefix_cache = getenv("ICER_EXPERIMENT_NO_CACHE") ? nullptr : e->prefix_cache.p;
+#endif
     }
     if (!use_wg) {
         // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
@@ -562,7 +573,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *sw = getenv("ICER_HIP_SPLIT_WGS")) { const int v = atoi(sw); if (v >= 1 && v <= 4096) e->split_wgs = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *ns = getenv("ICER_HIP_NOSPLIT")) { const int v = atoi(ns); if (v >= 1 && v <= 101) e->nosplit_percent = v; }
-    if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2) e->list_waves = v; }
+    if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2 || v == 4) e->list_waves = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
         if (v >= 1 && v <= 24) e->bits_per_pixel = (unsigned)v;
@@ -600,6 +611,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgOne>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg1::Shared)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgFour>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg4::Shared)) != hipSuccess ||
         hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->join, hipEventDisableTiming) != hipSuccess) {

@@ -26,3 +26,17 @@
 #include "coder_wg_impl.hpp"
 #undef ICER_WG_NS
 #pragma pop_macro("ICER_WG_WAVES")
+
+// A fourth instance with FOUR wavefronts per workgroup, icer::wg4 (round 4, last day): the list kernel of a LONE frame.  Its list
+// is led by fifty mid-sparse level-1 units -- one chunk in ten not blank, scattered: chains of 4-6 ms in the two-wave instance
+// and what the whole launch waits for (tools/list_trace.py).  Per wave-cycle the window coder is as efficient there as the
+// pipeline, there are just too few waves on a unit: four waves take four chunks per window and the launch 6.07 instead of
+// 6.38 ms; eight waves need so much LDS that they push the pipeline's workgroups off the compute units (8.7 ms;
+// profiles/r04_logs/r04_zh_list_kernel_width.log).  Batches keep the one-wave instance.
+#pragma push_macro("ICER_WG_WAVES")
+#undef ICER_WG_WAVES
+#define ICER_WG_WAVES 4
+#define ICER_WG_NS wg4
+#include "coder_wg_impl.hpp"
+#undef ICER_WG_NS
+#pragma pop_macro("ICER_WG_WAVES")

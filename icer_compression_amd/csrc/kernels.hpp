@@ -110,6 +110,12 @@ struct SplitLaunch {
     Snapshot *snaps = nullptr;              // [frames][entries][kMaxSnaps]
     uint32_t *snap_valid = nullptr;         // [frames][entries][kMaxSnaps]
     SubRecord *recs = nullptr;              // [frames][entries]
+#ifdef ICER_EXPERIMENT_PREFIX_CACHE
+    // EXPERIMENT, never in the product build (tools/prefix_cache_probe.sh): the counts at every sub-range start, kept from the
+    // launch before -- what the launch would cost if a sub-range's counts came for free.  [frames][entries][36]: 17 zero counts,
+    // 17 totals, -, valid.  Right only while the same frames are coded again, which is all the probe does.
+    uint32_t *prefix_cache = nullptr;
+#endif
 };
 
 // a launch shared by the two coders (route_units_kernel): which one takes a unit
@@ -255,11 +261,28 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         j0 = layout.first[layout.index];
         constexpr uint32_t npw1 = (uint32_t)(WAVES - 1) < kMaxPixelWaves ? (uint32_t)(WAVES - 1) : kMaxPixelWaves;
         const uint32_t k = wave < kCount ? wave : wave - 1u;
+#ifdef ICER_EXPERIMENT_PREFIX_CACHE
+        uint32_t *pc = sp.prefix_cache ? sp.prefix_cache + (((size_t)frame * sp.entries + u.sub_entry + layout.index) * 36u) : nullptr;
+        const bool cached = pc && pc[35] == 1u;
+        if (cached) {
+            const int lane_ = (int)(threadIdx.x & 63);
+            if (wave == kCount && lane_ < 17) { cs.czer = pc[lane_]; cs.ctot = pc[17 + lane_]; }
+        } else {
+#endif
         if (wave == kCount) count_wave_run(s, a, cs, 0, j0, npw1, true);
         else if (k < npw1) {
             PixelWave pw;
             pixel_wave_run(s, a, pw, 0, j0, k, npw1, true);
         }
+#ifdef ICER_EXPERIMENT_PREFIX_CACHE
+            if (pc && wave == kCount) {
+                const int lane_ = (int)(threadIdx.x & 63);
+                if (lane_ < 17) { pc[lane_] = cs.czer; pc[17 + lane_] = cs.ctot; }
+                __threadfence();
+                if (lane_ == 0) pc[35] = 1u;
+            }
+        }
+#endif
         __syncthreads();
         const uint32_t ab1 = s.abort;               // (a bounded spin expired in the prefix pass: the workgroup reports failure)
         __syncthreads();
@@ -502,6 +525,14 @@ struct WgSmall {
     static __device__ __forceinline__ void init(Shared &s, const UnitArgs &a) { wgs::unit_state_init(s, a); }
     static __device__ __forceinline__ bool spent(const UnitArgs &a) { return wgs::quota_already_spent(a); }
     static __device__ __forceinline__ uint32_t code(Shared &s, const UnitArgs &a, Wave &r) { return wgs::code_unit_wg(s, a, r); }
+};
+
+struct WgFour {
+    using Shared = wg4::Shared; using UnitArgs = wg4::UnitArgs; using Wave = wg4::Wave;
+    static constexpr uint32_t kWaves = wg4::kWgWaves;
+    static __device__ __forceinline__ void init(Shared &s, const UnitArgs &a) { wg4::unit_state_init(s, a); }
+    static __device__ __forceinline__ bool spent(const UnitArgs &a) { return wg4::quota_already_spent(a); }
+    static __device__ __forceinline__ uint32_t code(Shared &s, const UnitArgs &a, Wave &r) { return wg4::code_unit_wg(s, a, r); }
 };
 
 struct WgOne {

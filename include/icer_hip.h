@@ -219,11 +219,11 @@ int icerx_info(icerx_encoder *enc, uint32_t *units_per_frame, uint32_t *slot_bit
  * out[3] = coder selection in force (0 automatic, 1 pipeline only, 2 workgroup coder only; env ICER_HIP_CODER=pipe|wg).
  * Automatic: the wave pipeline; the workgroup coder for byte quotas below half a byte per sample (progressive mode);
  * in launches of two or more planes (frames x channels), and of one gray frame whose dense units are cut into sub-ranges
- * (icerx_encoder_launch_info), the coding units with >= 95 % (90 %) blank chunks go to the workgroup coder's two-wave
- * instance, which runs beside the pipeline kernel (env ICER_HIP_HYBRID=<percent, 0 = off>, ICER_HIP_HYBRID_FRAMES=<n>).
+ * (icerx_encoder_launch_info), the coding units with >= 95 % (90 %) blank chunks go to a small instance of the workgroup coder
+ * (one wave per workgroup in a batch, four for a lone frame; ICER_HIP_LIST_WAVES=1|2|4), which runs beside the pipeline kernel (env ICER_HIP_HYBRID=<percent, 0 = off>, ICER_HIP_HYBRID_FRAMES=<n>).
  * None of this changes a byte of the streams. */
 int icerx_encoder_stats(icerx_encoder *enc, uint64_t out[4]);
-/* out[0] = coding units (summed over frames and calls) that went to the workgroup coder's two-wave instance beside the
+/* out[0] = coding units (summed over frames and calls) that went to the workgroup coder's small instance beside the
  * pipeline kernel, out[1] = encode calls in which that routing was active (see above: launches of >= 2 planes). */
 int icerx_encoder_routing(icerx_encoder *enc, uint64_t out[2]);
 /* The shape of the encoder's last launch: out[0] = 1 if its dense coding units were cut into sub-ranges coded by a workgroup

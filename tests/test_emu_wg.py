@@ -14,10 +14,10 @@ from icer_compression_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=[16, 2, 1], ids=["16_waves", "2_waves", "1_wave"])
+@pytest.fixture(scope="module", params=[16, 4, 2, 1], ids=["16_waves", "4_waves", "2_waves", "1_wave"])
 def wg(request):
-    """the instances the product builds: icer::wg (16 wavefronts per workgroup), icer::wgs (2, coder_wg_small.hpp) and
-    icer::wg1 (a single wavefront: no barrier skew at all, coder_wg_small.hpp)"""
+    """the instances the product builds: icer::wg (16 wavefronts per workgroup), icer::wg4 (4: the list kernel of a lone frame),
+    icer::wgs (2) and icer::wg1 (a single wavefront: no barrier skew at all) -- coder_wg_small.hpp"""
     src = os.path.join(ROOT, "tests", "emu", "wg_emu.cpp")
     so = os.path.join(ROOT, "tests", "emu", f"libwg_emu_{request.param}.so")
     csrc = os.path.join(ROOT, "icer_compression_amd", "csrc")

@@ -30,7 +30,7 @@ def main():
     lib.icerx_prof_read_wgs(enc.handle, out, 1)
     li = enc.launch_info()
     t = np.array(list(out), dtype=np.float64).reshape(9, 32)
-    waves = 2
+    waves = int(os.environ.get("ICER_HIP_LIST_WAVES", "4"))          # (the instance the launch of a lone frame uses)
     print(f"{w}x{h} st={st} seg={sg}, launch {li}: level-1 units coded by the two-wave window coder, sums over the units of a plane")
     print("(cycles of BOTH waves added up; a unit's wall time is about the sum / 2 / units of the plane)")
     print(" " * 34 + "  ".join(f"{'lsb%d' % p:>9s}" for p in range(9)))
