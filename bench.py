@@ -202,13 +202,14 @@ class HostWorkload:
     """the same block of frames in page-locked HOST memory, coded by icerx_compress_batch_uint16_devices on this rank's
     device: copy-in, kernels and copy-out of sub-batches overlap on three streams (csrc/api.hip)"""
 
-    def __init__(self, name, rank, dev, local_rank, first=None, count=None):
+    def __init__(self, name, rank, dev, local_rank, first=None, count=None, devices="own"):
         import torch
         from icer_compression_amd import api, synth
         self.api = api
         self.name, self.cfg = name, CONFIGS[name]
         c = self.cfg
         self.w, self.h, self.local_rank = c["w"], c["h"], local_rank
+        self.devices = [local_rank] if devices == "own" else devices      # None = icerx_compress_batch_uint16(n_gpus = 0): every visible device
         self.quota = 2 * self.w * self.h
         self.first = (0 if name == "C2" else (rank * c["per_gpu"]) % c["total"]) if first is None else first
         self.B = c["per_gpu"] if count is None else count
@@ -229,7 +230,7 @@ class HostWorkload:
 
     def step(self):
         c = self.cfg
-        rc = self.api.compress_batch(self.frames, c["stages"], FILT, c["segments"], self.quota, self.out, self.sizes, self.rcs, devices=[self.local_rank])
+        rc = self.api.compress_batch(self.frames, c["stages"], FILT, c["segments"], self.quota, self.out, self.sizes, self.rcs, devices=self.devices)
         if rc != 0:
             raise RuntimeError(f"icerx_compress_batch_uint16_devices rc={rc}: {self.api.load_library().icerx_last_error().decode()}")
 
@@ -558,25 +559,99 @@ def batch_decode_object(bw):
             "parity": bool(ok), "parity_note": "every decoded frame equals the encoder's input (lossless streams)"}
 
 
+def c2_per_rank_object(rank, dev, local_rank, barrier, all_ranks_ok, world, red_dev, steps=10):
+    """secondary object of an N > 1 line: the lone C2 frame (BASELINE configs[1], the N = 1 headline) on every rank at once"""
+    from icer_compression_amd import shard
+    w2 = Workload("C2", rank, dev, local_rank)
+    w2.step()
+    bad, _ = w2.verify()
+    t_el, _, st_ms, calls = run_timed(w2, steps, 2, barrier, dev, red_dev)
+    bad2, _ = w2.verify()
+    ok = all_ranks_ok(not bad and not bad2)
+    w2.close()
+    return {"workload": "BASELINE configs[1]: one 4096x4096 frame per rank per step (weak: every rank the same frame), device-resident",
+            "value": round(world * w2.w * w2.h * steps / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(t_el / steps * 1e3, 4), "steps": steps,
+            "n_gpus": world, "parity": ok, "code_units_ms": round(st_ms.get("code_units", 0.0) / max(calls, 1), 4)}
+
+
+def one_process_object(name, dev, local_rank, calls=2):
+    """SURVEY 8(b) "our additions": ONE process, every visible device -- icerx_compress_batch_uint16(..., n_gpus = 0) on the WHOLE
+    batch of configuration `name` in page-locked host memory (a worker thread and a pool of sub-batch encoders per device inside
+    the library, no torch.distributed); every frame against its reference golden"""
+    import torch
+    hw = HostWorkload(name, 0, dev, local_rank, first=0, count=CONFIGS[name]["total"], devices=None)
+    try:
+        hw.step()
+        bad, nbytes = hw.verify()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            hw.step()
+        t_el = time.perf_counter() - t0
+        bad2, _ = hw.verify()
+        c = hw.cfg
+        return {"workload": f"{c['what']}: all {c['total']} x {c['w']}x{c['h']} frames in page-locked host memory -> streams in page-locked host memory, "
+                            "icerx_compress_batch_uint16(n_gpus = 0) from one process over every visible device",
+                "value": round(c["total"] * c["w"] * c["h"] * calls / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_call": round(t_el / calls * 1e3, 3), "calls": calls,
+                "devices": torch.cuda.device_count(), "logical_devices": int(os.environ.get("ICER_HIP_VIRTUAL_DEVICES", "0")) or torch.cuda.device_count(),
+                "frames_checked": c["total"], "frames_not_bit_exact": bad + [b for b in bad2 if b not in bad], "parity": not bad and not bad2,
+                "pinned": hw.pinned, "bytes_out": nbytes}
+    finally:
+        hw.close()
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: re-run this very command line as N ranks through
+    torch.distributed.run on 127.0.0.1 (a free port), one rank per GPU; with fewer visible GPUs than ranks the ranks share
+    devices (the dry-run path of main(): logical devices + gloo).  Returns the launcher's exit code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=list(CONFIGS), default="C2", help="timed workload (default C2 = BASELINE configs[1])")
+    ap.add_argument("--config", choices=list(CONFIGS), default=None, help="timed workload (default: C2 = BASELINE configs[1] on one GPU; "
+                    "C4, the 256-frame batch split over the ranks, with --gpus N > 1)")
     ap.add_argument("--sweep", action="store_true", help="with --config C4|C5 on one GPU: run the share of every rank of an 8-GPU job in turn "
                     "(all 256 / 64 frames), every frame against its reference golden")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="strong (--config C4|C5): the WHOLE batch split over the ranks, "
-                    "N = 1 codes all of it; weak: every rank its 1/8 share")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="strong (--config C4|C5): the WHOLE batch split over the ranks, "
+                    "N = 1 codes all of it; weak: every rank its 1/8 share (default: weak on one GPU and for C2, strong for a batch with --gpus N > 1)")
     ap.add_argument("--source", choices=["device", "host"], default="device", help="host: frames and streams in page-locked host memory, "
                     "icerx_compress_batch_uint16_devices (PCIe overlapped with the kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-configs", action="store_true", help="skip the secondary C4 / C5 figures")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip C3, decode, batch_host and host_buffers (the child runs under rocprofv3)")
+    ap.add_argument("--launch-probe", action="store_true", help="launcher check only (runs without a GPU): the ranks rendezvous over gloo, reduce their "
+                    "shard sizes of the timed configuration and rank 0 prints one JSON line; no encode")
+    ap.add_argument("--all-extras", action="store_true", help="with --gpus N > 1: also the host-fed, decode and in-flight legs (default: N = 1 only)")
+    ap.add_argument("--no-one-process", action="store_true", help="skip the one_process object (icerx_compress_batch_uint16 over every visible device)")
     ap.add_argument("--batched-probe", type=int, default=8,
                     help="also report C2 throughput with this many frames per launch (secondary figure, 0 = skip)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    # N > 1: the whole C4 batch (256 frames, BASELINE configs[3]: what north_star says scales) split over the ranks, every frame
+    # checked; the lone C2 frame per rank is a secondary object of that line.  N = 1: C2, the configuration the metric is quoted on.
+    if args.config is None:
+        args.config = "C2" if args.gpus == 1 else "C4"
+    if args.scaling is None:
+        args.scaling = "strong" if (args.gpus > 1 and args.config != "C2") else "weak"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly (`python bench.py --gpus N`): this process becomes the launcher of one rank per GPU (SURVEY 8e) and
+        # passes the ranks' output through; under torch.distributed.run (the driver's form) WORLD_SIZE is set and we are a rank.
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -586,11 +661,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run "
-                             f"--nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` plainly (it launches its own ranks) "
+                         f"or under torch.distributed.run --nproc-per-node N")
+    if args.launch_probe:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        lo, hi = shard.shard_range(CONFIGS[args.config]["total"], rank, world)
+        t = torch.tensor([hi - lo, rank], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_probe": True, "n_gpus": world, "config": args.config, "scaling": args.scaling,
+                              "frames_over_ranks": int(t[0]), "rank_sum": int(t[1])}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if world > 1 and not args.all_extras:
+        args.no_extras = True                                     # an N > 1 line: the headline, batch_configs, c2_per_rank, one_process
     # One process per GPU.  A dry run of the multi-rank path on a box with FEWER GPUs than ranks (gpurun exposes one) maps
     # rank r onto physical device r % devices: the library's logical devices (ICER_HIP_VIRTUAL_DEVICES) and the gloo backend
     # for the three collectives of this file (RCCL refuses two ranks on one device).  Nothing else changes.
@@ -821,6 +912,41 @@ def main():
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 extras["decode"] = {"error": repr(exc)}
 
+    # secondary objects of an N > 1 line whose headline is a batch: the lone C2 frame on every rank; at N = 1 (headline C2): the
+    # WHOLE C4 batch on this one GPU -- the N = 1 point of the strong-scaling curve the N > 1 lines continue
+    c2_rank = scaling_ref = None
+    if device_wl and have_bg:
+        if world > 1 and args.config != "C2":
+            try:
+                c2_rank = c2_per_rank_object(rank, dev, local_rank, barrier, all_ranks_ok, world, red_dev)
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                c2_rank = {"error": repr(exc)}
+        elif world == 1 and args.config == "C2" and not args.no_batch_configs:
+            try:
+                sw = Workload("C4", 0, dev, local_rank, first=0, count=CONFIGS["C4"]["total"])
+                sw.step()
+                bads, _ = sw.verify()
+                t_el, _, _, _ = run_timed(sw, 2, 0, barrier, dev, red_dev)
+                bads2, _ = sw.verify()
+                scaling_ref = {"workload": "BASELINE configs[3], the headline of the N > 1 lines (--gpus N: the 256 frames split over N ranks), at N = 1: "
+                                           "all 256 x 2048x2048 frames on this GPU per step, 8 launches of 32",
+                               "value": round(CONFIGS["C4"]["total"] * sw.w * sw.h * 2 / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(t_el / 2 * 1e3, 3),
+                               "steps": 2, "n_gpus": 1, "scaling": "strong", "frames_checked": sw.B, "parity": not bads and not bads2}
+                sw.close()
+                del sw
+                torch.cuda.empty_cache()
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                scaling_ref = {"error": repr(exc)}
+    one_proc = None
+    if device_wl and have_bg and not args.no_one_process and not args.no_batch_configs:
+        barrier()                                                  # the other ranks wait here while rank 0's library drives every device
+        if rank == 0:
+            try:
+                one_proc = one_process_object("C4", dev, local_rank)
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                one_proc = {"error": repr(exc)}
+        barrier()
+
     if rank == 0:
         n_pix = world * B * W * H * args.steps
         if args.scaling == "strong":
@@ -829,7 +955,7 @@ def main():
         src = ("input and output stream resident in HBM" if device_wl else
                "frames and streams in page-locked HOST memory (icerx_compress_batch_uint16_devices: PCIe overlapped with the kernels)")
         line = {
-            "metric": "Mpixels/s encode (bit-exact), 4096x4096 gray", "value": round(value, 3), "unit": "Mpixels/s",
+            "metric": f"Mpixels/s encode (bit-exact), {W}x{H} gray", "value": round(value, 3), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": f"{cfg['what']}: {B} x {W}x{H} 8-bit gray (uint16 API) on rank 0 per step"
@@ -868,6 +994,15 @@ def main():
             line["batch_configs"] = batch_cfgs
         if batch_host:
             line["batch_host"] = batch_host
+        if c2_rank:
+            line["c2_per_rank"] = c2_rank
+        if scaling_ref:
+            line["scaling_reference"] = scaling_ref
+        if one_proc:
+            line["one_process"] = one_proc
+        if world > 1 and args.config != "C2":
+            line["scaling_note"] = ("the N > 1 headline is the C4 batch split over the ranks (strong scaling); its N = 1 point is "
+                                    "`scaling_reference` of the --gpus 1 line (same 256 frames on one GPU), not that line's C2 `value`")
         if streaming:
             line["streaming"] = streaming
         line.update(extras)

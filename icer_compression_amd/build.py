@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 
@@ -9,16 +10,33 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libicer_hip.so")
 SOURCES = ["api.hip"]
-# the decoder's own sources do not go into libicer_hip.so; every other file under csrc/ is a dependency
-DEC_ONLY = {"decoder.hip", "decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp"}
+INCLUDE = os.path.join(PKG, "..", "include")
+
+
+def _deps(source: str):
+    """every file a translation unit pulls in, transitively, by following its quoted #include lines (csrc/ and include/):
+    the dependency list of a library is read from the sources, never kept by hand"""
+    seen, todo = [], [os.path.join(CSRC, source)]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f, errors="replace") as fh:
+            for m in re.finditer(r'^\s*#\s*include\s*"([^"]+)"', fh.read(), re.M):
+                for base in (os.path.dirname(f), CSRC, INCLUDE):
+                    cand = os.path.join(base, m.group(1))
+                    if os.path.exists(cand):
+                        todo.append(cand)
+                        break
+    return seen
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f not in DEC_ONLY] + [os.path.join(PKG, "..", "include", "icer_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for s in SOURCES for d in _deps(s))
 
 
 def _tuning_flags():
@@ -57,12 +75,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 DEC_LIB = os.path.join(PKG, "libicer_hip_dec.so")
-DEC_DEPS = ["decoder.hip", "decoder_core.hpp", "decoder_plan.hpp", "decoder_wave.hpp", "wave.hpp", "plan.hpp", "icer_tables.hpp"]
 
 
 def build_decoder_library(force: bool = False, verbose: bool = False) -> str:
     """libicer_hip_dec.so: the decoder, a separate library -- see include/icer_hip_dec.h."""
-    deps = [os.path.join(CSRC, f) for f in DEC_DEPS] + [os.path.join(PKG, "..", "include", "icer_hip_dec.h")]
+    deps = _deps("decoder.hip")
     if not force and os.path.exists(DEC_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(DEC_LIB) for d in deps):
         return DEC_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

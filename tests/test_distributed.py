@@ -88,3 +88,24 @@ def test_batch_configurations_cover_every_frame_once_and_have_goldens():
             seen += list(range(lo, lo + c["per_gpu"]))
         assert seen == list(range(c["total"]))
     assert bench.frame_goldens("C2", 5) == [(g["C2_4096_gray_5st_10seg"]["size"], g["C2_4096_gray_5st_10seg"]["crc32"])]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` started plainly (no torch.distributed.run around it, WORLD_SIZE unset) becomes the launcher
+    of N ranks: --launch-probe makes the ranks rendezvous over gloo on 127.0.0.1, reduce their shares of the timed
+    configuration and print one line -- the N > 1 default is the whole C4 batch split over the ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for n in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launch-probe"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+        assert len(lines) == 1                                            # rank 0 alone reports
+        assert lines[0] == {"launch_probe": True, "n_gpus": n, "config": "C4", "scaling": "strong", "frames_over_ranks": 256,
+                            "rank_sum": n * (n - 1) // 2}
+    # one GPU: no launcher, C2, weak
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--launch-probe"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["config"] == "C2"
