@@ -179,6 +179,7 @@ struct icerx_encoder {
     DevBuf<uint64_t> final_off;
     DevBuf<uint8_t> slots;
     DevBuf<uint8_t> sig;                // chunk tables (chunk_sig_kernel), max_frames * plan.sig_bytes
+    DevBuf<uint32_t> sig_hist;          // per frame and family: chunks by the bit plane from which they are blank, 16 entries (chunk_sig_kernel -> route_units_kernel)
     DevBuf<uint32_t> sig_blocks;        // Plan::sig_blocks on the device
     DevBuf<uint8_t> route;              // max_frames * units: the coder of each unit when both share a launch
     DevBuf<uint32_t> route_list, route_ctl;   // the units of the workgroup coder (frame * units + unit), [length, cursor]
@@ -417,15 +418,16 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     e->last_split = split;
     const bool hybrid = split || (e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames);
     if (use_wg || hybrid) {
+        if (hybrid) HIP_TRY(hipMemsetAsync(e->sig_hist.p, 0, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,
-                           e->plan.sig_bytes);
+                           e->plan.sig_bytes, hybrid ? e->sig_hist.p : nullptr, e->plan.n_families);
     }
     const uint8_t *route = nullptr;
     e->last_routed = hybrid;
     if (hybrid) {
         HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(route_units_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig.p, e->plan.sig_bytes,
+        hipLaunchKernelGGL(route_units_kernel, dim3((unsigned)((n_units + 255) / 256), n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig_hist.p, e->plan.n_families,
                            (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p,
                            (uint32_t)e->nosplit_percent);
         route = e->route.p;
@@ -598,7 +600,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
-        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure((size_t)max_frames * n_units) || e->route_ctl.ensure(2) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure((size_t)max_frames * n_units) || e->route_ctl.ensure(2) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) || e->sig_hist.ensure((size_t)max_frames * e->plan.n_families * 16 + 16) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -637,7 +639,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
-    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->sig_blocks.release(); e->route.release(); e->route_list.release(); e->route_ctl.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->sig_hist.release(); e->sig_blocks.release(); e->route.release(); e->route_list.release(); e->route_ctl.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     e->subs.release(); e->sub_order.release(); e->snap_valid.release(); e->snaps.release(); e->sub_recs.release();

@@ -428,7 +428,7 @@ splice_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const 
 __global__ void __launch_bounds__(256)
 chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, int channels,
                  const UnitDesc *__restrict__ units, const uint32_t *__restrict__ blocks, const int *__restrict__ frame_skip,
-                 uint8_t *__restrict__ sig, size_t sig_frame_stride)
+                 uint8_t *__restrict__ sig, size_t sig_frame_stride, uint32_t *__restrict__ hist, uint32_t n_families)
 {
     const UnitDesc u = units[blocks[2u * blockIdx.x]];
     const uint32_t frame = blockIdx.y, nchunks = (u.w * u.h + 63u) / 64u, first = blocks[2u * blockIdx.x + 1u] * 64u;
@@ -444,6 +444,7 @@ chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w
     uint32_t j = first + wave * 16u;
     uint32_t np = j * 64u + lane;
     uint32_t r = np / sw, c = np - r * sw;
+    uint32_t mine = 0;                                           // lane v: this wave's chunks whose value is v (the family's histogram)
     for (uint32_t i = 0; i < 16u && j < nchunks; i++, j++) {
         const bool in_ = np < npix;
         const uint32_t r_ = in_ ? r : 0u, c_ = in_ ? c : 0u;
@@ -463,41 +464,42 @@ chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w
         for (uint32_t step = 8u; step; step >>= 1) tmax += __ballot(in_ && t >= tmax + step) ? step : 0u;
         const bool partial = __ballot(!in_) != 0ull;                 // a chunk with fewer than 64 pixels is never blank
         if (lane == 0u) out[j] = (uint8_t)(partial ? 255u : tmax);
+        mine += (!partial && lane == tmax) ? 1u : 0u;
         np += 64u;
         c += 64u;
         if (sw >= 64u) { if (c >= sw) { c -= sw; r++; } }
         else { r = np / sw; c = np - r * sw; }
     }
+    // hist[v] = chunks of the family that are blank from bit plane v on and at none below (route_units_kernel sums the
+    // entries up to a unit's plane instead of reading the whole table once per plane)
+    if (hist && lane < 16u && mine) atomicAdd(&hist[((size_t)frame * n_families + u.family) * 16u + lane], mine);
 }
 
 // Which coder takes a unit when both share a launch: the pipeline (code_units_kernel) is the faster one on dense bit planes,
 // the workgroup coder (code_units_wg_kernel) on planes that are mostly runs of blank chunks, which it closes in closed form
-// (wg::blank_run).  One workgroup per unit and frame counts the unit's blank chunks in the chunk table:
+// (wg::blank_run).  One thread per unit and frame takes the unit's number of blank chunks from the histogram chunk_sig_kernel left
+// for the unit's family (round 5; before: a workgroup per unit counted them in the chunk table, 0.40 ms of a C4 launch):
 // route = windows when at least `percent` % of the chunks are blank; those units are also appended to a list
-// (list_ctl[0] = its length).  grid = (units, frames), block = 256.
+// (list_ctl[0] = its length).  grid = (ceil(units / 256), frames), block = 256.
 __global__ void __launch_bounds__(256)
-route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const uint8_t *__restrict__ sig, size_t sig_frame_stride,
+route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const uint32_t *__restrict__ hist, uint32_t n_families,
                    uint32_t percent, uint32_t min_chunks, uint8_t *__restrict__ route, uint32_t *__restrict__ list,
                    uint32_t *__restrict__ list_ctl, uint32_t nosplit_percent)
 {
-    const UnitDesc u = units[blockIdx.x];
-    const uint32_t frame = blockIdx.y, nfull = (u.w * u.h) / 64u, nchunks = (u.w * u.h + 63u) / 64u;
-    const uint8_t *t = sig + (size_t)frame * sig_frame_stride + u.sig_off;
-    uint32_t blank = 0;
-    for (uint32_t j = threadIdx.x; j < nfull; j += 256u) blank += (uint32_t)u.lsb >= (uint32_t)t[j] ? 1u : 0u;
-    __shared__ uint32_t total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    for (int o = 32; o > 0; o >>= 1) blank += (uint32_t)__shfl_xor((int)blank, o);
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(&total, blank);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const bool windows = nchunks >= min_chunks && total * 100u >= percent * nchunks;
-        // (a unit with a fifth of its chunks blank and more: its words stay open for long stretches, sub-ranges would not
-        // meet -- see coder_core.hpp "Sub-ranges")
-        route[(size_t)frame * n_units + blockIdx.x] = windows ? kRouteWindows : (total * 100u >= nosplit_percent * nchunks ? kRouteNoSplit : kRoutePipeline);
-        if (windows) list[atomicAdd(&list_ctl[0], 1u)] = frame * n_units + blockIdx.x;      // (code_units_wg_list_kernel)
-    }
+    const uint32_t ui = blockIdx.x * 256u + threadIdx.x, frame = blockIdx.y;
+    if (ui >= n_units) return;
+    const UnitDesc u = units[ui];
+    const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
+    // blank chunks of the unit = chunks of its family that are blank from a plane <= the unit's on (chunk_sig_kernel's histogram;
+    // a last chunk with fewer than 64 pixels is in no entry: never blank)
+    const uint32_t *h = hist + ((size_t)frame * n_families + u.family) * 16u;
+    uint32_t total = 0;
+    for (uint32_t v = 0; v < 16u; v++) total += v <= u.lsb ? h[v] : 0u;
+    const bool windows = nchunks >= min_chunks && total * 100u >= percent * nchunks;
+    // (a unit with a fifth of its chunks blank and more: its words stay open for long stretches, sub-ranges would not
+    // meet -- see coder_core.hpp "Sub-ranges")
+    route[(size_t)frame * n_units + ui] = windows ? kRouteWindows : (total * 100u >= nosplit_percent * nchunks ? kRouteNoSplit : kRoutePipeline);
+    if (windows) list[atomicAdd(&list_ctl[0], 1u)] = frame * n_units + ui;      // (code_units_list_kernel)
 }
 
 // ------------------------------------------------------------------------------------------ coder (workgroup windows)

@@ -38,7 +38,7 @@ struct UnitDesc {
     uint32_t n_sub;                 // sub-ranges the unit is cut into when a launch is too small to fill the chip (coder_core.hpp "Sub-ranges"); <= 1: none
     uint32_t sub_first;             // index of its sub-range 1 in Plan::subs (sub-ranges 1 .. n_sub-1 are consecutive)
     uint32_t sub_entry;             // index of its sub-range 0 in the per-frame arrays of records / snapshots (n_sub consecutive entries)
-    uint32_t pad_;
+    uint32_t family;                // index of the unit's family (its chunk table, its histogram of blank planes: Plan::n_families per frame)
 };
 
 // One extra workgroup of a split unit: sub-range `index` >= 1 (device-visible)
@@ -161,6 +161,7 @@ struct Plan {
     std::vector<uint32_t> work_order;      // launch order (largest units first) -> index into units
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
     size_t sig_bytes = 0;                  // per-frame chunk-table area (UnitDesc::sig_off)
+    uint32_t n_families = 0;               // families per frame (UnitDesc::family): (channel, level, subband, segment)
     std::vector<uint32_t> sig_blocks;      // the work list of chunk_sig_kernel: pairs (unit, block of 64 chunks), one family member (plane 0) each
     std::vector<SubDesc> subs;             // sub-range workgroups of split launches: unit order, a unit's sub-ranges 1 .. n_sub-1 consecutive
     std::vector<uint32_t> split_launch;    // launch order of a split launch: bit 31 set = sub-range workgroup (index into subs), else a unit;
@@ -275,13 +276,18 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
     // chunk tables: one per family, in unit order
     {
         std::vector<int64_t> off_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
+        std::vector<uint32_t> index_of_family(off_of_family.size(), 0u);
         size_t off = 0;
+        uint32_t families = 0;
         for (UnitDesc &u : p->units) {
-            int64_t &o = off_of_family[((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg];
-            if (o < 0) { o = (int64_t)off; off += (((size_t)u.w * u.h + 63) / 64 + 3) & ~(size_t)3; }
+            const size_t key = ((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg;
+            int64_t &o = off_of_family[key];
+            if (o < 0) { o = (int64_t)off; off += (((size_t)u.w * u.h + 63) / 64 + 3) & ~(size_t)3; index_of_family[key] = families++; }
             u.sig_off = (uint32_t)o;
+            u.family = index_of_family[key];
         }
         p->sig_bytes = off;
+        p->n_families = families;
         p->sig_blocks.clear();
         for (size_t i = 0; i < p->units.size(); i++) {
             const UnitDesc &u = p->units[i];
