@@ -27,6 +27,12 @@
 #endif
 #include "icer_tables.hpp"
 
+#if defined(__HIPCC__)
+#define DWT_UNROLL _Pragma("unroll")
+#else
+#define DWT_UNROLL
+#endif
+
 namespace icer {
 
 constexpr int kTileKX = 64, kTileKY = 16;                    // output pairs per tile
@@ -34,14 +40,19 @@ constexpr int kWinW = 2 * kTileKX + 8, kWinH = 2 * kTileKY + 8;
 constexpr int kWinPX = kWinW / 2, kWinPY = kWinH / 2;        // pairs per window row / column (the window starts 2 pairs before the tile)
 constexpr int kTileThreads = 256;
 
+// (two blocks of LDS, each used twice: 21.8 KB per workgroup, seven workgroups per compute unit; round 4: 32 KB, five)
 struct DwtTileShared {
     union {
-        int16_t win[kWinH][kWinW];          // input window (dead once the row lows / differences exist)
-        struct { int16_t lo[2][kWinPY][kTileKX], di[2][kWinPY][kTileKX]; } col;   // column step 1: [low / high column set]
+        int16_t win[kWinH][kWinW];          // input window (dead once the row lows / differences exist) ...
+        struct {                            // ... then the row pass result: lows / highs of the tile's pair columns, per window row
+            int16_t lo[kWinH][kTileKX];
+            int16_t hi[kWinH][kTileKX];
+        };
     };
-    int16_t rlo[kWinH][kWinPX], rdi[kWinH][kWinPX];   // row step 1: lows and differences of every pair of every window row
-    int16_t lo[kWinH][kTileKX];             // row pass result: lows / highs of the tile's pair columns, per window row
-    int16_t hi[kWinH][kTileKX];
+    union {
+        struct { int16_t rlo[kWinH][kWinPX], rdi[kWinH][kWinPX]; };   // row step 1: lows and differences of every pair of every window row (dead after row step 2) ...
+        struct { int16_t lo[2][kWinPY][kTileKX], di[2][kWinPY][kTileKX]; } col;   // ... then column step 1: [low / high column set]
+    };
 };
 
 struct DwtStageArgs {
@@ -236,23 +247,36 @@ DWT_HD bool dwt_tile_cols_step2(DwtTileShared &sh, const DwtStageArgs &a, int tx
 // ------------------------------------------------------------------------------------------ interior tiles
 // A tile whose whole input window lies inside the region and none of whose pairs sits at a line end -- nine tenths of the
 // tiles of a large stage -- needs none of the generic phases' bounds tests, clamps and boundary rules, and its phases map
-// threads to (row, pair) by shifts: 256 threads = 4 rows x 64 pairs per step.  Lows and differences travel as ONE 32-bit
+// threads to (row, pair of pairs) by shifts: 256 threads = 8 rows x 32 x 2 pairs per step.  Lows and differences travel as ONE 32-bit
 // LDS word per pair (low | difference << 16), so row step 2 reads four words where the generic phase reads six halves, and
 // row step 1 is done on the loaded words themselves: the input window never goes to LDS.  Same arithmetic, same results
 // (tests/test_emu_pipeline.py runs both paths against the oracle).
+struct alignas(8) DwtW2 { uint32_t x, y; };           // two adjacent pairs' words: one 64-bit LDS / global access
 struct DwtFastShared {
-    uint32_t rw[kWinH][kWinPX];           // row step 1: low | dif << 16 of every pair of every window row
-    uint32_t rr[kWinH][kTileKX];          // row pass: low | high << 16 of the tile's pair columns, per window row
-    uint32_t cl[kWinPY][kTileKX];         // column step 1 down the low columns: low | dif << 16
-    uint32_t chh[kWinPY][kTileKX];        // ... and down the high columns
+    union {
+        alignas(8) uint32_t rw[kWinH][kWinPX];        // row step 1: low | dif << 16 of every pair of every window row (dead after row step 2) ...
+        struct {                                      // ... then column step 1, low | dif << 16:
+            alignas(8) uint32_t cl[kWinPY][kTileKX];  //     down the low columns
+            alignas(8) uint32_t chh[kWinPY][kTileKX]; //     down the high columns
+        };
+    };
+    alignas(8) uint32_t rr[kWinH][kTileKX];           // row pass: low | high << 16 of the tile's pair columns, per window row
 };
+static_assert(sizeof(DwtFastShared) <= sizeof(DwtTileShared), "the kernel's LDS block is the generic path's");
 
+// Round 5: a thread owns TWO adjacent pairs in every phase (64-bit loads from HBM and LDS, 32-bit stores of two coefficients:
+// half the memory instructions per byte), the loads of a phase are issued together before anything waits for one of them
+// (the loops are unrolled by hand: left as loops the compiler kept one load in flight per thread, ten round trips to HBM in a
+// row per tile), and the column pass keeps a thread on two adjacent output rows (five LDS rows read for two, not eight).
 DWT_HD bool dwt_tile_is_interior(const DwtStageArgs &a, int tx, int ty)
 {
     const int x0 = tile_x0(tx), y0 = tile_y0(ty);
-    // (window inside the region; then every pair k of the tile has 2 <= k, k + 1 < n / 2 - 1 + 1, i.e. only the general rule applies)
-    return x0 >= 0 && y0 >= 0 && x0 + kWinW <= a.cw && y0 + kWinH <= a.ch && (a.src_stride & 1u) == 0u &&
-           (reinterpret_cast<uintptr_t>(a.src) & 3u) == 0u;
+    const int nlw = (a.cw + 1) >> 1;
+    // (window inside the region; then every pair k of the tile has 2 <= k, k + 1 < n / 2 - 1 + 1, i.e. only the general rule applies;
+    // rows of the source 8-byte aligned for the 64-bit loads, every destination 4-byte aligned at even columns for the 32-bit stores)
+    return x0 >= 0 && y0 >= 0 && x0 + kWinW <= a.cw && y0 + kWinH <= a.ch && (a.src_stride & 3u) == 0u &&
+           (reinterpret_cast<uintptr_t>(a.src) & 7u) == 0u && (a.coef_stride & 1u) == 0u && (reinterpret_cast<uintptr_t>(a.coef) & 3u) == 0u &&
+           (a.ll_stride & 1u) == 0u && (reinterpret_cast<uintptr_t>(a.ll) & 3u) == 0u && (nlw & 1) == 0;
 }
 DWT_HD uint32_t dwt_pack(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 DWT_HD int32_t dwt_lo16(uint32_t w) { return (int32_t)(int16_t)(w & 0xFFFFu); }
@@ -274,64 +298,104 @@ DWT_HD int32_t dwt_fast_step2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3
     *ovf |= h < -lim - 1 || h > lim;
     return h;
 }
+DWT_HD DwtW2 dwt_ld2(const uint32_t *p) { return *reinterpret_cast<const DwtW2 *>(p); }
+DWT_HD void dwt_st2(uint32_t *p, uint32_t x, uint32_t y) { DwtW2 v; v.x = x; v.y = y; *reinterpret_cast<DwtW2 *>(p) = v; }
 
-// phase F1, thread t: load the window as 32-bit words and leave low | dif of every pair in LDS
+constexpr int kFastRowGroups = kTileThreads / 32;                 // 8: a thread = (row group, pair of pairs)
+constexpr int kFastRowIters = kWinH / kFastRowGroups;             // 5 window rows per thread in the row phases
+static_assert(kWinH % kFastRowGroups == 0 && kTileKY == 2 * kFastRowGroups && kWinPX == kTileKX + 4, "thread map of the interior path");
+
+// phase F1, thread t: load the window as 64-bit words (two pairs) and leave low | dif of every pair in LDS
 DWT_HD bool dwt_fast_rows_step1(DwtFastShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
 {
     const int x0 = tile_x0(tx), y0 = tile_y0(ty);
-    const uint32_t *base = reinterpret_cast<const uint32_t *>(a.src + (size_t)y0 * a.src_stride + x0);
-    const size_t row_words = a.src_stride >> 1;
-    const int p = t & 63, r0 = t >> 6;
+    const DwtW2 *base = reinterpret_cast<const DwtW2 *>(a.src + (size_t)y0 * a.src_stride + x0);
+    const size_t row_w2 = a.src_stride >> 2;
+    const int pp = t & 31, rg = t >> 5;
     bool ovf = false;
-    for (int r = r0; r < kWinH; r += 4) {
-        const uint32_t w = base[(size_t)r * row_words + p];
-        sh.rw[r][p] = dwt_fast_step1((int16_t)(w & 0xFFFFu), (int16_t)(w >> 16), a.lim, &ovf);
+    DwtW2 v[kFastRowIters];
+    DWT_UNROLL
+    for (int i = 0; i < kFastRowIters; i++) v[i] = base[(size_t)(rg + kFastRowGroups * i) * row_w2 + pp];       // (all in flight together)
+    const bool extra = t < 2 * kWinH;                         // the four pairs beyond the 64th of every row: two lanes per row
+    const int er = t >> 1, ep = 32 + (t & 1);
+    DwtW2 ve; ve.x = 0; ve.y = 0;
+    if (extra) ve = base[(size_t)er * row_w2 + ep];
+    DWT_UNROLL
+    for (int i = 0; i < kFastRowIters; i++) {
+        const int r = rg + kFastRowGroups * i;
+        dwt_st2(&sh.rw[r][2 * pp], dwt_fast_step1((int16_t)(v[i].x & 0xFFFFu), (int16_t)(v[i].x >> 16), a.lim, &ovf),
+                dwt_fast_step1((int16_t)(v[i].y & 0xFFFFu), (int16_t)(v[i].y >> 16), a.lim, &ovf));
     }
-    if (t < 4 * kWinH) {                                      // the four pairs beyond the 64th of every row
-        const int r = t >> 2, q = 64 + (t & 3);
-        const uint32_t w = base[(size_t)r * row_words + q];
-        sh.rw[r][q] = dwt_fast_step1((int16_t)(w & 0xFFFFu), (int16_t)(w >> 16), a.lim, &ovf);
-    }
+    if (extra)
+        dwt_st2(&sh.rw[er][2 * ep], dwt_fast_step1((int16_t)(ve.x & 0xFFFFu), (int16_t)(ve.x >> 16), a.lim, &ovf),
+                dwt_fast_step1((int16_t)(ve.y & 0xFFFFu), (int16_t)(ve.y >> 16), a.lim, &ovf));
     return ovf;
 }
 // phase F2: row highs of the tile's 64 pair columns for every window row (pair kk of the tile = window pair kk + 2)
 DWT_HD bool dwt_fast_rows_step2(DwtFastShared &sh, const DwtStageArgs &a, int t)
 {
-    const int kk = t & 63, r0 = t >> 6;
+    const int kk = 2 * (t & 31), rg = t >> 5;
     bool ovf = false;
-    for (int r = r0; r < kWinH; r += 4) {
-        const uint32_t *q = &sh.rw[r][kk];
-        const int32_t h = dwt_fast_step2(q[0], q[1], q[2], q[3], a.f, a.lim, &ovf);
-        sh.rr[r][kk] = dwt_pack(dwt_lo16(q[2]), h);
+    DwtW2 q0[kFastRowIters], q1[kFastRowIters], q2[kFastRowIters];
+    DWT_UNROLL
+    for (int i = 0; i < kFastRowIters; i++) {
+        const uint32_t *q = &sh.rw[rg + kFastRowGroups * i][kk];
+        q0[i] = dwt_ld2(q); q1[i] = dwt_ld2(q + 2); q2[i] = dwt_ld2(q + 4);
+    }
+    DWT_UNROLL
+    for (int i = 0; i < kFastRowIters; i++) {
+        const int32_t h0 = dwt_fast_step2(q0[i].x, q0[i].y, q1[i].x, q1[i].y, a.f, a.lim, &ovf);
+        const int32_t h1 = dwt_fast_step2(q0[i].y, q1[i].x, q1[i].y, q2[i].x, a.f, a.lim, &ovf);
+        dwt_st2(&sh.rr[rg + kFastRowGroups * i][kk], dwt_pack(dwt_lo16(q1[i].x), h0), dwt_pack(dwt_lo16(q1[i].y), h1));
     }
     return ovf;
 }
-// phase F3: step 1 down the low and the high columns (window pair rows q = 0 .. 19)
+// phase F3: step 1 down the low and the high columns (window pair rows q = 0 .. 19) -- into the LDS block the row words lived in
 DWT_HD bool dwt_fast_cols_step1(DwtFastShared &sh, const DwtStageArgs &a, int t)
 {
-    const int kk = t & 63, q0 = t >> 6;
+    const int kk = 2 * (t & 31), rg = t >> 5;
     bool ovf = false;
-    for (int q = q0; q < kWinPY; q += 4) {
-        const uint32_t u = sh.rr[2 * q][kk], v = sh.rr[2 * q + 1][kk];
-        sh.cl[q][kk] = dwt_fast_step1(dwt_lo16(u), dwt_lo16(v), a.lim, &ovf);
-        sh.chh[q][kk] = dwt_fast_step1(dwt_hi16(u), dwt_hi16(v), a.lim, &ovf);
+    constexpr int iters = (kWinPY + kFastRowGroups - 1) / kFastRowGroups;     // 3 (8 + 8 + 4 rows)
+    DwtW2 u[iters], v[iters];
+    DWT_UNROLL
+    for (int i = 0; i < iters; i++) {
+        const int q = rg + kFastRowGroups * i;
+        if (q < kWinPY) { u[i] = dwt_ld2(&sh.rr[2 * q][kk]); v[i] = dwt_ld2(&sh.rr[2 * q + 1][kk]); }
+        else { u[i].x = u[i].y = v[i].x = v[i].y = 0; }
+    }
+    DWT_UNROLL
+    for (int i = 0; i < iters; i++) {
+        const int q = rg + kFastRowGroups * i;
+        if (q >= kWinPY) continue;
+        dwt_st2(&sh.cl[q][kk], dwt_fast_step1(dwt_lo16(u[i].x), dwt_lo16(v[i].x), a.lim, &ovf), dwt_fast_step1(dwt_lo16(u[i].y), dwt_lo16(v[i].y), a.lim, &ovf));
+        dwt_st2(&sh.chh[q][kk], dwt_fast_step1(dwt_hi16(u[i].x), dwt_hi16(v[i].x), a.lim, &ovf), dwt_fast_step1(dwt_hi16(u[i].y), dwt_hi16(v[i].y), a.lim, &ovf));
     }
     return ovf;
 }
-// phase F4: column highs and the four stores (tile pair row jj = window pair row jj + 2)
+// phase F4: column highs and the four stores, two adjacent coefficients per store (tile pair row jj = window pair row jj + 2);
+// a thread takes the two adjacent pair rows 2 * rg, 2 * rg + 1
 DWT_HD bool dwt_fast_cols_step2(DwtFastShared &sh, const DwtStageArgs &a, int tx, int ty, int t)
 {
     const int nlw = (a.cw + 1) >> 1, nlh = (a.ch + 1) >> 1;
-    const int kk = t & 63, j0 = t >> 6, kx = tx * kTileKX + kk;
+    const int kk = 2 * (t & 31), jj0 = 2 * (t >> 5), kx = tx * kTileKX + kk;
     bool ovf = false;
-    for (int jj = j0; jj < kTileKY; jj += 4) {
-        const int ky = ty * kTileKY + jj;
-        const int32_t hl = dwt_fast_step2(sh.cl[jj][kk], sh.cl[jj + 1][kk], sh.cl[jj + 2][kk], sh.cl[jj + 3][kk], a.f, a.lim, &ovf);
-        const int32_t hh = dwt_fast_step2(sh.chh[jj][kk], sh.chh[jj + 1][kk], sh.chh[jj + 2][kk], sh.chh[jj + 3][kk], a.f, a.lim, &ovf);
-        a.ll[(size_t)ky * a.ll_stride + kx] = (int16_t)dwt_lo16(sh.cl[jj + 2][kk]);
-        a.coef[(size_t)(nlh + ky) * a.coef_stride + kx] = to_coder_word((int16_t)hl, a.sm);
-        a.coef[(size_t)ky * a.coef_stride + nlw + kx] = to_coder_word((int16_t)dwt_lo16(sh.chh[jj + 2][kk]), a.sm);
-        a.coef[(size_t)(nlh + ky) * a.coef_stride + nlw + kx] = to_coder_word((int16_t)hh, a.sm);
+    DwtW2 c[5], h[5];
+    DWT_UNROLL
+    for (int i = 0; i < 5; i++) { c[i] = dwt_ld2(&sh.cl[jj0 + i][kk]); h[i] = dwt_ld2(&sh.chh[jj0 + i][kk]); }
+    DWT_UNROLL
+    for (int d = 0; d < 2; d++) {
+        const int ky = ty * kTileKY + jj0 + d;
+        const int32_t lh0 = dwt_fast_step2(c[d].x, c[d + 1].x, c[d + 2].x, c[d + 3].x, a.f, a.lim, &ovf);
+        const int32_t lh1 = dwt_fast_step2(c[d].y, c[d + 1].y, c[d + 2].y, c[d + 3].y, a.f, a.lim, &ovf);
+        const int32_t hh0 = dwt_fast_step2(h[d].x, h[d + 1].x, h[d + 2].x, h[d + 3].x, a.f, a.lim, &ovf);
+        const int32_t hh1 = dwt_fast_step2(h[d].y, h[d + 1].y, h[d + 2].y, h[d + 3].y, a.f, a.lim, &ovf);
+        *reinterpret_cast<uint32_t *>(a.ll + (size_t)ky * a.ll_stride + kx) = dwt_pack(dwt_lo16(c[d + 2].x), dwt_lo16(c[d + 2].y));
+        *reinterpret_cast<uint32_t *>(a.coef + (size_t)(nlh + ky) * a.coef_stride + kx) =
+            dwt_pack(to_coder_word((int16_t)lh0, a.sm), to_coder_word((int16_t)lh1, a.sm));
+        *reinterpret_cast<uint32_t *>(a.coef + (size_t)ky * a.coef_stride + nlw + kx) =
+            dwt_pack(to_coder_word((int16_t)dwt_lo16(h[d + 2].x), a.sm), to_coder_word((int16_t)dwt_lo16(h[d + 2].y), a.sm));
+        *reinterpret_cast<uint32_t *>(a.coef + (size_t)(nlh + ky) * a.coef_stride + nlw + kx) =
+            dwt_pack(to_coder_word((int16_t)hh0, a.sm), to_coder_word((int16_t)hh1, a.sm));
     }
     return ovf;
 }
