@@ -144,7 +144,15 @@ bool pin_thread_near_device(int physical)
         for (long k = lo; k <= hi && k < CPU_SETSIZE; k++) { CPU_SET((int)k, &set); n_set++; }
         while (*c == ',' || *c == '\n' || *c == ' ') c++;
     }
-    return n_set > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
+    if (n_set == 0) return false;
+    // never widen what the caller was given (taskset, numactl, cgroup cpusets, isolcpus): the node's cores AND the thread's
+    // current mask; an empty intersection leaves the thread where it is
+    cpu_set_t cur;
+    CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof cur, &cur) != 0) return false;
+    CPU_AND(&set, &set, &cur);
+    if (CPU_COUNT(&set) == 0) return false;
+    return sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
 }  // namespace
@@ -480,7 +488,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // A launch of one frame is bound by the chains of its largest units, not by occupancy: it runs the build without the
         // register budget, padded to the LDS footprint of the queue-depth-8 build (49 KiB; the padding is static: the
         // `dynamic LDS' launch parameter had no effect on a kernel that declares none).  Measured on the headline frame: 37 KiB
-        // 7.5 ms, 45.6 KiB 6.8 ms, 49.5 KiB 6.7-6.8 ms (profiles/r03_logs/r03_aa.log, r03_ab.log).
+        // 7.5 ms, 45.6 KiB 6.8 ms, 49.5 KiB 6.7-6.8 ms (profiles/archive/r03_logs/r03_aa.log, r03_ab.log).
         const bool lone = n_frames * C <= e->split_frames;
 #define ICER_LAUNCH_PIPE(NW, OCC, PAD)                                                                                                       \
         hipLaunchKernelGGL((code_units_kernel<NW, OCC, PAD>), dim3(n_units + sp.n_subs, n_frames), dim3(64 * NW), 0, st,                     \
@@ -950,7 +958,7 @@ void warn_hw_queues_once()
 {
     static std::atomic<bool> said{false};
     if (getenv("GPU_MAX_HW_QUEUES") || said.exchange(true)) return;
-    fprintf(stderr, "libicer_hip: GPU_MAX_HW_QUEUES is not set: the host-fed batch pipeline uses 5 streams per device and the HIP runtime's "
+    fprintf(stderr, "libicer_hip: GPU_MAX_HW_QUEUES is not set: the host-fed batch pipeline uses 6 streams per device (copy-in, copy-out, three encoder streams and the side stream their list kernels share) and the HIP runtime's "
                     "default of 4 hardware queues makes them take turns (measured 0.80-0.85 x instead of 0.92-0.95 x the device-resident rate); "
                     "set GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP\n");
 }
@@ -1390,6 +1398,7 @@ int icerx_prof_read_wgs(icerx_encoder *e, uint64_t out[9 * 32], int reset)
 // lsb | level << 8 | subband << 16 | segment << 24 | chunks << 32
 int icerx_prof_list_trace(icerx_encoder *e, uint64_t *out, int n_entries, int reset)
 {
+    if (!e || !out || n_entries < 0) return ICER_INVALID_INPUT;
     HIP_TRY(hipSetDevice(e->device));
     if (n_entries > kListTrace) n_entries = kListTrace;
     HIP_TRY(hipMemcpy(out, e->prof.p + kProfWgsOffset + 9 * 32, (size_t)n_entries * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1399,6 +1408,7 @@ int icerx_prof_list_trace(icerx_encoder *e, uint64_t *out, int n_entries, int re
 // per workgroup of frame 0 (launch position b < kTraceUnits): start / end (100 MHz wall clock), HW_ID | XCC_ID << 32, unit index
 int icerx_prof_trace(icerx_encoder *e, uint64_t *out, int n_blocks)
 {
+    if (!e || !out || n_blocks < 0) return ICER_INVALID_INPUT;
     HIP_TRY(hipSetDevice(e->device));
     if (n_blocks > kTraceUnits) n_blocks = kTraceUnits;
     HIP_TRY(hipMemcpy(out, e->prof.p + 9 * 32, (size_t)n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));

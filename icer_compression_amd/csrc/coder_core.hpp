@@ -194,7 +194,7 @@ constexpr uint32_t kSpinLimit = 1u << 25;
 #define ICER_QUEUE_DEPTH 4
 #endif
 constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between the waves of a unit.  4: 37 KiB of LDS per workgroup, four per
-                                                     // CU (8: 48 KiB, three per CU).  Round 3, profiles/r03_logs/r03_x.log: the depth itself does
+                                                     // CU (8: 48 KiB, three per CU).  Round 3, profiles/archive/r03_logs/r03_x.log: the depth itself does
                                                      // not matter (4 and 8 at three per CU are equal on C2 and C4); four workgroups per CU are
                                                      // + 7 % on C4, + 3 % on C5 -- and - 14 % on a lone frame, which therefore pads its LDS (api.hip)
 // The pixel stage keeps no state from chunk to chunk, so several wavefronts can share it: wave k of `npw` takes the
@@ -1969,7 +1969,7 @@ ICER_DEV void drain_wave_run(CoderShared &s, const UnitArgs &a, uint32_t max_ste
         // this wave could see a hold it had already acknowledged (hs = 23), then -- the merge wave releasing that hold and
         // ending the unit in between -- drain_exit = 1, acknowledge the stale 23 and leave, the merge wave waiting for 25 until
         // its spin bound: the rare coding-unit time-out (one unit in ~10^5 whose last chunk took the exact path; seen once
-        // more at four workgroups per compute unit: profiles/r03_logs/r03_full_bench_timeout.err).  With this order
+        // more at four workgroups per compute unit: profiles/archive/r03_logs/r03_full_bench_timeout.err).  With this order
         // drain_exit = 1 implies that the hold_seq read afterwards is the final request or the even value before it.
         const uint32_t ex_ = ICER_LOAD_CNT(s.drain_exit);
         ICER_ACQUIRE()

@@ -260,6 +260,7 @@ struct icerx_decoder {
     Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list, err;
     int n_cus = 256;                   // compute units of the device
     bool planes_lds_raised = false;    // decode_chains_planes_kernel has been granted more than 64 KiB of dynamic LDS
+    bool planes_lds_refused = false;   // ... or the runtime refused: chains that need more than 48 KiB go to the lane-per-plane kernel from then on
     // the lane-per-plane kernel is launched once per size class of row ring, side by side (decode_batch)
     static constexpr int kRingClasses = 4;
     hipStream_t side[kRingClasses] = {};
@@ -406,7 +407,21 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
 #ifdef ICER_HOST_MOCK
         const size_t planes_lds_limit = (size_t)1 << 20;
 #else
-        const size_t planes_lds_limit = 150u * 1024u;
+        // what a workgroup of this device may take (gfx950: 160 KiB), less 10 KiB for the kernel's static block and the runtime
+        size_t planes_lds_limit = 0;
+        {
+            int max_lds = 0;
+            if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d->device) != hipSuccess) { (void)hipGetLastError(); max_lds = 64 * 1024; }
+            planes_lds_limit = max_lds > 10 * 1024 ? (size_t)max_lds - 10u * 1024u : 0u;
+            // more than 48 KiB of dynamic LDS has to be granted; a runtime / device that refuses loses nothing but the fast kernel
+            // for the chains that need it (they go to decode_chains_wave_kernel below)
+            if (planes_lds_limit > 48u * 1024u && !d->planes_lds_raised && !d->planes_lds_refused) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_chains_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_lds_limit) == hipSuccess)
+                    d->planes_lds_raised = true;
+                else { (void)hipGetLastError(); d->planes_lds_refused = true; }
+            }
+            if (d->planes_lds_refused) planes_lds_limit = std::min(planes_lds_limit, (size_t)48u * 1024u);
+        }
 #endif
         std::stable_partition(chains.begin(), chains.end(), [&](const ChainDesc &c) {
             return want_planes && c.fast && frames[c.frame].stream_len >= 4u && pw_lds_bytes(c.w, nplanes) <= planes_lds_limit; });
@@ -454,12 +469,6 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         if (n_fast) {
             HIP_TRY(ensure(d->err, sizeof(uint32_t)));
             HIP_TRY(hipMemset(d->err.p, 0, sizeof(uint32_t)));
-#ifndef ICER_HOST_MOCK
-            if (planes_lds > 48u * 1024u && !d->planes_lds_raised) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_chains_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_lds_limit));
-                d->planes_lds_raised = true;
-            }
-#endif
             ICER_LAUNCH_PLANES(decode_chains_planes_kernel, n_fast, planes_lds, d_planes, frame_stride, channels, (const ChainDesc *)d->chains.p,
                                d_data, d_frames, (const DecoderTables *)d->dtables.p, nplanes, sign_bit, (uint32_t *)d->err.p);
             HIP_TRY(hipGetLastError());

@@ -42,8 +42,13 @@
 // M0 / lane-select hazards itself.  (The first versions used a compare of the lane number and a select: three vector
 // instructions per write on gfx9 -- a second scalar operand does not fit a VALU instruction's constant bus, so the value went
 // through a v_mov -- and, worse, the compiler then computed the value's whole uniform chain on the vector unit.)
+// (a compiler that has the builtin uses it; either way `hipcc -S` of decoder.hip must show v_writelane_b32: 405 of them with ROCm 7.2, whose clang has no such builtin)
+#if defined(__has_builtin) && __has_builtin(__builtin_amdgcn_writelane)
+#define PW_WRITELANE(X, L, V) { (X) = (uint32_t)__builtin_amdgcn_writelane((int)(V), (int)(L), (int)(X)); }
+#else
 extern "C" __device__ int pw_writelane_i32(int value, int lane_select, int old) __asm("llvm.amdgcn.writelane.i32");
 #define PW_WRITELANE(X, L, V) { (X) = (uint32_t)pw_writelane_i32((int)(V), (int)(L), (int)(X)); }
+#endif
 #define PW_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define PW_RCP(x) __builtin_amdgcn_rcpf(x)
 // (a minimum of three uniform values: the instruction selector takes v_min3_u32 -- there is no scalar one -- and the pass that

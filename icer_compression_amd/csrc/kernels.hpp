@@ -130,7 +130,7 @@ constexpr uint8_t kRoutePipeline = 0, kRouteWindows = 1, kRouteNoSplit = 2;   //
 // OCC = resident waves per SIMD the register budget is cut for.  8 (64 VGPRs; with 37 KiB of LDS: four workgroups of the
 // small shape per compute unit) is what a batch wants: + 7 % on C4, + 3 % on C5 over three per CU.  The budget costs ~ 280
 // more SGPR spills (v_writelane / v_readlane), and a lone frame -- bound by the chains of its largest units, not by
-// occupancy -- is 14 % slower with it: it runs the OCC = 1 build (profiles/r03_logs/r03_x.log, r03_y.log).
+// occupancy -- is 14 % slower with it: it runs the OCC = 1 build (profiles/archive/r03_logs/r03_x.log, r03_y.log).
 // LDS_PAD = bytes of LDS the workgroup takes on top of what it uses (single-frame launches, api.hip enqueue).
 template <int WAVES, int OCC, int LDS_PAD>
 __global__ void __launch_bounds__(64 * WAVES, OCC)

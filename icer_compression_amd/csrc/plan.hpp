@@ -54,6 +54,30 @@ struct SegmentGrid {
     uint16_t w, h, r, c, r_t, h_t, x_t, c_t0, y_t, r_t0, x_b, c_b0, y_b, r_b0, s;
 };
 
+// XCD-aware launch orders: entries are dealt to one list per XCD by family and the lists interleaved, position 8k + x = the
+// k-th entry of list x (workgroup b runs on XCD b % 8).  A new family goes to the list that is shortest so far, and once a list
+// has run out its positions are filled from the longest remaining one, so position % 8 keeps naming the XCD to the very end.
+inline int shortest_list(const std::vector<std::vector<uint32_t>> &lists)
+{
+    int best = 0;
+    for (int x = 1; x < (int)lists.size(); x++) if (lists[x].size() < lists[best].size()) best = x;
+    return best;
+}
+inline void interleave_lists(const std::vector<std::vector<uint32_t>> &lists, std::vector<uint32_t> *out)
+{
+    size_t total = 0;
+    for (const auto &l : lists) total += l.size();
+    std::vector<size_t> pos(lists.size(), 0);
+    out->clear();
+    while (out->size() < total)
+        for (size_t x = 0; x < lists.size() && out->size() < total; x++) {
+            size_t y = x;
+            if (pos[y] >= lists[y].size())
+                for (size_t z = 0; z < lists.size(); z++) if (lists[z].size() - pos[z] > lists[y].size() - pos[y]) y = z;
+            out->push_back(lists[y][pos[y]++]);
+        }
+}
+
 inline size_t dim_low(size_t d, int level) { return (d + ((size_t(1) << level) - 1)) >> level; }
 inline size_t dim_high(size_t d, int level) { return dim_low(d, level - 1) / 2; }
 
@@ -261,17 +285,12 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
         auto family = [&](const UnitDesc &u) { return ((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg; };
         std::vector<int> xcd_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
         std::vector<std::vector<uint32_t>> lists(kXcds);
-        int next_xcd = 0;
         for (uint32_t u : by_size) {                                 // families meet their XCD in size order
             int &x = xcd_of_family[family(p->units[u])];
-            if (x < 0) { x = next_xcd; next_xcd = (next_xcd + 1) % kXcds; }
+            if (x < 0) x = shortest_list(lists);
             lists[x].push_back(u);
         }
-        p->work_order.clear();
-        for (size_t k = 0; p->work_order.size() < n; k++)
-            for (int x = 0; x < kXcds; x++)
-                if (k < lists[x].size()) p->work_order.push_back(lists[x][k]);
-                // (a shorter list simply stops contributing; the tail then drifts off the b % 8 pattern, harmless)
+        interleave_lists(lists, &p->work_order);
     }
     // chunk tables: one per family, in unit order
     {
@@ -371,16 +390,12 @@ inline void assign_slots(Plan *p, size_t quota, unsigned bits_per_pixel, uint32_
         };
         std::vector<int> xcd_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
         std::vector<std::vector<uint32_t>> lists(kXcds);
-        int next_xcd = 0;
         for (const auto &c : cost) {
             int &x = xcd_of_family[family(c.second)];
-            if (x < 0) { x = next_xcd; next_xcd = (next_xcd + 1) % kXcds; }
+            if (x < 0) x = shortest_list(lists);
             lists[x].push_back(c.second);
         }
-        p->split_launch.clear();
-        for (size_t k = 0; p->split_launch.size() < cost.size(); k++)
-            for (int x = 0; x < kXcds; x++)
-                if (k < lists[x].size()) p->split_launch.push_back(lists[x][k]);
+        interleave_lists(lists, &p->split_launch);
     }
 }
 

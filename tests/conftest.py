@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-# the host-fed batch tests keep five streams per device busy: more hardware queues than the HIP runtime's default of 4 (a
+# the host-fed batch tests keep six streams per device busy: more hardware queues than the HIP runtime's default of 4 (a
 # process-wide setting, read once when the runtime starts; the library itself never touches the environment)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

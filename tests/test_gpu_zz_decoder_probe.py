@@ -1,5 +1,5 @@
 """The plain-C decode example (tests/c_abi/dropin_decode_example.c) against libicer_hip_dec.so, every decode kernel, on the
-configurations of the decoder's first GPU run (profiles/r01_decoder_first_gpu_run.log): 16-bit gray frames, lossless streams.
+configurations of the decoder's first GPU run (profiles/archive/r01_decoder_first_gpu_run.log): 16-bit gray frames, lossless streams.
 The example runs in a child process, so a fault in the decoder cannot take the test session with it.  (The wide decoder suite
 -- YUV, uint8, damaged streams, goldens, the batch object -- is tests/test_gpu_decoder.py, also in the default `-m gpu` run.)
 """

@@ -10,7 +10,7 @@ ICER_ACQUIRE site, nothing else changes) and checks, in the ISA of code_units_ke
   WAIT     the site's poll loop (ds_read of the counter, compare, branch, s_sleep) ends with an `s_waitcnt lgkmcnt(0)` and
            no LDS read of anything but the polled words precedes the marker's end, i.e. no payload read was hoisted above
            the acquire.
-Writes profiles/r03_handoff_isa_audit.md.   python tools/handoff_isa_audit.py        (no GPU needed)"""
+Writes profiles/archive/r03_handoff_isa_audit.md.   python tools/handoff_isa_audit.py        (no GPU needed)"""
 import os
 import re
 import subprocess

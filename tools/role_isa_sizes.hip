@@ -1,6 +1,6 @@
 // tools/role_isa_sizes.hip -- measurement aid, not part of the library: every role of the wave pipeline as a kernel of its own,
 // for static ISA sizes (hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only tools/role_isa_sizes.hip;
-// profiles/r02_pipeline_role_isa_static.md)
+// profiles/archive/r02_pipeline_role_isa_static.md)
 #include <hip/hip_runtime.h>
 #include "../icer_compression_amd/csrc/assemble_core.hpp"
 #include "../icer_compression_amd/csrc/coder_core.hpp"
