@@ -54,15 +54,12 @@ struct SegmentGrid {
     uint16_t w, h, r, c, r_t, h_t, x_t, c_t0, y_t, r_t0, x_b, c_b0, y_b, r_b0, s;
 };
 
-// XCD-aware launch orders: entries are dealt to one list per XCD by family and the lists interleaved, position 8k + x = the
-// k-th entry of list x (workgroup b runs on XCD b % 8).  A new family goes to the list that is shortest so far, and once a list
-// has run out its positions are filled from the longest remaining one, so position % 8 keeps naming the XCD to the very end.
-inline int shortest_list(const std::vector<std::vector<uint32_t>> &lists)
-{
-    int best = 0;
-    for (int x = 1; x < (int)lists.size(); x++) if (lists[x].size() < lists[best].size()) best = x;
-    return best;
-}
+// XCD-aware launch orders: entries are dealt to one list per XCD by family (families in turn, in the order they are met) and the
+// lists interleaved, position 8k + x = the k-th entry of list x (workgroup b runs on XCD b % 8).  Once a list has run out its
+// positions are filled from the longest remaining one, so position % 8 keeps naming the XCD of every entry that is not borrowed.
+// (Dealing a new family to the list that is shortest so far, as a review suggested, measured badly: the lists' lengths at the
+// moment a family is first met say little about their final lengths -- 216 of C2's 1 440 units ended up off their family's
+// XCD against 0 with families dealt in turn, and the launch order lost its cost order: C2 10.9 ms against 6.1.)
 inline void interleave_lists(const std::vector<std::vector<uint32_t>> &lists, std::vector<uint32_t> *out)
 {
     size_t total = 0;
@@ -285,9 +282,10 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
         auto family = [&](const UnitDesc &u) { return ((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg; };
         std::vector<int> xcd_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
         std::vector<std::vector<uint32_t>> lists(kXcds);
+        int next_xcd = 0;
         for (uint32_t u : by_size) {                                 // families meet their XCD in size order
             int &x = xcd_of_family[family(p->units[u])];
-            if (x < 0) x = shortest_list(lists);
+            if (x < 0) { x = next_xcd; next_xcd = (next_xcd + 1) % kXcds; }
             lists[x].push_back(u);
         }
         interleave_lists(lists, &p->work_order);
@@ -390,9 +388,10 @@ inline void assign_slots(Plan *p, size_t quota, unsigned bits_per_pixel, uint32_
         };
         std::vector<int> xcd_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
         std::vector<std::vector<uint32_t>> lists(kXcds);
+        int next_xcd = 0;
         for (const auto &c : cost) {
             int &x = xcd_of_family[family(c.second)];
-            if (x < 0) x = shortest_list(lists);
+            if (x < 0) { x = next_xcd; next_xcd = (next_xcd + 1) % kXcds; }
             lists[x].push_back(c.second);
         }
         interleave_lists(lists, &p->split_launch);
