@@ -218,6 +218,7 @@ struct icerx_encoder {
     hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
     int hybrid_wgs = 1;                 // staying workgroups of the small coder per compute unit (ICER_HIP_HYBRID_WGS)
+    int list_grid = 0;                  // ... or their number outright in a batch launch (ICER_HIP_LIST_GRID; 0: per compute unit as above)
     int hybrid_frames = 2;              // ... in launches of at least this many planes (frames x channels; ICER_HIP_HYBRID_FRAMES): one gray frame alone is bound by its dense units
     DevBuf<CoderTables> tables;
     // host-API staging
@@ -451,7 +452,8 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // 6.4 with two, 6.07 with FOUR, 8.7 with eight -- LDS; profiles/r04_logs/r04_zh_list_kernel_width.log): its list is led by
         // fifty long mid-sparse chains, where every further wave's chunk of a window is progress.
         // ICER_HIP_LIST_WAVES=1|2|4 pins one.
-        const unsigned list_grid = (unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs);
+        unsigned list_grid = (unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs);
+        if (!split && e->list_grid) list_grid = (unsigned)e->list_grid;
         const int list_waves = e->list_waves ? e->list_waves : (split ? 4 : 1);
 #define ICER_LAUNCH_LIST(I, NS)                                                                                                          \
         hipLaunchKernelGGL((code_units_list_kernel<I>), dim3(list_grid), dim3(64 * NS::kWgWaves), sizeof(NS::Shared), e->side_stream,    \
@@ -576,6 +578,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
     if (const char *hy = getenv("ICER_HIP_HYBRID")) { const int v = atoi(hy); if (v >= 0 && v <= 100) e->hybrid_percent = v; }
     if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
+    if (const char *lg = getenv("ICER_HIP_LIST_GRID")) { const int v = atoi(lg); if (v >= 1 && v <= 65536) e->list_grid = v; }
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }
     if (const char *sh = getenv("ICER_HIP_SPLIT_HYBRID")) { const int v = atoi(sh); if (v >= 1 && v <= 101) e->split_hybrid_percent = v; }     // (101: no unit goes to the small coder)

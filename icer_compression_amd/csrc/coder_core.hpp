@@ -540,7 +540,7 @@ ICER_DEV bool flush_stage(CoderShared &s, const UnitArgs &a, bool final_partial)
         if (lane == 0) s.flushed_words = last;
     }
     WAVE_SYNC();
-    // a unit whose complete bytes reach the capacity can never fit (see P3 in DESIGN.md)
+    // a unit whose complete bytes reach the capacity can never fit (P3 of SURVEY.md 2.3; HISTORY.md 3)
     return fits && (bp >> 3) < a.cap_words * 4u;
 }
 

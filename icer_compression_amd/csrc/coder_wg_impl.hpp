@@ -376,7 +376,7 @@ ICER_DEV bool flush_stage(Shared &s, const UnitArgs &a, bool final_partial)
         if (lane == 0) s.flushed_words = last;
     }
     WAVE_SYNC();
-    // a unit whose complete bytes reach the capacity can never fit (see P3 in DESIGN.md)
+    // a unit whose complete bytes reach the capacity can never fit (P3 of SURVEY.md 2.3; HISTORY.md 3)
     return fits && (bp >> 3) < a.cap_words * 4u;
 }
 
@@ -1658,7 +1658,7 @@ ICER_DEV void store_stage_words(Shared &s, const UnitArgs &a, Wave &R, uint32_t 
         }
     }
     R.flushed_words = last;
-    // a unit whose complete bytes reach the capacity can never fit (see P3 in DESIGN.md)
+    // a unit whose complete bytes reach the capacity can never fit (P3 of SURVEY.md 2.3; HISTORY.md 3)
     if (!(fits && (R.bitpos >> 3) < a.cap_words * 4u)) R.too_big = 1u;
 }
 

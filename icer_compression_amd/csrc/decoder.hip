@@ -5,7 +5,7 @@
 //   chains of all streams (one wavefront per chain; one thread per chain with ICER_DEC_WAVE=0) | sign-magnitude
 //   removal + LL mean | inverse DWT, one level at a time, one thread per line, all frames of a geometry per launch
 //   | clamp, narrow, copy back.
-// First version: correctness before speed; every loop is bounded by the stream / image size and no
+// First version: correctness before speed (HISTORY.md 6b (summary: DESIGN.md 8)); every loop is bounded by the stream / image size and no
 // kernel waits on another thread.
 #ifdef ICER_HOST_MOCK
 #define ICER_LAUNCH_PLANES(kernel, grid, shmem, ...) ICER_LAUNCH_WAVE(kernel, grid, shmem, __VA_ARGS__)

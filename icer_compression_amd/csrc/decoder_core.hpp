@@ -4,7 +4,7 @@
 //
 // STATUS: bit-exact against the decoder oracle on the CPU build (tests/test_emu_decoder.py) and on an MI355X
 // (tests/test_gpu_decoder.py, default-on in the GPU gate); two decode kernels use it: one thread per chain (decoder.hip) and
-// one wavefront per chain with a lane per bit plane (decoder_wave.hpp, the default).  Numbers: DESIGN.md 6.2 / 6b.  It is
+// one wavefront per chain with a lane per bit plane (decoder_wave.hpp, the default).  Numbers: HISTORY.md 6.2 / 6b.  It is
 // not part of libicer_hip.so.
 //
 // Restates, per segment ("chain": the bit planes of one segment of one subband of one channel, top plane first):
@@ -13,7 +13,7 @@
 //   plane loop             icer_decompress_partition_uint16/_uint8  icer_partition.c:427-443
 // and per line of a level:
 //   inverse lifting step   icer_inverse_wavelet_transform_1d_uint16/_uint8   icer_wavelet.c:467-550 / :298-383
-// The quirks listed in DESIGN.md 6b (no end-of-packet check, one-code-word packets refused, "2048 code words ago"
+// The quirks listed in HISTORY.md 6b (summary: DESIGN.md 8) (no end-of-packet check, one-code-word packets refused, "2048 code words ago"
 // flush rule, filter C, the uint8 interleave of odd lines) are reproduced.
 #pragma once
 #include <stdint.h>

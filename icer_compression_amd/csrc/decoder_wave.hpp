@@ -5,7 +5,7 @@
 //
 // STATUS: the default decode kernel (decoder.hip uses it whenever the segment rows fit the LDS ring; ICER_DEC_WAVE=0
 // selects the thread-per-chain kernel).  Bit-exact on the CPU build and on an MI355X (tests/test_gpu_decoder.py);
-// 1.28 s for the 160 chains of the 4096 x 4096 headline frame (profiles/archive/r02_decoder_v1_rocprof.md), DESIGN.md 6b.
+// 1.28 s for the 160 chains of the 4096 x 4096 headline frame (profiles/archive/r02_decoder_v1_rocprof.md), HISTORY.md 6b (summary: DESIGN.md 8).
 //
 // Lane j < planes decodes plane planes-1-j.  All lanes are in one wavefront, so there are no waits: every iteration a
 // lane either decodes its next sample or sits out (its upper neighbour is not far enough ahead, or the ring has no room).

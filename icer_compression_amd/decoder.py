@@ -3,7 +3,7 @@
 
 STATUS: the device code behind it is checked against the decoder oracle in its CPU builds (tests/test_emu_decoder.py) and,
 on an MI355X, by tests/test_gpu_decoder.py (gray / YUV, 16 / 8 bit, damaged streams, golden digests, the batch object;
-all in the default `pytest -m gpu` run).
+all in the default `pytest -m gpu` run, HISTORY.md 6b (summary: DESIGN.md 8)).
 
 The reference's callers do (example/src/example_decode.c, example/src/icer_util.c `decompress`)
     icer_get_image_dimensions(stream, len, &w, &h);  buf = malloc(w * h * 2);

@@ -123,7 +123,7 @@ void icerx_encoder_destroy(icerx_encoder *enc);
  *   d_rcs      device pointer, n_frames int32: per-frame reference return codes
  *   stream     hipStream_t (as void*), NULL = default stream.  All work is enqueued on it; the call returns
  *              after it has completed there (it has to read back one word: whether a coding unit outgrew
- *              its provisioned slot, in which case the batch is redone with larger slots, see DESIGN.md).
+ *              its provisioned slot, in which case the batch is redone with larger slots, see DESIGN.md 3).
  * Returns 0 or ICER_FATAL_ERROR (HIP failure) / ICER_INVALID_INPUT. */
 int icerx_encode_device(icerx_encoder *enc, const uint16_t *d_frames, int n_frames, size_t byte_quota,
                         uint8_t *d_out, size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, void *stream);

@@ -5,7 +5,7 @@
  * (tests/test_gpu_decoder.py: gray / YUV, 16 / 8 bit, damaged and truncated streams, wrong decode parameters, the golden
  * decoder digests up to 4096 x 4096, the batch object, all three decode kernels; the reference-held fixtures and the
  * reference's own example programs linked against this library, tests/test_gpu_parity.py / test_gpu_examples.py).
- * Speed (round 4, bench.py `decode` object and tools/decode_bench.py): a chain (segment of a subband) is a serial
+ * Speed (round 4, bench.py `decode` object and tools/decode_bench.py; HISTORY.md 6b (summary: DESIGN.md 8)): a chain (segment of a subband) is a serial
  * adaptive decode, one decision at a time per bit plane.  One 4096 x 4096 headline stream: 55 Mpix/s (303 ms; one wavefront per
  * bit plane with wave-uniform decisions, decoder_planes.hpp) = 14 x the reference decoder on one core of the same box; the
  * kernels around the chains (payload CRCs, inverse DWT, sample post-processing) take 0.6 ms together.  Batches (chains of all

@@ -3,7 +3,7 @@
 (both workgroup shapes and the batch default with the small workgroup coder beside it, taking turns) and the barrier-only workgroup coder -- encode the same random batches (random geometry, filter, segment
 count, quota class, content made on the device) and must produce the same return codes, lengths and bytes; a sample of
 the frames is also checked against the oracle.  No oracle call sits in the inner loop, so this runs thousands of
-encodes per second: it is the campaign that looks for the hand-off stall of the pipeline.
+encodes per second: it is the campaign that looks for the hand-off stall of the pipeline (HISTORY.md 4.1).
    python tests/stress_gpu_diff.py [seconds] [seed]
 Prints one summary line; exit code 1 on any difference or any coding-unit time-out (icerx_process_stats)."""
 import os

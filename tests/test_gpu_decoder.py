@@ -1,7 +1,7 @@
 """GPU parity tests of the decoder (libicer_hip_dec.so through its C ABI) against the decoder oracle: random gray / YUV,
 uint16 / uint8 streams incl. quota-cut ones, wrong decode parameters, damaged / truncated / re-ordered streams, the golden
 decoder digests up to 4096 x 4096 and the batch decoder object, for all three decode kernels (one thread per chain, one
-wavefront per chain with a lane per bit plane, one wavefront per bit plane -- the default since round 4).  See DESIGN.md 6b.
+wavefront per chain with a lane per bit plane, one wavefront per bit plane -- the default since round 4).  See HISTORY.md 6b (summary: DESIGN.md 8).
 """
 import hashlib
 import json

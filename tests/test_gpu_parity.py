@@ -87,7 +87,7 @@ def test_batch_extension_equals_per_frame_calls(oracle):
 
 def test_batch_routes_blank_units_to_the_small_coder(oracle):
     """in a launch of several frames the all-but-blank coding units (the upper bit planes) are coded by the workgroup coder's
-    small instance beside the pipeline kernel: the streams are the reference's, and the counters show
+    small instance beside the pipeline kernel (HISTORY.md 4.1c): the streams are the reference's, and the counters show
     that the routing really took place -- and that a single frame goes through the pipeline alone"""
     w, h, st, sg, n = 512, 384, 3, 8, 4
     frames = synth.gray_batch(n, w, h, 7, 1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Decode benchmark of libicer_hip_dec.so -- NOT bench.py's metric.
+"""Decode benchmark of libicer_hip_dec.so (HISTORY.md 6b (summary: DESIGN.md 8)) -- NOT bench.py's metric.
 
     python tools/decode_bench.py [--batch 16] [--reps 3] [--no-cpu-baseline]
 
