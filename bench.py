@@ -600,6 +600,41 @@ def one_process_object(name, dev, local_rank, calls=2):
         hw.close()
 
 
+def crowded_host_object(name, rank, dev, local_rank, device_value):
+    """The host-fed batch in a process that is NOT the library's alone: two torch streams that have done work and stay alive,
+    and a live decoder with its side streams (the runtime shares its hardware queues out over every live stream of the process,
+    INTEGRATION.md 4).  Same call, same frames, every frame checked; the rate beside the quiet-process one."""
+    import torch
+    from icer_compression_amd import api, decoder
+    others = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    junk = []
+    for st in others:
+        with torch.cuda.stream(st):
+            junk.append(torch.ones(1 << 20, device=dev) * 2)
+    torch.cuda.synchronize(dev)
+    c = CONFIGS[name]
+    dec = decoder.Decoder(1, c["stages"], FILT, c["segments"])
+    hw = HostWorkload(name, rank, dev, local_rank)
+    try:
+        hw.step()
+        bad, _ = hw.verify()
+        n = 6 if name == "C4" else 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            hw.step()
+        t_el = time.perf_counter() - t0
+        bad2, _ = hw.verify()
+        val = n * c["per_gpu"] * c["w"] * c["h"] / t_el / 1e6
+        st = api.process_stats()
+        return {"value": round(val, 3), "unit": "Mpixels/s", "ms_per_call": round(t_el / n * 1e3, 3), "calls": n, "parity": not bad and not bad2,
+                "frames_checked": c["per_gpu"], "live_streams_besides_the_library": "2 torch streams + a decoder's", "unit_timeouts": st["unit_timeouts"],
+                "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "vs_device_resident": round(val / device_value, 3) if device_value else None}
+    finally:
+        hw.close()
+        dec.close()
+        del junk, others
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher around it: re-run this very command line as N ranks through
     torch.distributed.run on 127.0.0.1 (a free port), one rank per GPU; with fewer visible GPUs than ranks the ranks share
@@ -859,6 +894,14 @@ def main():
             bw.close()
         kept.clear()
         torch.cuda.empty_cache()
+        # ... and last among these: the host-fed call again with other streams alive in the process (they stay alive from here on)
+        if not args.no_extras and world == 1:
+            for name in ("C4", "C5"):
+                if name in batch_host and "value" in batch_host[name]:
+                    try:
+                        batch_host[name]["crowded_process"] = crowded_host_object(name, rank, dev, local_rank, batch_cfgs.get(name, {}).get("value"))
+                    except Exception as exc:                           # noqa: BLE001 -- secondary figure
+                        batch_host[name]["crowded_process"] = {"error": repr(exc)}
 
     # secondary figure: a STREAM of single frames (not `value`, which times one frame at a time): two encoders taking the frames in
     # turns, two launches in flight.  (First among the secondary legs: the two launches overlap only while their streams sit on

@@ -494,6 +494,44 @@ def test_batch_share_of_another_rank(name, rank):
     assert not bad, (name, rank, bad)
 
 
+def test_host_batch_in_a_crowded_process():
+    """The host-fed batch call beside streams that are not the library's: two torch streams that have run kernels and stay alive
+    and a live decoder (side streams of its own).  The runtime shares its hardware queues out over every live stream, so this is
+    where the pipeline's six streams per device double up; what must hold whatever the queue lottery gives: every frame
+    bit-exact, no unit time-out, no fall-back."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from icer_compression_amd import decoder
+    dev = torch.device("cuda", 0)
+    others = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    keep = []
+    for st in others:
+        with torch.cuda.stream(st):
+            keep.append(torch.ones(1 << 18, device=dev) + 1)
+    torch.cuda.synchronize(dev)
+    c = bench.CONFIGS["C4"]
+    dec = decoder.Decoder(1, c["stages"], 0, c["segments"])
+    before = api.process_stats()
+    hw = bench.HostWorkload("C4", 2, dev, 0)
+    try:
+        for _ in range(3):
+            hw.step()
+            with torch.cuda.stream(others[0]):                     # the other streams are busy in between, too
+                keep[0].add_(1)
+        bad, nbytes = hw.verify()
+    finally:
+        hw.close()
+        dec.close()
+    after = api.process_stats()
+    assert not bad and nbytes > 0, bad
+    assert after["unit_timeouts"] == before["unit_timeouts"] and after["fallback_batches"] == before["fallback_batches"], (before, after)
+
+
 # ---- the multi-device code path on one GPU: ICER_HIP_VIRTUAL_DEVICES -----------------------------------------------------------
 def test_virtual_devices_batch(monkeypatch):
     """ICER_HIP_VIRTUAL_DEVICES=4: icerx_compress_batch_uint16 over four logical devices (four host threads, four pooled
