@@ -25,3 +25,15 @@ def test_bench_gpus_2_starts_itself_and_reports_the_c4_batch():
     assert line["config"]["frames_per_gpu_per_step"] == 128 and "BASELINE configs[3]" in line["config"]["workload"]
     assert line["value"] > 0 and line["coder_events"]["unit_timeouts"] == 0
     assert line["c2_per_rank"]["parity"] is True and line["c2_per_rank"]["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("name,frames", [("C4", 256), ("C5", 64)])
+def test_every_frame_of_the_batch_configurations(name, frames):
+    """bench.py --sweep: this one GPU plays every rank of the 8-GPU job in turn -- ALL 256 / 64 frames of BASELINE configs[3] / [4],
+    each against the reference CPU encoder's length and CRC-32 (tests/golden/batch_golden.json), after the first encode and again
+    after two timed ones.  (The gate used to see ranks 0, 3 and 5 only.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ICER_HIP_VIRTUAL_DEVICES")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep", "--config", name], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith('{"sweep"')][-1])
+    assert line["frames_checked"] == frames and line["frames_not_bit_exact"] == [] and line["parity"] is True
