@@ -708,6 +708,7 @@ def main():
     ap.add_argument("--launch-probe", action="store_true", help="launcher check only (runs without a GPU): the ranks rendezvous over gloo, reduce their "
                     "shard sizes of the timed configuration and rank 0 prints one JSON line; no encode")
     ap.add_argument("--all-extras", action="store_true", help="with --gpus N > 1: also the host-fed, decode and in-flight legs (default: N = 1 only)")
+    ap.add_argument("--one-process-child", action="store_true", help=argparse.SUPPRESS)     # (internal: the one_process object in a process of its own)
     ap.add_argument("--no-one-process", action="store_true", help="skip the one_process object (icerx_compress_batch_uint16 over every visible device)")
     ap.add_argument("--batched-probe", type=int, default=8,
                     help="also report C2 throughput with this many frames per launch (secondary figure, 0 = skip)")
@@ -721,6 +722,15 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if (args.gpus > 1 and args.config != "C2") else "weak"
 
+    if args.one_process_child:
+        # the one_process object, in a process of its own (started by rank 0 with the launcher's variables removed): a hang or a
+        # crash of the multi-device host batch -- a path no box with more than one GPU has run yet -- costs the line this object only
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("no HIP device")
+        torch.zeros(1, device="cuda")
+        print(json.dumps({"one_process": one_process_object(args.config or "C4", torch.device("cuda", 0), 0)}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started plainly (`python bench.py --gpus N`): this process becomes the launcher of one rank per GPU and
         # passes the ranks' output through; under torch.distributed.run (the driver's form) WORLD_SIZE is set and we are a rank.
@@ -1023,8 +1033,15 @@ def main():
         barrier()                                                  # the other ranks wait here while rank 0's library drives every device
         if rank == 0:
             try:
-                one_proc = one_process_object("C4", dev, local_rank)
-            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                         "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "ICER_HIP_VIRTUAL_DEVICES")}
+                if oversubscribed:
+                    env["ICER_HIP_VIRTUAL_DEVICES"] = str(world)        # (the dry run: as many logical devices as ranks)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-process-child", "--config", "C4"], env=env, cwd=ROOT,
+                                   capture_output=True, text=True, timeout=420)
+                objs = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{"one_process"')]
+                one_proc = objs[-1]["one_process"] if objs else {"error": f"child rc={r.returncode}: {r.stderr[-400:]}"}
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure (a time-out included)
                 one_proc = {"error": repr(exc)}
         barrier()
 
