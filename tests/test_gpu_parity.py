@@ -99,10 +99,26 @@ def test_batch_routes_blank_units_to_the_small_coder(oracle):
     r = enc.routing()
     units = enc.info()["units_per_frame"]
     assert r["routed_calls"] == 1 and n * units // 10 < r["routed_units"] < n * units, (r, units)
+    # the routing decision itself (it cannot be seen in the streams): round 5 takes a unit's number of blank chunks from the
+    # family histogram chunk_sig_kernel leaves; the round-4 kernel, which counted them in the chunk table per unit, routed
+    # exactly these many units of these frames (tools/gpu/r05_route_check.py, both libraries on the same box)
+    assert r["routed_units"] == 866, r
     assert enc.encode_host(frames[:1], 2 * w * h)[0] == got[0]
     assert enc.routing() == r                                      # one frame: no routing
     assert enc.stats()["unit_timeouts"] == 0
     enc.close()
+
+
+@pytest.mark.parametrize("w,h,st,sg,n,seed,routed", [(2048, 2048, 4, 16, 4, 12345, 4368), (1024, 768, 2, 2, 3, 11, 183), (640, 480, 4, 5, 6, 3, 811)])
+def test_routing_counts_equal_the_per_unit_count_of_round_4(w, h, st, sg, n, seed, routed):
+    """the units route_units_kernel sends to the list kernel, from the family histograms: the same numbers the round-4 kernel (a
+    workgroup per unit counting blank chunks in the chunk table) gave on these frames (tools/gpu/r05_route_check.py)"""
+    frames = synth.gray_batch(n, w, h, seed, 1)
+    enc = api.Encoder(w, h, 1, st, 0, sg, max_frames=n)
+    enc.encode_host(frames, 2 * w * h)
+    r = enc.routing()
+    enc.close()
+    assert r["routed_units"] == routed, r
 
 
 def test_launch_info_reports_the_shape_of_a_launch(oracle, monkeypatch):
