@@ -942,6 +942,21 @@ def main():
             bw.close()
         kept.clear()
         torch.cuda.empty_cache()
+        # ... the host-fed call in a process that has NOT asked for more hardware queues (a child without GPU_MAX_HW_QUEUES: the
+        # library then gives its encoder streams high priority, INTEGRATION.md "Hardware queues"), quiet and crowded
+        if not args.no_extras and world == 1 and "C4" in batch_host and "value" in batch_host["C4"]:
+            try:
+                env = dict(os.environ, GPU_MAX_HW_QUEUES="default", ICER_HIP_QUIET="1")
+                env.pop("ICER_HIP_STREAM_PRIO", None)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_batch_probe.py"), "C4"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+                o = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+                dv = batch_cfgs.get("C4", {}).get("value")
+                batch_host["C4"]["runtime_default_hw_queues"] = {
+                    "value": o["quiet_Mpix_s"], "crowded_process": o["crowded_Mpix_s"], "unit": "Mpixels/s", "parity": o["parity"],
+                    "vs_device_resident": round(o["quiet_Mpix_s"] / dv, 3) if dv else None,
+                    "note": "a child process without GPU_MAX_HW_QUEUES (4 hardware queues per priority level): the pipeline's encoder streams are high-priority streams"}
+            except Exception as exc:                                   # noqa: BLE001 -- secondary figure
+                batch_host["C4"]["runtime_default_hw_queues"] = {"error": repr(exc)}
         # ... and last among these: the host-fed call again with other streams alive in the process (they stay alive from here on)
         if not args.no_extras and world == 1:
             for name in ("C4", "C5"):

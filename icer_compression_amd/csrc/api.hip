@@ -947,23 +947,32 @@ int icerx_device_count(void) { return logical_device_count(); }
 //     copy-out stream   D2H of the streams of the finished sub-batches (exactly size[f] bytes per frame)
 // (Streams are a scarce resource: the HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES = 4 hardware queues by default and
 // streams that share a queue run one after the other -- measured on C4 / C5: 0.80-0.85 x the device-resident rate with 4
-// queues, 0.92-0.95 x with 8: GPU_MAX_HW_QUEUES=8 in the environment of the process, see warn_hw_queues_once.  Copies on the
+// queues, 0.92-0.95 x with 8 -- see want_priority_streams below for what the library does about it.  Copies on the
 // encoder streams instead of streams of their own -- fewer streams -- measured slower: 0.78 x on C4.)
 // The encoders and their staging buffers stay alive between calls (per device, re-made when the geometry changes;
 // icerx_batch_release frees them): a call allocates nothing on the device.
 namespace {
 
-// More hardware queues than the runtime's default of 4 is a PROCESS-wide choice (GPU_MAX_HW_QUEUES, read once when the HIP
-// runtime starts): the library does not make it behind the caller's back -- bench.py, the command-line tool and the tests
-// set GPU_MAX_HW_QUEUES=8 themselves, INTEGRATION.md tells a host program to -- it only says so, once, when a host batch
-// runs without it.
+// Hardware queues.  The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default; a PROCESS-wide choice read
+// once when the HIP runtime starts, which the library does not make behind the caller's back) PER PRIORITY LEVEL, and a new stream gets
+// the least-used queue of its level's pool.  Round 5: unless the process has 6 or more queues per level, the four streams of a device's
+// pipeline whose kernels must overlap (three encoders + their shared side stream) are created with HIGH priority -- a pool of four
+// queues of their own, shared with nothing else in the process; the two copy streams stay at normal priority.  Measured on C4 / C5
+// (profiles/r05_logs/r05_r.log, quiet process and one with two torch streams and a decoder alive): default queues 0.68 / 0.71 x the
+// device-resident rate with plain streams, 0.92 / 0.89 x with the priority streams; GPU_MAX_HW_QUEUES=8 with plain streams 0.94-0.95 x
+// (0.91 / 0.88 with priority streams: so plain ones when the queues are there).  ICER_HIP_STREAM_PRIO=0|1 pins the choice.
+bool want_priority_streams()
+{
+    if (const char *pv = getenv("ICER_HIP_STREAM_PRIO")) return atoi(pv) != 0;
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    return !(q && atoi(q) >= 6);
+}
 void warn_hw_queues_once()
 {
     static std::atomic<bool> said{false};
-    if (getenv("GPU_MAX_HW_QUEUES") || said.exchange(true)) return;
-    fprintf(stderr, "libicer_hip: GPU_MAX_HW_QUEUES is not set: the host-fed batch pipeline uses 6 streams per device (copy-in, copy-out, three encoder streams and the side stream their list kernels share) and the HIP runtime's "
-                    "default of 4 hardware queues makes them take turns (measured 0.80-0.85 x instead of 0.92-0.95 x the device-resident rate); "
-                    "set GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP\n");
+    if (!want_priority_streams() || getenv("ICER_HIP_QUIET") || said.exchange(true)) return;
+    fprintf(stderr, "libicer_hip: host-fed batch: GPU_MAX_HW_QUEUES is below 6, so the pipeline's encoder streams are high-priority streams (a hardware-queue pool "
+                    "of their own: about 0.9 x the device-resident rate); GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP gives 0.94 x\n");
 }
 
 constexpr int kBatchSets = 3;
@@ -1096,7 +1105,25 @@ int batch_rebuild(BatchDevice *b, size_t w, size_t h, int channels, int stages, 
             b->enc[k]->side_stream = b->enc[0]->side_stream;
             b->enc[k]->side_stream_borrowed = true;
         }
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
+        // (high-priority streams for the encoders and their shared side stream unless the process has hardware queues to spare:
+        // want_priority_streams)
+        {
+            int least = 0, greatest = 0;
+            const bool prio = want_priority_streams() && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
+            if (prio) {
+                HIP_TRY(hipStreamCreateWithPriority(&b->s_enc[k], hipStreamNonBlocking, greatest));
+                if (k == 0 && b->enc[0]->side_stream && !b->enc[0]->side_stream_borrowed) {
+                    hipStream_t hs = nullptr;
+                    if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, greatest) == hipSuccess) {
+                        (void)hipStreamDestroy(b->enc[0]->side_stream);
+                        b->enc[0]->side_stream = hs;
+                    } else (void)hipGetLastError();
+                }
+            } else {
+                (void)hipGetLastError();
+                HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
+            }
+        }
         if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
         HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&b->coded[k], hipEventDisableTiming));

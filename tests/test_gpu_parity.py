@@ -510,11 +510,15 @@ def test_batch_share_of_another_rank(name, rank):
     assert not bad, (name, rank, bad)
 
 
-def test_host_batch_in_a_crowded_process():
+@pytest.mark.parametrize("prio", ["0", "1"])
+def test_host_batch_in_a_crowded_process(monkeypatch, prio):
     """The host-fed batch call beside streams that are not the library's: two torch streams that have run kernels and stay alive
     and a live decoder (side streams of its own).  The runtime shares its hardware queues out over every live stream, so this is
     where the pipeline's six streams per device double up; what must hold whatever the queue lottery gives: every frame
-    bit-exact, no unit time-out, no fall-back."""
+    bit-exact, no unit time-out, no fall-back.  Both kinds of encoder streams: plain ones (what the library takes when the process
+    has GPU_MAX_HW_QUEUES >= 6, as this test process does) and high-priority ones (its choice when hardware queues are scarce)."""
+    monkeypatch.setenv("ICER_HIP_STREAM_PRIO", prio)
+    api.load_library().icerx_batch_release()                          # (the pooled pipeline is rebuilt with the streams asked for)
     import os
     import sys
     import torch
