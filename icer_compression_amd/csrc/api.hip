@@ -25,6 +25,9 @@
 using namespace icer;
 
 namespace {
+bool want_priority_streams();      // (defined with the host-fed batch, below)
+}
+namespace {
 
 thread_local std::string g_last_error;
 static std::atomic<uint64_t> g_stats[3];      // unit time-outs, fallback batches, slot re-runs (icerx_process_stats)
@@ -374,6 +377,20 @@ void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStr
     *cw_io = cw; *ch_io = ch;
 }
 
+// The stream the list kernel runs on beside the pipeline kernel of the same launch: the two must not share a hardware queue.  With
+// hardware queues to spare (GPU_MAX_HW_QUEUES >= 6) a plain stream; otherwise a HIGH-priority one -- the runtime keeps a pool of queues
+// per priority level, so it can never be given the queue of the caller's (normal-priority) stream, however many streams the process
+// has alive (want_priority_streams).
+hipError_t create_side_stream(hipStream_t *st)
+{
+    int least = 0, greatest = 0;
+    if (want_priority_streams() && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+        hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess)
+        return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 #ifndef ICER_LONE_PAD_BYTES
 #define ICER_LONE_PAD_BYTES 12288
 #endif
@@ -625,7 +642,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgOne>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg1::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgFour>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg4::Shared)) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        create_side_stream(&e->side_stream) != hipSuccess ||
         hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
@@ -1112,13 +1129,6 @@ int batch_rebuild(BatchDevice *b, size_t w, size_t h, int channels, int stages, 
             const bool prio = want_priority_streams() && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
             if (prio) {
                 HIP_TRY(hipStreamCreateWithPriority(&b->s_enc[k], hipStreamNonBlocking, greatest));
-                if (k == 0 && b->enc[0]->side_stream && !b->enc[0]->side_stream_borrowed) {
-                    hipStream_t hs = nullptr;
-                    if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, greatest) == hipSuccess) {
-                        (void)hipStreamDestroy(b->enc[0]->side_stream);
-                        b->enc[0]->side_stream = hs;
-                    } else (void)hipGetLastError();
-                }
             } else {
                 (void)hipGetLastError();
                 HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
