@@ -943,7 +943,7 @@ def main():
         kept.clear()
         torch.cuda.empty_cache()
         # ... the host-fed call in a process that has NOT asked for more hardware queues (a child without GPU_MAX_HW_QUEUES: the
-        # library then gives its encoder streams high priority, INTEGRATION.md "Hardware queues"), quiet and crowded
+        # library then puts its encoder streams on the low priority level's queue pool, INTEGRATION.md "Hardware queues"), quiet and crowded
         if not args.no_extras and world == 1 and "C4" in batch_host and "value" in batch_host["C4"]:
             try:
                 env = dict(os.environ, GPU_MAX_HW_QUEUES="default", ICER_HIP_QUIET="1")
@@ -954,7 +954,7 @@ def main():
                 batch_host["C4"]["runtime_default_hw_queues"] = {
                     "value": o["quiet_Mpix_s"], "crowded_process": o["crowded_Mpix_s"], "unit": "Mpixels/s", "parity": o["parity"],
                     "vs_device_resident": round(o["quiet_Mpix_s"] / dv, 3) if dv else None,
-                    "note": "a child process without GPU_MAX_HW_QUEUES (4 hardware queues per priority level): the pipeline's encoder streams are high-priority streams"}
+                    "note": "a child process without GPU_MAX_HW_QUEUES (4 hardware queues per priority level): the pipeline's encoder streams are on the low priority level's own queue pool"}
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 batch_host["C4"]["runtime_default_hw_queues"] = {"error": repr(exc)}
         # ... and last among these: the host-fed call again with other streams alive in the process (they stay alive from here on)

@@ -381,15 +381,27 @@ void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStr
 // hardware queues to spare (GPU_MAX_HW_QUEUES >= 6) a plain stream; otherwise a HIGH-priority one -- the runtime keeps a pool of queues
 // per priority level, so it can never be given the queue of the caller's (normal-priority) stream, however many streams the process
 // has alive (want_priority_streams).
-hipError_t create_side_stream(hipStream_t *st)
+// a stream of the level `which` names ("high" / "low"; anything else, or a runtime without levels: a plain stream)
+hipError_t create_level_stream(hipStream_t *st, const char *which)
 {
     int least = 0, greatest = 0;
-    if (want_priority_streams() && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
-        hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess)
-        return hipSuccess;
+    if (which && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
+        const bool hi = !strcmp(which, "high"), lo = !strcmp(which, "low");
+        if ((hi || lo) && hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi ? greatest : least) == hipSuccess) return hipSuccess;
+    }
     (void)hipGetLastError();
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
+hipError_t create_side_stream(hipStream_t *st)
+{
+    return create_level_stream(st, want_priority_streams() ? "high" : nullptr);
+}
+// The host-fed pipeline of a device has four streams whose kernels must overlap (three encoders + the side stream they share).  When
+// hardware queues are scarce they go to the LOW level's pool together: measured with the runtime's default queues on C4 / C5, quiet
+// process or crowded -- low 0.93-0.95 x the device-resident rate (what 8 queues and plain streams give), high 0.89-0.90 x (high-priority
+// compute gets in the way of the copy streams' transfers), plain streams 0.68-0.71 x; the copy streams stay plain
+// (profiles/r05_logs/r05_r.log, r05_t.log).  Low priority also means what it says: kernels of the host program's own streams go first.
+const char *pool_compute_level() { const char *v = getenv("ICER_HIP_COMPUTE_LEVEL"); return v ? v : "low"; }
 
 #ifndef ICER_LONE_PAD_BYTES
 #define ICER_LONE_PAD_BYTES 12288
@@ -973,11 +985,10 @@ namespace {
 // Hardware queues.  The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default; a PROCESS-wide choice read
 // once when the HIP runtime starts, which the library does not make behind the caller's back) PER PRIORITY LEVEL, and a new stream gets
 // the least-used queue of its level's pool.  Round 5: unless the process has 6 or more queues per level, the four streams of a device's
-// pipeline whose kernels must overlap (three encoders + their shared side stream) are created with HIGH priority -- a pool of four
-// queues of their own, shared with nothing else in the process; the two copy streams stay at normal priority.  Measured on C4 / C5
-// (profiles/r05_logs/r05_r.log, quiet process and one with two torch streams and a decoder alive): default queues 0.68 / 0.71 x the
-// device-resident rate with plain streams, 0.92 / 0.89 x with the priority streams; GPU_MAX_HW_QUEUES=8 with plain streams 0.94-0.95 x
-// (0.91 / 0.88 with priority streams: so plain ones when the queues are there).  ICER_HIP_STREAM_PRIO=0|1 pins the choice.
+// pipeline whose kernels must overlap (three encoders + their shared side stream) are created at another level than the host program's
+// streams -- a pool of four queues of their own, shared with nothing else in the process (which level: pool_compute_level above); the two
+// copy streams stay plain.  With queues to spare (GPU_MAX_HW_QUEUES >= 6) everything is a plain stream.  ICER_HIP_STREAM_PRIO=0|1 pins
+// the choice.
 bool want_priority_streams()
 {
     if (const char *pv = getenv("ICER_HIP_STREAM_PRIO")) return atoi(pv) != 0;
@@ -988,8 +999,8 @@ void warn_hw_queues_once()
 {
     static std::atomic<bool> said{false};
     if (!want_priority_streams() || getenv("ICER_HIP_QUIET") || said.exchange(true)) return;
-    fprintf(stderr, "libicer_hip: host-fed batch: GPU_MAX_HW_QUEUES is below 6, so the pipeline's encoder streams are high-priority streams (a hardware-queue pool "
-                    "of their own: about 0.9 x the device-resident rate); GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP gives 0.94 x\n");
+    fprintf(stderr, "libicer_hip: host-fed batch: GPU_MAX_HW_QUEUES is below 6, so the pipeline's encoder streams are low-priority streams (a hardware-queue pool "
+                    "of their own; kernels of the program's own streams go first); GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP makes them plain ones\n");
 }
 
 constexpr int kBatchSets = 3;
@@ -1109,8 +1120,8 @@ int batch_rebuild(BatchDevice *b, size_t w, size_t h, int channels, int stages, 
     b->sub = sub;
     b->sets = sets;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
+    HIP_TRY(create_level_stream(&b->s_in, want_priority_streams() ? getenv("ICER_HIP_COPY_LEVEL") : nullptr));
+    HIP_TRY(create_level_stream(&b->s_out, want_priority_streams() ? getenv("ICER_HIP_COPY_LEVEL") : nullptr));
     for (int k = 0; k < sets; k++) {
         const int rc = icerx_encoder_create(&b->enc[k], b->logical, w, h, channels, stages, filt, segments, sub);
         if (rc) return rc;
@@ -1122,17 +1133,12 @@ int batch_rebuild(BatchDevice *b, size_t w, size_t h, int channels, int stages, 
             b->enc[k]->side_stream = b->enc[0]->side_stream;
             b->enc[k]->side_stream_borrowed = true;
         }
-        // (high-priority streams for the encoders and their shared side stream unless the process has hardware queues to spare:
-        // want_priority_streams)
-        {
-            int least = 0, greatest = 0;
-            const bool prio = want_priority_streams() && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
-            if (prio) {
-                HIP_TRY(hipStreamCreateWithPriority(&b->s_enc[k], hipStreamNonBlocking, greatest));
-            } else {
-                (void)hipGetLastError();
-                HIP_TRY(hipStreamCreateWithFlags(&b->s_enc[k], hipStreamNonBlocking));
-            }
+        // (the encoders' streams and their shared side stream at a level of their own unless the process has hardware queues to
+        // spare: want_priority_streams, pool_compute_level)
+        HIP_TRY(create_level_stream(&b->s_enc[k], want_priority_streams() ? pool_compute_level() : nullptr));
+        if (k == 0 && want_priority_streams() && b->enc[0]->side_stream && !b->enc[0]->side_stream_borrowed) {
+            hipStream_t ss = nullptr;                           // (the shared side stream at the encoders' level)
+            if (create_level_stream(&ss, pool_compute_level()) == hipSuccess) { (void)hipStreamDestroy(b->enc[0]->side_stream); b->enc[0]->side_stream = ss; }
         }
         if (b->in[k].ensure((size_t)sub * channels * w * h) || b->d_sizes[k].ensure(sub) || b->d_rcs[k].ensure(sub)) return ICER_FATAL_ERROR;
         HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));

@@ -178,9 +178,9 @@ int icerx_encode_host(icerx_encoder *enc, const uint16_t *frames, int n_frames, 
  * Env: ICER_HIP_BATCH_SUB=<frames per sub-batch>, ICER_HIP_BATCH_RAMP=<0|1|2> (smaller sub-batches at the start / and the
  * end of a block; 0 = off is the default), ICER_HIP_NUMA=0 (do not pin the per-device host threads to their GPU's NUMA node).
  * The pipeline keeps six streams per device busy.  With GPU_MAX_HW_QUEUES=8 exported before the process initialises HIP they
- * are plain streams (0.94 x the device-resident rate); with fewer hardware queues the encoders' streams are created with high
- * priority -- a queue pool of their own, about 0.9 x, whatever else the process has alive (ICER_HIP_STREAM_PRIO=0|1 pins the
- * choice; the library does not touch the environment) -- INTEGRATION.md "Hardware queues".
+ * are plain streams (0.94 x the device-resident rate); with fewer hardware queues the encoders' streams are created at the low
+ * priority level -- a queue pool of their own: the same 0.94 x whatever else the process has alive, and the program's own kernels
+ * go first (ICER_HIP_STREAM_PRIO=0|1 pins the choice; the library does not touch the environment) -- INTEGRATION.md "Hardware queues".
  *
  * icerx_device_count(): devices the batch calls and icerx_encoder_create accept (0 .. count-1).  ICER_HIP_VIRTUAL_DEVICES=<N>
  * makes that N LOGICAL devices mapped round-robin onto the physical ones: a dry run of every multi-device code path (N host
