@@ -250,6 +250,27 @@ extern "C" int emu_plan_units(size_t w, size_t h, int channels, int stages, int 
     return n;
 }
 
+// the launch orders: work_order (every launch) and, with split_chunks > 0, split_launch (a lone frame: units and sub-range workgroups);
+// per entry: unit index, family index of the unit, 1 if the entry is a sub-range workgroup.  Returns the number of entries.
+extern "C" int emu_plan_orders(size_t w, size_t h, int channels, int stages, int segments, uint32_t split_chunks, uint32_t *out /* n*3 */, int cap,
+                               uint32_t *n_families)
+{
+    Plan plan;
+    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    if (rc) return rc;
+    assign_slots(&plan, 2 * w * h * (size_t)channels, 3, split_chunks);
+    *n_families = plan.n_families;
+    const std::vector<uint32_t> &ord = split_chunks ? plan.split_launch : plan.work_order;
+    int n = (int)ord.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const uint32_t e = ord[(size_t)i];
+        const bool sub = split_chunks && (e >> 31);
+        const uint32_t ui = sub ? plan.subs[e & 0x7FFFFFFFu].unit : e;
+        out[3 * (size_t)i] = ui; out[3 * (size_t)i + 1] = plan.units[ui].family; out[3 * (size_t)i + 2] = sub ? 1u : 0u;
+    }
+    return n;
+}
+
 // the work list of chunk_sig_kernel: per entry unit index, block, the unit's chunk-table offset and chunk count, its plane
 extern "C" int emu_plan_sig_blocks(size_t w, size_t h, int channels, int stages, int segments, uint32_t *out /* n*5 */, int cap, size_t *sig_bytes)
 {

@@ -163,6 +163,38 @@ def test_chunk_table_work_list_covers_every_family_once(emu):
         assert areas[-1][0] + areas[-1][1] <= sig_bytes.value
 
 
+def test_launch_orders_are_permutations_and_keep_families_on_their_xcd(emu):
+    """Plan::work_order / Plan::split_launch: every unit (and every sub-range workgroup) exactly once; the nine planes of a family sit
+    at positions of one residue mod 8 (workgroup b runs on XCD b % 8: one L2 reads the family's coefficients) -- all of them where the
+    eight lists are equally long, all but the entries borrowed for an exhausted list's positions otherwise; family indices are dense"""
+    import ctypes as C
+    emu.lib.emu_plan_orders.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+    for (w, h, ch, st, sg, split) in [(4096, 4096, 1, 5, 10, 0), (4096, 4096, 1, 5, 10, 3072), (2048, 2048, 1, 4, 16, 0), (8192, 8192, 1, 6, 32, 0),
+                                      (517, 389, 3, 4, 7, 0), (1024, 768, 1, 2, 2, 128)]:
+        buf = np.zeros((40000, 3), np.uint32)
+        nf = C.c_uint32(0)
+        n = emu.lib.emu_plan_orders(w, h, ch, st, sg, split, buf.ctypes.data, len(buf), C.byref(nf))
+        assert 0 < n <= len(buf)
+        e = buf[:n]
+        units = (3 * st + 1) * 9 * sg * ch
+        assert nf.value == (3 * st + 1) * sg * ch and set(e[:, 1].tolist()) == set(range(nf.value))
+        whole = e[e[:, 2] == 0]
+        assert sorted(whole[:, 0].tolist()) == list(range(units))          # every unit once as itself
+        if not split:
+            assert n == units
+        off = 0
+        home = {}
+        for pos, (_, fam, _) in enumerate(e.tolist()):
+            if fam not in home:
+                home[fam] = pos % 8
+            elif home[fam] != pos % 8:
+                off += 1
+        if nf.value % 8 == 0:                                            # (else the eight lists differ in length by whole families: entries are borrowed)
+            assert off <= n // 50, (w, h, split, off, n)                 # (C2: 0 of 1 440, 12 of 1 710 with sub-ranges)
+        if (w, h, split) == (4096, 4096, 0):
+            assert off == 0
+
+
 def _subband_area(w, h, lv, sb):
     low = lambda d, l: -(-d // (1 << l))
     high = lambda d, l: low(d, l - 1) // 2
