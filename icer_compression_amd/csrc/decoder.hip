@@ -250,6 +250,28 @@ finish_kernel(uint16_t *__restrict__ planes, size_t frame_stride, int channels, 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ decoder object
+// The side streams carry the kernels of the ring size classes side by side with the plane kernel on the call's own stream.  The HIP runtime
+// shares GPU_MAX_HW_QUEUES (4 by default) hardware queues PER PRIORITY LEVEL out over the live streams of the process, and streams on one
+// queue take turns: unless the process has asked for 6 queues or more, the side streams are created at the low priority level -- a pool of
+// their own, whatever else the process has alive (the encoder library does the same, api.hip want_priority_streams).  In a quiet process
+// the A/B shows no difference (64 streams per call 886-915 Mpix/s with plain or low-level side streams at 8 / 4 / default queues,
+// profiles/r05_logs/r05_u.log; one earlier run with plain streams on 4 queues had given 782): it is there for the crowded process.
+// ICER_HIP_STREAM_PRIO=0|1 pins the choice.
+#ifndef ICER_HOST_MOCK
+static hipError_t create_side_stream(hipStream_t *st)
+{
+    bool level = true;
+    if (const char *pv = getenv("ICER_HIP_STREAM_PRIO")) level = atoi(pv) != 0;
+    else if (const char *q = getenv("GPU_MAX_HW_QUEUES")) level = atoi(q) < 6;
+    int least = 0, greatest = 0;
+    if (level && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+        hipStreamCreateWithPriority(st, hipStreamNonBlocking, least) == hipSuccess)
+        return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+#endif
+
 struct icerx_decoder {
     int device = 0, channels = 1, stages = 1, filt = 0, bits = 16;
     unsigned segments = 1;
@@ -485,7 +507,7 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
 #ifndef ICER_HOST_MOCK
                 if (!d->side_ok) {
                     bool made = true;
-                    for (hipStream_t &st : d->side) made = made && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+                    for (hipStream_t &st : d->side) made = made && create_side_stream(&st) == hipSuccess;
                     if (!made) {                                    // (none is kept half-made: the next call tries again)
                         for (hipStream_t &st : d->side) { if (st) (void)hipStreamDestroy(st); st = nullptr; }
                         (void)hipGetLastError();
