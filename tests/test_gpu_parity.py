@@ -71,6 +71,34 @@ def test_geometry_errors(oracle):
     assert api.icer_init_output_struct(out, buf, 100, 51) == api.ICER_OUTPUT_BUF_TOO_SMALL
 
 
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_device_frames_at_odd_alignments(oracle, shift):
+    """icerx_encode_device on frames whose first sample sits 2, 4 or 6 bytes past an 8-byte boundary: the transform's interior path
+    (64-bit loads, round 5) must step aside for the generic one -- same streams, same coefficient planes (filter A and C, a size whose
+    tiles are interior ones when the pointer is aligned)"""
+    import torch
+    w, h, st, sg, n = 640, 512, 3, 4, 2
+    frames = synth.gray_batch(n, w, h, 77, 1)
+    dev = torch.device("cuda", 0)
+    flat = torch.zeros(n * w * h + 8, dtype=torch.int16, device=dev)
+    view = flat[shift: shift + n * w * h].view(n, h, w)
+    view.copy_(torch.from_numpy(frames.view(np.int16)).to(dev))
+    assert view.data_ptr() % 8 == 2 * shift
+    quota = 2 * w * h
+    out = torch.empty((n, quota), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros(n, dtype=torch.int64, device=dev)
+    rcs = torch.zeros(n, dtype=torch.int32, device=dev)
+    for filt in (0, 2):
+        enc = api.Encoder(w, h, 1, st, filt, sg, max_frames=n)
+        enc.encode_torch(view, quota, out, sizes, rcs)
+        torch.cuda.synchronize()
+        for k in range(n):
+            rc, stream, planes = oracle.compress([frames[k]], st, filt, sg, quota)
+            assert int(rcs[k]) == rc and out[k, : int(sizes[k])].cpu().numpy().tobytes() == stream, (shift, filt, k)
+            assert np.array_equal(enc.coefficients(k, 0), planes[0])
+        enc.close()
+
+
 def test_batch_extension_equals_per_frame_calls(oracle):
     w, h, st, sg = 256, 192, 3, 6
     frames = synth.gray_batch(5, w, h, 100, 1)
