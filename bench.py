@@ -7,9 +7,13 @@ dominant kernel against the 8 TB/s roofline).  Workload = BASELINE.json configs[
 10 error-containment segments, lossless byte quota (2*W*H).  A "step" is one pass of the whole encode
 hot path (DWT -> LL mean -> sign-magnitude -> all coding units -> quota scan -> final stream) over one
 batch (default: ONE frame, as the config says) whose input already sits in HBM; the final stream stays
-in HBM.  With --gpus N every rank encodes its own copy of the workload per step (frames are independent; no
-collective on the data path) -> weak scaling; value = all ranks' pixels / max-over-ranks time.  EVERY rank checks
-its streams against the reference goldens before anything is timed AND again after the timed loop.
+in HBM.  EVERY rank checks its streams against the reference goldens before anything is timed AND again after the timed loop.
+
+--gpus N > 1 (started plainly, bench.py launches its own N ranks; under torch.distributed.run it is a rank): the timed workload is
+BASELINE configs[3] ("C4"), the WHOLE batch of 256 x 2048x2048 frames split over the ranks (strong scaling; no collective on the
+data path), a rank's launches of 32 frames coded with two launches in flight; value = 256 frames' pixels x steps / max-over-ranks
+time.  Its N = 1 point is `scaling_reference` of the --gpus 1 line (whose own `value` is the lone C2 frame).  --config C2 --gpus N:
+every rank its own copy of the C2 frame (weak).
 
 Secondary objects of the same line (none of them is `value`):
   batched        C2 geometry, 8 frames per launch
@@ -25,6 +29,12 @@ Secondary objects of the same line (none of them is `value`):
                  icer_compress_image_uint16 on the C2 frame and icer_compress_image_yuv_uint16 on C3, pageable caller
                  memory, coefficient write-back included
   host_buffers, cpu_baseline, cpu_all_cores, roofline.traffic / roofline.issue (child rocprofv3 passes)
+  scaling_reference  (N = 1) all 256 C4 frames on this GPU per step: the N = 1 point of the N > 1 headline
+  c2_per_rank        (N > 1) the lone C2 frame on every rank at once
+  one_process        icerx_compress_batch_uint16(n_gpus = 0): all 256 C4 frames from page-locked host memory over every visible
+                     device from ONE process (run in a child process)
+  batch_host[*].crowded_process / .runtime_default_hw_queues   the host-fed call beside live torch streams and a decoder; and in
+                     a child process that has not asked for more hardware queues
 
 --config C4|C5 makes one of the batch configurations the timed workload; with --sweep it is run as every rank of an
 8-GPU job in turn on this one GPU (all 256 / 64 frames, each against its reference golden); with --scaling strong the
