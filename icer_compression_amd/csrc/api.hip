@@ -221,6 +221,7 @@ struct icerx_encoder {
     hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
     int hybrid_wgs = 1;                 // staying workgroups of the small coder per compute unit (ICER_HIP_HYBRID_WGS)
+    bool unit_major = true;             // batches: the pipeline kernel's workgroups position-major over the frames (ICER_HIP_UNIT_MAJOR=0: frame by frame)
     int list_grid = 0;                  // ... or their number outright in a batch launch (ICER_HIP_LIST_GRID; 0: per compute unit as above)
     int hybrid_frames = 2;              // ... in launches of at least this many planes (frames x channels; ICER_HIP_HYBRID_FRAMES): one gray frame alone is bound by its dense units
     DevBuf<CoderTables> tables;
@@ -521,11 +522,16 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         // `dynamic LDS' launch parameter had no effect on a kernel that declares none).  Measured on the headline frame: 37 KiB
         // 7.5 ms, 45.6 KiB 6.8 ms, 49.5 KiB 6.7-6.8 ms (profiles/archive/r03_logs/r03_aa.log, r03_ab.log).
         const bool lone = n_frames * C <= e->split_frames;
+        // (a batch that is not in progressive mode -- there the priority order across frames does not matter, the order within a frame does --
+        // is launched position-major over its frames: code_units_kernel; ICER_HIP_UNIT_MAJOR=0: frame by frame as before)
+        const bool unit_major = n_frames > 1 && !progressive && e->unit_major;
+        const dim3 pipe_grid = unit_major ? dim3((unsigned)((n_units + sp.n_subs) * (unsigned)n_frames), 1) : dim3(n_units + sp.n_subs, n_frames);
 #define ICER_LAUNCH_PIPE(NW, OCC, PAD)                                                                                                       \
-        hipLaunchKernelGGL((code_units_kernel<NW, OCC, PAD>), dim3(n_units + sp.n_subs, n_frames), dim3(64 * NW), 0, st,                     \
+        hipLaunchKernelGGL((code_units_kernel<NW, OCC, PAD>), pipe_grid, dim3(64 * NW), 0, st,                                               \
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,                  \
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp)
+                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp, \
+                           unit_major ? (uint32_t)n_frames : 1u)
         e->last_waves = large ? kUnitWavesLarge : kUnitWavesSmall;
         e->last_subs = sp.n_subs;
         if (large) ICER_LAUNCH_PIPE(kUnitWavesLarge, 1, 0);
@@ -607,6 +613,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *cd = getenv("ICER_HIP_CODER")) e->coder_mode = !strcmp(cd, "pipe") ? 1 : !strcmp(cd, "wg") ? 2 : 0;
     if (const char *hy = getenv("ICER_HIP_HYBRID")) { const int v = atoi(hy); if (v >= 0 && v <= 100) e->hybrid_percent = v; }
     if (const char *hf = getenv("ICER_HIP_HYBRID_FRAMES")) { const int v = atoi(hf); if (v >= 1) e->hybrid_frames = v; }
+    if (const char *um = getenv("ICER_HIP_UNIT_MAJOR")) e->unit_major = atoi(um) != 0;
     if (const char *lg = getenv("ICER_HIP_LIST_GRID")) { const int v = atoi(lg); if (v >= 1 && v <= 65536) e->list_grid = v; }
     if (const char *hw = getenv("ICER_HIP_HYBRID_WGS")) { const int v = atoi(hw); if (v >= 1 && v <= 4) e->hybrid_wgs = v; }
     if (const char *sc = getenv("ICER_HIP_SPLIT")) { const int v = atoi(sc); if (v == 0 || v >= 128) e->split_chunks = (uint32_t)v; }

@@ -139,17 +139,28 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                   size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp)
+                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp, uint32_t n_frames_1d)
 {
     __shared__ CoderShared s;
     if constexpr (LDS_PAD > 0) {
         __shared__ uint32_t lds_pad[LDS_PAD / 4];
         if (early_quota == ~0ull) lds_pad[threadIdx.x] = 1u;          // (never: keeps the array in the kernel's LDS size)
     }
-    const uint32_t frame = blockIdx.y;
+    // Which (launch position, frame) this workgroup is.  A two-dimensional grid (positions, frames) is dispatched frame by frame: the
+    // LAST frame's largest units then start when the launch is nearly over and the chip idles through their chains.  A one-dimensional
+    // grid (gridDim.y == 1, several frames; round 5) is walked position-major instead -- eight positions (one per XCD: position % 8 still
+    // names the XCD, so a family keeps its L2) of every frame, then the next eight -- so that the largest units of ALL frames start first
+    // and what is left at the end are the smallest units of all frames.
+    uint32_t frame = blockIdx.y, lpos = blockIdx.x;
+    if (gridDim.y == 1u && n_frames_1d > 1u) {
+        const uint32_t per_frame = n_units + sp.n_subs, g = blockIdx.x / (8u * n_frames_1d), base = g * 8u;
+        const uint32_t width = per_frame - base < 8u ? per_frame - base : 8u, r = blockIdx.x - g * 8u * n_frames_1d;
+        frame = r / width;
+        lpos = base + r % width;
+    }
     // A split launch (sp.n_subs > 0) has extra workgroups for its split units: an entry of sp.launch with bit 31 set codes a later
     // sub-range of a unit (coder_core.hpp "Sub-ranges"), the others one unit from its first chunk as always.
-    const uint32_t entry = sp.n_subs ? sp.launch[blockIdx.x] : (work_order ? work_order[blockIdx.x] : blockIdx.x);   // (null: priority order = unit order)
+    const uint32_t entry = sp.n_subs ? sp.launch[lpos] : (work_order ? work_order[lpos] : lpos);   // (null: priority order = unit order)
     const bool sub_block = sp.n_subs != 0u && (entry >> 31) != 0u;
     const SubDesc sd = sub_block ? sp.subs[entry & 0x7FFFFFFFu] : SubDesc{};
     const uint32_t ui = sub_block ? sd.unit : entry;
@@ -158,13 +169,13 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     if (rt == kRouteWindows) return;
     if (sub_block && rt != kRoutePipeline) return;                  // only dense units are split
 #ifdef ICER_PHASE_TIMERS
-    uint64_t *trace = (timers && frame == 0 && blockIdx.x < (uint32_t)kTraceUnits) ? timers + 9 * 32 + 4 * blockIdx.x : nullptr;
+    uint64_t *trace = (timers && frame == 0 && lpos < (uint32_t)kTraceUnits) ? timers + 9 * 32 + 4 * lpos : nullptr;
     if (trace && threadIdx.x == 0) {
         trace[0] = wall_clock64();
         trace[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
         trace[3] = entry;
     }
-    if (timers && frame == 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+    if (timers && frame == 0 && lpos == 0 && (threadIdx.x & 63) == 0)
         timers[9 * 32 + 4 * kTraceUnits + (threadIdx.x >> 6)] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
     // (as a scalar: the roles below are then uniform branches with a register allocation of their own -- seen as divergent,
