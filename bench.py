@@ -967,14 +967,6 @@ def main():
                     "note": "a child process without GPU_MAX_HW_QUEUES (4 hardware queues per priority level): the pipeline's encoder streams are on the low priority level's own queue pool"}
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 batch_host["C4"]["runtime_default_hw_queues"] = {"error": repr(exc)}
-        # ... and last among these: the host-fed call again with other streams alive in the process (they stay alive from here on)
-        if not args.no_extras and world == 1:
-            for name in ("C4", "C5"):
-                if name in batch_host and "value" in batch_host[name]:
-                    try:
-                        batch_host[name]["crowded_process"] = crowded_host_object(name, rank, dev, local_rank, batch_cfgs.get(name, {}).get("value"))
-                    except Exception as exc:                           # noqa: BLE001 -- secondary figure
-                        batch_host[name]["crowded_process"] = {"error": repr(exc)}
 
     # secondary figure: a STREAM of single frames (not `value`, which times one frame at a time): two encoders taking the frames in
     # turns, two launches in flight.  (First among the secondary legs: the two launches overlap only while their streams sit on
@@ -1053,6 +1045,15 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 scaling_ref = {"error": repr(exc)}
+    # ... and last of the legs of this process: the host-fed call again with other streams alive in the process (torch's stream pool stays
+    # alive from here on, which is why nothing that overlaps launches on streams of its own comes after this)
+    if not args.no_extras and world == 1 and not args.no_batch_configs and have_bg:
+        for name in ("C4", "C5"):
+            if name in batch_host and "value" in batch_host[name]:
+                try:
+                    batch_host[name]["crowded_process"] = crowded_host_object(name, rank, dev, local_rank, batch_cfgs.get(name, {}).get("value"))
+                except Exception as exc:                               # noqa: BLE001 -- secondary figure
+                    batch_host[name]["crowded_process"] = {"error": repr(exc)}
     one_proc = None
     if device_wl and have_bg and not args.no_one_process and not args.no_batch_configs:
         barrier()                                                  # the other ranks wait here while rank 0's library drives every device
