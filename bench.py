@@ -11,8 +11,9 @@ in HBM.  EVERY rank checks its streams against the reference goldens before anyt
 
 --gpus N > 1 (started plainly, bench.py launches its own N ranks; under torch.distributed.run it is a rank): the timed workload is
 BASELINE configs[3] ("C4"), the WHOLE batch of 256 x 2048x2048 frames split over the ranks (strong scaling; no collective on the
-data path), a rank's launches of 32 frames coded with two launches in flight; value = 256 frames' pixels x steps / max-over-ranks
-time.  Its N = 1 point is `scaling_reference` of the --gpus 1 line (whose own `value` is the lone C2 frame).  --config C2 --gpus N:
+data path), a rank's launches of 32 frames coded with two launches in flight (within a step when a rank has several, across steps
+when it has one: step k is submitted before step k - 1 is waited for, everything complete before the closing barrier); value = 256
+frames' pixels x steps / max-over-ranks time.  Its N = 1 point is `scaling_reference` of the --gpus 1 line (whose own `value` is the lone C2 frame).  --config C2 --gpus N:
 every rank its own copy of the C2 frame (weak).
 
 Secondary objects of the same line (none of them is `value`):
@@ -165,7 +166,7 @@ class Workload:
     """a block of frames of one configuration, resident in HBM, with an encoder and output buffers; coded in launches of
     at most `per_gpu` frames"""
 
-    def __init__(self, name, rank, dev, local_rank, first=None, count=None):
+    def __init__(self, name, rank, dev, local_rank, first=None, count=None, in_flight=1):
         import torch
         from icer_compression_amd import api, synth
         self.name, self.cfg = name, CONFIGS[name]
@@ -186,8 +187,17 @@ class Workload:
         # with a queue of batches does it: two encoders taking the launches in turns through the asynchronous half of the API, a
         # stream each, two launches in flight -- the transform and the tail of one launch hide behind the other's coding units.
         self.pipelined = self.B > self.launch
+        # ... and a block that is ONE launch per step (the strong-scaling headline at 8 ranks) the same way ACROSS steps when asked to
+        # (in_flight = 2): step k is submitted before step k - 1 is waited for, into a second set of output buffers; finish() waits for
+        # the last one -- run_timed calls it before the closing barrier, verify() before it looks at anything
+        self.cross_step = in_flight == 2 and not self.pipelined and name != "C2"
+        self._prev, self._k, self.out2 = None, 0, None
+        if self.cross_step:
+            self.out2 = torch.empty((self.B, self.quota), dtype=torch.uint8, device=dev)
+            self.sizes2 = torch.zeros(self.B, dtype=torch.int64, device=dev)
+            self.rcs2 = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.enc2, self._hip, self._streams = None, None, []
-        if self.pipelined:
+        if self.pipelined or self.cross_step:
             import ctypes
             self.enc2 = api.Encoder(self.w, self.h, 1, c["stages"], FILT, c["segments"], max_frames=self.launch, device=local_rank)
             self._hip = ctypes.CDLL("libamdhip64.so")
@@ -200,7 +210,23 @@ class Workload:
                 self._streams.append(st_)
         torch.cuda.synchronize(dev)                                     # (the frames were made on torch's stream)
 
+    def finish(self):
+        if self._prev is not None:
+            self._prev.wait()
+            self._prev = None
+
     def step(self):
+        if self.cross_step:
+            k = self._k & 1
+            e = (self.enc, self.enc2)[k]
+            out, sizes, rcs = ((self.out, self.sizes, self.rcs), (self.out2, self.sizes2, self.rcs2))[k]
+            e.encode_device_async_ptrs(self.frames.data_ptr(), self.B, self.quota, out.data_ptr(), out.stride(0), sizes.data_ptr(), rcs.data_ptr(),
+                                       self._streams[k].value)
+            if self._prev is not None:
+                self._prev.wait()
+            self._prev = e
+            self._k += 1
+            return
         if self.pipelined:
             encs, prev = (self.enc, self.enc2), None
             for k, lo in enumerate(range(0, self.B, self.launch)):
@@ -220,16 +246,21 @@ class Workload:
     def verify(self):
         """every frame of this block: return code, stream length and CRC-32 equal the reference's"""
         import torch
+        self.finish()
         torch.cuda.synchronize()
         sizes, rcs = self.sizes.cpu().numpy(), self.rcs.cpu().numpy()
         bad = []
-        for k in range(self.B):
-            size, crc = self.gold[k]
-            ok = int(rcs[k]) == 0 and int(sizes[k]) == size
-            if ok:
-                ok = ("%08x" % zlib.crc32(self.out[k, :size].cpu().numpy().tobytes())) == crc
-            if not ok:
-                bad.append(self.first + k)
+        sets = [(self.out, sizes, rcs)]
+        if self.cross_step and self._k >= 2:                        # (the second set of buffers has been written, too)
+            sets.append((self.out2, self.sizes2.cpu().numpy(), self.rcs2.cpu().numpy()))
+        for out, sz, rc in sets:
+            for k in range(self.B):
+                size, crc = self.gold[k]
+                ok = int(rc[k]) == 0 and int(sz[k]) == size
+                if ok:
+                    ok = ("%08x" % zlib.crc32(out[k, :size].cpu().numpy().tobytes())) == crc
+                if not ok and self.first + k not in bad:
+                    bad.append(self.first + k)
         return bad, int(sizes.sum())
 
     def close(self):
@@ -239,6 +270,7 @@ class Workload:
         for st_ in self._streams:
             self._hip.hipStreamDestroy(st_)
         self._streams = []
+        self.out2 = None
         del self.frames, self.out
 
 
@@ -341,6 +373,8 @@ def run_timed(wl, steps, warmup, barrier, dev, red_dev=None):
     from icer_compression_amd import shard
     for _ in range(warmup):
         wl.step()
+    if hasattr(wl, "finish"):
+        wl.finish()
     torch.cuda.synchronize(dev)
     if wl.enc is not None:
         wl.enc.timing_enable(True)
@@ -355,6 +389,8 @@ def run_timed(wl, steps, warmup, barrier, dev, red_dev=None):
         ts = time.perf_counter()
         wl.step()
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
+    if hasattr(wl, "finish"):
+        wl.finish()                                                   # (a step still in flight belongs to the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -715,6 +751,8 @@ def main():
     ap.add_argument("--no-batch-configs", action="store_true", help="skip the secondary C4 / C5 figures")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip C3, decode, batch_host and host_buffers (the child runs under rocprofv3)")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=None, help="launches in flight for a batch workload whose step is ONE launch (--config C4|C5): "
+                    "2 = step k is submitted before step k - 1 is waited for (default: 2 with --scaling strong, else 1)")
     ap.add_argument("--launch-probe", action="store_true", help="launcher check only (runs without a GPU): the ranks rendezvous over gloo, reduce their "
                     "shard sizes of the timed configuration and rank 0 prints one JSON line; no encode")
     ap.add_argument("--all-extras", action="store_true", help="with --gpus N > 1: also the host-fed, decode and in-flight legs (default: N = 1 only)")
@@ -814,6 +852,7 @@ def main():
     if args.sweep and (args.config == "C2" or world != 1):
         raise SystemExit("--sweep needs --config C4|C5 on one GPU")
     WL = HostWorkload if args.source == "host" else Workload
+    device_mode = args.source != "host"
 
     # ---- sweep: this GPU plays every rank of the 8-GPU job in turn ----------------------------------------------------
     if args.sweep:
@@ -843,9 +882,9 @@ def main():
     # ---- the timed workload ----------------------------------------------------------------------------------------------
     if args.scaling == "strong":
         lo, hi = shard.shard_range(cfg["total"], rank, world)
-        wl = WL(args.config, rank, dev, local_rank, first=lo, count=hi - lo)
+        wl = WL(args.config, rank, dev, local_rank, first=lo, count=hi - lo, **({"in_flight": args.in_flight or 2} if device_mode else {}))
     else:
-        wl = WL(args.config, rank, dev, local_rank)
+        wl = WL(args.config, rank, dev, local_rank, **({"in_flight": args.in_flight or 1} if device_mode else {}))
     B = wl.B
 
     # parity gate first (one extra untimed encode): EVERY rank checks EVERY one of its frames against the reference
@@ -1086,7 +1125,7 @@ def main():
                                    + (f" (the whole batch of {cfg['total']} split over {world} ranks)" if args.scaling == "strong" else " (every rank the same amount)")
                                    + f", {cfg['stages']} DWT stages, filter A, {cfg['segments']} segments, lossless quota 2*W*H; {src}",
                        "frames_per_gpu_per_step": B, "launches_per_step": launches_per_step, "units_per_frame": units_per_frame,
-                       "launches_in_flight": 2 if getattr(wl, "pipelined", False) else 1,
+                       "launches_in_flight": 2 if (getattr(wl, "pipelined", False) or getattr(wl, "cross_step", False)) else 1,
                        "parity": "every frame of every rank: rc, stream length and CRC-32 equal the reference golden (checked before timing and again "
                                  "on the output of the last timed step)"},
             "parity_after_timing": parity_after,
@@ -1099,7 +1138,7 @@ def main():
             # roofline of the dominant kernel (the coding-unit kernel): algorithmic bytes per launch =
             # SURVEY 8(d) per-frame figure (input planes read once + final stream written once) x frames per launch
             k_ms = stage_ms["code_units"] / max(calls, 1)
-            if getattr(wl, "pipelined", False):
+            if getattr(wl, "pipelined", False) or getattr(wl, "cross_step", False):
                 # two launches in flight: a launch's own events span the time it shared the chip with its neighbour; what a launch
                 # costs is the step's time over its launches
                 k_ms = elapsed_max / args.steps / launches_per_step * 1e3
@@ -1117,7 +1156,7 @@ def main():
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
                                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(k_ms, 4)}
             line["stage_ms_per_step"] = {k: round(v / max(calls, 1) * launches_per_step, 4) for k, v in stage_ms.items()}
-            if getattr(wl, "pipelined", False):
+            if getattr(wl, "pipelined", False) or getattr(wl, "cross_step", False):
                 line["stage_ms_note"] = ("two launches in flight: the stage times are each launch's own event spans (they overlap its neighbour's and add up to "
                                          "more than the step); roofline.avg_launch_ms = step time / launches")
         if batched:
