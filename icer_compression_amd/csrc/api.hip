@@ -189,9 +189,10 @@ struct icerx_encoder {
     DevBuf<uint32_t> work_order, final_order, unit_bits, done_bytes;
     DevBuf<uint64_t> final_off;
     DevBuf<uint8_t> slots;
-    DevBuf<uint8_t> sig;                // chunk tables (chunk_sig_kernel), max_frames * plan.sig_bytes
-    DevBuf<uint32_t> sig_hist;          // per frame and family: chunks by the bit plane from which they are blank, 16 entries (chunk_sig_kernel -> route_units_kernel)
+    DevBuf<uint8_t> sig;                // chunk tables (family_events_kernel), max_frames * plan.sig_bytes
+    DevBuf<uint32_t> sig_hist;          // per frame and family: chunks by the bit plane from which they are blank, 16 entries (family_events_kernel -> route_units_kernel)
     DevBuf<uint32_t> sig_blocks;        // Plan::sig_blocks on the device
+    DevBuf<uint8_t> events;             // event bytes (events.hpp): max_frames x bit planes x plan.sig_bytes chunks x 64, allocated at the first pipeline launch
     DevBuf<uint8_t> route;              // max_frames * units: the coder of each unit when both share a launch
     DevBuf<uint32_t> route_list, route_ctl;   // the units of the workgroup coder (frame * units + unit), [length, cursor]
     // sub-range splitting (coder_core.hpp "Sub-ranges"): launches of at most split_frames planes cut their dense units into
@@ -456,11 +457,17 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                        !e->plan.subs.empty() && e->hybrid_percent > 0;
     e->last_split = split;
     const bool hybrid = split || (e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames);
-    if (use_wg || hybrid) {
+    // the stateless half of the context modeller, once per family: event bytes for the pipeline coder's pixel waves, the chunk
+    // table for both coders (family_events_kernel; the window coder on its own reads the coefficients itself: table only)
+    const int n_planes = e->sample_bits == 8 ? kPlanes8 : kPlanes;
+    const size_t ev_frame_bytes = (size_t)n_planes * e->plan.sig_bytes * 64u;
+    if (!use_wg && e->events.ensure((size_t)e->max_frames * ev_frame_bytes + 64)) return ICER_FATAL_ERROR;
+    {
         if (hybrid) HIP_TRY(hipMemsetAsync(e->sig_hist.p, 0, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(chunk_sig_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
+        hipLaunchKernelGGL(family_events_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,
-                           e->plan.sig_bytes, hybrid ? e->sig_hist.p : nullptr, e->plan.n_families);
+                           e->plan.sig_bytes, hybrid ? e->sig_hist.p : nullptr, e->plan.n_families,
+                           use_wg ? nullptr : e->events.p, ev_frame_bytes, (uint32_t)n_planes);
     }
     const uint8_t *route = nullptr;
     e->last_routed = hybrid;
@@ -531,7 +538,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
                            reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,                  \
                            e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp, \
-                           unit_major ? (uint32_t)n_frames : 1u)
+                           unit_major ? (uint32_t)n_frames : 1u, e->events.p, ev_frame_bytes, e->sig.p, e->plan.sig_bytes)
         e->last_waves = large ? kUnitWavesLarge : kUnitWavesSmall;
         e->last_subs = sp.n_subs;
         if (large) ICER_LAUNCH_PIPE(kUnitWavesLarge, 1, 0);
@@ -653,6 +660,11 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         icerx_encoder_destroy(e);
         return ICER_FATAL_ERROR;
     }
+    // event bytes of the pipeline coder (events.hpp): one per pixel and bit plane, in chunk order
+    if (e->coder_mode != 2 && e->events.ensure((size_t)max_frames * (size_t)(sample_bits == 8 ? kPlanes8 : kPlanes) * e->plan.sig_bytes * 64u + 64)) {
+        icerx_encoder_destroy(e);
+        return ICER_FATAL_ERROR;
+    }
     CREATE_TRY(hipMemcpy(e->tables.p, &g_tables, sizeof g_tables, hipMemcpyHostToDevice));
     // the workgroup coder's LDS block is above the 64 KiB a kernel gets without asking
     // A device / runtime that refuses it loses only the paths that need that coder (progressive mode then runs on the
@@ -686,7 +698,7 @@ void icerx_encoder_destroy(icerx_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     e->coef.release(); e->tmp.release(); e->sums.release(); e->means.release(); e->flags.release();
-    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->sig_hist.release(); e->sig_blocks.release(); e->route.release(); e->route_list.release(); e->route_ctl.release();
+    e->units.release(); e->work_order.release(); e->final_order.release(); e->unit_bits.release(); e->done_bytes.release(); e->sig.release(); e->events.release(); e->sig_hist.release(); e->sig_blocks.release(); e->route.release(); e->route_list.release(); e->route_ctl.release();
     e->final_off.release(); e->slots.release(); e->tables.release(); e->in.release(); e->in8.release(); e->out.release();
     e->sizes.release(); e->rcs.release(); e->prof.release();
     e->subs.release(); e->sub_order.release(); e->snap_valid.release(); e->snaps.release(); e->sub_recs.release();

@@ -46,6 +46,7 @@
 //
 // Written with the SPMD macros of wave.hpp (see there for the tests-only CPU build).
 #pragma once
+#include "events.hpp"
 #include "icer_tables.hpp"
 #include "wave.hpp"
 
@@ -272,7 +273,6 @@ struct CoderShared {
     RunSlot kq[kQueueDepth];
     int32_t bin_slot[kNumBins]; // ring index of the bin's open word, -1 if none
     uint32_t bin_state[kNumBins];   // as RecSlot::binst, as of the last retired chunk (bits 0..7 unused)
-    uint8_t ctx_tab[48];            // pixel wave: context table of the unit's subband (see pixel_wave_run)
     uint8_t srank[128];             // merge wave: position of a word start -> number of word starts before it in the chunk (merge_commit)
     uint32_t gk[kNumBins];          // golomb wave: zero-run length of each Golomb bin's open word as of its last chunk (0 = none)
     // ring occupancy = alloc - popped (both count words since the start of the unit; slot = count mod 2048)
@@ -349,6 +349,8 @@ struct SubLayout {                              // one per (frame, split unit), 
 
 struct UnitArgs {
     const uint16_t *seg;        // first coefficient of the segment (sign-magnitude words)
+    const uint8_t *ev;          // the unit's event bytes (events.hpp): chunk j = bytes [64 j, 64 j + 64), unwritten where the chunk is blank
+    const uint8_t *sig;         // chunk table of the unit's family: chunk j is blank at every bit plane >= sig[j]
     uint32_t stride;            // plane row stride in elements
     uint32_t w, h;              // segment size
     int subband, lsb;
@@ -433,25 +435,6 @@ ICER_DEV void seq_complete_head(CoderShared &s)
             s.bin_slot[bin] = -1;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// context tables as arithmetic (icer_config.c:26-67)
-// ------------------------------------------------------------------------------------------
-ICER_DEV uint32_t ctx_plain(uint32_t h, uint32_t v, uint32_t d)      // LL / LH / (swapped) HL
-{
-    if (h == 2) return 8;
-    if (h == 1) return (v == 0) ? (d < 2 ? 5 + d : 7u) : 7u;
-    if (v == 0) return d > 2 ? 2u : d;
-    return 2 + v;                                                    // v = 1 -> 3, v = 2 -> 4
-}
-ICER_DEV uint32_t ctx_hh(uint32_t hv, uint32_t d)
-{
-    if (d >= 3) return 8;
-    const uint32_t k = hv > 2 ? 2u : hv;
-    if (d == 0) return k;
-    if (d == 1) return 3 + k;
-    return hv == 0 ? 6u : 7u;
 }
 
 // pick the coder bin from a folded (zero >= total/2) probability estimate: the number of
@@ -660,138 +643,61 @@ ICER_DEV uint32_t wave_drain(CoderShared &s, uint32_t limit, uint32_t max_rounds
 // ==========================================================================================
 // pixel wave
 // ==========================================================================================
-struct PixelWave {                // next chunk's 3x3 coefficient window, one pixel per lane
-    LANEVAR(uint32_t, nC); LANEVAR(uint32_t, nW); LANEVAR(uint32_t, nE); LANEVAR(uint32_t, nN); LANEVAR(uint32_t, nS);
-    LANEVAR(uint32_t, nNW); LANEVAR(uint32_t, nNE); LANEVAR(uint32_t, nSW); LANEVAR(uint32_t, nSE);
-    LANEVAR(uint32_t, has);                             // which neighbours exist: bit 0 W, 1 E, 2 N, 3 S
-    LANEVAR(uint32_t, row); LANEVAR(uint32_t, col);     // raster coordinates of this lane's pixel in the next chunk
-    uint32_t fetched = ~0u;                             // chunk whose window is in the registers above (~0: none yet)
+struct PixelWave {                // this wave's next chunk, prefetched
+    LANEVAR(uint32_t, nb);          // event byte of pixel `lane` (events.hpp); not loaded for a blank chunk
+    uint32_t fetched = ~0u;         // chunk whose bytes are in flight / in the register above (~0: none yet)
+    uint64_t blank = 0;             // chunks [blank_base, blank_base + 64) of the unit that are blank at its plane (chunk table)
+    uint32_t blank_base = ~0u;
 };
 
-// fetch the 3x3 windows of the 64 pixels starting at BASE; (cw.row, cw.col) = raster coordinates of pixel
-// BASE + lane, advanced to this wave's next chunk without a division when the segment is wide enough
-#define ICER_FETCH_WINDOW(BASE)                                                                        \
-    FOR_LANES                                                                                          \
-    {                                                                                                  \
-        const bool in_ = (BASE) + (uint32_t)lane < npix;                                               \
-        const uint32_t r_ = in_ ? LV(cw.row) : 0u, c_ = in_ ? LV(cw.col) : 0u;                          \
-        const bool hasW_ = c_ > 0, hasE_ = c_ + 1 < a.w, hasN_ = r_ > 0, hasS_ = r_ + 1 < a.h;          \
-        /* nine unconditional loads from clamped (always valid) positions, then selects: no divergent branches */ \
-        const uint32_t cW_ = hasW_ ? c_ - 1u : c_, cE_ = hasE_ ? c_ + 1u : c_;                          \
-        const uint16_t *pC_ = a.seg + (size_t)r_ * a.stride;                                           \
-        const uint16_t *pN_ = hasN_ ? pC_ - a.stride : pC_, *pS_ = hasS_ ? pC_ + a.stride : pC_;        \
-        const uint32_t vC_ = pC_[c_], vW_ = pC_[cW_], vE_ = pC_[cE_];                                   \
-        const uint32_t vN_ = pN_[c_], vNW_ = pN_[cW_], vNE_ = pN_[cE_];                                 \
-        const uint32_t vS_ = pS_[c_], vSW_ = pS_[cW_], vSE_ = pS_[cE_];                                 \
-        /* the loaded values are not touched before the next chunk needs them (the loads stay in flight meanwhile):  \
-         * which neighbours exist is kept as a mask and applied then */                                \
-        LV(cw.nC) = vC_; LV(cw.nW) = vW_; LV(cw.nE) = vE_; LV(cw.nN) = vN_; LV(cw.nS) = vS_;             \
-        LV(cw.nNW) = vNW_; LV(cw.nNE) = vNE_; LV(cw.nSW) = vSW_; LV(cw.nSE) = vSE_;                     \
-        LV(cw.has) = (hasW_ ? 1u : 0u) | (hasE_ ? 2u : 0u) | (hasN_ ? 4u : 0u) | (hasS_ ? 8u : 0u);     \
-        /* advance to the same lane of this wave's next chunk (npw chunks further on) */               \
-        if (a.w >= 64u * npw) {                                                                        \
-            uint32_t nc_ = LV(cw.col) + 64u * npw;                                                     \
-            if (nc_ >= a.w) { nc_ -= a.w; LV(cw.row)++; }                                              \
-            LV(cw.col) = nc_;                                                                          \
-        } else {                                                                                       \
-            const uint32_t np_ = (BASE) + 64u * npw + (uint32_t)lane;                                  \
-            LV(cw.row) = np_ / a.w;                                                                    \
-            LV(cw.col) = np_ - LV(cw.row) * a.w;                                                       \
-        }                                                                                              \
+// The unit's chunk table (family_events_kernel): chunk j is blank at the unit's bit plane iff sig[j] <= lsb.  Read 64 chunks at a
+// time -- one byte per lane, one ballot -- so that a chunk costs the pixel wave a scalar bit test.
+#define ICER_BLANK_MASK(J)                                                                             \
+    if (((J) & ~63u) != cw.blank_base) {                                                               \
+        cw.blank_base = (J) & ~63u;                                                                    \
+        cw.blank = BALLOT(cw.blank_base + (uint32_t)lane < nchunks && (uint32_t)a.sig[cw.blank_base + (uint32_t)lane] <= lsb); \
     }
+#define ICER_IS_BLANK(J) (((cw.blank >> ((J) & 63u)) & 1ull) != 0ull)
 
-// context of a not-yet-significant pixel by neighbour counts (icer_config.c:26-67) for the unit's subband: HH indexed
-// (h + v) * 5 + d, the other subbands (h * 3 + v) * 5 + d with h, v <= 2, d <= 4.  One wave, before the pixel waves start.
-ICER_DEV void pixel_tables_init(CoderShared &s, const UnitArgs &a)
-{
-    DECL_LANE;
-    const bool is_hh = a.subband == kHH;
-    FOR_LANES
-    {
-        if (lane < 45) s.ctx_tab[lane] = (uint8_t)(is_hh ? ctx_hh((uint32_t)lane / 5u, (uint32_t)lane % 5u)
-                                                        : ctx_plain((uint32_t)lane / 15u, ((uint32_t)lane / 5u) % 3u, (uint32_t)lane % 5u));
-    }
-    WAVE_SYNC();
-}
-
-// pixel wave k of npw: its chunks (j % npw == k) among [j0, j1); consecutive calls continue the window prefetch (cw.fetched)
+// pixel wave k of npw: its chunks (j % npw == k) among [j0, j1); consecutive calls continue the prefetch (cw.fetched)
 // `counts_only`: for the counts-only pass of the count wave -- the events' context / bit and the per-context totals, no ranks
+// The events themselves -- category, bit, 8-neighbour context, sign context and prediction (C1-C6) -- were made once for all bit
+// planes of the unit's family (events.hpp, family_events_kernel): one byte per pixel, 64 consecutive bytes per chunk.
 ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw, bool counts_only = false)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
-    const uint32_t npix = a.w * a.h;
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
     const uint32_t lsb = (uint32_t)a.lsb;
-    const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
     const uint32_t jfirst = j0 + (k + npw - j0 % npw) % npw;                        // first chunk >= j0 of this wave
-    if (cw.fetched != jfirst && jfirst * 64u < npix) {                                // (first call, or a new start: no window in flight)
-        FOR_LANES
-        {
-            const uint32_t np = jfirst * 64u + (uint32_t)lane;
-            LV(cw.row) = np / a.w; LV(cw.col) = np - LV(cw.row) * a.w;
-        }
-        ICER_FETCH_WINDOW(jfirst * 64u)
+    if (cw.fetched != jfirst && jfirst < nchunks) {                                  // (first call, or a new start: nothing in flight)
+        ICER_BLANK_MASK(jfirst)
+        if (!ICER_IS_BLANK(jfirst)) { FOR_LANES { LV(cw.nb) = a.ev[(size_t)jfirst * 64u + (uint32_t)lane]; } }
         cw.fetched = jfirst;
     }
 
     for (uint32_t j = jfirst; j < j1; j += npw) {
-        const uint32_t base = j * 64u;
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
-        LANEVAR(uint32_t, cC); LANEVAR(uint32_t, cW); LANEVAR(uint32_t, cE); LANEVAR(uint32_t, cN); LANEVAR(uint32_t, cS);
-        LANEVAR(uint32_t, cNW); LANEVAR(uint32_t, cNE); LANEVAR(uint32_t, cSW); LANEVAR(uint32_t, cSE);
-        FOR_LANES
-        {
-            const uint32_t hm = LV(cw.has);
-            const bool hW = hm & 1u, hE = hm & 2u, hN = hm & 4u, hS = hm & 8u;
-            LV(cC) = LV(cw.nC); LV(cW) = hW ? LV(cw.nW) : 0u; LV(cE) = hE ? LV(cw.nE) : 0u;
-            LV(cN) = hN ? LV(cw.nN) : 0u; LV(cS) = hS ? LV(cw.nS) : 0u;
-            LV(cNW) = (hN && hW) ? LV(cw.nNW) : 0u; LV(cNE) = (hN && hE) ? LV(cw.nNE) : 0u;
-            LV(cSW) = (hS && hW) ? LV(cw.nSW) : 0u; LV(cSE) = (hS && hE) ? LV(cw.nSE) : 0u;
+        ICER_BLANK_MASK(j)
+        const bool blank = ICER_IS_BLANK(j);
+        LANEVAR(uint32_t, eb);
+        FOR_LANES { LV(eb) = blank ? 0u : LV(cw.nb); }
+        // this wave's next chunk is fetched while this one is processed (the LDS-only fences never drain vmcnt)
+        if (j + npw < nchunks) {
+            ICER_BLANK_MASK(j + npw)
+            if (!ICER_IS_BLANK(j + npw)) { FOR_LANES { LV(cw.nb) = a.ev[(size_t)(j + npw) * 64u + (uint32_t)lane]; } }
         }
-        // this wave's next chunk's window is fetched while this one is processed (the LDS-only fences never drain vmcnt)
-        if (base + 64u * npw < npix) ICER_FETCH_WINDOW(base + 64u * npw)
         cw.fetched = j + npw;
-
-        // ---- context formation (C1-C6) ------------------------------------------------------------
         FOR_LANES
         {
-            const bool valid = base + (uint32_t)lane < npix;
-            const uint32_t x = LV(cC), xW = LV(cW), xE = LV(cE), xN = LV(cN), xS = LV(cS);
-            const uint32_t xNW = LV(cNW), xNE = LV(cNE), xSW = LV(cSW), xSE = LV(cSE);
-
-            const uint32_t mag = x & 0x7FFFu;
-            const int msb = 31 - clz32(mag | 1u);
-            int cat = msb - (int)lsb;
-            cat = cat < 0 ? 0 : (cat > 3 ? 3 : cat);
-            const uint32_t bit = (mag >> lsb) & 1u;
-            // already-visited neighbours are judged at this plane, the others one plane up
-#define ICER_SIG(v, l) ((((v)&0x7FFFu) >> (l)) != 0u ? 1u : 0u)
-            const uint32_t sW = ICER_SIG(xW, lsb), sE = ICER_SIG(xE, lsb + 1);
-            const uint32_t sN = ICER_SIG(xN, lsb), sS = ICER_SIG(xS, lsb + 1);
-            uint32_t hh = sW + sE, vv = sN + sS;
-            const uint32_t dd = ICER_SIG(xNW, lsb) + ICER_SIG(xNE, lsb) + ICER_SIG(xSW, lsb + 1) + ICER_SIG(xSE, lsb + 1);
-#undef ICER_SIG
-            // category 0: the subband's context table (built once per unit, ctx_tab); 1: 9 / 10; 2: 11; 3: uncoded
-            if (is_hl) { const uint32_t t = hh; hh = vv; vv = t; }
-            const uint32_t c0 = s.ctx_tab[is_hh ? (hh + vv) * 5u + dd : (hh * 3u + vv) * 5u + dd];
-            const uint32_t c1 = (hh + vv == 0) ? 9u : 10u;
-            const uint32_t ctx = cat == 0 ? c0 : cat == 1 ? c1 : cat == 2 ? 11u : 31u;
-            LV(valid1) = valid ? 1u : 0u;
-            LV(ctx1) = ctx;
-            LV(bit1) = bit;
-
-            // sign event (C6): only negative significant neighbours count
-            const bool sgn = valid && cat == 0 && bit;
-            uint32_t sh = 2 - ((xW >> 15) & sW) - ((xE >> 15) & sE);
-            uint32_t sv = 2 - ((xN >> 15) & sN) - ((xS >> 15) & sS);
-            if (is_hl) { const uint32_t t = sh; sh = sv; sv = t; }
-            // icer_sign_context_table / icer_sign_prediction_table restricted to sh, sv in {0,1,2}
-            const uint32_t sctx = (sh == 2) ? (sv == 2 ? 12u : 13u) : (sv == 2 ? 15u : 14u);
-            const uint32_t pred = (sh == 2) ? 0u : 1u;
-            LV(valid2) = sgn ? 1u : 0u;
-            LV(ctx2) = sctx;
-            LV(bit2) = (pred ^ (x >> 15)) & 1u;
+            const uint32_t b = LV(eb), c4 = b & 15u;
+            LV(valid1) = c4 != kEvNone ? 1u : 0u;
+            LV(ctx1) = c4 == kEvUncoded ? 31u : c4;
+            LV(bit1) = (b >> 4) & 1u;
+            LV(valid2) = (c4 <= 8u && (b & 16u)) ? 1u : 0u;          // the pixel becomes significant here: its sign follows (C6)
+            LV(ctx2) = 12u + ((b >> 5) & 3u);
+            LV(bit2) = (b >> 7) & 1u;
         }
         // ---- context groups --------------------------------------------------------------------------
         // What the adaptive counts (C5) need from the chunk depends on the coefficients alone and is prepared
@@ -804,7 +710,9 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
         // A blank chunk -- 64 pixels that are and stay insignificant with no significant neighbour, i.e. 64 zero events
         // of context 0 and no sign event; more than half of all chunks, the high planes mostly -- needs no matching:
         // the rank of an event is its lane number and so is the number of zeros before it.
-        const bool blank = BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull;
+#ifdef ICER_WAVE_EMU
+        assert(blank == (BALLOT(!LV(valid1) || LV(ctx1) != 0u || LV(bit1) != 0u || LV(valid2)) == 0ull));     // (tests) the chunk table agrees with the events
+#endif
         if (blank) {
             FOR_LANES
             {

@@ -15,6 +15,7 @@
 #include "coder_wg.hpp"
 #include "coder_wg_small.hpp"
 #include "dwt_tile.hpp"
+#include "events.hpp"
 #include "plan.hpp"
 
 namespace icer {
@@ -139,7 +140,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                   size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
-                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp, uint32_t n_frames_1d)
+                  uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp, uint32_t n_frames_1d,
+                  const uint8_t *__restrict__ ev, size_t ev_frame_stride, const uint8_t *__restrict__ sig, size_t sig_frame_stride)
 {
     __shared__ CoderShared s;
     if constexpr (LDS_PAD > 0) {
@@ -232,6 +234,9 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     UnitArgs a;
     a.seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
     a.stride = img_w;
+    // the family's events at this unit's bit plane and its chunk table (family_events_kernel)
+    a.ev = ev + (size_t)frame * ev_frame_stride + ev_offset(u.lsb, sig_frame_stride, u.sig_off, 0u);
+    a.sig = sig + (size_t)frame * sig_frame_stride + u.sig_off;
     a.w = u.w; a.h = u.h;
     a.subband = (int)u.subband; a.lsb = (int)u.lsb;
     a.out_words = slot_words + kHeaderBytes / 4;
@@ -261,7 +266,6 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     // profiling build: per-wave cycle counters of the level-1 (largest) units, one row per bit plane
     a.timers = (timers && u.level == 1) ? timers + u.lsb * 32 : nullptr;
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
-    if (wave == kCount) pixel_tables_init(s, a);
     __syncthreads();
 
     // A later sub-range starts with the adaptive counts at its first chunk j0: they depend on the coefficients before it
@@ -432,24 +436,37 @@ splice_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const 
     if (threadIdx.x == 0) unit_bits[(size_t)frame * n_units + ui] = bits;
 }
 
-// ------------------------------------------------------------------------------------------ chunk tables
-// One byte per 64-pixel chunk of every (channel, level, subband, segment): the lowest bit plane from which the chunk
-// is blank (wg::chunk_blank_plane), for all bit planes of the family at once.  Work list (Plan::sig_blocks): one (unit, block) pair per
-// family and block of 64 chunks; grid = (entries, frames), block = 256 (16 chunks per wavefront).
+// ------------------------------------------------------------------------------------------ family events + chunk tables
+// The stateless half of the context modeller once per FAMILY (events.hpp): for every 64-pixel chunk of every (channel, level,
+// subband, segment) one pass over the chunk's 3x3 windows leaves
+//   * the chunk table: one byte per chunk, the lowest bit plane from which the chunk is blank (wg::chunk_blank_plane), and the family's
+//     histogram of those values (route_units_kernel);
+//   * with `ev` != null, one event byte per pixel for every bit plane below that (events.hpp: context, bit, sign context, sign bit), in
+//     the coding order of the plane's unit -- what code_units_kernel's pixel wave reads instead of gathering and classifying the nine
+//     words again for each of the family's planes (icer_context_modeller.c:340-440 once per pixel, not once per pixel and plane).
+// Work list (Plan::sig_blocks): one (unit, block) pair per family and block of 64 chunks; grid = (entries, frames), block = 256
+// (16 chunks per wavefront).  HBM: reads the coefficient plane once (2 B / pixel, 3x3 windows through L1 / L2), writes one byte per pixel
+// and NON-BLANK bit plane (8-bit content: about five of nine).
 __global__ void __launch_bounds__(256)
-chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, int channels,
-                 const UnitDesc *__restrict__ units, const uint32_t *__restrict__ blocks, const int *__restrict__ frame_skip,
-                 uint8_t *__restrict__ sig, size_t sig_frame_stride, uint32_t *__restrict__ hist, uint32_t n_families)
+family_events_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, int channels,
+                     const UnitDesc *__restrict__ units, const uint32_t *__restrict__ blocks, const int *__restrict__ frame_skip,
+                     uint8_t *__restrict__ sig, size_t sig_frame_stride, uint32_t *__restrict__ hist, uint32_t n_families,
+                     uint8_t *__restrict__ ev, size_t ev_frame_stride, uint32_t n_planes)
 {
+    __shared__ uint8_t ctx_tab[48];
     const UnitDesc u = units[blocks[2u * blockIdx.x]];
     const uint32_t frame = blockIdx.y, nchunks = (u.w * u.h + 63u) / 64u, first = blocks[2u * blockIdx.x + 1u] * 64u;
     if (frame_skip[frame]) return;
+    const bool is_hl = u.subband == kHL, is_hh = u.subband == kHH;
+    if (ev) {
+        if (threadIdx.x < 45u) ctx_tab[threadIdx.x] = (uint8_t)ev_ctx_entry(is_hh, threadIdx.x);
+        __syncthreads();
+    }
     const uint16_t *seg = coef + ((size_t)frame * channels + u.chan) * plane + (size_t)u.y0 * img_w + u.x0;
     uint8_t *out = sig + (size_t)frame * sig_frame_stride + u.sig_off;
-    // The value of wg::chunk_blank_plane (its definition, and what the tests-only CPU builds call) for 16 consecutive chunks
-    // per wavefront, without its per-chunk costs: the lane's pixel coordinates advance by 64 with one wrap instead of a
-    // division per chunk, and the maximum over the lanes is five ballots (the values are bit lengths, 0 .. 16) instead of
-    // six cross-lane shuffles through LDS.  81 -> ~ 30 us on the headline frame.
+    uint8_t *evf = ev ? ev + (size_t)frame * ev_frame_stride : nullptr;
+    // 16 consecutive chunks per wavefront: the lane's pixel coordinates advance by 64 with one wrap instead of a division per
+    // chunk, and the maximum over the lanes is four ballots (the values are bit lengths, 0 .. 15) instead of six cross-lane shuffles.
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t sw = u.w, sh = u.h, npix = sw * sh;
     uint32_t j = first + wave * 16u;
@@ -466,16 +483,19 @@ chunk_sig_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w
         // nine unconditional loads from clamped positions, masked afterwards (as wg::chunk_blank_plane)
         const uint32_t vC = pC_[c_], vW = pC_[cW_], vE = pC_[cE_], vN = pN_[c_], vNW = pN_[cW_], vNE = pN_[cE_];
         const uint32_t vS = pS_[c_], vSW = pS_[cW_], vSE = pS_[cE_];
-        const uint32_t a_ = (vC | vW | vN | vNW | ((hasN_ && hasE_) ? vNE : 0u)) & 0x7FFFu;
-        const uint32_t b_ = ((hasE_ ? vE : 0u) | (hasS_ ? vS : 0u) | ((hasS_ && hasW_) ? vSW : 0u) | ((hasS_ && hasE_) ? vSE : 0u)) & 0x7FFFu;
-        const uint32_t la_ = a_ ? 32u - (uint32_t)__builtin_clz(a_) : 0u, lb_ = b_ ? 32u - (uint32_t)__builtin_clz(b_) : 0u;      // bit lengths
-        const uint32_t lb1_ = lb_ - (lb_ ? 1u : 0u);
-        const uint32_t t = la_ > lb1_ ? la_ : lb1_;                  // 0 .. 15
+        const PixelLens L = pixel_lens(vC, hasW_ ? vW : 0u, hasE_ ? vE : 0u, hasN_ ? vN : 0u, hasS_ ? vS : 0u, (hasN_ && hasW_) ? vNW : 0u,
+                                       (hasN_ && hasE_) ? vNE : 0u, (hasS_ && hasW_) ? vSW : 0u, (hasS_ && hasE_) ? vSE : 0u);
         uint32_t tmax = 0;
-        for (uint32_t step = 8u; step; step >>= 1) tmax += __ballot(in_ && t >= tmax + step) ? step : 0u;
+        for (uint32_t step = 8u; step; step >>= 1) tmax += __ballot(in_ && L.t >= tmax + step) ? step : 0u;
         const bool partial = __ballot(!in_) != 0ull;                 // a chunk with fewer than 64 pixels is never blank
         if (lane == 0u) out[j] = (uint8_t)(partial ? 255u : tmax);
         mine += (!partial && lane == tmax) ? 1u : 0u;
+        if (evf) {
+            // the planes at which the chunk is not blank (a partial chunk: all of them)
+            const uint32_t top = partial ? n_planes : (tmax < n_planes ? tmax : n_planes);
+            for (uint32_t p = 0; p < top; p++)
+                evf[ev_offset(p, sig_frame_stride, u.sig_off, j) + lane] = (uint8_t)(in_ ? event_byte(L, p, is_hl, is_hh, ctx_tab) : kEvNone);
+        }
         np += 64u;
         c += 64u;
         if (sw >= 64u) { if (c >= sw) { c -= sw; r++; } }

@@ -11,7 +11,10 @@
 //   final stream order          icer_compress.c:409-423, icer_color.c:508-527
 #pragma once
 #include <algorithm>
+#include <array>
+#include <map>
 #include <stdint.h>
+#include <utility>
 #include <vector>
 
 #include "icer_tables.hpp"
@@ -183,7 +186,7 @@ struct Plan {
     size_t slot_bytes = 0;                 // per-frame slot area for the current capacity rule
     size_t sig_bytes = 0;                  // per-frame chunk-table area (UnitDesc::sig_off)
     uint32_t n_families = 0;               // families per frame (UnitDesc::family): (channel, level, subband, segment)
-    std::vector<uint32_t> sig_blocks;      // the work list of chunk_sig_kernel: pairs (unit, block of 64 chunks), one family member (plane 0) each
+    std::vector<uint32_t> sig_blocks;      // the work list of family_events_kernel: pairs (unit, block of 64 chunks), one member of every family
     std::vector<SubDesc> subs;             // sub-range workgroups of split launches: unit order, a unit's sub-ranges 1 .. n_sub-1 consecutive
     std::vector<uint32_t> split_launch;    // launch order of a split launch: bit 31 set = sub-range workgroup (index into subs), else a unit;
                                            // longest expected run first (a sub-range = its chunks + a tenth of its prefix pass)
@@ -290,28 +293,31 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
         }
         interleave_lists(lists, &p->work_order);
     }
-    // chunk tables: one per family, in unit order
+    // chunk tables and event bytes: one set per family, in unit order.  A family is the units that code the SAME rectangle of the same
+    // (channel, level, subband) at different bit planes -- normally all planes of a (channel, level, subband, segment); under quirk P1
+    // (a failed grid keeps the previous PACKET's one, and which packet came before depends on the plane) the planes of one segment
+    // number can have different rectangles: those are families of their own.
     {
-        std::vector<int64_t> off_of_family((size_t)3 * (kMaxStages + 1) * 4 * (kMaxSegments + 1), -1);
-        std::vector<uint32_t> index_of_family(off_of_family.size(), 0u);
+        std::map<std::array<uint32_t, 8>, std::pair<size_t, uint32_t>> fam;       // rectangle -> (chunk offset, family index)
         size_t off = 0;
         uint32_t families = 0;
-        for (UnitDesc &u : p->units) {
-            const size_t key = ((u.chan * (kMaxStages + 1) + u.level) * 4 + u.subband) * (kMaxSegments + 1) + u.seg;
-            int64_t &o = off_of_family[key];
-            if (o < 0) { o = (int64_t)off; off += (((size_t)u.w * u.h + 63) / 64 + 3) & ~(size_t)3; index_of_family[key] = families++; }
-            u.sig_off = (uint32_t)o;
-            u.family = index_of_family[key];
+        p->sig_blocks.clear();
+        for (size_t i = 0; i < p->units.size(); i++) {
+            UnitDesc &u = p->units[i];
+            const std::array<uint32_t, 8> key{u.chan, u.level, u.subband, u.seg, u.x0, u.y0, u.w, u.h};
+            auto it = fam.find(key);
+            if (it == fam.end()) {
+                it = fam.emplace(key, std::make_pair(off, families++)).first;
+                const uint32_t nchunks = ((uint32_t)u.w * u.h + 63u) / 64u;
+                off += ((size_t)nchunks + 3) & ~(size_t)3;
+                // the work list of family_events_kernel: this unit stands for its family, one entry per block of 64 chunks
+                for (uint32_t b = 0; b < (nchunks + 63u) / 64u; b++) { p->sig_blocks.push_back((uint32_t)i); p->sig_blocks.push_back(b); }
+            }
+            u.sig_off = (uint32_t)it->second.first;
+            u.family = it->second.second;
         }
         p->sig_bytes = off;
         p->n_families = families;
-        p->sig_blocks.clear();
-        for (size_t i = 0; i < p->units.size(); i++) {
-            const UnitDesc &u = p->units[i];
-            if (u.lsb != 0u) continue;
-            const uint32_t blocks = (((uint32_t)u.w * u.h + 63u) / 64u + 63u) / 64u;
-            for (uint32_t b = 0; b < blocks; b++) { p->sig_blocks.push_back((uint32_t)i); p->sig_blocks.push_back(b); }
-        }
     }
     // the launch is latency-bound by its largest units: give their waves issue priority over the small ones
     const uint64_t biggest = p->units.empty() ? 1 : (uint64_t)p->units[p->work_order[0]].w * p->units[p->work_order[0]].h;

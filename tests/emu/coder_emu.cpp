@@ -55,6 +55,8 @@ extern "C" long emu_code_unit(const uint16_t *seg, size_t w, size_t h, size_t st
     std::vector<uint32_t> words(a.cap_words + 1, 0);
     a.out_words = words.data();
     a.timers = nullptr;
+    EmuEvents evs;
+    evs.build(a);
     uint32_t bits = code_unit_emu(g_sh, a);
     long res = (bits == kUnitTooBig) ? -5 : (long)bits;
     if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
@@ -76,6 +78,8 @@ extern "C" long emu_code_unit_split(const uint16_t *seg, size_t w, size_t h, siz
     a.out_words = words.data();
     a.timers = nullptr;
     a.done_bytes = nullptr; a.prio_index = 0; a.early_quota = 0;
+    EmuEvents evs;
+    evs.build(a);
     const uint32_t bits = code_unit_emu_split(g_sh, a, n_sub, order, matches);
     const long res = bits == kUnitTooBig ? -5 : bits == kUnitFailed ? -10 : (long)bits;
     if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
@@ -95,6 +99,8 @@ extern "C" long emu_code_unit_random(const uint16_t *seg, size_t w, size_t h, si
     std::vector<uint32_t> words(a.cap_words + 1, 0);
     a.out_words = words.data();
     a.timers = nullptr;
+    EmuEvents evs;
+    evs.build(a);
     const uint32_t bits = code_unit_emu_random(g_sh, a, seed);
     const long res = bits == kUnitTooBig ? -5 : bits == kUnitFailed ? -10 : (long)bits;
     if (res >= 0) memcpy(out, words.data(), (size_t)(bits + 7) / 8);
@@ -211,6 +217,8 @@ extern "C" int emu_compress_bits(uint16_t *const planes[], int channels, size_t 
         a.out_words = slot_words + kHeaderBytes / 4;
         a.cap_words = u.cap_words;
         a.timers = nullptr;
+        EmuEvents evs;
+        if (!g_use_wg) evs.build(a);
         const uint32_t bits = g_use_wg ? wg_unit(a) : code_unit_emu(g_sh, a);
         if (bits != kUnitTooBig) {
             FinishArgs f;
@@ -284,6 +292,22 @@ extern "C" int emu_plan_sig_blocks(size_t w, size_t h, int channels, int stages,
         const UnitDesc &u = plan.units[ui];
         uint32_t *o = out + (size_t)i * 5;
         o[0] = ui; o[1] = blk; o[2] = u.sig_off; o[3] = (u.w * u.h + 63u) / 64u; o[4] = u.lsb;
+    }
+    return n;
+}
+
+// every unit's family: per unit family index, chunk-table offset, x0, y0, w, h (the units of a family must share the rectangle)
+extern "C" int emu_plan_families(size_t w, size_t h, int channels, int stages, int segments, uint32_t *out /* n*6 */, int cap, uint32_t *n_families)
+{
+    Plan plan;
+    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    if (rc) return rc;
+    *n_families = plan.n_families;
+    int n = (int)plan.units.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const UnitDesc &u = plan.units[(size_t)i];
+        uint32_t *o = out + (size_t)i * 6;
+        o[0] = u.family; o[1] = u.sig_off; o[2] = u.x0; o[3] = u.y0; o[4] = u.w; o[5] = u.h;
     }
     return n;
 }

@@ -10,6 +10,42 @@
 
 namespace icer {
 
+// tests only: what family_events_kernel leaves for ONE unit -- the event bytes of its bit plane (events.hpp) and the chunk table of its
+// family --, made pixel by pixel from the same per-pixel functions the kernel calls.  Blank chunks keep a poison byte: the pixel wave
+// must not read them.
+struct EmuEvents {
+    std::vector<uint8_t> ev, sig;
+    void build(UnitArgs &a)
+    {
+        const uint32_t w = a.w, h = a.h, npix = w * h, nchunks = (npix + 63u) / 64u, p = (uint32_t)a.lsb;
+        const bool is_hl = a.subband == kHL, is_hh = a.subband == kHH;
+        uint8_t tab[48];
+        for (uint32_t i = 0; i < 45u; i++) tab[i] = (uint8_t)ev_ctx_entry(is_hh, i);
+        ev.assign((size_t)nchunks * 64u, 0xCD);
+        sig.assign(nchunks + 64u, 0xEE);
+        auto at = [&](uint32_t r, uint32_t c) { return (uint32_t)a.seg[(size_t)r * a.stride + c]; };
+        for (uint32_t j = 0; j < nchunks; j++) {
+            uint32_t tmax = 0;
+            uint8_t bytes[64];
+            for (uint32_t l = 0; l < 64u; l++) {
+                const uint32_t np = j * 64u + l;
+                if (np >= npix) { bytes[l] = (uint8_t)kEvNone; tmax = 255; continue; }
+                const uint32_t r = np / w, c = np - r * w;
+                const bool hW = c > 0, hE = c + 1 < w, hN = r > 0, hS = r + 1 < h;
+                const PixelLens L = pixel_lens(at(r, c), hW ? at(r, c - 1) : 0u, hE ? at(r, c + 1) : 0u, hN ? at(r - 1, c) : 0u, hS ? at(r + 1, c) : 0u,
+                                               (hN && hW) ? at(r - 1, c - 1) : 0u, (hN && hE) ? at(r - 1, c + 1) : 0u,
+                                               (hS && hW) ? at(r + 1, c - 1) : 0u, (hS && hE) ? at(r + 1, c + 1) : 0u);
+                if (tmax != 255u && L.t > tmax) tmax = L.t;
+                bytes[l] = (uint8_t)event_byte(L, p, is_hl, is_hh, tab);
+            }
+            sig[j] = (uint8_t)tmax;
+            if (tmax > p) memcpy(&ev[(size_t)j * 64u], bytes, 64);
+        }
+        a.ev = ev.data();
+        a.sig = sig.data();
+    }
+};
+
 // the shape of the emulated workgroup: pixel waves (1 or 2) and golomb workers (0 = one golomb wave without a state wave,
 // 2 = state wave + two workers), as code_units_kernel<8> / <11>
 static uint32_t g_emu_npw = 2, g_emu_ngw = 2;
@@ -23,7 +59,6 @@ static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
     s.nchunks = nchunks;
     uint32_t bits = kUnitTooBig;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    pixel_tables_init(s, a);
     std::thread t[8], tp[4];
     for (uint32_t k = 1; k < g_emu_npw; k++) tp[k] = std::thread([&s, &a, nchunks, k] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks, k, g_emu_npw); });
     t[0] = std::thread([&] { PixelWave pw; pixel_wave_run(s, a, pw, 0, nchunks, 0, g_emu_npw); });
@@ -49,7 +84,6 @@ static inline uint32_t code_unit_threads(CoderShared &s, const UnitArgs &a)
 static inline uint32_t code_unit_emu(CoderShared &s, const UnitArgs &a)
 {
     unit_state_init(s);
-    pixel_tables_init(s, a);
     PixelWave pw[4];
     CountWave cs;
     WalkWave ww;
@@ -85,7 +119,6 @@ static inline void code_subrange_emu(CoderShared &s, const UnitArgs &a)
     const SubLayout &L = *a.sub;
     const uint32_t j0 = L.first[L.index];
     unit_state_init(s);
-    pixel_tables_init(s, a);
     PixelWave pw[8];
     CountWave cs;
     if (j0) {
@@ -171,7 +204,6 @@ static inline uint32_t code_unit_emu_split(CoderShared &s, const UnitArgs &a0, u
 static inline uint32_t code_unit_emu_random(CoderShared &s, const UnitArgs &a, uint32_t seed)
 {
     unit_state_init(s);
-    pixel_tables_init(s, a);
     PixelWave pw[4];
     CountWave cs;
     WalkWave ww;

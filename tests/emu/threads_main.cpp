@@ -48,6 +48,8 @@ int main(int argc, char **argv)
         a.out_words = words.data();
         a.timers = nullptr;
         a.done_bytes = nullptr; a.prio_index = 0; a.early_quota = 0;
+        EmuEvents evs;
+        evs.build(a);
         uint32_t stop_flag = 0;
         std::thread clock;
         if (stop_us > 0) {

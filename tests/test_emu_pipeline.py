@@ -137,8 +137,8 @@ def test_planner_units_match_oracle_geometry(emu, oracle):
 
 
 def test_chunk_table_work_list_covers_every_family_once(emu):
-    """Plan::sig_blocks (the grid of chunk_sig_kernel): every block of 64 chunks of every family (channel, level, subband,
-    segment) exactly once, through that family's plane-0 unit; the families' table areas tile the per-frame area"""
+    """Plan::sig_blocks (the grid of family_events_kernel): every block of 64 chunks of every family (channel, level, subband,
+    segment) exactly once, through one unit of the family; the families' table areas tile the per-frame area"""
     import ctypes as C
     emu.lib.emu_plan_sig_blocks.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
     for (w, h, ch, st, sg) in [(4096, 4096, 1, 5, 10), (2048, 2048, 1, 4, 16), (517, 389, 3, 4, 7), (100, 75, 1, 3, 32), (8192, 8192, 1, 6, 32),
@@ -148,7 +148,6 @@ def test_chunk_table_work_list_covers_every_family_once(emu):
         n = emu.lib.emu_plan_sig_blocks(w, h, ch, st, sg, buf.ctypes.data, len(buf), C.byref(sig_bytes))
         assert 0 < n <= len(buf)
         e = buf[:n]
-        assert (e[:, 4] == 0).all()                                    # plane-0 units only
         fams = {}
         for unit, blk, off, nchunks, _ in e.tolist():
             fams.setdefault((unit, off, nchunks), []).append(blk)
@@ -161,6 +160,30 @@ def test_chunk_table_work_list_covers_every_family_once(emu):
         for (o0, n0), (o1, _) in zip(areas, areas[1:]):
             assert o0 + n0 <= o1                                       # table areas do not overlap
         assert areas[-1][0] + areas[-1][1] <= sig_bytes.value
+
+
+def test_a_family_is_one_rectangle_even_under_the_stale_grid_quirk(emu):
+    """The units of a family share the chunk table and the event bytes, so they must code the SAME rectangle.  Under quirk P1 (a
+    failed segment grid keeps the previous packet's one) the planes of one (channel, level, subband, segment) can have different
+    rectangles: the planner must make those families of their own (151 x 66, 5 stages, 15 segments: 224 such units)."""
+    import ctypes as C
+    emu.lib.emu_plan_families.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+    for (w, h, ch, st, sg) in [(151, 66, 1, 5, 15), (151, 66, 3, 5, 15), (100, 75, 1, 3, 32), (517, 389, 3, 4, 7), (2048, 2048, 1, 4, 16)]:
+        buf = np.zeros((20000, 6), np.uint32)
+        nf = C.c_uint32(0)
+        n = emu.lib.emu_plan_families(w, h, ch, st, sg, buf.ctypes.data, len(buf), C.byref(nf))
+        assert 0 < n <= len(buf)
+        fams = {}
+        for fam, off, x0, y0, uw, uh in buf[:n].tolist():
+            assert fams.setdefault(fam, (off, x0, y0, uw, uh)) == (off, x0, y0, uw, uh)
+        assert sorted(fams) == list(range(nf.value))
+        areas = sorted((off, (uw * uh + 63) // 64) for off, _, _, uw, uh in fams.values())
+        for (o0, n0), (o1, _) in zip(areas, areas[1:]):
+            assert o0 + n0 <= o1
+        if (w, h, sg) == (151, 66, 15):
+            assert nf.value > (3 * st + 1) * sg * ch                     # the quirk is exercised
+        if (w, h) == (2048, 2048):
+            assert nf.value == (3 * st + 1) * sg * ch
 
 
 def test_launch_orders_are_permutations_and_keep_families_on_their_xcd(emu):
