@@ -98,7 +98,10 @@ extern unsigned long long g_emu_chunks[4];          // tests only: [0] fast-path
 // counters live in LDS; data written before a PUBLISH is visible to a wave that has seen the new value.
 // LDS-only fences: they wait for this wave's LDS traffic (lgkmcnt), never for its global loads/stores.
 #define ICER_LOAD_CNT(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define ICER_POLL_PAUSE(n) __builtin_amdgcn_s_sleep(n)
+#ifndef ICER_SLEEP_SCALE
+#define ICER_SLEEP_SCALE 1
+#endif
+#define ICER_POLL_PAUSE(n) __builtin_amdgcn_s_sleep((n) * ICER_SLEEP_SCALE)
 // (the first wave to give up also leaves its wave number and the source line of the wait: code_units_kernel passes them
 // on with the unit's counters, so that a time-out names the hand-off it happened in)
 #define ICER_SET_ABORT2() { if (__hip_atomic_load(&s.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2u)            \
@@ -145,8 +148,15 @@ static __device__ __forceinline__ uint32_t icer_agent_acquire_load(const uint32_
         ICER_POLL_PAUSE(SLEEP);                                                                                       \
         if (++spins_ > kPollLimit) { ICER_SET_ABORT2(); AB = 2u; break; } }                                           \
     ICER_FENCE_ACQ(); ICER_MARK("WAIT_END") }
-#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); ICER_MARK("PUBLISH_BEGIN") ICER_FENCE_REL(); ICER_LANE0 ICER_STORE_CNT(x, pv_); ICER_MARK("PUBLISH_END") }
-#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); ICER_MARK("PUBLISH_BEGIN") ICER_FENCE_REL(); ICER_LANE0 { ICER_STORE_CNT(x1, pv1_); ICER_STORE_CNT(x2, pv2_); } ICER_MARK("PUBLISH_END") }
+// (experiments: -DICER_USE_WAKEUP pings the workgroup's sleeping waves after every publish; -DICER_BP_SLEEP=<n> sets the sleep of the
+// back-pressure waits)
+#if defined(ICER_USE_WAKEUP) && !defined(ICER_WAVE_EMU)
+#define ICER_WAKE() asm volatile("s_wakeup");
+#else
+#define ICER_WAKE()
+#endif
+#define ICER_PUBLISH(x, v) { const uint32_t pv_ = (v); ICER_MARK("PUBLISH_BEGIN") ICER_FENCE_REL(); ICER_LANE0 ICER_STORE_CNT(x, pv_); ICER_WAKE() ICER_MARK("PUBLISH_END") }
+#define ICER_PUBLISH2(x1, v1, x2, v2) { const uint32_t pv1_ = (v1), pv2_ = (v2); ICER_MARK("PUBLISH_BEGIN") ICER_FENCE_REL(); ICER_LANE0 { ICER_STORE_CNT(x1, pv1_); ICER_STORE_CNT(x2, pv2_); } ICER_WAKE() ICER_MARK("PUBLISH_END") }
 #define ICER_ACQUIRE() { ICER_MARK("ACQUIRE") ICER_FENCE_ACQ(); }
 #define ICER_IDLE() { ICER_POLL_PAUSE(1); if (++idle_spins_ > kPollLimit) { ICER_SET_ABORT2(); break; } }
 #define ICER_IDLE_DECL uint32_t idle_spins_ = 0;
@@ -193,6 +203,9 @@ constexpr uint32_t kFailWords = 16;
 constexpr uint32_t kSpinLimit = 1u << 25;
 #ifndef ICER_QUEUE_DEPTH
 #define ICER_QUEUE_DEPTH 4
+#endif
+#ifndef ICER_BP_SLEEP
+#define ICER_BP_SLEEP 6
 #endif
 constexpr uint32_t kQueueDepth = ICER_QUEUE_DEPTH;   // chunks in flight between the waves of a unit.  4: 37 KiB of LDS per workgroup, four per
                                                      // CU (8: 48 KiB, three per CU).  Round 3, profiles/archive/r03_logs/r03_x.log: the depth itself does
@@ -659,11 +672,22 @@ struct PixelWave {                // this wave's next chunk, prefetched
     }
 #define ICER_IS_BLANK(J) (((cw.blank >> ((J) & 63u)) & 1ull) != 0ull)
 
+// event byte -> the pixel's two events (events.hpp)
+#define ICER_UNPACK_EVENT_BYTE(B, V1, C1, B1, V2, C2, B2)                                              \
+    {                                                                                                  \
+        const uint32_t b_ = (B), c4_ = b_ & 15u;                                                       \
+        V1 = c4_ != kEvNone ? 1u : 0u;                                                                 \
+        C1 = c4_ == kEvUncoded ? 31u : c4_;                                                            \
+        B1 = (b_ >> 4) & 1u;                                                                           \
+        V2 = (c4_ <= 8u && (b_ & 16u)) ? 1u : 0u;       /* the pixel becomes significant here: its sign follows (C6) */ \
+        C2 = 12u + ((b_ >> 5) & 3u);                                                                   \
+        B2 = (b_ >> 7) & 1u;                                                                           \
+    }
+
 // pixel wave k of npw: its chunks (j % npw == k) among [j0, j1); consecutive calls continue the prefetch (cw.fetched)
-// `counts_only`: for the counts-only pass of the count wave -- the events' context / bit and the per-context totals, no ranks
 // The events themselves -- category, bit, 8-neighbour context, sign context and prediction (C1-C6) -- were made once for all bit
 // planes of the unit's family (events.hpp, family_events_kernel): one byte per pixel, 64 consecutive bytes per chunk.
-ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw, bool counts_only = false)
+ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -689,16 +713,7 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
             if (!ICER_IS_BLANK(j + npw)) { FOR_LANES { LV(cw.nb) = a.ev[(size_t)(j + npw) * 64u + (uint32_t)lane]; } }
         }
         cw.fetched = j + npw;
-        FOR_LANES
-        {
-            const uint32_t b = LV(eb), c4 = b & 15u;
-            LV(valid1) = c4 != kEvNone ? 1u : 0u;
-            LV(ctx1) = c4 == kEvUncoded ? 31u : c4;
-            LV(bit1) = (b >> 4) & 1u;
-            LV(valid2) = (c4 <= 8u && (b & 16u)) ? 1u : 0u;          // the pixel becomes significant here: its sign follows (C6)
-            LV(ctx2) = 12u + ((b >> 5) & 3u);
-            LV(bit2) = (b >> 7) & 1u;
-        }
+        FOR_LANES { ICER_UNPACK_EVENT_BYTE(LV(eb), LV(valid1), LV(ctx1), LV(bit1), LV(valid2), LV(ctx2), LV(bit2)) }
         // ---- context groups --------------------------------------------------------------------------
         // What the adaptive counts (C5) need from the chunk depends on the coefficients alone and is prepared
         // here, off the serial path: an event sees the counts at chunk start + its rank among the chunk's events
@@ -749,33 +764,29 @@ ICER_DEV void pixel_wave_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, u
                 LV(x1) = LV(ctx1) & 31u; LV(x2) = LV(ctx2) & 31u;                   // (context 31, uncoded: lane 31 holds an empty mask)
                 LV(g1l) = 0; LV(g1h) = 0; LV(g2l) = 0; LV(g2h) = 0;
             }
-            if (!counts_only) {
-                WAVE_GATHER(g1l, om_lo, x1) WAVE_GATHER(g1h, om_hi, x1)
-                if (U) { WAVE_GATHER(g2l, om_lo, x2) WAVE_GATHER(g2h, om_hi, x2) }
-            }
+            WAVE_GATHER(g1l, om_lo, x1) WAVE_GATHER(g1h, om_hi, x1)
+            if (U) { WAVE_GATHER(g2l, om_lo, x2) WAVE_GATHER(g2h, om_hi, x2) }
             FOR_LANES
             {
                 LV(w1) = 0; LV(w2) = 0;
                 if (LV(valid1)) {
                     LV(w1) = 0x80u | (LV(bit1) << 5) | LV(ctx1);
-                    if (LV(ctx1) != 31u && !counts_only) {
+                    if (LV(ctx1) != 31u) {
                         const uint64_t m = (uint64_t)LV(g1l) | ((uint64_t)LV(g1h) << 32);
                         LV(w1) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZM, lane) << 16);
                     }
                 }
                 if (LV(valid2)) {
                     LV(w2) = 0x80u | (LV(bit2) << 5) | LV(ctx2);
-                    if (!counts_only) {
-                        const uint64_t m = (uint64_t)LV(g2l) | ((uint64_t)LV(g2h) << 32);
-                        LV(w2) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZN, lane) << 16);
-                    }
+                    const uint64_t m = (uint64_t)LV(g2l) | ((uint64_t)LV(g2h) << 32);
+                    LV(w2) |= ((uint32_t)mbcnt64(m, lane) << 8) | ((uint32_t)mbcnt64(m & ZN, lane) << 16);
                 }
             }
         }
 #undef ICER_MATCH
         ICER_TICK(0)
         // queue slot j % D is free once the count wave has consumed chunk j - D
-        ICER_WAIT_CNT(s.a_done, ad_, j < ad_ + kQueueDepth, ab_, 6)
+        ICER_WAIT_CNT(s.a_done, ad_, j < ad_ + kQueueDepth, ab_, ICER_BP_SLEEP)
         if (ab_) break;
         ICER_TICK(1)
         PixelSlot &o = s.pq[j % kQueueDepth];
@@ -799,9 +810,7 @@ struct CountWave {              // lane c: adaptive counts of context c (icer_co
     LANEVAR(uint32_t, ctot);
 };
 
-// `counts_only`: advance the counts over [j0, j1) and nothing else -- no bins, no events for the other waves (the prefix pass of a
-// sub-range workgroup: the adaptive counts at its first chunk depend on the coefficients before it alone)
-ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1, uint32_t npw, bool counts_only = false)
+ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1, uint32_t npw)
 {
     DECL_LANE;
     ICER_TIMERS_DECL
@@ -816,39 +825,6 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         if (ab_) break;
         ICER_TICK(2)
         const PixelSlot &in = s.pq[j % kQueueDepth];
-        if (counts_only) {
-            // the per-context totals of the chunk; its events are looked at only when a context reaches the rescale point
-            LANEVAR(uint32_t, cross);
-            FOR_LANES
-            {
-                const uint32_t w = lane < 17 ? (uint32_t)in.cn[lane] : 0u;
-                LV(cross) = 0;
-                if (lane < 17) {
-                    if (LV(ctot) + (w & 255u) < kRescaleCap) { LV(ctot) += w & 255u; LV(czer) += w >> 8; }
-                    else LV(cross) = 1;
-                }
-            }
-            uint64_t rem = BALLOT(LV(cross) != 0u);
-            if (rem) {
-                LANEVAR(uint32_t, v1); LANEVAR(uint32_t, c1); LANEVAR(uint32_t, b1); LANEVAR(uint32_t, v2); LANEVAR(uint32_t, c2); LANEVAR(uint32_t, b2);
-                LANEVAR(uint32_t, zo); LANEVAR(uint32_t, to);
-                FOR_LANES
-                {
-                    const uint32_t e1 = in.e[lane][0], e2 = in.e[lane][1];
-                    LV(v1) = (e1 >> 7) & 1u; LV(c1) = e1 & 31u; LV(b1) = (e1 >> 5) & 1u;
-                    LV(v2) = (e2 >> 7) & 1u; LV(c2) = e2 & 31u; LV(b2) = (e2 >> 5) & 1u;
-                    LV(zo) = 0; LV(to) = 0;
-                }
-                (void)zo; (void)to;             // (ICER_CTX_STEP also leaves what every event sees: not needed here)
-                for (; rem; rem &= rem - 1ull) {
-                    const uint32_t c = (uint32_t)ffs64(rem);
-                    if (c < 12u) ICER_CTX_STEP(c, LV(v1) && LV(c1) == c, LV(b1) == 0u, zo, to)
-                    else ICER_CTX_STEP(c, LV(v2) && LV(c2) == c, LV(b2) == 0u, zo, to)
-                }
-            }
-            ICER_PUBLISH(s.a_done, j + 1u)
-            continue;
-        }
         LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
         LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
         LANEVAR(uint32_t, z1); LANEVAR(uint32_t, t1); LANEVAR(uint32_t, z2); LANEVAR(uint32_t, t2);
@@ -924,7 +900,7 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
         }
         ICER_TICK(4)
         // queue slot j % D is free once the assembly wave has retired chunk j - D
-        ICER_WAIT_CNT(s.b_done, bd_, j < bd_ + kQueueDepth, ab2_, 6)
+        ICER_WAIT_CNT(s.b_done, bd_, j < bd_ + kQueueDepth, ab2_, ICER_BP_SLEEP)
         if (ab2_) break;
         ICER_TICK(5)
         EventSlot &q = s.eq[j % kQueueDepth];
@@ -939,6 +915,157 @@ ICER_DEV void count_wave_run(CoderShared &s, const UnitArgs &a, CountWave &cs, u
     }
     FOR_LANES { LV(cs.czer) = LV(czer); LV(cs.ctot) = LV(ctot); }
     ICER_TIMERS_STORE(a.timers)
+}
+
+// ==========================================================================================
+// the counts-only prefix pass of a sub-range workgroup ("Sub-ranges" above)
+// ==========================================================================================
+// The adaptive counts at the workgroup's first chunk j0 depend on the events of [0, j0) alone: per chunk and context the number of
+// events and of zeros among them (a sum), and, where a context reaches the rescale point inside a chunk (total 500 -> 250, quirk C5),
+// the zeros among its events up to that one.  All waves but one make the per-chunk totals (pixel_prefix_run, chunks dealt round-robin);
+// the count wave adds them up in order (count_prefix_run) and looks at a chunk's events only when a context rescales in it.  The waves
+// meet through a ring of kPrefixRing chunks -- totals and event bytes, 100 B per chunk, laid over the (idle) event queue -- and the
+// count wave takes whatever the ring holds per look at the hand-off counters: its cost per chunk is one LDS read and a dozen
+// instructions, not a poll and a publish (round 6; before, 0.3 us per chunk: a fifth of a lone frame's time went into this pass).
+constexpr uint32_t kPrefixRing = 32;
+struct PrefixRing {
+    uint16_t cn[kPrefixRing][20];       // per chunk and context: events | zeros among them << 8
+    uint8_t ev[kPrefixRing][64];        // the chunk's event bytes (events.hpp)
+};
+static_assert(sizeof(PrefixRing) <= sizeof(EventSlot) * kQueueDepth, "the prefix ring lies over the event queue");
+ICER_DEV PrefixRing &prefix_ring(CoderShared &s) { return *reinterpret_cast<PrefixRing *>(&s.eq[0]); }
+
+// pixel wave k of npw in the prefix pass: the per-context totals of its chunks (j % npw == k) among [j0, j1)
+ICER_DEV void pixel_prefix_run(CoderShared &s, const UnitArgs &a, PixelWave &cw, uint32_t j0, uint32_t j1, uint32_t k, uint32_t npw)
+{
+    DECL_LANE;
+    PrefixRing &ring = prefix_ring(s);
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    const uint32_t lsb = (uint32_t)a.lsb;
+    const uint32_t jfirst = j0 + (k + npw - j0 % npw) % npw;
+    if (cw.fetched != jfirst && jfirst < nchunks) {
+        ICER_BLANK_MASK(jfirst)
+        if (!ICER_IS_BLANK(jfirst)) { FOR_LANES { LV(cw.nb) = a.ev[(size_t)jfirst * 64u + (uint32_t)lane]; } }
+        cw.fetched = jfirst;
+    }
+    for (uint32_t j = jfirst; j < j1; j += npw) {
+        ICER_BLANK_MASK(j)
+        const bool blank = ICER_IS_BLANK(j);
+        LANEVAR(uint32_t, eb); LANEVAR(uint32_t, cnw);
+        FOR_LANES { LV(eb) = blank ? 0u : LV(cw.nb); }
+        if (j + npw < nchunks) {
+            ICER_BLANK_MASK(j + npw)
+            if (!ICER_IS_BLANK(j + npw)) { FOR_LANES { LV(cw.nb) = a.ev[(size_t)(j + npw) * 64u + (uint32_t)lane]; } }
+        }
+        cw.fetched = j + npw;
+        if (blank) {
+            FOR_LANES { LV(cnw) = lane == 0 ? (64u | (64u << 8)) : 0u; }
+        } else {
+            LANEVAR(uint32_t, valid1); LANEVAR(uint32_t, ctx1); LANEVAR(uint32_t, bit1);
+            LANEVAR(uint32_t, valid2); LANEVAR(uint32_t, ctx2); LANEVAR(uint32_t, bit2);
+            FOR_LANES { ICER_UNPACK_EVENT_BYTE(LV(eb), LV(valid1), LV(ctx1), LV(bit1), LV(valid2), LV(ctx2), LV(bit2)) }
+#define ICER_MATCH(KEY, V, B0, B1, B2, B3) \
+            ((V) & (((KEY)&1u) ? (B0) : ~(B0)) & (((KEY)&2u) ? (B1) : ~(B1)) & (((KEY)&4u) ? (B2) : ~(B2)) & (((KEY)&8u) ? (B3) : ~(B3)))
+            const uint64_t V = BALLOT(LV(valid1) && LV(ctx1) != 31u);
+            const uint64_t B0 = BALLOT(LV(ctx1) & 1u), B1 = BALLOT(LV(ctx1) & 2u), B2 = BALLOT(LV(ctx1) & 4u), B3 = BALLOT(LV(ctx1) & 8u);
+            const uint64_t ZM = BALLOT(LV(bit1) == 0u);
+            const uint64_t U = BALLOT(LV(valid2) != 0u);
+            const uint64_t C0 = BALLOT((LV(ctx2) - 12u) & 1u), C1 = BALLOT((LV(ctx2) - 12u) & 2u), C2 = BALLOT((LV(ctx2) - 12u) & 4u);
+            const uint64_t ZN = BALLOT(LV(bit2) == 0u);
+            FOR_LANES
+            {
+                // (magnitude contexts on lanes 0..11, sign contexts on lanes 12..16: one match on selected ballots)
+                const bool sg = lane >= 12;
+                const uint32_t key = sg ? (uint32_t)lane - 12u : (uint32_t)lane;
+                const uint64_t vv = sg ? U : V, b0 = sg ? C0 : B0, b1 = sg ? C1 : B1, b2 = sg ? C2 : B2, b3 = sg ? 0ull : B3;
+                const uint64_t m = lane <= 16 ? ICER_MATCH(key, vv, b0, b1, b2, b3) : 0ull;
+                LV(cnw) = (uint32_t)popc64(m) | ((uint32_t)popc64(m & (sg ? ZN : ZM)) << 8);
+            }
+#undef ICER_MATCH
+        }
+        // ring slot j % R is free once the count wave has consumed chunk j - R
+        ICER_WAIT_CNT(s.a_done, ad_, j < ad_ + kPrefixRing, ab_, 2)
+        if (ab_) break;
+        FOR_LANES
+        {
+            if (lane < 17) ring.cn[j % kPrefixRing][lane] = (uint16_t)LV(cnw);
+            ring.ev[j % kPrefixRing][lane] = (uint8_t)LV(eb);
+        }
+        ICER_PUBLISH(s.p_done[k], j + 1u)
+    }
+}
+
+// chunks [0, result) have been handed over by the npw pixel waves of the prefix pass (wave k: chunks k, k + npw, ...; p_done[k] =
+// 1 + its last one, 0 before its first)
+ICER_DEV uint32_t prefix_frontier(CoderShared &s, uint32_t npw)
+{
+    DECL_LANE;
+    LANEVAR(uint32_t, nxt);
+    FOR_LANES
+    {
+        const uint32_t pd = (uint32_t)lane < npw ? ICER_LOAD_CNT(s.p_done[lane]) : 0u;
+        LV(nxt) = (uint32_t)lane < npw ? ~(pd ? pd - 1u + npw : (uint32_t)lane) : 0u;       // (complement: the minimum through WAVE_MAX)
+    }
+    uint32_t m;
+    WAVE_MAX(m, nxt)
+    return ~m;
+}
+
+// the count wave in the prefix pass: the adaptive counts advanced over [j0, j1) and nothing else -- no bins, no events for the other waves
+ICER_DEV void count_prefix_run(CoderShared &s, const UnitArgs &a, CountWave &cs, uint32_t j0, uint32_t j1, uint32_t npw)
+{
+    DECL_LANE;
+    (void)a;
+    PrefixRing &ring = prefix_ring(s);
+    LANEVAR(uint32_t, czer); LANEVAR(uint32_t, ctot);
+    FOR_LANES
+    {
+        LV(czer) = j0 == 0 ? 2u : LV(cs.czer);                    // icer_context_modeller.c:607-613
+        LV(ctot) = j0 == 0 ? 4u : LV(cs.ctot);
+    }
+    uint32_t avail = j0;                                          // chunks below this one are in the ring
+    for (uint32_t j = j0; j < j1; j++) {
+        if (j >= avail) {
+            avail = prefix_frontier(s, npw);
+            if (avail <= j) {
+                // (what has been consumed is given back BEFORE waiting: the pixel wave that owes chunk j may be waiting for its slot)
+                ICER_PUBLISH(s.a_done, j)
+                ICER_WAIT_UNTIL((avail = prefix_frontier(s, npw)) > j || ICER_LOAD_CNT(s.abort))
+            }
+            if (ICER_LOAD_CNT(s.abort)) break;
+            ICER_ACQUIRE()
+        }
+        // the per-context totals of the chunk; its events are looked at only when a context reaches the rescale point
+        LANEVAR(uint32_t, cross);
+        FOR_LANES
+        {
+            const uint32_t w = lane < 17 ? (uint32_t)ring.cn[j % kPrefixRing][lane] : 0u;
+            LV(cross) = 0;
+            if (lane < 17) {
+                if (LV(ctot) + (w & 255u) < kRescaleCap) { LV(ctot) += w & 255u; LV(czer) += w >> 8; }
+                else LV(cross) = 1;
+            }
+        }
+        uint64_t rem = BALLOT(LV(cross) != 0u);
+        if (rem) {
+            LANEVAR(uint32_t, v1); LANEVAR(uint32_t, c1); LANEVAR(uint32_t, b1); LANEVAR(uint32_t, v2); LANEVAR(uint32_t, c2); LANEVAR(uint32_t, b2);
+            LANEVAR(uint32_t, zo); LANEVAR(uint32_t, to);
+            FOR_LANES
+            {
+                ICER_UNPACK_EVENT_BYTE((uint32_t)ring.ev[j % kPrefixRing][lane], LV(v1), LV(c1), LV(b1), LV(v2), LV(c2), LV(b2))
+                LV(zo) = 0; LV(to) = 0;
+            }
+            (void)zo; (void)to;             // (ICER_CTX_STEP also leaves what every event sees: not needed here)
+            for (; rem; rem &= rem - 1ull) {
+                const uint32_t c = (uint32_t)ffs64(rem);
+                if (c < 12u) ICER_CTX_STEP(c, LV(v1) && LV(c1) == c, LV(b1) == 0u, zo, to)
+                else ICER_CTX_STEP(c, LV(v2) && LV(c2) == c, LV(b2) == 0u, zo, to)
+            }
+        }
+        if ((j & 7u) == 7u) ICER_PUBLISH(s.a_done, j + 1u)
+    }
+    ICER_PUBLISH(s.a_done, j1)
+    FOR_LANES { LV(cs.czer) = LV(czer); LV(cs.ctot) = LV(ctot); }
 }
 
 // ==========================================================================================
@@ -1552,6 +1679,7 @@ ICER_DEV bool merge_gather(CoderShared &s, MergeChunk &c, uint32_t j, uint32_t g
     if (ab_) return false;
     ICER_ACQUIRE()
     ICER_TICK(18)
+    ICER_MARK("SEC merge_unpack")
     FOR_LANES
     {
         const uint32_t r1 = rq.rec[2 * lane], r2 = rq.rec[2 * lane + 1];
@@ -1945,6 +2073,24 @@ ICER_DEV bool sub_checkpoint(const SubLayout &L, uint32_t nj, int *write_m, uint
     return *write_m >= 0 || *match_m >= 0;
 }
 
+// The first chunk count nj >= from at which sub_checkpoint fires (~0u: none).  The merge wave keeps it in a register and looks at the
+// layout again only there -- the layout sits behind a generic pointer, three dependent loads per look (0.5 k cycles per chunk of the
+// merge wave of a split unit, the slowest stage of a lone frame's pipeline, before round 6).
+ICER_DEV uint32_t sub_next_checkpoint(const SubLayout &L, uint32_t from)
+{
+    const uint32_t i = L.index, n = L.n_sub, end = L.first[n];
+    uint32_t best = ~0u;
+    for (uint32_t t = i ? i : 1u; t < n; t++) {
+        // t == i: this workgroup's own snapshots; t > i: those of a later sub-range, compared while t is the latest start passed
+        const uint32_t f = L.first[t];
+        const uint32_t m = from > f ? (from - f + kSnapEvery - 1u) / kSnapEvery : 1u;
+        const uint32_t nj = f + (m ? m : 1u) * kSnapEvery;
+        const uint32_t last = (t == i || t + 1u >= n) ? end - 1u : L.first[t + 1u];     // (a later start passed: its snapshots take over)
+        if ((m ? m : 1u) <= kMaxSnaps && nj < end && nj <= last && nj < best) best = nj;
+    }
+    return best;
+}
+
 // The coder state before chunk `nj`, with the drain wave parked and everything finished popped: written to `out` (writer)
 // or compared with `ref` (returns true when equal).  `q` = the event slot of chunk nj - 1 (its counts), `tail` = the
 // allocation count.  One wavefront.
@@ -1989,6 +2135,7 @@ ICER_DEV uint32_t merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0,
     ICER_TIMERS_DECL
     uint32_t tail = s.alloc;                                // allocation count (this wave owns it)
     uint32_t gen = s.exact_seq;                             // generation (this wave bumps it)
+    uint32_t next_cp = a.sub ? sub_next_checkpoint(*a.sub, j0 + 1u) : ~0u;   // sub-ranges: the next chunk count with a snapshot to write or to compare
     for (uint32_t j = j0; j < j1; j++) {
         MergeChunk c;
         uint32_t popped_seen;
@@ -1998,6 +2145,7 @@ ICER_DEV uint32_t merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0,
         // if they all fit none happens.  The drain wave's pop count may lag, which only over-estimates the
         // occupancy; when the test fails with it the drain wave is parked, everything finished is popped (the
         // reference's state) and the test repeated.
+        ICER_MARK("SEC merge_test")
         const uint32_t nstarts = (uint32_t)(popc64(c.S1) + popc64(c.S2));
         bool held = false, fast = true;
         ICER_COUNT(31)
@@ -2011,7 +2159,9 @@ ICER_DEV uint32_t merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0,
             ICER_COUNT(30)
         }
         if (fast) {
+            ICER_MARK("SEC merge_commit")
             merge_commit(s, c, tail);
+            ICER_MARK("SEC merge_commit_end")
             tail += nstarts;
             ICER_EMU_COUNT(0);
             ICER_TICK(14)
@@ -2036,9 +2186,14 @@ ICER_DEV uint32_t merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0,
             ICER_TICK(16)
         }
         // sub-ranges: a snapshot of the state before the next chunk, or the comparison with a later sub-range's one
-        if (a.sub) {
+        ICER_MARK("SEC merge_retire")
+#ifdef ICER_WAVE_EMU
+        if (a.sub) { int wm_, mm_; uint32_t mt_; assert(sub_checkpoint(*a.sub, j + 1u, &wm_, &mt_, &mm_) == (j + 1u == next_cp) || j + 1u > next_cp); }
+#endif
+        if (a.sub && j + 1u >= next_cp) {
             int write_m, match_m;
             uint32_t match_t;
+            next_cp = sub_next_checkpoint(*a.sub, j + 2u);
             if (sub_checkpoint(*a.sub, j + 1u, &write_m, &match_t, &match_m)) {
                 WAVE_SYNC();
                 if (!held) {
@@ -2095,6 +2250,7 @@ ICER_DEV uint32_t merge_wave_run(CoderShared &s, const UnitArgs &a, uint32_t j0,
             // the new words (and the finished ones) become visible to the drain wave; the chunk's queue slots are free
             ICER_PUBLISH2(s.alloc, tail, s.b_done, j + 1u)
         }
+        ICER_MARK("SEC merge_retire_end")
         ICER_TICK(17)
     }
     ICER_TIMERS_STORE(a.timers)

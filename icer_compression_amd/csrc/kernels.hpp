@@ -284,10 +284,10 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
             if (wave == kCount && lane_ < 17) { cs.czer = pc[lane_]; cs.ctot = pc[17 + lane_]; }
         } else {
 #endif
-        if (wave == kCount) count_wave_run(s, a, cs, 0, j0, npw1, true);
+        if (wave == kCount) count_prefix_run(s, a, cs, 0, j0, npw1);
         else if (k < npw1) {
             PixelWave pw;
-            pixel_wave_run(s, a, pw, 0, j0, k, npw1, true);
+            pixel_prefix_run(s, a, pw, 0, j0, k, npw1);
         }
 #ifdef ICER_EXPERIMENT_PREFIX_CACHE
             if (pc && wave == kCount) {

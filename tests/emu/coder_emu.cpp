@@ -312,6 +312,36 @@ extern "C" int emu_plan_families(size_t w, size_t h, int channels, int stages, i
     return n;
 }
 
+// statistics tap (tools/event_stats.py): the events of one coding unit by coder bin -- the pixel and count stages alone, chunk by chunk.
+// hist[bin] = magnitude-bit events, hist[17 + bin] = sign events, hist[34] = chunks, hist[35] = blank chunks,
+// hist[36] = chunks without an event of bins 1..7, hist[37] = chunks with a sign event in a Golomb bin
+extern "C" void emu_unit_bin_hist(const uint16_t *seg, size_t w, size_t h, size_t stride, int subband, int lsb, unsigned long long *hist)
+{
+    memset(&g_sh, 0xA5, sizeof g_sh);
+    build_coder_tables(&g_sh.tab);
+    UnitArgs a;
+    a.seg = seg; a.stride = (uint32_t)stride; a.w = (uint32_t)w; a.h = (uint32_t)h; a.subband = subband; a.lsb = lsb;
+    a.cap_words = 0; a.out_words = nullptr; a.timers = nullptr;
+    EmuEvents evs;
+    evs.build(a);
+    unit_state_init(g_sh);
+    PixelWave pw;
+    CountWave cs;
+    const uint32_t nchunks = (a.w * a.h + 63u) / 64u;
+    for (uint32_t j = 0; j < nchunks; j++) {
+        g_sh.b_done = j;
+        pixel_wave_run(g_sh, a, pw, j, j + 1, 0, 1);
+        count_wave_run(g_sh, a, cs, j, j + 1, 1);
+        const EventSlot &q = g_sh.eq[j % kQueueDepth];
+        bool v2v = false, sg = false;
+        for (int l = 0; l < 64; l++) {
+            if (q.ev1[l] & 0x80) { hist[q.ev1[l] & 31]++; if ((q.ev1[l] & 31) >= 1 && (q.ev1[l] & 31) <= 7) v2v = true; }
+            if (q.ev2[l] & 0x80) { hist[17 + (q.ev2[l] & 31)]++; if ((q.ev2[l] & 31) >= 1 && (q.ev2[l] & 31) <= 7) v2v = true; if ((q.ev2[l] & 31) >= 8) sg = true; }
+        }
+        hist[34]++; hist[35] += q.blank ? 1 : 0; hist[36] += v2v ? 0 : 1; hist[37] += sg ? 1 : 0;
+    }
+}
+
 // raw copy of the product's coder tables (csrc/icer_tables.hpp) for tests/test_tables.py
 extern "C" size_t emu_get_tables(void *dst, size_t cap)
 {

@@ -122,9 +122,10 @@ static inline void code_subrange_emu(CoderShared &s, const UnitArgs &a)
     PixelWave pw[8];
     CountWave cs;
     if (j0) {
+        uint32_t jc0 = 0;
         for (uint32_t j = 0; j < j0; j++) {
-            pixel_wave_run(s, a, pw[j % 8u], j, j + 1, j % 8u, 8u, true);
-            count_wave_run(s, a, cs, j, j + 1, 8u, true);
+            pixel_prefix_run(s, a, pw[j % 7u], j, j + 1, j % 7u, 7u);
+            if (j % 5u == 4u || j + 1 == j0) { count_prefix_run(s, a, cs, jc0, j + 1, 7u); jc0 = j + 1; }     // (the count wave takes several chunks per look)
         }
         unit_state_init(s, j0);
     }
