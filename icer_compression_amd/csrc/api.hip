@@ -160,6 +160,8 @@ bool pin_thread_near_device(int physical)
 
 }  // namespace
 
+constexpr int kMaxParts = 4;             // parts of a batch in flight per call (enqueue)
+
 struct icerx_encoder {
     int device = 0;                     // physical HIP device (hipSetDevice)
     int logical_device = 0;             // what the caller named (ICER_HIP_VIRTUAL_DEVICES maps several onto one)
@@ -217,7 +219,12 @@ struct icerx_encoder {
 #endif
     hipStream_t side_stream = nullptr;  // the list kernel runs beside the pipeline kernel
     bool side_stream_borrowed = false;  // ... on a stream another encoder owns (the pooled encoders of a host batch share one)
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork[kMaxParts] = {}, join[kMaxParts] = {};   // per part of a batch (enqueue): list kernel on the side stream
+    hipStream_t half_stream = nullptr;  // the odd parts of a batch coded by a synchronous call (enqueue)
+    hipEvent_t part_fork = nullptr, part_join = nullptr;
+    int overlap_parts = 2;              // parts a synchronous batch call is enqueued in (ICER_HIP_OVERLAP_PARTS; 1: one stream, as the asynchronous calls)
+    int last_parts = 1;
+    int overlap_first = 50;             // two parts: the first part's share of the frames in percent (ICER_HIP_OVERLAP_FIRST)
     hipEvent_t coef_ready = nullptr;    // the transform of the last enqueue is complete (coef, means, frame status): recorded before the coder
     hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
@@ -351,8 +358,11 @@ int accumulate_timing(icerx_encoder *e)
 // HL/LH/HH to their final place in `coef` (as the coder's sign-magnitude words when `sm` != 0) and its LL band to a
 // compact side buffer in `tmp` that the next stage reads (the last stage writes LL into `coef`), so no workgroup reads
 // what another one of the same stage writes.  *cw, *ch: in the frame size, out the LL size.
-void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStream_t st, int sm, int *dwt_ovf, size_t *cw_io, size_t *ch_io)
+void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStream_t st, int sm, int *dwt_ovf, size_t *cw_io, size_t *ch_io,
+                int16_t *coef = nullptr, int16_t *tmp = nullptr)
 {
+    if (!coef) coef = e->coef.p;            // (a part of a batch: its own planes of the encoder's buffers, enqueue_part)
+    if (!tmp) tmp = e->tmp.p;
     const size_t W = e->w, plane = W * e->h;
     const int P = n_frames * e->channels;
     size_t cw = *cw_io, ch = *ch_io, ll_off = 0;
@@ -360,15 +370,15 @@ void launch_dwt(icerx_encoder *e, const uint16_t *d_frames, int n_frames, hipStr
     da.f = filter_taps(e->filt);
     da.lim = e->sample_bits == 8 ? 127 : 32767;
     da.sm = sm;
-    da.coef = e->coef.p; da.coef_stride = (uint32_t)W;
+    da.coef = coef; da.coef_stride = (uint32_t)W;
     da.src = reinterpret_cast<const int16_t *>(d_frames); da.src_stride = (uint32_t)W;
     size_t src_plane = plane;
     for (int s = 0; s < e->stages; s++) {
         const int nlw = (int)((cw + 1) / 2), nlh = (int)((ch + 1) / 2);
         da.cw = (int)cw; da.ch = (int)ch;
         size_t ll_plane;
-        if (s == e->stages - 1) { da.ll = e->coef.p; da.ll_stride = (uint32_t)W; ll_plane = plane; }
-        else { da.ll = e->tmp.p + ll_off; da.ll_stride = (uint32_t)nlw; ll_plane = plane; }
+        if (s == e->stages - 1) { da.ll = coef; da.ll_stride = (uint32_t)W; ll_plane = plane; }
+        else { da.ll = tmp + ll_off; da.ll_stride = (uint32_t)nlw; ll_plane = plane; }
         hipLaunchKernelGGL(dwt_tile_kernel, dim3((nlw + kTileKX - 1) / kTileKX, (nlh + kTileKY - 1) / kTileKY, P),
                            dim3(kTileThreads), 0, st, da, src_plane, plane, ll_plane, dwt_ovf);
         da.src = da.ll; da.src_stride = da.ll_stride; src_plane = ll_plane;
@@ -398,6 +408,22 @@ hipError_t create_side_stream(hipStream_t *st)
 {
     return create_level_stream(st, want_priority_streams() ? "high" : nullptr);
 }
+// the per-part events of an encoder and, for encoders of several frames, the stream of a batch's odd parts (enqueue)
+hipError_t create_part_events(icerx_encoder *e)
+{
+    for (int k = 0; k < kMaxParts; k++) {
+        hipError_t r = hipEventCreateWithFlags(&e->fork[k], hipEventDisableTiming);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&e->join[k], hipEventDisableTiming);
+        if (r != hipSuccess) return r;
+    }
+    if (e->max_frames >= 4 && e->overlap_parts > 1) {
+        hipError_t r = hipEventCreateWithFlags(&e->part_fork, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&e->part_join, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->half_stream, hipStreamNonBlocking);
+        if (r != hipSuccess) return r;
+    }
+    return hipSuccess;
+}
 // The host-fed pipeline of a device has four streams whose kernels must overlap (three encoders + the side stream they share).  When
 // hardware queues are scarce they go to the LOW level's pool together: measured with the runtime's default queues on C4 / C5, quiet
 // process or crowded -- low 0.93-0.95 x the device-resident rate (what 8 queues and plain streams give), high 0.89-0.90 x (high-priority
@@ -410,36 +436,52 @@ const char *pool_compute_level() { const char *v = getenv("ICER_HIP_COMPUTE_LEVE
 #endif
 constexpr int kLonePadBytes = ICER_LONE_PAD_BYTES;      // see enqueue: LDS padding of the pipeline's workgroups in a launch of one frame
 
-// enqueue the whole pipeline once; returns 0 or ICER_FATAL_ERROR
-int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
-            unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
+// enqueue the whole pipeline for the frames [f0, f0 + n_frames) of a batch on `st` (d_frames, d_out, d_sizes, d_rcs: of frame f0); every
+// per-frame buffer of the encoder is used from frame f0 on, so that parts of a batch can be in flight on different streams (enqueue).
+// `part`: which set of the per-launch resources (route list cursor, fork / join events) it takes; `timed`: it records the stage events.
+// Returns 0 or ICER_FATAL_ERROR.
+int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
+                 unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
 {
     const size_t W = e->w, H = e->h, plane = W * H;
     const int C = e->channels, P = n_frames * C;
     const uint32_t n_units = (uint32_t)e->plan.units.size();
-    int *dwt_ovf = e->flags.p, *mean_ovf = e->flags.p + (size_t)e->max_frames * C;
-    int *skip = mean_ovf + (size_t)e->max_frames * C, *bound_ovf = skip + e->max_frames;
-    HIP_TRY(hipMemsetAsync(e->flags.p, 0, e->flags.n * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(e->sums.p, 0, (size_t)P * sizeof(unsigned long long), st));
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
+    int *dwt_ovf = e->flags.p + (size_t)f0 * C, *mean_ovf = e->flags.p + (size_t)e->max_frames * C + (size_t)f0 * C;
+    int *skip = e->flags.p + 2 * (size_t)e->max_frames * C + f0, *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * C + e->max_frames;
+    // this part's planes of the encoder's per-frame buffers
+    int16_t *const coef = e->coef.p + (size_t)f0 * C * plane, *const tmp = e->tmp.p + (size_t)f0 * C * plane;
+    unsigned long long *const sums = e->sums.p + (size_t)f0 * C;
+    uint16_t *const means = e->means.p + (size_t)f0 * C;
+    uint8_t *const sig = e->sig.p + (size_t)f0 * e->plan.sig_bytes;
+    uint32_t *const sig_hist = e->sig_hist.p + (size_t)f0 * e->plan.n_families * 16;
+    uint8_t *const route_buf = e->route.p + (size_t)f0 * n_units;
+    uint32_t *const route_list = e->route_list.p + (size_t)f0 * n_units, *const route_ctl = e->route_ctl.p + 2 * (size_t)part;
+    uint8_t *const slots = e->slots.p + (size_t)f0 * e->plan.slot_bytes;
+    uint32_t *const unit_bits = e->unit_bits.p + (size_t)f0 * n_units, *const done_bytes = e->done_bytes.p + (size_t)f0 * n_units;
+    uint64_t *const final_off = e->final_off.p + (size_t)f0 * n_units;
+    HIP_TRY(hipMemsetAsync(dwt_ovf, 0, (size_t)P * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(mean_ovf, 0, (size_t)P * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(skip, 0, (size_t)n_frames * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(sums, 0, (size_t)P * sizeof(unsigned long long), st));
+    if (timed && e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
 
     size_t cw = W, ch = H;
-    launch_dwt(e, d_frames, n_frames, st, e->sample_bits, dwt_ovf, &cw, &ch);
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
+    launch_dwt(e, d_frames, n_frames, st, e->sample_bits, dwt_ovf, &cw, &ch, coef, tmp);
+    if (timed && e->timing) HIP_TRY(hipEventRecord(e->ev[1], st));
 
     // ---- LL mean, frame status, sign-magnitude
     const uint32_t llw = (uint32_t)cw, llh = (uint32_t)ch;
     unsigned sum_blocks = (llw * llh + 255) / 256;
     if (sum_blocks > 64) sum_blocks = 64;
-    hipLaunchKernelGGL(ll_sum_kernel, dim3(sum_blocks, P), dim3(256), 0, st, reinterpret_cast<const uint16_t *>(e->coef.p),
-                       plane, (uint32_t)W, llw, llh, e->sums.p, e->sample_bits == 8 ? 0xFFu : 0xFFFFu);
-    hipLaunchKernelGGL(ll_mean_kernel, dim3((P + 63) / 64), dim3(64), 0, st, e->sums.p, (uint32_t)P, llw * llh,
-                       e->means.p, mean_ovf, e->sample_bits);
+    hipLaunchKernelGGL(ll_sum_kernel, dim3(sum_blocks, P), dim3(256), 0, st, reinterpret_cast<const uint16_t *>(coef),
+                       plane, (uint32_t)W, llw, llh, sums, e->sample_bits == 8 ? 0xFFu : 0xFFFFu);
+    hipLaunchKernelGGL(ll_mean_kernel, dim3((P + 63) / 64), dim3(64), 0, st, sums, (uint32_t)P, llw * llh,
+                       means, mean_ovf, e->sample_bits);
     hipLaunchKernelGGL(frame_status_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, st, dwt_ovf, mean_ovf, C, n_frames, skip);
     hipLaunchKernelGGL(finalize_ll_kernel, dim3((llw + 63u) / 64u, (llh + 3u) / 4u, P), dim3(256), 0, st,
-                       reinterpret_cast<uint16_t *>(e->coef.p), plane, (uint32_t)W, llw, llh, e->means.p, skip, C, e->sample_bits);
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
-    if (e->coef_ready) HIP_TRY(hipEventRecord(e->coef_ready, st));
+                       reinterpret_cast<uint16_t *>(coef), plane, (uint32_t)W, llw, llh, means, skip, C, e->sample_bits);
+    if (timed && e->timing) HIP_TRY(hipEventRecord(e->ev[2], st));
+    if (e->coef_ready && f0 == 0) HIP_TRY(hipEventRecord(e->coef_ready, st));
 
     // ---- coding units
     // Progressive mode: with a byte quota far below the lossless size only the first part of the priority order can end
@@ -447,7 +489,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     // higher-priority predecessors alone already exceed it stops (at its start, or at its next check) -- see
     // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
-    if (progressive) HIP_TRY(hipMemsetAsync(e->done_bytes.p, 0, (size_t)n_frames * n_units * 4, st));
+    if (progressive) HIP_TRY(hipMemsetAsync(done_bytes, 0, (size_t)n_frames * n_units * 4, st));
     const bool use_wg = e->wg_available && (e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive));
     // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
     // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
@@ -463,24 +505,24 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
     const size_t ev_frame_bytes = (size_t)n_planes * e->plan.sig_bytes * 64u;
     if (!use_wg && e->events.ensure((size_t)e->max_frames * ev_frame_bytes + 64)) return ICER_FATAL_ERROR;
     {
-        if (hybrid) HIP_TRY(hipMemsetAsync(e->sig_hist.p, 0, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t), st));
+        if (hybrid) HIP_TRY(hipMemsetAsync(sig_hist, 0, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(family_events_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, e->sig.p,
-                           e->plan.sig_bytes, hybrid ? e->sig_hist.p : nullptr, e->plan.n_families,
-                           use_wg ? nullptr : e->events.p, ev_frame_bytes, (uint32_t)n_planes);
+                           reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, sig,
+                           e->plan.sig_bytes, hybrid ? sig_hist : nullptr, e->plan.n_families,
+                           use_wg ? nullptr : e->events.p + (size_t)f0 * ev_frame_bytes, ev_frame_bytes, (uint32_t)n_planes);
     }
     const uint8_t *route = nullptr;
     e->last_routed = hybrid;
     if (hybrid) {
-        HIP_TRY(hipMemsetAsync(e->route_ctl.p, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(route_units_kernel, dim3((unsigned)((n_units + 255) / 256), n_frames), dim3(256), 0, st, e->units.p, n_units, e->sig_hist.p, e->plan.n_families,
-                           (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, e->route.p, e->route_list.p, e->route_ctl.p,
+        HIP_TRY(hipMemsetAsync(route_ctl, 0, 2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(route_units_kernel, dim3((unsigned)((n_units + 255) / 256), n_frames), dim3(256), 0, st, e->units.p, n_units, sig_hist, e->plan.n_families,
+                           (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, route_buf, route_list, route_ctl,
                            (uint32_t)e->nosplit_percent);
-        route = e->route.p;
+        route = route_buf;
         // the workgroup coder takes its list on a second stream, beside the pipeline kernel (it is submitted first: its
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
-        HIP_TRY(hipEventRecord(e->fork, st));
-        HIP_TRY(hipStreamWaitEvent(e->side_stream, e->fork, 0));
+        HIP_TRY(hipEventRecord(e->fork[part], st));
+        HIP_TRY(hipStreamWaitEvent(e->side_stream, e->fork[part], 0));
         // (a split launch wants the compute units' LDS for its pipeline workgroups: fewer staying workgroups of the small coder, ICER_HIP_SPLIT_WGS)
         // Which instance: measured (profiles/r04_logs/r04_h_list_waves.log).  A batch runs the ONE-wave instance: C4 + 4.2 %,
         // C5 + 2.0 % -- its list is thousands of all-blank units (a first window, then closed-form runs: nothing for a second
@@ -494,12 +536,12 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         const int list_waves = e->list_waves ? e->list_waves : (split ? 4 : 1);
 #define ICER_LAUNCH_LIST(I, NS)                                                                                                          \
         hipLaunchKernelGGL((code_units_list_kernel<I>), dim3(list_grid), dim3(64 * NS::kWgWaves), sizeof(NS::Shared), e->side_stream,    \
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,     \
-                           e->tables.p, e->means.p, skip, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, e->sig.p,                     \
-                           e->plan.sig_bytes, e->route_list.p, e->route_ctl.p, e->prof.p ? e->prof.p + kProfWgsOffset : nullptr)
+                           reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,     \
+                           e->tables.p, means, skip, slots, e->plan.slot_bytes, unit_bits, sig,                     \
+                           e->plan.sig_bytes, route_list, route_ctl, e->prof.p ? e->prof.p + kProfWgsOffset : nullptr)
         if (list_waves == 1) ICER_LAUNCH_LIST(WgOne, wg1); else if (list_waves == 4) ICER_LAUNCH_LIST(WgFour, wg4); else ICER_LAUNCH_LIST(WgSmall, wgs);
 #undef ICER_LAUNCH_LIST
-        HIP_TRY(hipEventRecord(e->join, e->side_stream));
+        HIP_TRY(hipEventRecord(e->join[part], e->side_stream));
     }
     SplitLaunch sp;
     if (split) {
@@ -535,10 +577,10 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         const dim3 pipe_grid = unit_major ? dim3((unsigned)((n_units + sp.n_subs) * (unsigned)n_frames), 1) : dim3(n_units + sp.n_subs, n_frames);
 #define ICER_LAUNCH_PIPE(NW, OCC, PAD)                                                                                                       \
         hipLaunchKernelGGL((code_units_kernel<NW, OCC, PAD>), pipe_grid, dim3(64 * NW), 0, st,                                               \
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
-                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,                  \
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull, route, sp, \
-                           unit_major ? (uint32_t)n_frames : 1u, e->events.p, ev_frame_bytes, e->sig.p, e->plan.sig_bytes)
+                           reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, means, skip, slots,                  \
+                           e->plan.slot_bytes, unit_bits, e->prof.p, done_bytes, progressive ? (uint64_t)quota : 0ull, route, sp, \
+                           unit_major ? (uint32_t)n_frames : 1u, e->events.p + (size_t)f0 * ev_frame_bytes, ev_frame_bytes, sig, e->plan.sig_bytes)
         e->last_waves = large ? kUnitWavesLarge : kUnitWavesSmall;
         e->last_subs = sp.n_subs;
         if (large) ICER_LAUNCH_PIPE(kUnitWavesLarge, 1, 0);
@@ -546,29 +588,70 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         else ICER_LAUNCH_PIPE(kUnitWavesSmall, 8, 0);
 #undef ICER_LAUNCH_PIPE
         if (split)
-            hipLaunchKernelGGL(splice_units_kernel, dim3(n_units, n_frames), dim3(64 * kSpliceWaves), 0, st, e->units.p, n_units, e->tables.p, e->means.p, skip, C,
-                               (uint32_t)W, (uint32_t)H, e->slots.p, e->plan.slot_bytes, e->unit_bits.p, route, sp);
-        if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join, 0));
+            hipLaunchKernelGGL(splice_units_kernel, dim3(n_units, n_frames), dim3(64 * kSpliceWaves), 0, st, e->units.p, n_units, e->tables.p, means, skip, C,
+                               (uint32_t)W, (uint32_t)H, slots, e->plan.slot_bytes, unit_bits, route, sp);
+        if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join[part], 0));
     }
     if (use_wg) e->last_waves = 0, e->last_subs = 0;
     if (use_wg)
         hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
-                           reinterpret_cast<const uint16_t *>(e->coef.p), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, e->means.p, skip, e->slots.p,
-                           e->plan.slot_bytes, e->unit_bits.p, e->prof.p, e->done_bytes.p, progressive ? (uint64_t)quota : 0ull,
-                           e->sig.p, e->plan.sig_bytes);
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
+                           reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, means, skip, slots,
+                           e->plan.slot_bytes, unit_bits, e->prof.p, done_bytes, progressive ? (uint64_t)quota : 0ull,
+                           sig, e->plan.sig_bytes);
+    if (timed && e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
-    hipLaunchKernelGGL(scan_kernel, dim3(n_frames), dim3(64), 0, st, e->unit_bits.p, e->final_order.p, n_units,
-                       (uint64_t)quota, skip, e->final_off.p, d_sizes, d_rcs, e->units.p, bound_ovf);
-    hipLaunchKernelGGL(gather_kernel, dim3(n_units, n_frames), dim3(256), 0, st, e->slots.p, e->plan.slot_bytes,
-                       e->units.p, n_units, e->unit_bits.p, e->final_off.p, d_out, out_stride);
-    if (e->timing) {
+    hipLaunchKernelGGL(scan_kernel, dim3(n_frames), dim3(64), 0, st, unit_bits, e->final_order.p, n_units,
+                       (uint64_t)quota, skip, final_off, d_sizes, d_rcs, e->units.p, bound_ovf);
+    hipLaunchKernelGGL(gather_kernel, dim3(n_units, n_frames), dim3(256), 0, st, slots, e->plan.slot_bytes,
+                       e->units.p, n_units, unit_bits, final_off, d_out, out_stride);
+    if (timed && e->timing) {
         HIP_TRY(hipEventRecord(e->ev[4], st));
         e->ev_pending = true;
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One call = one batch.  A batch of several frames coded by the SYNCHRONOUS entry points is enqueued in parts on two streams -- the
+// caller's and one of the encoder's own --, so that a part's transform and event pass run beside the coder kernels of the part before
+// it and the tail of a coder kernel (its last long units, most of the chip idle) hides behind the next part's: what a caller gets from two
+// encoders and the asynchronous calls, inside one call.  Not for the asynchronous entry points (the caller overlaps
+// whole batches itself), progressive mode, or single frames.  ICER_HIP_OVERLAP_PARTS=<1..4> (1: off).
+int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
+            unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st, bool overlap_ok)
+{
+    const int C = e->channels;
+    int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * C + e->max_frames;
+    HIP_TRY(hipMemsetAsync(bound_ovf, 0, sizeof(int), st));
+    const bool progressive = quota < (size_t)e->w * e->h * C / 2;
+    int parts = 1;
+    if (overlap_ok && e->overlap_parts > 1 && e->half_stream && !progressive && e->coder_mode == 0 && !e->wg_once && n_frames >= 2 * e->overlap_parts &&
+        n_frames * C >= e->hybrid_frames)
+        parts = e->overlap_parts;
+    e->last_parts = parts;
+    if (parts == 1) return enqueue_part(e, 0, 0, true, d_frames, n_frames, quota, d_out, out_stride, d_sizes, d_rcs, st);
+    const size_t plane = e->w * e->h;
+    HIP_TRY(hipEventRecord(e->part_fork, st));                          // (the second stream starts behind whatever the caller's stream holds)
+    HIP_TRY(hipStreamWaitEvent(e->half_stream, e->part_fork, 0));
+    // (the stages of the parts overlap: the call's span is booked on the coder stage -- bench.py's roofline divides the call's bytes by it)
+    if (e->timing) { HIP_TRY(hipEventRecord(e->ev[0], st)); HIP_TRY(hipEventRecord(e->ev[1], st)); HIP_TRY(hipEventRecord(e->ev[2], st)); }
+    for (int k = 0, f0 = 0; k < parts; k++) {
+        // (two parts: the first one smaller -- its transform and event pass have nothing to hide behind)
+        int n = n_frames / parts + (k < n_frames % parts ? 1 : 0);
+        if (parts == 2) { const int n0 = std::max(1, std::min(n_frames - 1, (n_frames * e->overlap_first + 50) / 100)); n = k == 0 ? n0 : n_frames - n0; }
+        hipStream_t ps = (k & 1) ? e->half_stream : st;
+        if (int rc = enqueue_part(e, f0, k, false, d_frames + (size_t)f0 * C * plane, n, quota, d_out + (size_t)f0 * out_stride, out_stride,
+                                  d_sizes + f0, d_rcs + f0, ps)) return rc;
+        f0 += n;
+    }
+    HIP_TRY(hipEventRecord(e->part_join, e->half_stream));
+    HIP_TRY(hipStreamWaitEvent(st, e->part_join, 0));
+    if (e->timing) {
+        HIP_TRY(hipEventRecord(e->ev[3], st)); HIP_TRY(hipEventRecord(e->ev[4], st));
+        e->ev_pending = true;
+    }
     return 0;
 }
 
@@ -629,6 +712,8 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *sw = getenv("ICER_HIP_SPLIT_WGS")) { const int v = atoi(sw); if (v >= 1 && v <= 4096) e->split_wgs = v; }
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *ns = getenv("ICER_HIP_NOSPLIT")) { const int v = atoi(ns); if (v >= 1 && v <= 101) e->nosplit_percent = v; }
+    if (const char *op = getenv("ICER_HIP_OVERLAP_PARTS")) { const int v = atoi(op); if (v >= 1 && v <= kMaxParts) e->overlap_parts = v; }
+    if (const char *of = getenv("ICER_HIP_OVERLAP_FIRST")) { const int v = atoi(of); if (v >= 5 && v <= 95) e->overlap_first = v; }
     if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2 || v == 4) e->list_waves = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
         const int v = atoi(bpp);
@@ -654,7 +739,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
-        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure((size_t)max_frames * n_units) || e->route_ctl.ensure(2) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) || e->sig_hist.ensure((size_t)max_frames * e->plan.n_families * 16 + 16) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure((size_t)max_frames * n_units) || e->route_ctl.ensure(2 * kMaxParts) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) || e->sig_hist.ensure((size_t)max_frames * e->plan.n_families * 16 + 16) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -674,8 +759,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgOne>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg1::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgFour>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg4::Shared)) != hipSuccess ||
         create_side_stream(&e->side_stream) != hipSuccess ||
-        hipEventCreateWithFlags(&e->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->join, hipEventDisableTiming) != hipSuccess) {
+        create_part_events(e) != hipSuccess) {
         (void)hipGetLastError();
         e->wg_available = false;
         if (e->coder_mode == 2) { set_error("ICER_HIP_CODER=wg, but this device does not grant the workgroup coder its LDS block"); icerx_encoder_destroy(e); return ICER_FATAL_ERROR; }
@@ -686,7 +770,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     CREATE_TRY(hipMemset(e->prof.p, 0, kProfWords * sizeof(uint64_t)));
 #endif
     for (auto &ev : e->ev) CREATE_TRY(hipEventCreate(&ev));
-    CREATE_TRY(hipHostMalloc((void **)&e->h_flag, 2 * sizeof(int), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void **)&e->h_flag, (2 + kMaxParts) * sizeof(int), hipHostMallocDefault));
     CREATE_TRY(hipEventCreateWithFlags(&e->done, hipEventDisableTiming));
 #undef CREATE_TRY
     *out = e;
@@ -704,8 +788,11 @@ void icerx_encoder_destroy(icerx_encoder *e)
     e->subs.release(); e->sub_order.release(); e->snap_valid.release(); e->snaps.release(); e->sub_recs.release();
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->done) (void)hipEventDestroy(e->done);
-    if (e->fork) (void)hipEventDestroy(e->fork);
-    if (e->join) (void)hipEventDestroy(e->join);
+    for (auto &ev : e->fork) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->join) if (ev) (void)hipEventDestroy(ev);
+    if (e->part_fork) (void)hipEventDestroy(e->part_fork);
+    if (e->part_join) (void)hipEventDestroy(e->part_join);
+    if (e->half_stream) (void)hipStreamDestroy(e->half_stream);
     if (e->side_stream && !e->side_stream_borrowed) (void)hipStreamDestroy(e->side_stream);
     if (e->coef_ready) (void)hipEventDestroy(e->coef_ready);
     if (e->io_stream) (void)hipStreamDestroy(e->io_stream);
@@ -745,7 +832,7 @@ static void report_timeouts(icerx_encoder *e, int n_frames)
 // `flag` = two pinned host words that receive the batch's verdict: [0] bit 0 a coding unit outgrew its provisioned slot,
 // bit 1 a unit timed out; [1] units on the route list.
 static int encode_begin(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t byte_quota, uint8_t *d_out,
-                        size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, hipStream_t st, int *flag, hipEvent_t done, bool *regrow)
+                        size_t out_stride, uint64_t *d_sizes, int32_t *d_rcs, hipStream_t st, int *flag, hipEvent_t done, bool *regrow, bool overlap_ok = false)
 {
     if (upload_units(e, byte_quota, st)) return ICER_FATAL_ERROR;
     if (e->slots.ensure((size_t)e->max_frames * e->plan.slot_bytes)) return ICER_FATAL_ERROR;
@@ -755,10 +842,13 @@ static int encode_begin(icerx_encoder *e, const uint16_t *d_frames, int n_frames
         return ICER_INVALID_INPUT;
     }
     int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * e->channels + e->max_frames;
-    if (enqueue(e, d_frames, n_frames, byte_quota, d_out, out_stride, (unsigned long long *)d_sizes, d_rcs, st))
+    if (enqueue(e, d_frames, n_frames, byte_quota, d_out, out_stride, (unsigned long long *)d_sizes, d_rcs, st, overlap_ok && flag == e->h_flag))
         return ICER_FATAL_ERROR;
     HIP_TRY(hipMemcpyAsync(flag, bound_ovf, sizeof(int), hipMemcpyDeviceToHost, st));
     if (e->last_routed) HIP_TRY(hipMemcpyAsync(flag + 1, e->route_ctl.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // (a batch enqueued in parts: the other parts' list lengths behind the two words every caller has -- only e->h_flag is that long)
+    for (int k = 1; k < e->last_parts; k++)
+        if (e->last_routed) HIP_TRY(hipMemcpyAsync(flag + 1 + k, e->route_ctl.p + 2 * k, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(done, st));
     return 0;
 }
@@ -784,7 +874,10 @@ static int encode_verdict(icerx_encoder *e, int n_frames, const int *flag)
 {
     const int ovf = flag[0];
     if (!ovf) {
-        if (e->last_routed) { e->n_routed_units += (uint64_t)(uint32_t)flag[1]; e->n_routed_launches++; }
+        if (e->last_routed) {
+            e->n_routed_units += (uint64_t)(uint32_t)flag[1]; e->n_routed_launches++;
+            if (flag == e->h_flag) for (int k = 1; k < e->last_parts; k++) e->n_routed_units += (uint64_t)(uint32_t)flag[1 + k];
+        }
         return 0;
     }
     if (ovf & 2) {
@@ -837,7 +930,8 @@ static int encode_device_impl(icerx_encoder *e, const uint16_t *d_frames, int n_
     for (bool begun = already_begun;; begun = false) {
         if (!begun) {
             bool rg = false;
-            const int rc = encode_begin(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, st, e->h_flag, e->done, regrow ? &rg : nullptr);
+            const int rc = encode_begin(e, d_frames, n_frames, byte_quota, d_out, out_stride, d_sizes, d_rcs, st, e->h_flag, e->done, regrow ? &rg : nullptr,
+                                        /* overlap_ok = */ !already_begun || e->last_parts > 1);
             if (rc) return rc;
             if (rg) { *regrow = true; return 0; }
         }
