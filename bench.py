@@ -326,7 +326,7 @@ class HostWorkload:
         del self.frames, self.out
 
 
-PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+PMC_PASSES = (("stats", None), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"]),
               # hardware's own account of the waves' time (quad-cycles, MI355X_MICROARCH.md "rocprofv3 PMC slots"): no
               # cycles-per-instruction assumption needed
@@ -334,7 +334,7 @@ PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]))
 
 
-def measure_traffic(args):
+def measure_traffic(args, config=None, passes=None):
     """HBM traffic and issue counters of the dominant kernel, measured on THIS build in child runs under rocprofv3:
     --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, kernel trace only; gfx950 FETCH_SIZE counts half the bytes of a
     streaming read, calibrated on finalize_kernel, see tools/rocprof_summary.py) and the SQ counters.  A pass that fails
@@ -344,28 +344,82 @@ def measure_traffic(args):
         return None, "rocprofv3 not on PATH"
     import sqlite3
     import tempfile
-    res, failed = {}, []
+    res, failed, per_kernel = {}, [], {}
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batched-probe", "0",
-             "--no-batch-configs", "--no-traffic", "--no-extras", "--config", args.config]
+             "--no-batch-configs", "--no-traffic", "--no-extras", "--no-one-process", "--config", config or args.config]
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         for tag, ctrs in PMC_PASSES:
+            if passes and tag not in passes:
+                continue
             d = os.path.join(td, tag)
             try:
-                subprocess.run([exe, "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100)
+                # (counter passes: --kernel-trace + --pmc only; the duration pass: --kernel-trace --stats, no counters)
+                what = ["--kernel-trace", "--stats"] if ctrs is None else ["--kernel-trace", "--pmc"] + ctrs
+                subprocess.run([exe] + what + ["-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
                 db = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
                 cur = sqlite3.connect(db[0]).cursor()
+                if ctrs is None:
+                    # kernel durations without counters attached (what `rocprofv3 --kernel-trace --stats` of the same command reports)
+                    for k, calls, avg in cur.execute("select name, total_calls, average from top_kernels"):
+                        per_kernel.setdefault(short_kernel(k), {})["avg_us"] = avg
+                    continue
                 q = ("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%code_units_kernel%' "
                      "group by counter_name")
                 for n, v, _ in cur.execute(q):
                     res[n] = v
+                if tag in ("fetch", "write"):
+                    # every kernel of the launch: the counter summed over its dispatches (a DWT stage, a part of a batch: several per call)
+                    q = "select kernel_name, sum(value), count(*) from counters_collection where counter_name=? group by kernel_name"
+                    for k, v, cnt in cur.execute(q, (ctrs[0],)):
+                        e = per_kernel.setdefault(short_kernel(k), {})
+                        e[ctrs[0] + "_KiB_sum"] = v
+                        e["dispatches"] = cnt
             except Exception as exc:                                   # noqa: BLE001 -- the bench line survives a failed pass
                 failed.append(f"{tag}: {exc!r}")
     note = "measured in this run: rocprofv3 --kernel-trace --pmc passes on a child bench.py (3 steps)"
     if failed:
         note += "; failed passes: " + "; ".join(failed)
+    res["per_kernel"] = per_kernel
     return res, note
+
+
+def short_kernel(name: str) -> str:
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
+    head = n.split("<")[0]
+    return head.split("::")[-1].replace("void ", "") + n[len(head):].replace("icer::", "")
+
+
+# FETCH_SIZE on gfx950 counts a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM): x 2 for reads that arrive as 128-byte requests,
+# x 1 for reads that arrive as 64-byte ones.  Per kernel, calibrated on a known byte count in that kernel's own access pattern:
+#   finalize_ll_kernel   2.0   reads and writes exactly one LL rectangle: WRITE_SIZE exact, FETCH_SIZE 0.50 x (round 1)
+#   dwt_tile_kernel      1.0   stage 0 of a 4096^2 frame reads 33.5 MB + halo once: FETCH_SIZE uncorrected = 43 MiB over the five stages
+#                              = the compulsory 42.7 MiB (the blanket x 2 over-counted it)
+#   family_events_kernel 1.0   2-byte gathers of a 3x3 window, one 64-byte line per wave and row
+#   everything else      2.0   the guide's figure (an upper bound where the pattern is not a streaming one)
+FETCH_FACTOR = {"dwt_tile_kernel": 1.0, "family_events_kernel": 1.0}
+
+
+def launch_traffic(per_kernel, parts_per_call):
+    """HBM bytes of ONE call summed over every kernel it launches (ours only: the bench's own torch kernels are not the call's)"""
+    ours = ("dwt_tile", "ll_sum", "ll_mean", "frame_status", "finalize_ll", "family_events", "route_units", "code_units", "splice_units", "scan_kernel", "gather_kernel")
+    scan = per_kernel.get("scan_kernel", {}).get("dispatches", 0)
+    calls = scan / max(parts_per_call, 1)
+    if calls <= 0:
+        return None, {}
+    table, total = {}, 0.0
+    for k, e in sorted(per_kernel.items()):
+        if not k.startswith(ours) or "FETCH_SIZE_KiB_sum" not in e or "WRITE_SIZE_KiB_sum" not in e:
+            continue
+        f = FETCH_FACTOR.get(k.split("<")[0], 2.0)
+        b = (f * e["FETCH_SIZE_KiB_sum"] + e["WRITE_SIZE_KiB_sum"]) * 1024.0 / calls
+        total += b
+        table[k] = {"dispatches_per_call": round(e["dispatches"] / calls, 2), "FETCH_SIZE_KiB_per_call": round(e["FETCH_SIZE_KiB_sum"] / calls, 1),
+                    "WRITE_SIZE_KiB_per_call": round(e["WRITE_SIZE_KiB_sum"] / calls, 1), "fetch_factor": f, "bytes_per_call": int(b)}
+        if "avg_us" in e:
+            table[k]["avg_us_under_rocprof"] = round(e["avg_us"], 2)
+    return int(total), table
 
 
 def run_timed(wl, steps, warmup, barrier, dev, red_dev=None):
@@ -382,18 +436,20 @@ def run_timed(wl, steps, warmup, barrier, dev, red_dev=None):
     import gc
     gc.collect()
     gc.disable()                                                      # (no collector pause inside the timed region)
-    barrier()
-    t0 = time.perf_counter()
-    step_ms = []
-    for _ in range(steps):
-        ts = time.perf_counter()
-        wl.step()
-        step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
-    if hasattr(wl, "finish"):
-        wl.finish()                                                   # (a step still in flight belongs to the timed region)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        step_ms = []
+        for _ in range(steps):
+            ts = time.perf_counter()
+            wl.step()
+            step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
+        if hasattr(wl, "finish"):
+            wl.finish()                                               # (a step still in flight belongs to the timed region)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()                                                   # (also when a step raises: the secondary objects catch and carry on)
     stage_ms, calls = ({}, 0)
     if wl.enc is not None:
         stage_ms, calls = wl.enc.timing_read(reset=True)
@@ -724,14 +780,21 @@ def launch_ranks(n: int) -> int:
     torch.distributed.run on 127.0.0.1 (a free port), one rank per GPU; with fewer visible GPUs than ranks the ranks share
     devices (the dry-run path of main(): logical devices + gloo).  Returns the launcher's exit code."""
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    rc = 1
+    for attempt in range(3):                  # (a port found free by bind-then-close can be taken before the ranks bind it: try another one)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(p.stderr)
+        rc = p.returncode
+        if rc == 0 or not any(m in p.stderr for m in ("EADDRINUSE", "Address already in use", "address already in use")):
+            break
+    return rc
 
 
 def main():
@@ -750,6 +813,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-configs", action="store_true", help="skip the secondary C4 / C5 figures")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-batch-traffic", action="store_true", help="skip the rocprofv3 counter passes of the C4 / C5 batch configurations (batch_configs.*.roofline)")
     ap.add_argument("--no-extras", action="store_true", help="skip C3, decode, batch_host and host_buffers (the child runs under rocprofv3)")
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=None, help="launches in flight for a batch workload whose step is ONE launch (--config C4|C5): "
                     "2 = step k is submitted before step k - 1 is waited for (default: 2 with --scaling strong, else 1)")
@@ -907,7 +971,7 @@ def main():
 
     # the batch configurations BASELINE.json names for 8 GPUs, as this GPU's share of them: device-resident, and fed from
     # page-locked host memory through the overlapped batch call
-    batch_cfgs, batch_host, kept = {}, {}, {}
+    batch_cfgs, batch_host, kept, batch_roof = {}, {}, {}, {}
     have_bg = os.path.exists(os.path.join(ROOT, "tests", "golden", "batch_golden.json"))
     if not args.no_batch_configs and have_bg:
         for name in ("C4", "C5"):
@@ -936,7 +1000,13 @@ def main():
                 if rank == 0 and world == 1:
                     ab = float(c["per_gpu"] * c["w"] * c["h"] * 2 + out_bytes)
                     kms = st_ms["code_units"] / max(cl, 1)
+                    parts = bw.enc.parts()
                     batch_cfgs[name]["roofline_frac"] = round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)
+                    batch_cfgs[name]["parts_per_call"] = parts
+                    if parts > 1:
+                        batch_cfgs[name]["stage_note"] = (f"the call enqueues its frames in {parts} parts on two streams (their stages overlap): code_units_ms is the call's whole "
+                                                          "span, dwt_ms is booked inside it")
+                    batch_roof[name] = (ab, kms, parts, c["per_gpu"] * c["w"] * c["h"])
                 bw.close()
                 del bw
                 torch.cuda.empty_cache()
@@ -1084,6 +1154,28 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:                                   # noqa: BLE001 -- secondary figure
                 scaling_ref = {"error": repr(exc)}
+    # N > 1: the same strong-scaling split FED FROM THE HOST (icerx_compress_batch_uint16_devices on every rank's own device: frames and
+    # streams in page-locked host memory) beside the device-resident headline -- at 8 GPUs the ranks share the host's DRAM and PCIe root
+    # (about 270 MB in and 80 MB out per rank and step of 32 frames), so this is the curve that can bend first
+    host_fed = None
+    if world > 1 and args.config != "C2" and args.scaling == "strong" and device_wl and have_bg:
+        try:
+            lo, hi = shard.shard_range(cfg["total"], rank, world)
+            hw = HostWorkload(args.config, rank, dev, local_rank, first=lo, count=hi - lo)
+            hw.step()
+            badh, _ = hw.verify()
+            nst = 3
+            t_el, _, _, _ = run_timed(hw, nst, 1, barrier, dev, red_dev)
+            badh2, _ = hw.verify()
+            host_fed = {"workload": f"{cfg['what']}: the whole batch of {cfg['total']} frames split over {world} ranks, every rank's share in page-locked HOST memory -> "
+                                    "streams in page-locked host memory through icerx_compress_batch_uint16_devices on its own device (copies and kernels of sub-batches overlap)",
+                        "value": round(cfg["total"] * hw.w * hw.h * nst / t_el / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(t_el / nst * 1e3, 3), "steps": nst,
+                        "n_gpus": world, "scaling": "strong", "parity": all_ranks_ok(not badh and not badh2), "frames_checked_per_rank": hi - lo,
+                        "pinned": hw.pinned}
+            hw.close()
+            del hw
+        except Exception as exc:                                       # noqa: BLE001 -- secondary figure
+            host_fed = {"error": repr(exc)}
     # ... and last of the legs of this process: the host-fed call again with other streams alive in the process (torch's stream pool stays
     # alive from here on, which is why nothing that overlaps launches on streams of its own comes after this)
     if not args.no_extras and world == 1 and not args.no_batch_configs and have_bg:
@@ -1169,6 +1261,8 @@ def main():
             line["c2_per_rank"] = c2_rank
         if scaling_ref:
             line["scaling_reference"] = scaling_ref
+        if host_fed:
+            line["host_fed"] = host_fed
         if one_proc:
             line["one_process"] = one_proc
         if world > 1 and args.config != "C2":
@@ -1183,6 +1277,19 @@ def main():
             if ctr and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
                 line["roofline"]["traffic"] = int(2 * ctr["FETCH_SIZE"] * 1024 + ctr["WRITE_SIZE"] * 1024)
                 line["roofline"]["traffic_counters_KiB"] = {"FETCH_SIZE": round(ctr["FETCH_SIZE"], 1), "WRITE_SIZE": round(ctr["WRITE_SIZE"], 1)}
+                line["roofline"]["traffic_note"] = "the dominant kernel alone, per dispatch (2 x FETCH_SIZE + WRITE_SIZE); the whole call: traffic_launch"
+            if ctr and ctr.get("per_kernel"):
+                tl, table = launch_traffic(ctr["per_kernel"], wl.enc.parts())
+                if tl:
+                    line["roofline"]["traffic_launch"] = tl
+                    line["roofline"]["traffic_launch_over_algorithmic"] = round(tl / (alg_bytes * launches_per_step), 3)
+                    line["roofline"]["traffic_launch_kernels"] = table
+                    line["roofline"]["traffic_launch_note"] = ("HBM bytes of one call summed over every kernel it launches; per kernel fetch_factor x FETCH_SIZE + WRITE_SIZE, the "
+                                                               "factor calibrated per access pattern (bench.py FETCH_FACTOR); avg_us_under_rocprof = the kernel's duration in that pass")
+                    dom = max((k for k in table if k.startswith("code_units_kernel")), key=lambda k: table[k]["bytes_per_call"], default=None)
+                    if dom and "avg_us_under_rocprof" in table[dom]:
+                        line["roofline"]["kernel_avg_ms_rocprof"] = round(table[dom]["avg_us_under_rocprof"] / 1e3, 4)
+                        line["roofline"]["kernel_name_rocprof"] = dom
             if ctr and "SQ_INSTS_VALU" in ctr:
                 cyc = k_ms * 1e-3 * CLOCK_HZ
                 issue = {"valu_wave_insts_per_launch": int(ctr["SQ_INSTS_VALU"]), "salu_insts_per_launch": int(ctr.get("SQ_INSTS_SALU", 0)),
@@ -1204,6 +1311,36 @@ def main():
                 if "SQ_LDS_BANK_CONFLICT" in ctr and ctr.get("SQ_LDS_IDX_ACTIVE"):
                     issue["lds_bank_conflict_share_of_lds_cycles"] = round(ctr["SQ_LDS_BANK_CONFLICT"] / ctr["SQ_LDS_IDX_ACTIVE"], 4)
                 line["roofline"]["issue"] = issue
+        if world == 1 and not args.no_traffic and not args.no_batch_traffic and device_wl:
+            # the same audit for the batch configurations: counters of a child run of that configuration (three passes each)
+            for name, (ab, kms, parts, pix) in batch_roof.items():
+                try:
+                    ctr, src_note = measure_traffic(args, config=name, passes=("stats", "fetch", "write", "sq"))
+                    ro = {"bound": "hbm", "achieved": round(ab / (kms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6), "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(kms, 4),
+                          "traffic": None, "traffic_source": src_note + f"; sources {source_digest()}"}
+                    if ctr and ctr.get("per_kernel"):
+                        tl, table = launch_traffic(ctr["per_kernel"], parts)
+                        dom = max((k for k in table if k.startswith("code_units_kernel")), key=lambda k: table[k]["bytes_per_call"], default=None)
+                        if dom:
+                            ro["kernel"] = dom
+                            ro["traffic"] = table[dom]["bytes_per_call"]
+                            ro["kernel_dispatches_per_call"] = table[dom]["dispatches_per_call"]
+                            if "avg_us_under_rocprof" in table[dom]:
+                                ro["kernel_avg_ms_rocprof"] = round(table[dom]["avg_us_under_rocprof"] / 1e3, 4)
+                        if tl:
+                            ro["traffic_launch"] = tl
+                            ro["traffic_launch_over_algorithmic"] = round(tl / ab, 3)
+                            ro["traffic_launch_kernels"] = table
+                    if ctr and "SQ_INSTS_VALU" in ctr:
+                        disp = ro.get("kernel_dispatches_per_call", 1) or 1
+                        ro["issue"] = {"valu_wave_insts_per_call": int(ctr["SQ_INSTS_VALU"] * disp), "salu_insts_per_call": int(ctr.get("SQ_INSTS_SALU", 0) * disp),
+                                       "lds_insts_per_call": int(ctr.get("SQ_INSTS_LDS", 0) * disp),
+                                       "valu_wave_insts_per_pixel": round(ctr["SQ_INSTS_VALU"] * disp / pix, 2),
+                                       "note": "code_units_kernel alone (SQ_INSTS_* per dispatch x dispatches per call)"}
+                    batch_cfgs[name]["roofline"] = ro
+                except Exception as exc:                               # noqa: BLE001 -- secondary figure
+                    batch_cfgs[name]["roofline"] = {"error": repr(exc)}
         if world == 1 and args.config == "C2" and device_wl and not args.no_extras:
             # PCIe-inclusive figures of the host-buffer entry point (never `value`): H2D frame + kernels + D2H stream,
             # caller buffers pageable (the runtime stages them) and page-locked (icerx_pin_host: DMA at link speed)

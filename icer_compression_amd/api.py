@@ -95,6 +95,7 @@ def load_library() -> C.CDLL:
     L.icerx_encoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.icerx_encoder_routing.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.icerx_encoder_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.icerx_encoder_parts.argtypes = [C.c_void_p]
     L.icerx_process_stats.argtypes = [C.POINTER(C.c_uint64)]
     L.icerx_pin_host.argtypes = [C.c_void_p, C.c_size_t]
     L.icerx_unpin_host.argtypes = [C.c_void_p]
@@ -320,6 +321,10 @@ class Encoder:
         out = (C.c_uint32 * 4)()
         self.lib.icerx_encoder_launch_info(self.handle, out)
         return {"split": bool(out[0]), "sub_range_workgroups": int(out[1]), "pipeline_waves": int(out[2]), "window_coder_beside": bool(out[3])}
+
+    def parts(self) -> int:
+        """parts the last call was enqueued in (icerx_encoder_parts)"""
+        return int(self.lib.icerx_encoder_parts(self.handle))
 
     def info(self):
         u, b, s = C.c_uint32(), C.c_uint32(), C.c_uint64()

@@ -224,6 +224,7 @@ struct icerx_encoder {
     hipEvent_t part_fork = nullptr, part_join = nullptr;
     int overlap_parts = 2;              // parts a synchronous batch call is enqueued in (ICER_HIP_OVERLAP_PARTS; 1: one stream, as the asynchronous calls)
     int last_parts = 1;
+    int test_fail_frame = -1, test_fail_unit = -1, test_fail_calls = 0;   // ICER_HIP_TEST_FAIL_UNIT (test hook, enqueue_part)
     int overlap_first = 50;             // two parts: the first part's share of the frames in percent (ICER_HIP_OVERLAP_FIRST)
     hipEvent_t coef_ready = nullptr;    // the transform of the last enqueue is complete (coef, means, frame status): recorded before the coder
     hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
@@ -560,6 +561,13 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
         sp.prefix_cache = getenv("ICER_EXPERIMENT_NO_CACHE") ? nullptr : e->prefix_cache.p;
 #endif
     }
+    // TEST HOOK (ICER_HIP_TEST_FAIL_UNIT=<frame>:<unit>[:<calls>]): the pipeline kernel of the next <calls> (default 1) calls reports a time-out for
+    // that unit of that frame of the batch; nothing else changes.  tests/test_gpu_recovery.py.
+    uint32_t fail_inject = ~0u;
+    if (e->test_fail_calls > 0 && !use_wg && e->test_fail_frame >= f0 && e->test_fail_frame < f0 + n_frames && e->test_fail_unit < (int)n_units) {
+        fail_inject = ((uint32_t)(e->test_fail_frame - f0) << 20) | (uint32_t)e->test_fail_unit;
+        e->test_fail_calls--;
+    }
     if (!use_wg) {
         // the shape of the pipeline's workgroups: one frame alone cannot fill the chip and is bound by the chain of its
         // largest units, which the large shape (two pixel waves, golomb state wave + two workers) shortens; a batch wants
@@ -580,7 +588,7 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
                            reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,                 \
                            progressive ? nullptr : e->work_order.p, n_units, e->tables.p, means, skip, slots,                  \
                            e->plan.slot_bytes, unit_bits, e->prof.p, done_bytes, progressive ? (uint64_t)quota : 0ull, route, sp, \
-                           unit_major ? (uint32_t)n_frames : 1u, e->events.p + (size_t)f0 * ev_frame_bytes, ev_frame_bytes, sig, e->plan.sig_bytes)
+                           unit_major ? (uint32_t)n_frames : 1u, e->events.p + (size_t)f0 * ev_frame_bytes, ev_frame_bytes, sig, e->plan.sig_bytes, fail_inject)
         e->last_waves = large ? kUnitWavesLarge : kUnitWavesSmall;
         e->last_subs = sp.n_subs;
         if (large) ICER_LAUNCH_PIPE(kUnitWavesLarge, 1, 0);
@@ -713,6 +721,10 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     if (const char *sf = getenv("ICER_HIP_SPLIT_FRAMES")) { const int v = atoi(sf); if (v >= 0) e->split_frames = v; }
     if (const char *ns = getenv("ICER_HIP_NOSPLIT")) { const int v = atoi(ns); if (v >= 1 && v <= 101) e->nosplit_percent = v; }
     if (const char *op = getenv("ICER_HIP_OVERLAP_PARTS")) { const int v = atoi(op); if (v >= 1 && v <= kMaxParts) e->overlap_parts = v; }
+    if (const char *tf = getenv("ICER_HIP_TEST_FAIL_UNIT")) {
+        int f = -1, u = -1, c = 1;
+        if (sscanf(tf, "%d:%d:%d", &f, &u, &c) >= 2 && f >= 0 && f < (1 << 11) && u >= 0 && u < (1 << 20) && c >= 1) { e->test_fail_frame = f; e->test_fail_unit = u; e->test_fail_calls = c; }
+    }
     if (const char *of = getenv("ICER_HIP_OVERLAP_FIRST")) { const int v = atoi(of); if (v >= 5 && v <= 95) e->overlap_first = v; }
     if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2 || v == 4) e->list_waves = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
@@ -1111,7 +1123,9 @@ bool want_priority_streams()
 void warn_hw_queues_once()
 {
     static std::atomic<bool> said{false};
-    if (!want_priority_streams() || getenv("ICER_HIP_QUIET") || said.exchange(true)) return;
+    // (an informational notice, not a warning: only on request -- ICER_HIP_VERBOSE=1; INTEGRATION.md "Hardware queues" has the full story)
+    const char *vb = getenv("ICER_HIP_VERBOSE");
+    if (!want_priority_streams() || !vb || atoi(vb) == 0 || said.exchange(true)) return;
     fprintf(stderr, "libicer_hip: host-fed batch: GPU_MAX_HW_QUEUES is below 6, so the pipeline's encoder streams are low-priority streams (a hardware-queue pool "
                     "of their own; kernels of the program's own streams go first); GPU_MAX_HW_QUEUES=8 in the environment before the process initialises HIP makes them plain ones\n");
 }
@@ -1526,6 +1540,8 @@ int icerx_encoder_launch_info(icerx_encoder *e, uint32_t out[4])
     out[0] = e->last_split ? 1u : 0u; out[1] = e->last_subs; out[2] = (uint32_t)e->last_waves; out[3] = e->last_routed ? 1u : 0u;
     return 0;
 }
+
+int icerx_encoder_parts(icerx_encoder *e) { return e ? e->last_parts : ICER_INVALID_INPUT; }
 
 int icerx_info(icerx_encoder *e, uint32_t *units_per_frame, uint32_t *slot_bits_per_pixel, uint64_t *slot_bytes_per_frame)
 {

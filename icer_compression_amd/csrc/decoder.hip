@@ -441,6 +441,12 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_chains_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_lds_limit) == hipSuccess)
                     d->planes_lds_raised = true;
                 else { (void)hipGetLastError(); d->planes_lds_refused = true; }
+                // (said once per decoder: on a runtime that reports or grants less than gfx950's 160 KiB the fast planes kernel quietly loses
+                // the chains that need more -- correct, slower)
+                if (d->planes_lds_refused || planes_lds_limit < 150u * 1024u)
+                    fprintf(stderr, "libicer_hip_dec: %zu KiB of LDS per workgroup for the planes kernel (%s); chains that need more take the wave kernel\n",
+                            (d->planes_lds_refused ? std::min(planes_lds_limit, (size_t)48u * 1024u) : planes_lds_limit) / 1024u,
+                            d->planes_lds_refused ? "the runtime refused more than 48 KiB" : "what the device reports, less 10 KiB");
             }
             if (d->planes_lds_refused) planes_lds_limit = std::min(planes_lds_limit, (size_t)48u * 1024u);
         }

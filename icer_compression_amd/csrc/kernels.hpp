@@ -141,7 +141,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
                   const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                   size_t slot_frame_stride, uint32_t *__restrict__ unit_bits, uint64_t *__restrict__ timers,
                   uint32_t *__restrict__ done_bytes, uint64_t early_quota, const uint8_t *__restrict__ route, SplitLaunch sp, uint32_t n_frames_1d,
-                  const uint8_t *__restrict__ ev, size_t ev_frame_stride, const uint8_t *__restrict__ sig, size_t sig_frame_stride)
+                  const uint8_t *__restrict__ ev, size_t ev_frame_stride, const uint8_t *__restrict__ sig, size_t sig_frame_stride,
+                  uint32_t fail_inject)
 {
     __shared__ CoderShared s;
     if constexpr (LDS_PAD > 0) {
@@ -155,10 +156,8 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
     // and what is left at the end are the smallest units of all frames.
     uint32_t frame = blockIdx.y, lpos = blockIdx.x;
     if (gridDim.y == 1u && n_frames_1d > 1u) {
-        const uint32_t per_frame = n_units + sp.n_subs, g = blockIdx.x / (8u * n_frames_1d), base = g * 8u;
-        const uint32_t width = per_frame - base < 8u ? per_frame - base : 8u, r = blockIdx.x - g * 8u * n_frames_1d;
-        frame = r / width;
-        lpos = base + r % width;
+        position_major(blockIdx.x, n_units + sp.n_subs, n_frames_1d, &frame, &lpos);
+        if (frame >= n_frames_1d) return;               // (a grid that is not per_frame x n_frames: never launched, never out of bounds)
     }
     // A split launch (sp.n_subs > 0) has extra workgroups for its split units: an entry of sp.launch with bit 31 set codes a later
     // sub-range of a unit (coder_core.hpp "Sub-ranges"), the others one unit from its first chunk as always.
@@ -189,6 +188,9 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         return;
     }
     const UnitDesc u = units[ui];
+    // TEST HOOK (ICER_HIP_TEST_FAIL_UNIT, api.hip): this unit reports a time-out although it has not had one, so that the recovery path --
+    // diagnostics, the batch coded again by the barrier-only coder -- can be exercised on hardware.  ~0u (always, outside that test): none.
+    const bool injected = fail_inject == ((frame << 20) | ui);
     if (early_quota) {
         // progressive mode: units are launched in priority order; one whose higher-priority predecessors have already
         // used up the quota can not be in the stream (quota_already_spent)
@@ -344,7 +346,7 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
         const uint32_t how = merge_wave_run(s, a, j0, nchunks);
         if (how != kMergeMatched) {
             uint32_t bits = how == kMergeDone ? merge_wave_finish(s, a) : kUnitTooBig;
-            if (s.abort == 2u) bits = kUnitFailed;
+            if (s.abort == 2u || injected) bits = kUnitFailed;
             SubRecord &r = layout.rec[layout.index];
             if ((threadIdx.x & 63) == 0) { r.end_chunk = nchunks; r.end_bits = bits; r.match_sub = 0; r.match_snap = 0; }
             const int lane = (int)(threadIdx.x & 63);
@@ -355,8 +357,9 @@ code_units_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_
 #endif
     } else {
         uint32_t bits = merge_wave_run(s, a, 0, nchunks) ? merge_wave_finish(s, a) : kUnitTooBig;
-        if (s.abort == 2u) {                          // a bounded spin expired: internal error, never a silent hang
+        if (s.abort == 2u || injected) {              // a bounded spin expired: internal error, never a silent hang
             bits = kUnitFailed;
+            if (injected && (threadIdx.x & 63) == 0) s.abort_site = 0xFFFFu | (0xFFu << 16);      // (diagnostics: "wave 255 at line 65535" = the test hook)
             // leave the unit's hand-off counters where its payload would have been (api.hip prints them)
             if ((threadIdx.x & 63) == 0 && u.cap_words >= kFailWords) {
                 uint32_t *dbg = slot_words + kHeaderBytes / 4;

@@ -199,6 +199,21 @@ __host__ __device__
 #endif
 inline uint32_t sub_first_chunk(uint32_t nchunks, uint32_t n_sub, uint32_t i) { return (uint32_t)((uint64_t)nchunks * i / n_sub); }
 
+// The pipeline kernel of a batch is a ONE-dimensional grid of per_frame x n_frames workgroups walked position-major: eight launch
+// positions (one per XCD: position % 8 names the XCD while a group is full, so a family keeps its L2) of every frame, then the next
+// eight -- the largest units of ALL frames start first, the smallest of all frames end the launch.  Workgroup b -> (frame, launch
+// position); a bijection for every per_frame >= 1 (the last group of a frame may have fewer than eight positions).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void position_major(uint32_t b, uint32_t per_frame, uint32_t n_frames, uint32_t *frame, uint32_t *lpos)
+{
+    const uint32_t g = b / (8u * n_frames), base = g * 8u;
+    const uint32_t width = per_frame - base < 8u ? per_frame - base : 8u, r = b - g * 8u * n_frames;
+    *frame = r / width;
+    *lpos = base + r % width;
+}
+
 // quarter-octave size class of a unit (launch order treats units of one class as equally large)
 inline int size_class(uint64_t pixels)
 {

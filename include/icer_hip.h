@@ -234,6 +234,12 @@ int icerx_encoder_routing(icerx_encoder *enc, uint64_t out[2]);
  * the pipeline kernel (8 or 11; 0: the workgroup coder alone), out[3] = 1 if all-but-blank units went to the window coder
  * beside it.  None of this changes a byte of the streams. */
 int icerx_encoder_launch_info(icerx_encoder *enc, uint32_t out[4]);
+/* Parts the encoder's last call was enqueued in.  A SYNCHRONOUS batch call of four frames or more (icerx_encode_device and the _u8 / _rgb8 /
+ * _s8 twins; not progressive mode) enqueues its frames in two parts, the second on a stream of the encoder's own that starts behind
+ * whatever `stream` holds and is joined back before the call's own work on `stream` ends: a part's transform and event pass run beside
+ * the other part's coder kernels.  The asynchronous calls enqueue one part (their caller overlaps whole batches).  env
+ * ICER_HIP_OVERLAP_PARTS=<1..4> (1: off).  None of this changes a byte of the streams. */
+int icerx_encoder_parts(icerx_encoder *enc);
 /* out[0..2] summed over all encoders of the process, including the one behind the lib_icer-shaped entry points */
 int icerx_process_stats(uint64_t out[4]);
 

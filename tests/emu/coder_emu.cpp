@@ -296,6 +296,12 @@ extern "C" int emu_plan_sig_blocks(size_t w, size_t h, int channels, int stages,
     return n;
 }
 
+// the workgroup -> (frame, launch position) map of a batch's pipeline kernel (plan.hpp position_major)
+extern "C" void emu_position_major(uint32_t b, uint32_t per_frame, uint32_t n_frames, uint32_t *frame, uint32_t *lpos)
+{
+    position_major(b, per_frame, n_frames, frame, lpos);
+}
+
 // every unit's family: per unit family index, chunk-table offset, x0, y0, w, h (the units of a family must share the rectangle)
 extern "C" int emu_plan_families(size_t w, size_t h, int channels, int stages, int segments, uint32_t *out /* n*6 */, int cap, uint32_t *n_families)
 {

@@ -162,6 +162,25 @@ def test_chunk_table_work_list_covers_every_family_once(emu):
         assert areas[-1][0] + areas[-1][1] <= sig_bytes.value
 
 
+def test_position_major_launch_order_is_a_bijection(emu):
+    """plan.hpp position_major (the one-dimensional grid of a batch's pipeline kernel): every (frame, launch position) exactly once for
+    unit counts that are and are not multiples of eight and 1 .. 33 frames; in full groups of eight, workgroup b sits on launch position
+    b % 8 (mod 8): the XCD of its family"""
+    import ctypes as C
+    f, p = C.c_uint32(0), C.c_uint32(0)
+    emu.lib.emu_position_major.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    for per_frame in (1, 7, 8, 9, 63, 64, 1440 % 97 + 90, 1872, 1875):
+        for n_frames in (1, 2, 3, 8, 32, 33):
+            seen = set()
+            for b in range(per_frame * n_frames):
+                emu.lib.emu_position_major(b, per_frame, n_frames, C.byref(f), C.byref(p))
+                assert f.value < n_frames and p.value < per_frame
+                seen.add((f.value, p.value))
+                if p.value < per_frame - per_frame % 8:
+                    assert p.value % 8 == b % 8
+            assert len(seen) == per_frame * n_frames
+
+
 def test_a_family_is_one_rectangle_even_under_the_stale_grid_quirk(emu):
     """The units of a family share the chunk table and the event bytes, so they must code the SAME rectangle.  Under quirk P1 (a
     failed segment grid keeps the previous packet's one) the planes of one (channel, level, subband, segment) can have different

@@ -25,6 +25,8 @@ def test_bench_gpus_2_starts_itself_and_reports_the_c4_batch():
     assert line["config"]["frames_per_gpu_per_step"] == 128 and "BASELINE configs[3]" in line["config"]["workload"]
     assert line["value"] > 0 and line["coder_events"]["unit_timeouts"] == 0
     assert line["c2_per_rank"]["parity"] is True and line["c2_per_rank"]["n_gpus"] == 2
+    # the same split fed from page-locked host memory (icerx_compress_batch_uint16_devices on every rank's device), every frame checked
+    assert line["host_fed"]["parity"] is True and line["host_fed"]["n_gpus"] == 2 and line["host_fed"]["value"] > 0
 
 
 @pytest.mark.parametrize("name,frames", [("C4", 256), ("C5", 64)])
