@@ -282,6 +282,8 @@ struct icerx_decoder {
     Buf data, frames, crc, dtables, count, cands, chains, work, tmp, out8, pos, list, err;
     int n_cus = 256;                   // compute units of the device
     bool planes_lds_raised = false;    // decode_chains_planes_kernel has been granted more than 64 KiB of dynamic LDS
+    int is_gfx950 = -1;                // (-1: not asked yet)
+    size_t planes_lds_fallback = 0;    // ... or, refused the hardware's figure, this much (what the runtime reports)
     bool planes_lds_refused = false;   // ... or the runtime refused: chains that need more than 48 KiB go to the lane-per-plane kernel from then on
     // the lane-per-plane kernel is launched once per size class of row ring, side by side (decode_batch)
     static constexpr int kRingClasses = 4;
@@ -432,23 +434,41 @@ int decode_batch(icerx_decoder *d, int n, const uint8_t *data, bool data_on_devi
         // what a workgroup of this device may take (gfx950: 160 KiB), less 10 KiB for the kernel's static block and the runtime
         size_t planes_lds_limit = 0;
         {
-            int max_lds = 0;
-            if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d->device) != hipSuccess) { (void)hipGetLastError(); max_lds = 64 * 1024; }
+            int max_lds = 0, dev_id = d->device;
+            if (dev_id < 0 && hipGetDevice(&dev_id) != hipSuccess) { (void)hipGetLastError(); dev_id = 0; }      // (-1: the caller's current device)
+            if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_id) != hipSuccess) { (void)hipGetLastError(); max_lds = 64 * 1024; }
+            // (this runtime reports 64 KiB for gfx950, whose compute units have 160 KiB and grant a workgroup what hipFuncSetAttribute asks for --
+            // the encoder's window coder runs on 115 KiB --: ask for the hardware's figure first, the reported one is the fall-back)
+            if (d->is_gfx950 < 0) {
+                hipDeviceProp_t prop;
+                d->is_gfx950 = (hipGetDeviceProperties(&prop, dev_id) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+                (void)hipGetLastError();
+            }
+            const bool gfx950 = d->is_gfx950 == 1;
+            if (gfx950 && max_lds < 160 * 1024 && !d->planes_lds_refused) max_lds = 160 * 1024;
             planes_lds_limit = max_lds > 10 * 1024 ? (size_t)max_lds - 10u * 1024u : 0u;
             // more than 48 KiB of dynamic LDS has to be granted; a runtime / device that refuses loses nothing but the fast kernel
             // for the chains that need it (they go to decode_chains_wave_kernel below)
             if (planes_lds_limit > 48u * 1024u && !d->planes_lds_raised && !d->planes_lds_refused) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_chains_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_lds_limit) == hipSuccess)
                     d->planes_lds_raised = true;
-                else { (void)hipGetLastError(); d->planes_lds_refused = true; }
+                else {
+                    (void)hipGetLastError(); d->planes_lds_refused = true;
+                    int rep = 0;
+                    if (hipDeviceGetAttribute(&rep, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_id) != hipSuccess) { (void)hipGetLastError(); rep = 64 * 1024; }
+                    planes_lds_limit = rep > 10 * 1024 ? (size_t)rep - 10u * 1024u : 0u;
+                    if (planes_lds_limit > 48u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void *>(decode_chains_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_lds_limit) == hipSuccess)
+                        d->planes_lds_fallback = planes_lds_limit;
+                    else (void)hipGetLastError();
+                }
                 // (said once per decoder: on a runtime that reports or grants less than gfx950's 160 KiB the fast planes kernel quietly loses
                 // the chains that need more -- correct, slower)
                 if (d->planes_lds_refused || planes_lds_limit < 150u * 1024u)
                     fprintf(stderr, "libicer_hip_dec: %zu KiB of LDS per workgroup for the planes kernel (%s); chains that need more take the wave kernel\n",
-                            (d->planes_lds_refused ? std::min(planes_lds_limit, (size_t)48u * 1024u) : planes_lds_limit) / 1024u,
-                            d->planes_lds_refused ? "the runtime refused more than 48 KiB" : "what the device reports, less 10 KiB");
+                            (d->planes_lds_refused ? (d->planes_lds_fallback ? d->planes_lds_fallback : (size_t)48u * 1024u) : planes_lds_limit) / 1024u,
+                            d->planes_lds_refused ? "the runtime refused the hardware's 150 KiB" : "what the device reports, less 10 KiB");
             }
-            if (d->planes_lds_refused) planes_lds_limit = std::min(planes_lds_limit, (size_t)48u * 1024u);
+            if (d->planes_lds_refused) planes_lds_limit = d->planes_lds_fallback ? d->planes_lds_fallback : std::min(planes_lds_limit, (size_t)48u * 1024u);
         }
 #endif
         std::stable_partition(chains.begin(), chains.end(), [&](const ChainDesc &c) {
