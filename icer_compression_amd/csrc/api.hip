@@ -229,7 +229,9 @@ struct icerx_encoder {
     hipEvent_t coef_ready = nullptr;    // the transform of the last enqueue is complete (coef, means, frame status): recorded before the coder
     hipStream_t io_stream = nullptr, copy_stream = nullptr;   // lib_icer-shaped entry points: their encode stream, and the coefficient write-back beside the coder
     int hybrid_percent = 95;            // units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_HYBRID; 0: none)
-    int hybrid_wgs = 1;                 // staying workgroups of the small coder per compute unit (ICER_HIP_HYBRID_WGS)
+    int hybrid_wgs = 2;                 // staying workgroups of the small coder per compute unit in a batch launch (ICER_HIP_HYBRID_WGS).  Round 6: two (C4 6 525 ->
+                                        // 6 664, C5 6 526 -> 6 671 Mpix/s per call; 3: the same, 4: C5 + 0.5 %, C4 - 1.8 %, 8: C5 - 5 %; profiles/r06_logs/r06t_list_grid.log) --
+                                        // a call now enqueues its frames in two parts, each with a list kernel of its own
     bool unit_major = true;             // batches: the pipeline kernel's workgroups position-major over the frames (ICER_HIP_UNIT_MAJOR=0: frame by frame)
     int list_grid = 0;                  // ... or their number outright in a batch launch (ICER_HIP_LIST_GRID; 0: per compute unit as above)
     int hybrid_frames = 2;              // ... in launches of at least this many planes (frames x channels; ICER_HIP_HYBRID_FRAMES): one gray frame alone is bound by its dense units
