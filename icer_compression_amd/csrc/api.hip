@@ -534,7 +534,8 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
         // 6.4 with two, 6.07 with FOUR, 8.7 with eight -- LDS; profiles/r04_logs/r04_zh_list_kernel_width.log): its list is led by
         // fifty long mid-sparse chains, where every further wave's chunk of a window is progress.
         // ICER_HIP_LIST_WAVES=1|2|4 pins one.
-        unsigned list_grid = (unsigned)(split && e->split_wgs ? e->split_wgs : e->n_cus * e->hybrid_wgs);
+        // (a lone frame: one staying workgroup per compute unit -- 128: 6.8 ms, 256: 5.9, 512: 7.25, profiles/r06_logs/r06u_lone_list_grid.log)
+        unsigned list_grid = (unsigned)(split ? (e->split_wgs ? e->split_wgs : e->n_cus) : e->n_cus * e->hybrid_wgs);
         if (!split && e->list_grid) list_grid = (unsigned)e->list_grid;
         const int list_waves = e->list_waves ? e->list_waves : (split ? 4 : 1);
 #define ICER_LAUNCH_LIST(I, NS)                                                                                                          \
