@@ -1065,7 +1065,7 @@ def main():
         # library then puts its encoder streams on the low priority level's queue pool, INTEGRATION.md "Hardware queues"), quiet and crowded
         if not args.no_extras and world == 1 and "C4" in batch_host and "value" in batch_host["C4"]:
             try:
-                env = dict(os.environ, GPU_MAX_HW_QUEUES="default", ICER_HIP_QUIET="1")
+                env = dict(os.environ, GPU_MAX_HW_QUEUES="default")
                 env.pop("ICER_HIP_STREAM_PRIO", None)
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_batch_probe.py"), "C4"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
                 o = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])

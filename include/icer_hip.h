@@ -105,7 +105,12 @@ typedef struct icerx_encoder icerx_encoder;
 /* Create an encoder for frames of w x h with `channels` (1 = gray, 3 = Y,U,V planes) on HIP device
  * `device`.  All device memory for up to `max_frames` frames per call is allocated here.
  * Returns 0, a (negative) icer_status the reference would return for this geometry
- * (ICER_TOO_MANY_STAGES, ...), or ICER_FATAL_ERROR when no usable device exists. */
+ * (ICER_TOO_MANY_STAGES, ...), or ICER_FATAL_ERROR when no usable device exists.
+ * Memory: about 14 bytes per sample and frame (coefficients, the stage-to-stage LL buffer, one event byte per sample and bit plane) plus
+ * the coding units' slots.  Streams: an encoder owns a SIDE stream (a small kernel runs beside the main coder kernel of every launch)
+ * -- a HIGH-priority stream unless GPU_MAX_HW_QUEUES >= 6 (it must not share the caller's hardware queue: INTEGRATION.md "Hardware
+ * queues"; its kernels therefore go ahead of the program's normal-priority ones; ICER_HIP_STREAM_PRIO=0 makes it a plain stream) -- and,
+ * with max_frames >= 4, a second plain stream for the second half of a synchronous batch call (icerx_encoder_parts). */
 int icerx_encoder_create(icerx_encoder **enc, int device, size_t w, size_t h, int channels, int stages,
                          int filt, int segments, int max_frames);
 /* The same with the sample width: sample_bits = 16 (as icerx_encoder_create) or 8 for the uint8 twins. */
