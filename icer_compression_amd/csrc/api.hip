@@ -199,7 +199,7 @@ struct icerx_encoder {
     DevBuf<uint32_t> route_list, route_ctl;   // the units of the workgroup coder (frame * units + unit), [length, cursor]
     // sub-range splitting (coder_core.hpp "Sub-ranges"): launches of at most split_frames planes cut their dense units into
     // pieces of about split_chunks chunks, one workgroup each (ICER_HIP_SPLIT=<chunks, 0 = off>, ICER_HIP_SPLIT_FRAMES)
-    uint32_t split_chunks = 3072;
+    uint32_t split_chunks = 1;          // (1: chosen per geometry when the units are planned -- plan.hpp auto_split_chunks; 3 072 on the headline frame)
     int split_frames = 1;
     int split_hybrid_percent = 90;      // ... whose units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_SPLIT_HYBRID)
     bool last_split = false;
@@ -324,6 +324,7 @@ int upload_units(icerx_encoder *e, size_t quota, hipStream_t st)
     // no launch ever uses)
     const bool plan_split = e->wg_available && e->coder_mode == 0 && e->max_frames * e->channels <= 4 && e->split_frames > 0 &&
                             e->channels <= e->split_frames && e->hybrid_percent > 0 && e->split_chunks > 0;
+    if (plan_split && e->split_chunks == 1u) e->split_chunks = auto_split_chunks(e->plan.units, e->n_cus, e->sample_bits == 8 ? kPlanes8 : kPlanes);
     assign_slots(&e->plan, quota, e->bits_per_pixel, plan_split ? e->split_chunks : 0u);
     const size_t n = e->plan.units.size();
     if (!e->plan.subs.empty()) {

@@ -343,6 +343,29 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
     return p->error = kOk;
 }
 
+// Chunks per sub-range for a launch of ONE frame (coder_core.hpp "Sub-ranges"): the smallest piece size whose long pieces -- K per
+// unit of at least two pieces, over the units of the lower half of the bit planes (the dense ones on image content) -- still start
+// together, at most 1.25 per compute unit.  Smaller pieces shorten the chains that end the launch; more pieces than that queue for
+// workgroup slots and every piece pays its counts-only prefix and healing overlap.  Measured (round 6, 256 compute units,
+// profiles/r06_logs/r06x_split_by_geometry.log): 4096^2 / 10 segments 3 072 (5.9 ms; 2 048: 6.6), 2048^2 / 4 segments 1 024 (2.8 ms; 3 072: 5.1),
+// 3000 x 2000 / 10 segments 1 024 (2.45 ms; 3 072: 3.1), 2048^2 / 16 and 1024^2 / 8 segments: no split (512 / 256: slower).
+inline uint32_t auto_split_chunks(const std::vector<UnitDesc> &units, int n_cus, int planes)
+{
+    static const uint32_t sizes[] = {1024u, 1536u, 2048u, 3072u, 4096u, 6144u, 8192u, 12288u, 16384u, 32768u};
+    const uint64_t budget = (uint64_t)n_cus * 5u / 4u;
+    for (uint32_t p : sizes) {
+        uint64_t pieces = 0;
+        for (const UnitDesc &u : units) {
+            if ((int)u.lsb * 2 > planes) continue;
+            uint32_t k = ((u.w * u.h + 63u) / 64u) / p;
+            if (k > 8u) k = 8u;
+            if (k >= 2u) pieces += k;
+        }
+        if (pieces <= budget) return p;
+    }
+    return 32768u;
+}
+
 // Slot capacities: a unit's payload can never be useful beyond (quota - 28) bytes (P3), and we
 // provision `bits_per_pixel` bits per pixel otherwise (overflow of that bound is detected and the
 // batch is re-run with a larger bound).

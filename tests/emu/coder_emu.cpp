@@ -296,6 +296,18 @@ extern "C" int emu_plan_sig_blocks(size_t w, size_t h, int channels, int stages,
     return n;
 }
 
+// the sub-range size a lone frame of this geometry gets on a chip of n_cus compute units (plan.hpp auto_split_chunks) and the extra workgroups it makes
+extern "C" int emu_auto_split(size_t w, size_t h, int channels, int stages, int segments, int n_cus, uint32_t *chunks, uint32_t *extra)
+{
+    Plan plan;
+    int rc = build_plan(&plan, w, h, channels, stages, segments);
+    if (rc) return rc;
+    *chunks = auto_split_chunks(plan.units, n_cus, kPlanes);
+    assign_slots(&plan, 2 * w * h * (size_t)channels, 3, *chunks);
+    *extra = (uint32_t)plan.subs.size();
+    return 0;
+}
+
 // the workgroup -> (frame, launch position) map of a batch's pipeline kernel (plan.hpp position_major)
 extern "C" void emu_position_major(uint32_t b, uint32_t per_frame, uint32_t n_frames, uint32_t *frame, uint32_t *lpos)
 {

@@ -507,6 +507,23 @@ def test_production_split_through_other_tables(golden, name):
     assert (rc, len(stream), "%08x" % zlib.crc32(stream), hashlib.sha256(stream).hexdigest()[:16]) == (g["rc"], g["size"], g["crc32"], g["sha256_16"])
 
 
+@pytest.mark.parametrize("w,h,st,sg,filt,want_subs", [(2048, 2048, 4, 4, 0, True), (3000, 2000, 5, 10, 2, True), (2048, 2048, 4, 16, 0, False)])
+def test_split_size_chosen_per_geometry(oracle, w, h, st, sg, filt, want_subs):
+    """plan.hpp auto_split_chunks (round 6): a lone frame's sub-range size follows its geometry -- pieces of 1 024 chunks where the
+    headline frame takes 3 072 (2048^2 with 4 segments: K = 4 per level-1 unit; 3000 x 2000: K = 2), none where the units are short --
+    and the spliced streams are the oracle's"""
+    frame = synth.gray_frame(w, h, 4711, 1)
+    quota = 2 * w * h
+    want = oracle.compress([frame], st, filt, sg, quota)
+    enc = api.Encoder(w, h, 1, st, filt, sg, max_frames=1)
+    (rc, stream), = enc.encode_host(frame[None, None], quota)
+    li, stt = enc.launch_info(), enc.stats()
+    enc.close()
+    assert (rc, stream) == (want[0], want[1])
+    assert li["split"] == want_subs and (li["sub_range_workgroups"] > 0) == want_subs, li
+    assert stt["unit_timeouts"] == 0 and stt["fallback_batches"] == 0
+
+
 # ---- a rank != 0 share of the two batch configurations (frames 32*rank .. / 8*rank ..), both ways -----------------------------
 @pytest.mark.parametrize("name,rank", [("C4", 5), ("C5", 3)])
 def test_batch_share_of_another_rank(name, rank):
