@@ -8,7 +8,8 @@ passes (they do not fit one pass: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZ
 counters are in KiB.  Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports half
 of the bytes of a streaming read -- our own calibration point is finalize_kernel, which reads and writes
 exactly one plane set (W*H*2 bytes per plane): WRITE_SIZE matches exactly, FETCH_SIZE reads 0.50x.
-So traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.
+So traffic_bytes = factor*FETCH_SIZE*1024 + WRITE_SIZE*1024 with the factor calibrated per kernel (bench.py FETCH_FACTOR: 1 for
+dwt_tile_kernel -- its stage 0 reads a known byte count and FETCH_SIZE matches it uncorrected -- and family_events_kernel, 2 elsewhere).
 """
 import json
 import os
@@ -33,13 +34,16 @@ def main():
         q = "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name"
         for name, n, avg in c.execute(q, (ctr,)):
             out["kernels"].setdefault(short(name), {})[ctr + "_KiB_per_launch"] = round(avg, 3)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import FETCH_FACTOR
     for k, v in out["kernels"].items():
         if "FETCH_SIZE_KiB_per_launch" in v and "WRITE_SIZE_KiB_per_launch" in v:
-            v["traffic_bytes_per_launch"] = int(2 * v["FETCH_SIZE_KiB_per_launch"] * 1024 + v["WRITE_SIZE_KiB_per_launch"] * 1024)
+            v["fetch_factor"] = FETCH_FACTOR.get(k.split("<")[0], 2.0)
+            v["traffic_bytes_per_launch"] = int(v["fetch_factor"] * v["FETCH_SIZE_KiB_per_launch"] * 1024 + v["WRITE_SIZE_KiB_per_launch"] * 1024)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", f"{tag}_rocprof.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    lines = [f"# rocprofv3 summary `{tag}`", "", "| kernel | calls | avg us | % | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB (2*F+W) |", "|---|---|---|---|---|---|---|"]
+    lines = [f"# rocprofv3 summary `{tag}`", "", "| kernel | calls | avg us | % | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB (factor*F+W) |", "|---|---|---|---|---|---|---|"]
     for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("total_us", 0)):
         lines.append(f"| {k} | {v.get('calls','')} | {v.get('avg_us','')} | {v.get('pct','')} | {v.get('FETCH_SIZE_KiB_per_launch','')} | "
                      f"{v.get('WRITE_SIZE_KiB_per_launch','')} | {round(v['traffic_bytes_per_launch']/1e6,2) if 'traffic_bytes_per_launch' in v else ''} |")
