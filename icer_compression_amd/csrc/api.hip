@@ -263,6 +263,25 @@ struct icerx_encoder {
 
 namespace {
 
+// What a launch must find zeroed -- status flags, LL sums, histograms, list cursors, sub-range records -- in ONE small kernel instead
+// of a fill per range (round 6: a lone frame had nine fills of ~ 4 us each in front of its transform, + their dispatch gaps).
+struct ClearList {
+    static constexpr int kMax = 10;
+    uint32_t *p[kMax];
+    uint32_t words[kMax];
+    int n = 0;
+    void add(void *ptr, size_t bytes) { if (bytes && n < kMax) { p[n] = static_cast<uint32_t *>(ptr); words[n] = (uint32_t)(bytes / 4); n++; } }
+};
+__global__ void __launch_bounds__(256) clear_ranges_kernel(ClearList cl)
+{
+    uint32_t *p = cl.p[blockIdx.y];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cl.words[blockIdx.y]; i += gridDim.x * 256u) p[i] = 0u;
+}
+static void launch_clears(const ClearList &cl, hipStream_t st)
+{
+    if (cl.n) hipLaunchKernelGGL(clear_ranges_kernel, dim3(8, (unsigned)cl.n), dim3(256), 0, st, cl);
+}
+
 __global__ void frame_status_kernel(const int *dwt_ovf, const int *mean_ovf, int channels, int n_frames, int *skip)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,7 +464,7 @@ constexpr int kLonePadBytes = ICER_LONE_PAD_BYTES;      // see enqueue: LDS padd
 // `part`: which set of the per-launch resources (route list cursor, fork / join events) it takes; `timed`: it records the stage events.
 // Returns 0 or ICER_FATAL_ERROR.
 int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t *d_frames, int n_frames, size_t quota, uint8_t *d_out, size_t out_stride,
-                 unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st)
+                 unsigned long long *d_sizes, int32_t *d_rcs, hipStream_t st, bool clear_bound)
 {
     const size_t W = e->w, H = e->h, plane = W * H;
     const int C = e->channels, P = n_frames * C;
@@ -463,10 +482,37 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
     uint8_t *const slots = e->slots.p + (size_t)f0 * e->plan.slot_bytes;
     uint32_t *const unit_bits = e->unit_bits.p + (size_t)f0 * n_units, *const done_bytes = e->done_bytes.p + (size_t)f0 * n_units;
     uint64_t *const final_off = e->final_off.p + (size_t)f0 * n_units;
-    HIP_TRY(hipMemsetAsync(dwt_ovf, 0, (size_t)P * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(mean_ovf, 0, (size_t)P * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(skip, 0, (size_t)n_frames * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(sums, 0, (size_t)P * sizeof(unsigned long long), st));
+    // which coders this launch uses (decided from the call's arguments alone: what has to be cleared follows from it)
+    // Progressive mode: with a byte quota far below the lossless size only the first part of the priority order can end
+    // up in the stream.  The units are then launched in priority order with the quota: a unit whose finished
+    // higher-priority predecessors alone already exceed it stops (at its start, or at its next check) -- see
+    // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
+    const bool progressive = quota < (size_t)e->w * e->h * C / 2;
+    const bool use_wg = e->wg_available && (e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive));
+    // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
+    // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
+    // a launch of very few planes (a single frame) cannot fill the chip with whole coding units: its dense units are cut into
+    // sub-ranges, one workgroup each, and its all-but-blank ones go to the small workgroup coder as in a batch
+    const bool split = e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->split_chunks && n_frames * C <= e->split_frames &&
+                       !e->plan.subs.empty() && e->hybrid_percent > 0;
+    e->last_split = split;
+    const bool hybrid = split || (e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames);
+    const size_t sub_entries = e->plan.sub_entries;
+    if (split && (e->snaps.ensure((size_t)e->max_frames * sub_entries * kMaxSnaps) || e->snap_valid.ensure((size_t)e->max_frames * sub_entries * kMaxSnaps) ||
+                  e->sub_recs.ensure((size_t)e->max_frames * sub_entries))) return ICER_FATAL_ERROR;
+    {
+        ClearList cl;
+        if (f0 == 0 && n_frames == e->max_frames && clear_bound) cl.add(e->flags.p, e->flags.n * sizeof(int));       // (the whole block at once)
+        else {
+            cl.add(dwt_ovf, (size_t)P * sizeof(int)); cl.add(mean_ovf, (size_t)P * sizeof(int)); cl.add(skip, (size_t)n_frames * sizeof(int));
+            if (clear_bound) cl.add(bound_ovf, sizeof(int));
+        }
+        cl.add(sums, (size_t)P * sizeof(unsigned long long));
+        if (progressive) cl.add(done_bytes, (size_t)n_frames * n_units * 4);
+        if (hybrid) { cl.add(sig_hist, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t)); cl.add(route_ctl, 2 * sizeof(uint32_t)); }
+        if (split) { cl.add(e->snap_valid.p, (size_t)n_frames * sub_entries * kMaxSnaps * sizeof(uint32_t)); cl.add(e->sub_recs.p, (size_t)n_frames * sub_entries * sizeof(SubRecord)); }
+        launch_clears(cl, st);
+    }
     if (timed && e->timing) HIP_TRY(hipEventRecord(e->ev[0], st));
 
     size_t cw = W, ch = H;
@@ -488,28 +534,12 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
     if (e->coef_ready && f0 == 0) HIP_TRY(hipEventRecord(e->coef_ready, st));
 
     // ---- coding units
-    // Progressive mode: with a byte quota far below the lossless size only the first part of the priority order can end
-    // up in the stream.  The units are then launched in priority order with the quota: a unit whose finished
-    // higher-priority predecessors alone already exceed it stops (at its start, or at its next check) -- see
-    // quota_already_spent.  Not used for large quotas, where the launch order is largest-first instead.
-    const bool progressive = quota < (size_t)e->w * e->h * C / 2;
-    if (progressive) HIP_TRY(hipMemsetAsync(done_bytes, 0, (size_t)n_frames * n_units * 4, st));
-    const bool use_wg = e->wg_available && (e->wg_once || e->coder_mode == 2 || (e->coder_mode == 0 && progressive));
-    // both coders in one batch: the bit planes that are mostly runs of blank chunks go to the workgroup coder, which closes
-    // such runs in closed form; the dense ones to the pipeline (route_units_kernel)
-    // a launch of very few planes (a single frame) cannot fill the chip with whole coding units: its dense units are cut into
-    // sub-ranges, one workgroup each, and its all-but-blank ones go to the small workgroup coder as in a batch
-    const bool split = e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->split_chunks && n_frames * C <= e->split_frames &&
-                       !e->plan.subs.empty() && e->hybrid_percent > 0;
-    e->last_split = split;
-    const bool hybrid = split || (e->wg_available && !use_wg && !progressive && e->coder_mode == 0 && e->hybrid_percent > 0 && n_frames * C >= e->hybrid_frames);
     // the stateless half of the context modeller, once per family: event bytes for the pipeline coder's pixel waves, the chunk
     // table for both coders (family_events_kernel; the window coder on its own reads the coefficients itself: table only)
     const int n_planes = e->sample_bits == 8 ? kPlanes8 : kPlanes;
     const size_t ev_frame_bytes = (size_t)n_planes * e->plan.sig_bytes * 64u;
     if (!use_wg && e->events.ensure((size_t)e->max_frames * ev_frame_bytes + 64)) return ICER_FATAL_ERROR;
     {
-        if (hybrid) HIP_TRY(hipMemsetAsync(sig_hist, 0, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(family_events_kernel, dim3((unsigned)(e->plan.sig_blocks.size() / 2), n_frames), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, C, e->units.p, e->sig_blocks.p, skip, sig,
                            e->plan.sig_bytes, hybrid ? sig_hist : nullptr, e->plan.n_families,
@@ -518,7 +548,6 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
     const uint8_t *route = nullptr;
     e->last_routed = hybrid;
     if (hybrid) {
-        HIP_TRY(hipMemsetAsync(route_ctl, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(route_units_kernel, dim3((unsigned)((n_units + 255) / 256), n_frames), dim3(256), 0, st, e->units.p, n_units, sig_hist, e->plan.n_families,
                            (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, route_buf, route_list, route_ctl,
                            (uint32_t)e->nosplit_percent);
@@ -550,11 +579,7 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
     }
     SplitLaunch sp;
     if (split) {
-        const size_t entries = e->plan.sub_entries;
-        if (e->snaps.ensure((size_t)e->max_frames * entries * kMaxSnaps) || e->snap_valid.ensure((size_t)e->max_frames * entries * kMaxSnaps) ||
-            e->sub_recs.ensure((size_t)e->max_frames * entries)) return ICER_FATAL_ERROR;
-        HIP_TRY(hipMemsetAsync(e->snap_valid.p, 0, (size_t)n_frames * entries * kMaxSnaps * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(e->sub_recs.p, 0, (size_t)n_frames * entries * sizeof(SubRecord), st));
+        const size_t entries = sub_entries;
         sp.subs = e->subs.p; sp.launch = e->sub_order.p; sp.n_subs = (uint32_t)e->plan.subs.size(); sp.entries = (uint32_t)entries;
         sp.snaps = e->snaps.p; sp.snap_valid = e->snap_valid.p; sp.recs = e->sub_recs.p;
 #ifdef ICER_EXPERIMENT_PREFIX_CACHE
@@ -636,15 +661,15 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
 {
     const int C = e->channels;
     int *bound_ovf = e->flags.p + 2 * (size_t)e->max_frames * C + e->max_frames;
-    HIP_TRY(hipMemsetAsync(bound_ovf, 0, sizeof(int), st));
     const bool progressive = quota < (size_t)e->w * e->h * C / 2;
     int parts = 1;
     if (overlap_ok && e->overlap_parts > 1 && e->half_stream && !progressive && e->coder_mode == 0 && !e->wg_once && n_frames >= 2 * e->overlap_parts &&
         n_frames * C >= e->hybrid_frames)
         parts = e->overlap_parts;
     e->last_parts = parts;
-    if (parts == 1) return enqueue_part(e, 0, 0, true, d_frames, n_frames, quota, d_out, out_stride, d_sizes, d_rcs, st);
+    if (parts == 1) return enqueue_part(e, 0, 0, true, d_frames, n_frames, quota, d_out, out_stride, d_sizes, d_rcs, st, true);
     const size_t plane = e->w * e->h;
+    HIP_TRY(hipMemsetAsync(bound_ovf, 0, sizeof(int), st));             // (shared by the parts: before the second stream forks off)
     HIP_TRY(hipEventRecord(e->part_fork, st));                          // (the second stream starts behind whatever the caller's stream holds)
     HIP_TRY(hipStreamWaitEvent(e->half_stream, e->part_fork, 0));
     // (the stages of the parts overlap: the call's span is booked on the coder stage -- bench.py's roofline divides the call's bytes by it)
@@ -655,7 +680,7 @@ int enqueue(icerx_encoder *e, const uint16_t *d_frames, int n_frames, size_t quo
         if (parts == 2) { const int n0 = std::max(1, std::min(n_frames - 1, (n_frames * e->overlap_first + 50) / 100)); n = k == 0 ? n0 : n_frames - n0; }
         hipStream_t ps = (k & 1) ? e->half_stream : st;
         if (int rc = enqueue_part(e, f0, k, false, d_frames + (size_t)f0 * C * plane, n, quota, d_out + (size_t)f0 * out_stride, out_stride,
-                                  d_sizes + f0, d_rcs + f0, ps)) return rc;
+                                  d_sizes + f0, d_rcs + f0, ps, false)) return rc;
         f0 += n;
     }
     HIP_TRY(hipEventRecord(e->part_join, e->half_stream));
