@@ -1672,13 +1672,27 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
     uint32_t windows = 0, par = 0;
     bool store_pending = false;          // (uniform) drained payload words are waiting in the bit stage
     const uint32_t nfull = (a.w * a.h) / 64u;                    // (a last chunk with fewer than 64 pixels is never blank)
+    uint32_t look_base = ~0u;                                    // (uniform) the 64 chunks whose blank mask is in look_mask
+    uint64_t look_mask = 0;
     for (uint32_t j0 = 0; j0 < nchunks; windows++) {
         // progressive mode: has the byte quota been used up by units of higher priority in the meantime?
         const bool check_stop = a.early_quota && (windows & 15u) == 15u;
         // ---- a run of blank chunks (chunk table) is coded in closed form by one wave
         if (a.sig) {
             uint32_t nb;
-            {
+            // The 64 chunks around j0 as a mask (one byte of the chunk table per lane, one ballot), kept from iteration to iteration: in a
+            // mid-sparse unit -- a run of a few dozen blank chunks, a chunk with content, the next run -- most iterations start inside the
+            // block the last one looked at and cost no load at all.  Only a run that reaches the block's end takes the wide look below
+            // (round 6: the wide look at EVERY iteration, sixteen dependent-latency loads per lane, was half of such a unit's chain).
+            if ((j0 & ~63u) != look_base) {
+                look_base = j0 & ~63u;
+                look_mask = BALLOT(look_base + (uint32_t)lane < nfull && (uint32_t)a.lsb >= (uint32_t)a.sig[look_base + (uint32_t)lane < nfull ? look_base + (uint32_t)lane : 0u]);
+            }
+            const uint32_t in_block = 64u - (j0 & 63u);
+            const uint64_t not_blank = ~(look_mask >> (j0 & 63u));                       // (bits at and above in_block: ones)
+            const uint32_t run_here = (uint32_t)ffs64(not_blank) < in_block ? (uint32_t)ffs64(not_blank) : in_block;
+            if (run_here < in_block) nb = run_here;
+            else {
                 // (every lane looks at kBlankLook entries of the chunk table: 64 * kBlankLook chunks per look)
                 LANEVAR(uint32_t, lead);
                 FOR_LANES
@@ -1693,6 +1707,7 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
                 }
                 const uint32_t first = (uint32_t)ffs64(~BALLOT(LV(lead) == kBlankLook));
                 nb = first * kBlankLook + (first < 64u ? READLANE(lead, first) : 0u);
+                WG_ASSERT(nb >= run_here);
             }
             if (nb > kBlankRunMax) nb = kBlankRunMax;
             bool ok = false;
