@@ -199,7 +199,7 @@ struct icerx_encoder {
     DevBuf<uint32_t> route_list, route_ctl;   // the units of the workgroup coder (frame * units + unit), [length, cursor]
     // sub-range splitting (coder_core.hpp "Sub-ranges"): launches of at most split_frames planes cut their dense units into
     // pieces of about split_chunks chunks, one workgroup each (ICER_HIP_SPLIT=<chunks, 0 = off>, ICER_HIP_SPLIT_FRAMES)
-    uint32_t split_chunks = 1;          // (1: chosen per geometry when the units are planned -- plan.hpp auto_split_chunks; 3 072 on the headline frame)
+    uint32_t split_chunks = 1;          // (1: chosen per geometry when the units are planned -- plan.hpp auto_split_chunks; 2 048 on the headline frame)
     int split_frames = 1;
     int split_hybrid_percent = 90;      // ... whose units with at least this share of blank chunks go to the small workgroup coder (ICER_HIP_SPLIT_HYBRID)
     bool last_split = false;

@@ -345,14 +345,15 @@ inline int build_plan(Plan *p, size_t w, size_t h, int channels, int stages, int
 
 // Chunks per sub-range for a launch of ONE frame (coder_core.hpp "Sub-ranges"): the smallest piece size whose long pieces -- K per
 // unit of at least two pieces, over the units of the lower half of the bit planes (the dense ones on image content) -- still start
-// together, at most 1.25 per compute unit.  Smaller pieces shorten the chains that end the launch; more pieces than that queue for
-// workgroup slots and every piece pays its counts-only prefix and healing overlap.  Measured (round 6, 256 compute units,
-// profiles/r06_logs/r06x_split_by_geometry.log): 4096^2 / 10 segments 3 072 (5.9 ms; 2 048: 6.6), 2048^2 / 4 segments 1 024 (2.8 ms; 3 072: 5.1),
-// 3000 x 2000 / 10 segments 1 024 (2.45 ms; 3 072: 3.1), 2048^2 / 16 and 1024^2 / 8 segments: no split (512 / 256: slower).
+// together: at most two per compute unit, the pipeline workgroups a compute unit holds in such a launch.  Smaller pieces shorten the
+// chains that end the launch; more pieces than slots queue, and every piece pays its counts-only prefix and healing overlap.
+// Measured (round 6, 256 compute units, profiles/r06_logs/r06x_split_by_geometry.log, r06ad_split_budget.log): 4096^2 with 10 / 12 / 16 segments
+// 2 048 / 2 048 / 1 536 (5.43 / 5.66 / 4.45 ms; 3 072: 5.55 / 7.05 / -), 4096 x 2048 / 6 segments 1 024 (3.7 ms; 1 536: 4.1, 3 072: 6.8), 2048^2 / 4
+// segments 1 024 (2.8 ms; 3 072: 5.1), 3000 x 2000 / 10 segments 1 024 (2.45 ms; 3 072: 3.1), 2048^2 / 16 and 1024^2 / 8 segments: no split (512 / 256: slower).
 inline uint32_t auto_split_chunks(const std::vector<UnitDesc> &units, int n_cus, int planes)
 {
     static const uint32_t sizes[] = {1024u, 1536u, 2048u, 3072u, 4096u, 6144u, 8192u, 12288u, 16384u, 32768u};
-    const uint64_t budget = (uint64_t)n_cus * 5u / 4u;
+    const uint64_t budget = (uint64_t)n_cus * 2u;
     for (uint32_t p : sizes) {
         uint64_t pieces = 0;
         for (const UnitDesc &u : units) {

@@ -163,17 +163,18 @@ def test_chunk_table_work_list_covers_every_family_once(emu):
 
 
 def test_sub_range_size_follows_the_geometry(emu):
-    """plan.hpp auto_split_chunks: the smallest piece size whose pieces over the lower half of the bit planes stay within 1.25 per compute
+    """plan.hpp auto_split_chunks: the smallest piece size whose pieces over the lower half of the bit planes stay within two per compute
     unit (256 of them); the values the GPU measurements of round 6 chose"""
     import ctypes as C
     emu.lib.emu_auto_split.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    for (w, h, st, sg, chunks, split) in [(4096, 4096, 5, 10, 3072, True), (2048, 2048, 4, 4, 1024, True), (3000, 2000, 5, 10, 1024, True),
-                                          (2048, 2048, 4, 16, 1024, False), (1024, 1024, 3, 8, 1024, False), (8192, 8192, 6, 32, 6144, False)]:
+    for (w, h, st, sg, chunks, split) in [(4096, 4096, 5, 10, 2048, True), (4096, 4096, 5, 12, 2048, True), (4096, 4096, 5, 16, 1536, True), (4096, 2048, 5, 6, 1024, True),
+                                          (2048, 2048, 4, 4, 1024, True), (3000, 2000, 5, 10, 1024, True),
+                                          (2048, 2048, 4, 16, 1024, False), (1024, 1024, 3, 8, 1024, False), (8192, 8192, 6, 32, 4096, True)]:
         c, x = C.c_uint32(0), C.c_uint32(0)
         assert emu.lib.emu_auto_split(w, h, 1, st, sg, 256, C.byref(c), C.byref(x)) == 0
         assert c.value == chunks and (x.value > 0) == split, (w, h, sg, c.value, x.value)
-        # pieces over ALL planes (the run-time routing keeps the dense ones): at most 9 / 5 of the budget of 320
-        assert x.value <= 320 * 9 // 5
+        # pieces over ALL planes (the run-time routing keeps the dense ones): at most 9 / 5 of the budget of 512
+        assert x.value <= 512 * 9 // 5
 
 
 def test_position_major_launch_order_is_a_bijection(emu):

@@ -486,7 +486,7 @@ SPLIT_GOLDEN = ["split_4096_filtC", "split_4096_12bit_filtB", "split_4096_u8_gra
 
 @pytest.mark.parametrize("name", SPLIT_GOLDEN)
 def test_production_split_through_other_tables(golden, name):
-    """A lone 4096 x 4096 plane is cut into sub-ranges at the PRODUCTION setting (3 072 chunks per piece, no env knob): the
+    """A lone 4096 x 4096 plane is cut into sub-ranges at the PRODUCTION setting (the piece size plan.hpp auto_split_chunks picks: 2 048 chunks, no env knob): the
     reference build's streams for the filter with the W3 quirk, for 12-bit content through filter B, and for the uint8
     twin's 7 planes -- and the launch really was a split one"""
     import torch
@@ -510,7 +510,7 @@ def test_production_split_through_other_tables(golden, name):
 @pytest.mark.parametrize("w,h,st,sg,filt,want_subs", [(2048, 2048, 4, 4, 0, True), (3000, 2000, 5, 10, 2, True), (2048, 2048, 4, 16, 0, False)])
 def test_split_size_chosen_per_geometry(oracle, w, h, st, sg, filt, want_subs):
     """plan.hpp auto_split_chunks (round 6): a lone frame's sub-range size follows its geometry -- pieces of 1 024 chunks where the
-    headline frame takes 3 072 (2048^2 with 4 segments: K = 4 per level-1 unit; 3000 x 2000: K = 2), none where the units are short --
+    headline frame takes 2 048 (2048^2 with 4 segments: K = 4 per level-1 unit; 3000 x 2000: K = 2), none where the units are short --
     and the spliced streams are the oracle's"""
     frame = synth.gray_frame(w, h, 4711, 1)
     quota = 2 * w * h
