@@ -1684,30 +1684,38 @@ ICER_DEV uint32_t code_unit_wg(Shared &s, const UnitArgs &a, WG_REGS_PARAM(Wave,
             // mid-sparse unit -- a run of a few dozen blank chunks, a chunk with content, the next run -- most iterations start inside the
             // block the last one looked at and cost no load at all.  Only a run that reaches the block's end takes the wide look below
             // (round 6: the wide look at EVERY iteration, sixteen dependent-latency loads per lane, was half of such a unit's chain).
-            if ((j0 & ~63u) != look_base) {
-                look_base = j0 & ~63u;
-                look_mask = BALLOT(look_base + (uint32_t)lane < nfull && (uint32_t)a.lsb >= (uint32_t)a.sig[look_base + (uint32_t)lane < nfull ? look_base + (uint32_t)lane : 0u]);
+            // A run that reaches the block's end is followed block by block (one load each; the last block looked at is the one the next
+            // iteration starts in), up to four blocks; only a longer one takes the wide look at 1 024 chunks.
+            nb = 0;
+            bool ended = false;
+            for (uint32_t step = 0; step < 4u && !ended; step++) {
+                const uint32_t pos = j0 + nb;
+                if ((pos & ~63u) != look_base) {
+                    look_base = pos & ~63u;
+                    look_mask = BALLOT(look_base + (uint32_t)lane < nfull && (uint32_t)a.lsb >= (uint32_t)a.sig[look_base + (uint32_t)lane < nfull ? look_base + (uint32_t)lane : 0u]);
+                }
+                const uint32_t in_block = 64u - (pos & 63u);
+                const uint64_t not_blank = ~(look_mask >> (pos & 63u));                  // (bits at and above in_block: ones)
+                const uint32_t run_here = (uint32_t)ffs64(not_blank) < in_block ? (uint32_t)ffs64(not_blank) : in_block;
+                nb += run_here;
+                ended = run_here < in_block;
             }
-            const uint32_t in_block = 64u - (j0 & 63u);
-            const uint64_t not_blank = ~(look_mask >> (j0 & 63u));                       // (bits at and above in_block: ones)
-            const uint32_t run_here = (uint32_t)ffs64(not_blank) < in_block ? (uint32_t)ffs64(not_blank) : in_block;
-            if (run_here < in_block) nb = run_here;
-            else {
+            if (!ended) {
                 // (every lane looks at kBlankLook entries of the chunk table: 64 * kBlankLook chunks per look)
+                const uint32_t from = j0 + nb;
                 LANEVAR(uint32_t, lead);
                 FOR_LANES
                 {
                     uint32_t c = 0, open = 1u;
                     for (uint32_t i = 0; i < kBlankLook; i++) {
-                        const uint32_t j = j0 + (uint32_t)lane * kBlankLook + i;
+                        const uint32_t j = from + (uint32_t)lane * kBlankLook + i;
                         open &= (j < nfull && (uint32_t)a.lsb >= (uint32_t)a.sig[j < nfull ? j : 0u]) ? 1u : 0u;
                         c += open;
                     }
                     LV(lead) = c;
                 }
                 const uint32_t first = (uint32_t)ffs64(~BALLOT(LV(lead) == kBlankLook));
-                nb = first * kBlankLook + (first < 64u ? READLANE(lead, first) : 0u);
-                WG_ASSERT(nb >= run_here);
+                nb += first * kBlankLook + (first < 64u ? READLANE(lead, first) : 0u);
             }
             if (nb > kBlankRunMax) nb = kBlankRunMax;
             bool ok = false;
