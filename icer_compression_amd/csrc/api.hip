@@ -224,6 +224,7 @@ struct icerx_encoder {
     hipEvent_t part_fork = nullptr, part_join = nullptr;
     int overlap_parts = 2;              // parts a synchronous batch call is enqueued in (ICER_HIP_OVERLAP_PARTS; 1: one stream, as the asynchronous calls)
     int last_parts = 1;
+    uint32_t list_heavy_min = 64;       // listed units with at least this many chunks that are not blank are taken first (ICER_HIP_LIST_HEAVY; route_units_kernel)
     int test_fail_frame = -1, test_fail_unit = -1, test_fail_calls = 0;   // ICER_HIP_TEST_FAIL_UNIT (test hook, enqueue_part)
     int overlap_first = 50;             // two parts: the first part's share of the frames in percent (ICER_HIP_OVERLAP_FIRST)
     hipEvent_t coef_ready = nullptr;    // the transform of the last enqueue is complete (coef, means, frame status): recorded before the coder
@@ -478,7 +479,7 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
     uint8_t *const sig = e->sig.p + (size_t)f0 * e->plan.sig_bytes;
     uint32_t *const sig_hist = e->sig_hist.p + (size_t)f0 * e->plan.n_families * 16;
     uint8_t *const route_buf = e->route.p + (size_t)f0 * n_units;
-    uint32_t *const route_list = e->route_list.p + (size_t)f0 * n_units, *const route_ctl = e->route_ctl.p + 2 * (size_t)part;
+    uint32_t *const route_list = e->route_list.p + 2 * (size_t)f0 * n_units,       /* (a part's list: light entries, then heavy ones) */ *const route_ctl = e->route_ctl.p + 4 * (size_t)part;
     uint8_t *const slots = e->slots.p + (size_t)f0 * e->plan.slot_bytes;
     uint32_t *const unit_bits = e->unit_bits.p + (size_t)f0 * n_units, *const done_bytes = e->done_bytes.p + (size_t)f0 * n_units;
     uint64_t *const final_off = e->final_off.p + (size_t)f0 * n_units;
@@ -509,7 +510,7 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
         }
         cl.add(sums, (size_t)P * sizeof(unsigned long long));
         if (progressive) cl.add(done_bytes, (size_t)n_frames * n_units * 4);
-        if (hybrid) { cl.add(sig_hist, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t)); cl.add(route_ctl, 2 * sizeof(uint32_t)); }
+        if (hybrid) { cl.add(sig_hist, (size_t)n_frames * e->plan.n_families * 16 * sizeof(uint32_t)); cl.add(route_ctl, 4 * sizeof(uint32_t)); }
         if (split) { cl.add(e->snap_valid.p, (size_t)n_frames * sub_entries * kMaxSnaps * sizeof(uint32_t)); cl.add(e->sub_recs.p, (size_t)n_frames * sub_entries * sizeof(SubRecord)); }
         launch_clears(cl, st);
     }
@@ -550,7 +551,7 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
     if (hybrid) {
         hipLaunchKernelGGL(route_units_kernel, dim3((unsigned)((n_units + 255) / 256), n_frames), dim3(256), 0, st, e->units.p, n_units, sig_hist, e->plan.n_families,
                            (uint32_t)(split ? e->split_hybrid_percent : e->hybrid_percent), 16u, route_buf, route_list, route_ctl,
-                           (uint32_t)e->nosplit_percent);
+                           (uint32_t)e->nosplit_percent, (uint32_t)n_frames * n_units, e->list_heavy_min);
         route = route_buf;
         // the workgroup coder takes its list on a second stream, beside the pipeline kernel (it is submitted first: its
         // workgroups need most of a compute unit's LDS, which they would not find once the pipeline's have spread out)
@@ -572,7 +573,7 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
         hipLaunchKernelGGL((code_units_list_kernel<I>), dim3(list_grid), dim3(64 * NS::kWgWaves), sizeof(NS::Shared), e->side_stream,    \
                            reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p, n_units,     \
                            e->tables.p, means, skip, slots, e->plan.slot_bytes, unit_bits, sig,                     \
-                           e->plan.sig_bytes, route_list, route_ctl, e->prof.p ? e->prof.p + kProfWgsOffset : nullptr)
+                           e->plan.sig_bytes, route_list, route_ctl, e->prof.p ? e->prof.p + kProfWgsOffset : nullptr, (uint32_t)n_frames * n_units)
         if (list_waves == 1) ICER_LAUNCH_LIST(WgOne, wg1); else if (list_waves == 4) ICER_LAUNCH_LIST(WgFour, wg4); else ICER_LAUNCH_LIST(WgSmall, wgs);
 #undef ICER_LAUNCH_LIST
         HIP_TRY(hipEventRecord(e->join[part], e->side_stream));
@@ -754,6 +755,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         int f = -1, u = -1, c = 1;
         if (sscanf(tf, "%d:%d:%d", &f, &u, &c) >= 2 && f >= 0 && f < (1 << 11) && u >= 0 && u < (1 << 20) && c >= 1) { e->test_fail_frame = f; e->test_fail_unit = u; e->test_fail_calls = c; }
     }
+    if (const char *lh = getenv("ICER_HIP_LIST_HEAVY")) { const long v = atol(lh); if (v >= 1) e->list_heavy_min = (uint32_t)v; }
     if (const char *of = getenv("ICER_HIP_OVERLAP_FIRST")) { const int v = atoi(of); if (v >= 5 && v <= 95) e->overlap_first = v; }
     if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2 || v == 4) e->list_waves = v; }
     if (const char *bpp = getenv("ICER_HIP_SLOT_BPP")) {
@@ -780,7 +782,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     const size_t P = (size_t)max_frames * channels, plane = w * h, n_units = e->plan.units.size();
     if (e->coef.ensure(P * plane) || e->tmp.ensure(P * plane) || e->sums.ensure(P) || e->means.ensure(P) ||
         e->flags.ensure(2 * P + 2 * max_frames + 1) || e->unit_bits.ensure((size_t)max_frames * n_units) ||
-        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure((size_t)max_frames * n_units) || e->route_ctl.ensure(2 * kMaxParts) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) || e->sig_hist.ensure((size_t)max_frames * e->plan.n_families * 16 + 16) ||
+        e->done_bytes.ensure((size_t)max_frames * n_units) || e->route.ensure((size_t)max_frames * n_units) || e->route_list.ensure(2 * (size_t)max_frames * n_units) || e->route_ctl.ensure(4 * kMaxParts) || e->sig.ensure((size_t)max_frames * e->plan.sig_bytes + 64) || e->sig_hist.ensure((size_t)max_frames * e->plan.n_families * 16 + 16) ||
         e->final_off.ensure((size_t)max_frames * n_units) || e->tables.ensure(1) || e->sizes.ensure(max_frames) ||
         e->rcs.ensure(max_frames)) {
         icerx_encoder_destroy(e);
@@ -889,7 +891,7 @@ static int encode_begin(icerx_encoder *e, const uint16_t *d_frames, int n_frames
     if (e->last_routed) HIP_TRY(hipMemcpyAsync(flag + 1, e->route_ctl.p, sizeof(int), hipMemcpyDeviceToHost, st));
     // (a batch enqueued in parts: the other parts' list lengths behind the two words every caller has -- only e->h_flag is that long)
     for (int k = 1; k < e->last_parts; k++)
-        if (e->last_routed) HIP_TRY(hipMemcpyAsync(flag + 1 + k, e->route_ctl.p + 2 * k, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (e->last_routed) HIP_TRY(hipMemcpyAsync(flag + 1 + k, e->route_ctl.p + 4 * k, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(done, st));
     return 0;
 }

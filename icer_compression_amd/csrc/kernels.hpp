@@ -518,22 +518,44 @@ family_events_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
 __global__ void __launch_bounds__(256)
 route_units_kernel(const UnitDesc *__restrict__ units, uint32_t n_units, const uint32_t *__restrict__ hist, uint32_t n_families,
                    uint32_t percent, uint32_t min_chunks, uint8_t *__restrict__ route, uint32_t *__restrict__ list,
-                   uint32_t *__restrict__ list_ctl, uint32_t nosplit_percent)
+                   uint32_t *__restrict__ list_ctl, uint32_t nosplit_percent, uint32_t list_cap, uint32_t heavy_min)
 {
     const uint32_t ui = blockIdx.x * 256u + threadIdx.x, frame = blockIdx.y;
-    if (ui >= n_units) return;
-    const UnitDesc u = units[ui];
+    const bool valid = ui < n_units;
+    const UnitDesc u = units[valid ? ui : 0u];
     const uint32_t nchunks = (u.w * u.h + 63u) / 64u;
-    // blank chunks of the unit = chunks of its family that are blank from a plane <= the unit's on (chunk_sig_kernel's histogram;
+    // blank chunks of the unit = chunks of its family that are blank from a plane <= the unit's on (family_events_kernel's histogram;
     // a last chunk with fewer than 64 pixels is in no entry: never blank)
     const uint32_t *h = hist + ((size_t)frame * n_families + u.family) * 16u;
     uint32_t total = 0;
     for (uint32_t v = 0; v < 16u; v++) total += v <= u.lsb ? h[v] : 0u;
-    const bool windows = nchunks >= min_chunks && total * 100u >= percent * nchunks;
+    const bool windows = valid && nchunks >= min_chunks && total * 100u >= percent * nchunks;
     // (a unit with a fifth of its chunks blank and more: its words stay open for long stretches, sub-ranges would not
     // meet -- see coder_core.hpp "Sub-ranges")
-    route[(size_t)frame * n_units + ui] = windows ? kRouteWindows : (total * 100u >= nosplit_percent * nchunks ? kRouteNoSplit : kRoutePipeline);
-    if (windows) list[atomicAdd(&list_ctl[0], 1u)] = frame * n_units + ui;      // (code_units_list_kernel)
+    if (valid) route[(size_t)frame * n_units + ui] = windows ? kRouteWindows : (total * 100u >= nosplit_percent * nchunks ? kRouteNoSplit : kRoutePipeline);
+    // (code_units_list_kernel) The units with real content -- `heavy_min` chunks and more that are not blank: the mid-sparse planes of the
+    // large levels, milliseconds each -- go to a list of their own (the second half of the buffer) that the staying workgroups take FIRST, the
+    // all-blank ones (microseconds each) follow in their order of arrival: whatever order the threads of this kernel arrive in, the long
+    // chains start at once.  (Round 6: a long unit taken 0.6 ms into the kernel ended the launch 0.6 ms later.)
+    // list_ctl: [0] entries, [1] the consumers' cursor, [2] heavy, [3] light.  One atomic per wavefront and list, not one per unit: tens of
+    // thousands of units of a batch bumping one counter made this kernel 0.2 ms.
+    const bool heavy = windows && nchunks - total >= heavy_min, light = windows && !heavy;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t mh = __ballot(heavy), ml = __ballot(light);
+    if (mh | ml) {
+        const uint32_t nh = (uint32_t)__popcll(mh), nl = (uint32_t)__popcll(ml);
+        uint32_t bh = 0, bl = 0;
+        if (lane == 0u) {
+            if (nh) bh = atomicAdd(&list_ctl[2], nh);
+            if (nl) bl = atomicAdd(&list_ctl[3], nl);
+            atomicAdd(&list_ctl[0], nh + nl);
+        }
+        bh = (uint32_t)__shfl((int)bh, 0); bl = (uint32_t)__shfl((int)bl, 0);
+        const uint32_t rh = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
+        const uint32_t rl = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u));
+        if (heavy) list[list_cap + bh + rh] = frame * n_units + ui;
+        if (light) list[bl + rl] = frame * n_units + ui;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ coder (workgroup windows)
@@ -687,7 +709,7 @@ code_units_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t
                        const int *__restrict__ frame_skip, uint8_t *__restrict__ slots,
                        size_t slot_frame_stride, uint32_t *__restrict__ unit_bits,
                        const uint8_t *__restrict__ sig, size_t sig_frame_stride,
-                       const uint32_t *__restrict__ list, uint32_t *__restrict__ list_ctl, uint64_t *__restrict__ timers)
+                       const uint32_t *__restrict__ list, uint32_t *__restrict__ list_ctl, uint64_t *__restrict__ timers, uint32_t list_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     typename I::Shared &s = *reinterpret_cast<typename I::Shared *>(wg_lds);
@@ -696,14 +718,14 @@ code_units_list_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t
     // (`timers`: profiling build only -- the per-phase cycle counters of the level-1 units, rows of their own behind the pipeline's)
     const WgLaunch L{coef, plane, img_w, img_h, channels, units, n_units, means, frame_skip, slots, slot_frame_stride, unit_bits, timers,
                      nullptr, 0ull, sig, sig_frame_stride};
-    const uint32_t count = list_ctl[0];                       // entries in the list (route_units_kernel is done)
+    const uint32_t count = list_ctl[0], n_heavy = list_ctl[2];   // entries in the list, the heavy ones at its front (route_units_kernel is done)
     for (;;) {
         __syncthreads();                                      // (the last unit's reads of `s` and of next_entry are over)
         if (threadIdx.x == 0) next_entry = atomicAdd(&list_ctl[1], 1u);
         __syncthreads();
         const uint32_t at = next_entry;
         if (at >= count) break;
-        const uint32_t e = list[at];
+        const uint32_t e = at < n_heavy ? list[list_cap + at] : list[at - n_heavy];
 #ifdef ICER_PHASE_TIMERS
         const uint64_t t_start = wall_clock64();
 #endif
