@@ -551,7 +551,7 @@ def c3_object(dev, local_rank, barrier, all_ranks_ok, world, red_dev=None):
             "value": round(world * w * h * n / el / 1e6, 3), "unit": "Mpixels/s (pixels = W*H, not x channels)", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
             "parity": all_ranks_ok(ok), "parity_note": "rc, length and CRC-32 equal the reference golden, before and after the timed loop",
             "stage_ms_per_step": {k: round(v / max(calls, 1), 4) for k, v in st.items()},
-            "coder": "code_units_wg_kernel (progressive mode: units in priority order, early stop, blank runs in closed form)" if mode == 0 else f"coder_mode {mode}",
+            "coder": "code_units_wg_kernel<WgFour> (progressive mode: four-wave workgroups, units in priority order, early stop, blank runs in closed form)" if mode == 0 else f"coder_mode {mode}",
             "roofline_frac": round((w * h * 2 * 3 + g["size"]) / (st["code_units"] / max(calls, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6) if st.get("code_units") else None}
 
 

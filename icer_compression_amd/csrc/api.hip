@@ -224,6 +224,7 @@ struct icerx_encoder {
     hipEvent_t part_fork = nullptr, part_join = nullptr;
     int overlap_parts = 2;              // parts a synchronous batch call is enqueued in (ICER_HIP_OVERLAP_PARTS; 1: one stream, as the asynchronous calls)
     int last_parts = 1;
+    int wg_waves = 0;                   // 0: the window coder's instance by launch (kernels.hpp code_units_wg_kernel); 4 / 16: pinned (ICER_HIP_WG_WAVES)
     uint32_t list_heavy_min = 64;       // listed units with at least this many chunks that are not blank are taken first (ICER_HIP_LIST_HEAVY; route_units_kernel)
     int test_fail_frame = -1, test_fail_unit = -1, test_fail_calls = 0;   // ICER_HIP_TEST_FAIL_UNIT (test hook, enqueue_part)
     int overlap_first = 50;             // two parts: the first part's share of the frames in percent (ICER_HIP_OVERLAP_FIRST)
@@ -631,12 +632,18 @@ int enqueue_part(icerx_encoder *e, int f0, int part, bool timed, const uint16_t 
         if (hybrid) HIP_TRY(hipStreamWaitEvent(st, e->join[part], 0));
     }
     if (use_wg) e->last_waves = 0, e->last_subs = 0;
-    if (use_wg)
-        hipLaunchKernelGGL(code_units_wg_kernel, dim3(n_units, n_frames), dim3(64 * wg::kWgWaves), sizeof(wg::Shared), st,
-                           reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,
-                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, means, skip, slots,
-                           e->plan.slot_bytes, unit_bits, e->prof.p, done_bytes, progressive ? (uint64_t)quota : 0ull,
-                           sig, e->plan.sig_bytes);
+    if (use_wg) {
+        // (which instance: kernels.hpp code_units_wg_kernel; ICER_HIP_WG_WAVES=4|16 pins one)
+        const bool four = e->wg_waves ? e->wg_waves == 4 : (progressive || n_frames * C >= 4);
+#define ICER_LAUNCH_WG(I, NS)                                                                                                       \
+        hipLaunchKernelGGL((code_units_wg_kernel<I>), dim3(n_units, n_frames), dim3(64 * NS::kWgWaves), sizeof(NS::Shared), st,  \
+                           reinterpret_cast<const uint16_t *>(coef), plane, (uint32_t)W, (uint32_t)H, C, e->units.p,              \
+                           progressive ? nullptr : e->work_order.p, n_units, e->tables.p, means, skip, slots,                      \
+                           e->plan.slot_bytes, unit_bits, e->prof.p, done_bytes, progressive ? (uint64_t)quota : 0ull,              \
+                           sig, e->plan.sig_bytes)
+        if (four) ICER_LAUNCH_WG(WgFour, wg4); else ICER_LAUNCH_WG(WgFull, wg);
+#undef ICER_LAUNCH_WG
+    }
     if (timed && e->timing) HIP_TRY(hipEventRecord(e->ev[3], st));
 
     // ---- quota scan + gather into final stream order
@@ -755,6 +762,7 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
         int f = -1, u = -1, c = 1;
         if (sscanf(tf, "%d:%d:%d", &f, &u, &c) >= 2 && f >= 0 && f < (1 << 11) && u >= 0 && u < (1 << 20) && c >= 1) { e->test_fail_frame = f; e->test_fail_unit = u; e->test_fail_calls = c; }
     }
+    if (const char *ww = getenv("ICER_HIP_WG_WAVES")) { const int v = atoi(ww); if (v == 4 || v == 16) e->wg_waves = v; }
     if (const char *lh = getenv("ICER_HIP_LIST_HEAVY")) { const long v = atol(lh); if (v >= 1) e->list_heavy_min = (uint32_t)v; }
     if (const char *of = getenv("ICER_HIP_OVERLAP_FIRST")) { const int v = atoi(of); if (v >= 5 && v <= 95) e->overlap_first = v; }
     if (const char *lw = getenv("ICER_HIP_LIST_WAVES")) { const int v = atoi(lw); if (v == 1 || v == 2 || v == 4) e->list_waves = v; }
@@ -797,7 +805,8 @@ int icerx_encoder_create_ex(icerx_encoder **out, int device, size_t w, size_t h,
     // the workgroup coder's LDS block is above the 64 KiB a kernel gets without asking
     // A device / runtime that refuses it loses only the paths that need that coder (progressive mode then runs on the
     // pipeline, launches are not shared, a unit time-out becomes an error) -- reported by icerx_encoder_stats.
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)) != hipSuccess ||
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel<WgFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg::Shared)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_wg_kernel<WgFour>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg4::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wgs::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgOne>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg1::Shared)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(code_units_list_kernel<WgFour>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wg4::Shared)) != hipSuccess ||

@@ -678,7 +678,12 @@ __device__ __forceinline__ void wg_shared_tables(typename I::Shared &s, const Co
     if ((threadIdx.x >> 6) == (I::kWaves > 1u ? 1u : 0u)) build_crc_table(s);
 }
 
-__global__ void __launch_bounds__(64 * wg::kWgWaves)
+// Two instances (round 6): WgFull -- sixteen wavefronts per unit, the shortest chain for the units of a LONE frame coded losslessly (the
+// fall-back after a unit time-out: 13 ms against 18 with four waves) -- and WgFour, which everything else wants: progressive mode (a 4096^2
+// YUV frame at a 70 000-byte quota 1.22 -> 0.83 ms: windows of four chunks stop sooner, three workgroups fit a compute unit where the sixteen-wave
+// one -- 115 KiB of LDS, 128 VGPRs with 48 spilled -- fits once) and the fall-back of a batch (8 x 2048^2: 21.5 -> 13.9 ms).
+template <class I>
+__global__ void __launch_bounds__(64 * I::kWaves)
 code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t img_w, uint32_t img_h, int channels,
                      const UnitDesc *__restrict__ units, const uint32_t *__restrict__ work_order, uint32_t n_units,
                      const CoderTables *__restrict__ tables, const uint16_t *__restrict__ means,
@@ -688,12 +693,12 @@ code_units_wg_kernel(const uint16_t *__restrict__ coef, size_t plane, uint32_t i
                      const uint8_t *__restrict__ sig, size_t sig_frame_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
-    wg::Shared &s = *reinterpret_cast<wg::Shared *>(wg_lds);
+    typename I::Shared &s = *reinterpret_cast<typename I::Shared *>(wg_lds);
     const uint32_t ui = work_order ? work_order[blockIdx.x] : blockIdx.x;      // (null: priority order = unit order)
-    wg_shared_tables<WgFull>(s, tables);
+    wg_shared_tables<I>(s, tables);
     const WgLaunch L{coef, plane, img_w, img_h, channels, units, n_units, means, frame_skip, slots, slot_frame_stride, unit_bits, timers,
                      done_bytes, early_quota, sig, sig_frame_stride};
-    wg_code_one_unit<WgFull>(s, L, blockIdx.y, ui);
+    wg_code_one_unit<I>(s, L, blockIdx.y, ui);
 }
 
 // The coder's small instances (icer::wgs: two wavefronts, 40 KiB of LDS; icer::wg1: one) over a LIST of (frame, unit) pairs -- the units
