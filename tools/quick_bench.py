@@ -23,7 +23,7 @@ def main():
     steps = int(sys.argv[6]) if len(sys.argv) > 6 else 10
     dev = torch.device("cuda", 0)
     d = synth.gray_frames_torch(frames, w, h, synth.DEFAULT_SEED, dev, 1)
-    quota = 2 * w * h
+    quota = int(os.environ.get("QB_QUOTA", 2 * w * h))           # (QB_QUOTA=<bytes>: a rate-limited encode, progressive mode below W*H/2)
     out = torch.empty((frames, quota), dtype=torch.uint8, device=dev)
     sizes = torch.zeros(frames, dtype=torch.int64, device=dev)
     rcs = torch.zeros(frames, dtype=torch.int32, device=dev)
